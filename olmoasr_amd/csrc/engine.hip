@@ -1,0 +1,822 @@
+// Host-side engine: parameter layout, workspace planning and the explicit forward / backward schedule of the
+// OLMoASR training micro-step.  No autograd tape: every saved activation has a planned slot in the caller's
+// workspace and the backward is written out by hand, layer by layer, in the order gradients become final
+// (so per-segment events can release RCCL buckets while the rest of the backward is still running).
+//
+// Reference schedule being replaced: OLMoASR.forward (olmoasr/model.py:856-887) -> AudioEncoder.forward (:571-623)
+// -> TextDecoder.forward (:688-775) -> F.cross_entropy(ignore_index=51864)/accum (train_timestamps.py:1444-1450)
+// -> scaler.scale(loss).backward() (:1454) -> unscale_/clip_grad_norm_/AdamW (:1509-1512).
+#include <string>
+#include <vector>
+
+#include "../../include/oasr.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr long PAD_ID = 51864;
+
+struct Tensor {
+  std::string name;
+  int64_t off, numel;
+  int ndim;
+  int64_t shape[4];
+};
+
+struct AttnP {
+  int64_t qw, kw, vw, ow, qb, vb, ob;  // arena offsets (elements); qw,kw,vw are contiguous -> fused [3d,d]
+  int64_t fused_bias;                  // offset (floats) into the aux fp32 region: [qb | 0 | vb]
+};
+struct BlockP {
+  int64_t attn_ln_w, attn_ln_b, cln_w, cln_b, mlp_ln_w, mlp_ln_b, w1, b1, w2, b2;
+  AttnP attn, cattn;
+  bool cross;
+};
+struct Segment {
+  int64_t off, numel;
+};
+
+}  // namespace
+
+struct oasr_ctx {
+  oasr_dims dims;
+  int d, H, L_enc, L_dec, Te, T1, S_max, V, Vp;  // V = n_vocab+1 rows (train model), Vp = padded to 128
+  std::vector<Tensor> tensors;
+  std::vector<Segment> segments;
+  std::vector<BlockP> enc, dec;
+  int64_t dec_ln_w, dec_ln_b, dec_pos, enc_lnp_w, enc_lnp_b, conv1_w, conv1_b, conv2_w, conv2_b, tok_emb;
+  int64_t numel;
+  // bound memory
+  float *params = nullptr, *grads = nullptr, *m = nullptr, *v = nullptr;
+  const float* enc_pos = nullptr;
+  char* shadow = nullptr;
+  // shadow layout (bytes)
+  size_t sh_flat, sh_w1p, sh_w2p, sh_aux, sh_total;
+  int64_t aux_floats;
+  const bf16_t* W(int64_t off) const { return (const bf16_t*)(shadow + sh_flat) + off; }
+  const float* P(int64_t off) const { return params + off; }
+  float* G(int64_t off) const { return grads + off; }
+  const float* aux(int64_t off) const { return (const float*)(shadow + sh_aux) + off; }
+};
+
+namespace {
+
+struct Builder {
+  oasr_ctx* c;
+  int64_t cur = 0;
+  int64_t add(const std::string& name, std::initializer_list<int64_t> shape) {
+    Tensor t;
+    t.name = name;
+    t.off = cur;
+    t.ndim = (int)shape.size();
+    t.numel = 1;
+    int i = 0;
+    for (auto s : shape) {
+      t.shape[i++] = s;
+      t.numel *= s;
+    }
+    for (; i < 4; ++i) t.shape[i] = 1;
+    cur += t.numel;
+    c->tensors.push_back(t);
+    return t.off;
+  }
+  void attn(const std::string& p, AttnP& a, int d) {
+    a.qw = add(p + ".query.weight", {d, d});
+    a.kw = add(p + ".key.weight", {d, d});
+    a.vw = add(p + ".value.weight", {d, d});
+    a.ow = add(p + ".out.weight", {d, d});
+    a.qb = add(p + ".query.bias", {d});
+    a.vb = add(p + ".value.bias", {d});
+    a.ob = add(p + ".out.bias", {d});
+    a.fused_bias = c->aux_floats;
+    c->aux_floats += 3 * d;
+  }
+  void block(const std::string& p, BlockP& b, int d, bool cross) {
+    const int64_t start = cur;
+    b.cross = cross;
+    b.w2 = add(p + ".mlp.2.weight", {d, 4 * d});
+    b.b2 = add(p + ".mlp.2.bias", {d});
+    b.w1 = add(p + ".mlp.0.weight", {4 * d, d});
+    b.b1 = add(p + ".mlp.0.bias", {4 * d});
+    b.mlp_ln_w = add(p + ".mlp_ln.weight", {d});
+    b.mlp_ln_b = add(p + ".mlp_ln.bias", {d});
+    if (cross) {
+      attn(p + ".cross_attn", b.cattn, d);
+      b.cln_w = add(p + ".cross_attn_ln.weight", {d});
+      b.cln_b = add(p + ".cross_attn_ln.bias", {d});
+    }
+    attn(p + ".attn", b.attn, d);
+    b.attn_ln_w = add(p + ".attn_ln.weight", {d});
+    b.attn_ln_b = add(p + ".attn_ln.bias", {d});
+    c->segments.push_back({start, cur - start});
+  }
+};
+
+// ---- workspace bump allocator (dry-run when base == nullptr) --------------------------------------------------
+struct Arena {
+  char* base;
+  size_t cur = 0, cap;
+  Arena(void* b, size_t c) : base((char*)b), cap(c) {}
+  void* raw(size_t bytes) {
+    cur = (cur + 255) & ~(size_t)255;
+    void* p = base ? base + cur : (void*)(uintptr_t)(cur + 256);  // non-null fake in dry-run
+    cur += bytes;
+    return p;
+  }
+  bf16_t* bf(size_t n) { return (bf16_t*)raw(n * 2 + 64); }  // +64: conv windows / 16-byte tails may over-read
+  float* f32(size_t n) { return (float*)raw(n * 4); }
+};
+
+struct AttnSave {
+  bf16_t *ln, *qkv, *o;  // self: qkv [M,3d];  cross: qkv = q [M,d]
+  bf16_t* kv;            // cross only: [B*Te, 2d]
+  float *mean, *rstd, *lse;
+};
+struct BlockSave {
+  bf16_t* x_in;  // residual stream entering the block (owned by the previous stage)
+  AttnSave sa, ca;
+  bf16_t *x_mid, *x_mid2, *ln2, *u, *hg, *x_out;
+  float *mean2, *rstd2;
+};
+
+struct Plan {
+  // encoder
+  bf16_t *mel_tm, *u1, *h1, *u2, *x0, *xa;
+  float *mean_p, *rstd_p;
+  std::vector<BlockSave> enc, dec;
+  // decoder
+  bf16_t *dx0, *lnf, *logits;
+  float *mean_f, *rstd_f, *row_loss;
+  int32_t* n_valid;
+  // backward temporaries
+  bf16_t *ga, *gb, *gc, *gln, *gqkv, *go, *gu, *gxa, *gkv, *gq, *gA2;
+  float *delta, *tmp_w1p, *tmp_w2p;
+};
+
+void plan_attn(Arena& A, AttnSave& s, long M, long Mkv, int d, int B, int H, long Tq, bool cross, bool train) {
+  s.ln = A.bf(M * d);
+  s.qkv = A.bf(M * (cross ? d : 3 * d));
+  s.kv = cross ? A.bf(Mkv * 2 * d) : nullptr;
+  s.o = A.bf(M * d);
+  s.mean = A.f32(M);
+  s.rstd = A.f32(M);
+  s.lse = A.f32((long)B * H * Tq);
+  (void)train;
+}
+
+// In inference mode the per-layer buffers are shared between layers (allocated once); in training each layer
+// gets its own slots because the backward needs them.
+void make_plan(const oasr_ctx* c, Arena& A, Plan& p, int B, int S, bool train) {
+  const int d = c->d;
+  const long Me = (long)B * c->Te, M1 = (long)B * c->T1, Md = (long)B * S;
+  p.mel_tm = A.bf(M1 * c->dims.n_mels);
+  p.u1 = A.bf(M1 * d);
+  p.h1 = A.bf(M1 * d);
+  p.u2 = A.bf(Me * d);
+  p.x0 = A.bf(Me * d);
+  auto plan_block = [&](BlockSave& s, long M, long Tq, bool cross) {
+    plan_attn(A, s.sa, M, 0, d, B, c->H, Tq, false, train);
+    s.x_mid = A.bf(M * d);
+    if (cross) {
+      plan_attn(A, s.ca, M, Me, d, B, c->H, Tq, true, train);
+      s.x_mid2 = A.bf(M * d);
+    } else {
+      s.x_mid2 = nullptr;
+    }
+    s.ln2 = A.bf(M * d);
+    s.u = A.bf(M * 4 * d);
+    s.hg = A.bf(M * 4 * d);
+    s.mean2 = A.f32(M);
+    s.rstd2 = A.f32(M);
+    s.x_out = A.bf(M * d);
+  };
+  p.enc.resize(c->L_enc);
+  p.dec.resize(c->L_dec);
+  if (train) {
+    for (auto& s : p.enc) plan_block(s, Me, c->Te, false);
+  } else {
+    BlockSave s0, s1;
+    plan_block(s0, Me, c->Te, false);
+    s1 = s0;
+    s1.x_out = A.bf(Me * d);  // ping-pong the residual stream
+    for (int i = 0; i < c->L_enc; ++i) p.enc[i] = (i & 1) ? s1 : s0;
+  }
+  p.xa = A.bf(Me * d);
+  p.mean_p = A.f32(Me);
+  p.rstd_p = A.f32(Me);
+  p.dx0 = A.bf(Md * d);
+  if (train) {
+    for (auto& s : p.dec) plan_block(s, Md, S, true);
+  } else {
+    BlockSave s0, s1;
+    plan_block(s0, Md, S, true);
+    s1 = s0;
+    s1.x_out = A.bf(Md * d);
+    for (int i = 0; i < c->L_dec; ++i) p.dec[i] = (i & 1) ? s1 : s0;
+  }
+  p.lnf = A.bf(Md * d);
+  p.mean_f = A.f32(Md);
+  p.rstd_f = A.f32(Md);
+  p.logits = A.bf(Md * c->Vp);
+  p.row_loss = A.f32(Md);
+  p.n_valid = (int32_t*)A.raw(256);
+  if (train) {
+    const long Mmax = Me > Md ? Me : Md;
+    p.ga = A.bf(Mmax * d);
+    p.gb = A.bf(Mmax * d);
+    p.gc = A.bf(Mmax * d);
+    p.gln = A.bf(Mmax * d);
+    p.gqkv = A.bf(Mmax * 3 * d);
+    p.go = A.bf(Mmax * d);
+    p.gu = A.bf(M1 * d > Mmax * 4 * d ? M1 * d : Mmax * 4 * d);  // also holds dpre1 [B*3000, d]
+    p.gxa = A.bf(Me * d);
+    p.gkv = A.bf(Me * 2 * d);
+    p.gq = A.bf(Md * d);
+    p.gA2 = A.bf(Me * 3 * d);
+    p.delta = A.f32((long)B * c->H * c->Te);
+    p.tmp_w1p = A.f32((long)d * 256);
+    p.tmp_w2p = A.f32((long)d * 3 * d);
+  }
+}
+
+#define RC(x)            \
+  do {                   \
+    int _rc = (x);       \
+    if (_rc) return _rc; \
+  } while (0)
+
+struct Runner {
+  const oasr_ctx* c;
+  hipStream_t st;
+  int B, S;
+  const int32_t* text_len;
+
+  int linear(const bf16_t* x, long M, int K, const bf16_t* W, int N, const float* bias, int act, const bf16_t* resid, bf16_t* out,
+             bf16_t* out_pre) {
+    GemmArgs g = gemm_defaults();
+    g.A = plain_view(x, K);
+    g.B = plain_view(W, K);
+    g.M = (int)M;
+    g.N = N;
+    g.K = K;
+    g.bias = bias;
+    g.act = act;
+    g.resid = resid;
+    g.ldr = N;
+    g.out = out;
+    g.out_pre = out_pre;
+    g.ldc = N;
+    return launch_gemm(g, st);
+  }
+  // dx[M,K] = dy[M,N] . W[N,K]  (* gelu'(u))  (+ resid)
+  int dgrad(const bf16_t* dy, long M, int N, const bf16_t* W, int K, const bf16_t* dgelu_u, const bf16_t* resid, bf16_t* dx) {
+    GemmArgs g = gemm_defaults();
+    g.A = plain_view(dy, N);
+    g.B = plain_view(W, K);
+    g.tb = 1;
+    g.M = (int)M;
+    g.N = K;
+    g.K = N;
+    g.dgelu_u = dgelu_u;
+    g.ldu = K;
+    g.resid = resid;
+    g.ldr = K;
+    g.out = dx;
+    g.ldc = K;
+    return launch_gemm(g, st);
+  }
+  // dW[N,K] += dy[M,N]^T . x[M,K]   (fp32 atomics, split over the token dimension)
+  int wgrad(const bf16_t* dy, long ldy, long M, int N, const OperandView& x, int K, float* dW, long ldw) {
+    GemmArgs g = gemm_defaults();
+    g.A = plain_view(dy, ldy);
+    g.ta = 1;
+    g.B = x;
+    g.tb = 1;
+    g.M = N;
+    g.N = K;
+    g.K = (int)M;
+    g.out_f32 = dW;
+    g.ldc32 = ldw;
+    g.atomic = 1;
+    const long tiles = (long)cdiv(N, 128) * cdiv(K, 128);
+    const long kt = cdiv(M, 64);
+    long split = (1024 + tiles - 1) / tiles;
+    if (split > kt / 8) split = kt / 8;
+    if (split < 1) split = 1;
+    g.split_k = (int)split;
+    return launch_gemm(g, st);
+  }
+  int attn_args(AttnArgs& a, const AttnSave& s, bool cross, long Tq, long Tk, bool causal) {
+    const int d = c->d;
+    memset(&a, 0, sizeof(a));
+    if (!cross) {
+      a.q = s.qkv;
+      a.k = s.qkv + d;
+      a.v = s.qkv + 2 * d;
+      a.ldq = a.ldk = a.ldv = 3 * d;
+      a.bsq = a.bsk = a.bsv = Tq * 3 * d;
+    } else {
+      a.q = s.qkv;
+      a.ldq = d;
+      a.bsq = Tq * d;
+      a.k = s.kv;
+      a.v = s.kv + d;
+      a.ldk = a.ldv = 2 * d;
+      a.bsk = a.bsv = Tk * 2 * d;
+    }
+    a.o = s.o;
+    a.ldo = d;
+    a.bso = Tq * d;
+    a.lse = s.lse;
+    a.kv_len = causal ? text_len : nullptr;
+    a.B = B;
+    a.H = c->H;
+    a.Tq = (int)Tq;
+    a.Tk = (int)Tk;
+    a.causal = causal ? 1 : 0;
+    return OASR_OK;
+  }
+
+  int block_fwd(const BlockP& bp, BlockSave& s, const bf16_t* x_in, long M, long Tq, const bf16_t* xa, bool causal) {
+    const int d = c->d;
+    s.x_in = const_cast<bf16_t*>(x_in);
+    RC(launch_layernorm_fwd(x_in, c->P(bp.attn_ln_w), c->P(bp.attn_ln_b), s.sa.ln, s.sa.mean, s.sa.rstd, M, d, st));
+    RC(linear(s.sa.ln, M, d, c->W(bp.attn.qw), 3 * d, c->aux(bp.attn.fused_bias), 0, nullptr, s.sa.qkv, nullptr));
+    AttnArgs a;
+    attn_args(a, s.sa, false, Tq, Tq, causal);
+    RC(launch_attention_fwd(a, st));
+    RC(linear(s.sa.o, M, d, c->W(bp.attn.ow), d, c->P(bp.attn.ob), 0, x_in, s.x_mid, nullptr));
+    const bf16_t* xm = s.x_mid;
+    if (bp.cross) {
+      RC(launch_layernorm_fwd(xm, c->P(bp.cln_w), c->P(bp.cln_b), s.ca.ln, s.ca.mean, s.ca.rstd, M, d, st));
+      RC(linear(s.ca.ln, M, d, c->W(bp.cattn.qw), d, c->P(bp.cattn.qb), 0, nullptr, s.ca.qkv, nullptr));
+      RC(linear(xa, (long)B * c->Te, d, c->W(bp.cattn.kw), 2 * d, c->aux(bp.cattn.fused_bias) + d, 0, nullptr, s.ca.kv, nullptr));
+      attn_args(a, s.ca, true, Tq, c->Te, false);
+      RC(launch_attention_fwd(a, st));
+      RC(linear(s.ca.o, M, d, c->W(bp.cattn.ow), d, c->P(bp.cattn.ob), 0, xm, s.x_mid2, nullptr));
+      xm = s.x_mid2;
+    }
+    RC(launch_layernorm_fwd(xm, c->P(bp.mlp_ln_w), c->P(bp.mlp_ln_b), s.ln2, s.mean2, s.rstd2, M, d, st));
+    RC(linear(s.ln2, M, d, c->W(bp.w1), 4 * d, c->P(bp.b1), 1, nullptr, s.hg, s.u));
+    RC(linear(s.hg, M, 4 * d, c->W(bp.w2), d, c->P(bp.b2), 0, xm, s.x_out, nullptr));
+    return OASR_OK;
+  }
+
+  OperandView conv1_view(const bf16_t* mel_tm) const {
+    const int nm = c->dims.n_mels;
+    return OperandView{mel_tm, nm, c->T1, (long)c->T1 * nm, nm, 3 * nm, 2 * nm};
+  }
+  OperandView conv2_view(const bf16_t* h1) const {
+    const int d = c->d;
+    return OperandView{h1, 2L * d, c->Te, (long)c->T1 * d, d, 3 * d, 3 * d};
+  }
+
+  int encoder_fwd(Plan& p, const float* mel) {
+    const int d = c->d;
+    const long M1 = (long)B * c->T1, Me = (long)B * c->Te;
+    RC(launch_mel_to_time_major(mel, p.mel_tm, B, c->dims.n_mels, c->T1, st));
+    {
+      GemmArgs g = gemm_defaults();
+      g.A = conv1_view(p.mel_tm);
+      g.B = plain_view((const bf16_t*)(c->shadow + c->sh_w1p), 256);
+      g.M = (int)M1;
+      g.N = d;
+      g.K = 256;
+      g.bias = c->P(c->conv1_b);
+      g.act = 1;
+      g.out = p.h1;
+      g.out_pre = p.u1;
+      g.ldc = d;
+      RC(launch_gemm(g, st));
+    }
+    {
+      GemmArgs g = gemm_defaults();
+      g.A = conv2_view(p.h1);
+      g.B = plain_view((const bf16_t*)(c->shadow + c->sh_w2p), 3 * d);
+      g.M = (int)Me;
+      g.N = d;
+      g.K = 3 * d;
+      g.bias = c->P(c->conv2_b);
+      g.act = 1;
+      g.pos = c->enc_pos;
+      g.pos_period = c->Te;
+      g.out = p.x0;
+      g.out_pre = p.u2;
+      g.ldc = d;
+      RC(launch_gemm(g, st));
+    }
+    const bf16_t* x = p.x0;
+    for (int i = 0; i < c->L_enc; ++i) {
+      RC(block_fwd(c->enc[i], p.enc[i], x, Me, c->Te, nullptr, false));
+      x = p.enc[i].x_out;
+    }
+    RC(launch_layernorm_fwd(x, c->P(c->enc_lnp_w), c->P(c->enc_lnp_b), p.xa, p.mean_p, p.rstd_p, Me, d, st));
+    return OASR_OK;
+  }
+
+  int decoder_fwd(Plan& p, const int64_t* tokens) {
+    const int d = c->d;
+    const long Md = (long)B * S;
+    RC(launch_embedding_fwd(tokens, c->P(c->tok_emb), c->P(c->dec_pos), p.dx0, B, S, d, st));
+    const bf16_t* x = p.dx0;
+    for (int i = 0; i < c->L_dec; ++i) {
+      RC(block_fwd(c->dec[i], p.dec[i], x, Md, S, p.xa, true));
+      x = p.dec[i].x_out;
+    }
+    RC(launch_layernorm_fwd(x, c->P(c->dec_ln_w), c->P(c->dec_ln_b), p.lnf, p.mean_f, p.rstd_f, Md, d, st));
+    RC(linear(p.lnf, Md, d, c->W(c->tok_emb), c->Vp, nullptr, 0, nullptr, p.logits, nullptr));
+    return OASR_OK;
+  }
+
+  int record(void** ev, int idx) {
+    if (ev && ev[idx]) OASR_CHECK_HIP(hipEventRecord((hipEvent_t)ev[idx], st));
+    return OASR_OK;
+  }
+
+  // dx_out (grad of the block output) -> returns grad of the block input in *dx_in_out (ping-pong ga/gb)
+  int block_bwd(const BlockP& bp, const BlockSave& s, Plan& p, const bf16_t* dx_out, bf16_t* scratch_a, bf16_t* scratch_b, long M,
+                long Tq, bool causal, bool first_cross, const bf16_t** dx_in) {
+    const int d = c->d;
+    const bf16_t* xm = bp.cross ? s.x_mid2 : s.x_mid;
+    // ---- MLP -----------------------------------------------------------------------------------------------
+    RC(wgrad(dx_out, d, M, d, plain_view(s.hg, 4 * d), 4 * d, c->G(bp.w2), 4 * d));
+    RC(launch_colsum_accum(dx_out, d, M, d, c->G(bp.b2), st));
+    RC(dgrad(dx_out, M, d, c->W(bp.w2), 4 * d, s.u, nullptr, p.gu));
+    RC(wgrad(p.gu, 4 * d, M, 4 * d, plain_view(s.ln2, d), d, c->G(bp.w1), d));
+    RC(launch_colsum_accum(p.gu, 4 * d, M, 4 * d, c->G(bp.b1), st));
+    RC(dgrad(p.gu, M, 4 * d, c->W(bp.w1), d, nullptr, nullptr, p.gln));
+    RC(launch_layernorm_bwd(p.gln, xm, c->P(bp.mlp_ln_w), s.mean2, s.rstd2, dx_out, scratch_a, c->G(bp.mlp_ln_w), c->G(bp.mlp_ln_b), M,
+                            d, st));
+    const bf16_t* dx = scratch_a;
+    bf16_t* nxt = scratch_b;
+    // ---- cross attention ---------------------------------------------------------------------------------------
+    if (bp.cross) {
+      const long Mkv = (long)B * c->Te;
+      RC(wgrad(dx, d, M, d, plain_view(s.ca.o, d), d, c->G(bp.cattn.ow), d));
+      RC(launch_colsum_accum(dx, d, M, d, c->G(bp.cattn.ob), st));
+      RC(dgrad(dx, M, d, c->W(bp.cattn.ow), d, nullptr, nullptr, p.go));
+      AttnArgs a;
+      attn_args(a, s.ca, true, Tq, c->Te, false);
+      a.d_o = p.go;
+      a.delta = p.delta;
+      a.dq = p.gq;
+      a.dk = p.gkv;
+      a.dv = p.gkv + d;
+      RC(launch_attention_bwd(a, st));
+      RC(wgrad(p.gq, d, M, d, plain_view(s.ca.ln, d), d, c->G(bp.cattn.qw), d));
+      RC(launch_colsum_accum(p.gq, d, M, d, c->G(bp.cattn.qb), st));
+      RC(wgrad(p.gkv, 2 * d, Mkv, 2 * d, plain_view(p.xa, d), d, c->G(bp.cattn.kw), d));
+      RC(launch_colsum_accum(p.gkv + d, 2 * d, Mkv, d, c->G(bp.cattn.vb), st));
+      // d(xa) accumulates over the decoder layers (bf16, like autograd's accumulation into xa.grad)
+      RC(dgrad(p.gkv, Mkv, 2 * d, c->W(bp.cattn.kw), d, nullptr, first_cross ? nullptr : p.gxa, p.gxa));
+      RC(dgrad(p.gq, M, d, c->W(bp.cattn.qw), d, nullptr, nullptr, p.gln));
+      RC(launch_layernorm_bwd(p.gln, s.x_mid, c->P(bp.cln_w), s.ca.mean, s.ca.rstd, dx, nxt, c->G(bp.cln_w), c->G(bp.cln_b), M, d, st));
+      const bf16_t* t = dx;
+      dx = nxt;
+      nxt = const_cast<bf16_t*>(t);
+    }
+    // ---- self attention ----------------------------------------------------------------------------------------
+    RC(wgrad(dx, d, M, d, plain_view(s.sa.o, d), d, c->G(bp.attn.ow), d));
+    RC(launch_colsum_accum(dx, d, M, d, c->G(bp.attn.ob), st));
+    RC(dgrad(dx, M, d, c->W(bp.attn.ow), d, nullptr, nullptr, p.go));
+    AttnArgs a;
+    attn_args(a, s.sa, false, Tq, Tq, causal);
+    a.d_o = p.go;
+    a.delta = p.delta;
+    a.dq = p.gqkv;
+    a.dk = p.gqkv + d;
+    a.dv = p.gqkv + 2 * d;
+    RC(launch_attention_bwd(a, st));
+    RC(wgrad(p.gqkv, 3 * d, M, 3 * d, plain_view(s.sa.ln, d), d, c->G(bp.attn.qw), d));
+    RC(launch_colsum_accum(p.gqkv, 3 * d, M, d, c->G(bp.attn.qb), st));
+    RC(launch_colsum_accum(p.gqkv + 2 * d, 3 * d, M, d, c->G(bp.attn.vb), st));
+    RC(dgrad(p.gqkv, M, 3 * d, c->W(bp.attn.qw), d, nullptr, nullptr, p.gln));
+    RC(launch_layernorm_bwd(p.gln, s.x_in, c->P(bp.attn_ln_w), s.sa.mean, s.sa.rstd, dx, nxt, c->G(bp.attn_ln_w), c->G(bp.attn_ln_b), M, d,
+                            st));
+    *dx_in = nxt;
+    return OASR_OK;
+  }
+};
+
+int write_logits_f32(const bf16_t* logits, long ld, long rows, int V, float* out, hipStream_t st);
+
+}  // namespace
+
+// ---- small kernels local to the engine -------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void logits_to_f32_kernel(const bf16_t* __restrict__ lg, long ld, int V, float* __restrict__ out,
+                                                           long total) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / V;
+    const int col = (int)(i - r * V);
+    out[i] = bf2f(lg[r * ld + col]);
+  }
+}
+__global__ __launch_bounds__(256) void fused_bias_kernel(const float* __restrict__ qb, const float* __restrict__ vb, float* __restrict__ out,
+                                                        int d) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < 3 * d; i += gridDim.x * 256)
+    out[i] = i < d ? qb[i] : (i < 2 * d ? 0.f : vb[i - 2 * d]);
+}
+__global__ __launch_bounds__(256) void dgelu_mul_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ u, bf16_t* __restrict__ out,
+                                                       long n8) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const u32x4_t a = ((const u32x4_t*)dy)[i], b = ((const u32x4_t*)u)[i];
+    u32x4_t o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = pack_bf2(bf_lo(a[j]) * dgelu_f(bf_lo(b[j])), bf_hi(a[j]) * dgelu_f(bf_hi(b[j])));
+    ((u32x4_t*)out)[i] = o;
+  }
+}
+
+namespace {
+int write_logits_f32(const bf16_t* logits, long ld, long rows, int V, float* out, hipStream_t st) {
+  const long total = rows * V;
+  long nb = (total + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(logits_to_f32_kernel, dim3((unsigned)nb), dim3(256), 0, st, logits, ld, V, out, total);
+  OASR_LAUNCH_CHECK();
+  return OASR_OK;
+}
+int check_bound(const oasr_ctx* c, bool need_grads) {
+  OASR_REQUIRE(c, "null context");
+  if (!c->params || !c->shadow || !c->enc_pos || (need_grads && !c->grads)) {
+    oasr_set_error("context not fully bound (oasr_bind / oasr_bind_shadow)");
+    return OASR_ESTATE;
+  }
+  return OASR_OK;
+}
+}  // namespace
+
+// ================================================ C ABI ============================================================
+extern "C" oasr_ctx* oasr_create(const oasr_dims* dm) {
+  if (!dm) {
+    oasr_set_error("oasr_create: null dims");
+    return nullptr;
+  }
+  const int d = dm->n_audio_state;
+  if (dm->n_text_state != d || dm->n_audio_head != dm->n_text_head || d != 64 * dm->n_audio_head || dm->n_mels != 80 ||
+      (d % 64) != 0 || d > 2048 || dm->n_text_ctx > 448 || dm->n_text_ctx < 1) {
+    oasr_set_error("oasr_create: unsupported dims (need n_audio_state == n_text_state == 64*heads <= 2048, n_mels == 80, n_text_ctx <= 448)");
+    return nullptr;
+  }
+  oasr_ctx* c = new oasr_ctx();
+  c->dims = *dm;
+  c->d = d;
+  c->H = dm->n_audio_head;
+  c->L_enc = dm->n_audio_layer;
+  c->L_dec = dm->n_text_layer;
+  c->Te = dm->n_audio_ctx;
+  c->T1 = 2 * dm->n_audio_ctx;
+  c->S_max = dm->n_text_ctx;
+  c->V = dm->n_vocab + 1;  // training model carries the pad row (olmoasr/model.py:665-667)
+  c->Vp = (c->V + 127) / 128 * 128;
+  c->aux_floats = 0;
+  Builder b{c};
+  {  // decoder.ln
+    const int64_t s0 = b.cur;
+    c->dec_ln_w = b.add("decoder.ln.weight", {d});
+    c->dec_ln_b = b.add("decoder.ln.bias", {d});
+    c->segments.push_back({s0, b.cur - s0});
+  }
+  c->dec.resize(c->L_dec);
+  for (int i = c->L_dec - 1; i >= 0; --i) b.block("decoder.blocks." + std::to_string(i), c->dec[i], d, true);
+  {
+    const int64_t s0 = b.cur;
+    c->dec_pos = b.add("decoder.positional_embedding", {dm->n_text_ctx, d});
+    c->segments.push_back({s0, b.cur - s0});
+  }
+  const size_t emb_seg = c->segments.size();
+  c->segments.push_back({0, 0});  // token embedding: becomes final here in time, lives at the arena's end
+  {
+    const int64_t s0 = b.cur;
+    c->enc_lnp_w = b.add("encoder.ln_post.weight", {d});
+    c->enc_lnp_b = b.add("encoder.ln_post.bias", {d});
+    c->segments.push_back({s0, b.cur - s0});
+  }
+  c->enc.resize(c->L_enc);
+  for (int i = c->L_enc - 1; i >= 0; --i) b.block("encoder.blocks." + std::to_string(i), c->enc[i], d, false);
+  {
+    const int64_t s0 = b.cur;
+    c->conv2_w = b.add("encoder.conv2.weight", {d, d, 3});
+    c->conv2_b = b.add("encoder.conv2.bias", {d});
+    c->conv1_w = b.add("encoder.conv1.weight", {d, dm->n_mels, 3});
+    c->conv1_b = b.add("encoder.conv1.bias", {d});
+    c->segments.push_back({s0, b.cur - s0});
+  }
+  c->tok_emb = b.add("decoder.token_embedding.weight", {c->V, d});
+  c->segments[emb_seg] = {c->tok_emb, (int64_t)c->V * d};
+  c->numel = b.cur;
+  // shadow: [bf16 flat arena + zero pad rows for the padded vocab] [W1p d x 256] [W2p d x 3d] [aux fp32]
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  c->sh_flat = 0;
+  size_t off = al(((size_t)c->numel + (size_t)(c->Vp - c->V) * d + 64) * 2);
+  c->sh_w1p = off;
+  off = al(off + (size_t)d * 256 * 2);
+  c->sh_w2p = off;
+  off = al(off + (size_t)d * 3 * d * 2);
+  c->sh_aux = off;
+  off = al(off + (size_t)c->aux_floats * 4);
+  c->sh_total = off;
+  return c;
+}
+extern "C" void oasr_destroy(oasr_ctx* c) { delete c; }
+extern "C" int oasr_param_count(const oasr_ctx* c) { return c ? (int)c->tensors.size() : 0; }
+extern "C" int64_t oasr_param_numel(const oasr_ctx* c) { return c ? c->numel : 0; }
+extern "C" int oasr_param_info(const oasr_ctx* c, int idx, char* name, int name_cap, int64_t* offset, int64_t* numel, int* ndim,
+                               int64_t shape[4]) {
+  OASR_REQUIRE(c && idx >= 0 && idx < (int)c->tensors.size(), "param_info: bad index");
+  const Tensor& t = c->tensors[idx];
+  if (name && name_cap > 0) snprintf(name, name_cap, "%s", t.name.c_str());
+  if (offset) *offset = t.off;
+  if (numel) *numel = t.numel;
+  if (ndim) *ndim = t.ndim;
+  if (shape)
+    for (int i = 0; i < 4; ++i) shape[i] = t.shape[i];
+  return OASR_OK;
+}
+extern "C" int oasr_segment_count(const oasr_ctx* c) { return c ? (int)c->segments.size() : 0; }
+extern "C" int oasr_segment_info(const oasr_ctx* c, int idx, int64_t* offset, int64_t* numel) {
+  OASR_REQUIRE(c && idx >= 0 && idx < (int)c->segments.size(), "segment_info: bad index");
+  if (offset) *offset = c->segments[idx].off;
+  if (numel) *numel = c->segments[idx].numel;
+  return OASR_OK;
+}
+extern "C" int oasr_bind(oasr_ctx* c, float* params, float* grads, float* m, float* v, const float* enc_pos) {
+  OASR_REQUIRE(c && params && enc_pos, "oasr_bind: params and enc_pos are required");
+  c->params = params;
+  c->grads = grads;
+  c->m = m;
+  c->v = v;
+  c->enc_pos = enc_pos;
+  return OASR_OK;
+}
+extern "C" size_t oasr_shadow_bytes(const oasr_ctx* c) { return c ? c->sh_total : 0; }
+extern "C" int oasr_bind_shadow(oasr_ctx* c, void* shadow) {
+  OASR_REQUIRE(c && shadow, "oasr_bind_shadow: null");
+  c->shadow = (char*)shadow;
+  return OASR_OK;
+}
+
+static int refresh_packed(oasr_ctx* c, hipStream_t st) {
+  const int d = c->d;
+  RC(launch_pack_conv_weight(c->P(c->conv1_w), (bf16_t*)(c->shadow + c->sh_w1p), d, c->dims.n_mels, 256, st));
+  RC(launch_pack_conv_weight(c->P(c->conv2_w), (bf16_t*)(c->shadow + c->sh_w2p), d, d, 3 * d, st));
+  float* aux = (float*)(c->shadow + c->sh_aux);
+  auto fb = [&](const AttnP& a) {
+    hipLaunchKernelGGL(fused_bias_kernel, dim3(cdiv(3 * d, 256)), dim3(256), 0, st, c->P(a.qb), c->P(a.vb), aux + a.fused_bias, d);
+  };
+  for (auto& b : c->enc) fb(b.attn);
+  for (auto& b : c->dec) {
+    fb(b.attn);
+    fb(b.cattn);
+  }
+  OASR_LAUNCH_CHECK();
+  return OASR_OK;
+}
+
+extern "C" int oasr_refresh_shadow(oasr_ctx* c, void* stream) {
+  RC(check_bound(c, false));
+  hipStream_t st = (hipStream_t)stream;
+  bf16_t* flat = (bf16_t*)(c->shadow + c->sh_flat);
+  RC(launch_cast_f32_bf16(c->params, flat, c->numel, st));
+  OASR_CHECK_HIP(hipMemsetAsync(flat + c->numel, 0, ((size_t)(c->Vp - c->V) * c->d + 64) * 2, st));
+  return refresh_packed(c, st);
+}
+
+extern "C" size_t oasr_workspace_bytes(const oasr_ctx* c, int B, int S, int mode) {
+  if (!c || B <= 0 || S <= 0) return 0;
+  Arena A(nullptr, 0);
+  Plan p;
+  make_plan(c, A, p, B, S, mode == OASR_MODE_TRAIN);
+  return A.cur + 4096;
+}
+
+extern "C" int oasr_forward(oasr_ctx* c, const float* mel, const int64_t* tokens, const int32_t* text_len, int B, int S,
+                            float* logits_out, void* xa_out, void* workspace, size_t workspace_bytes, void* stream) {
+  RC(check_bound(c, false));
+  OASR_REQUIRE(mel && tokens && workspace && B > 0 && S > 0 && S <= c->S_max, "oasr_forward: bad args (B=%d S=%d)", B, S);
+  OASR_REQUIRE(workspace_bytes >= oasr_workspace_bytes(c, B, S, OASR_MODE_INFER), "oasr_forward: workspace too small");
+  Arena A(workspace, workspace_bytes);
+  Plan p;
+  make_plan(c, A, p, B, S, false);
+  Runner r{c, (hipStream_t)stream, B, S, text_len};
+  RC(r.encoder_fwd(p, mel));
+  RC(r.decoder_fwd(p, tokens));
+  if (xa_out)
+    OASR_CHECK_HIP(hipMemcpyAsync(xa_out, p.xa, (size_t)B * c->Te * c->d * 2, hipMemcpyDeviceToDevice, r.st));
+  if (logits_out) RC(write_logits_f32(p.logits, c->Vp, (long)B * S, c->V, logits_out, r.st));
+  return OASR_OK;
+}
+
+extern "C" int oasr_zero_grad(oasr_ctx* c, void* stream) {
+  RC(check_bound(c, true));
+  OASR_CHECK_HIP(hipMemsetAsync(c->grads, 0, (size_t)c->numel * 4, (hipStream_t)stream));
+  return OASR_OK;
+}
+
+extern "C" int oasr_train_fwd_bwd(oasr_ctx* c, const float* mel, const int64_t* tokens, const int64_t* targets, const int32_t* text_len,
+                                  int B, float loss_scale, float inv_accum, float* loss_out, int accumulate_loss, float* logits_out,
+                                  void** ev, void* workspace, size_t workspace_bytes, void* stream) {
+  RC(check_bound(c, true));
+  const int S = c->S_max;
+  OASR_REQUIRE(mel && tokens && targets && text_len && loss_out && workspace && B > 0, "oasr_train_fwd_bwd: bad args");
+  OASR_REQUIRE(workspace_bytes >= oasr_workspace_bytes(c, B, S, OASR_MODE_TRAIN), "oasr_train_fwd_bwd: workspace too small");
+  const int d = c->d;
+  const long Md = (long)B * S, Me = (long)B * c->Te, M1 = (long)B * c->T1;
+  Arena A(workspace, workspace_bytes);
+  Plan p;
+  make_plan(c, A, p, B, S, true);
+  Runner r{c, (hipStream_t)stream, B, S, text_len};
+  hipStream_t st = r.st;
+
+  // ---------------- forward ----------------
+  RC(r.encoder_fwd(p, mel));
+  RC(r.decoder_fwd(p, tokens));
+  if (logits_out) RC(write_logits_f32(p.logits, c->Vp, Md, c->V, logits_out, st));
+  RC(launch_count_valid(targets, Md, PAD_ID, p.n_valid, st));
+  RC(launch_cross_entropy(p.logits, c->Vp, c->V, targets, Md, PAD_ID, loss_scale * inv_accum, p.n_valid, p.row_loss, 1, st));
+  RC(launch_loss_reduce(p.row_loss, Md, p.n_valid, inv_accum, loss_out, accumulate_loss, st));
+
+  // ---------------- backward: decoder ----------------
+  int seg = 0;
+  // tied logits: dE += dlogits^T . lnf ; d(lnf) = dlogits . E
+  RC(r.wgrad(p.logits, c->Vp, Md, c->V, plain_view(p.lnf, d), d, c->G(c->tok_emb), d));
+  RC(r.dgrad(p.logits, Md, c->Vp, c->W(c->tok_emb), d, nullptr, nullptr, p.gln));
+  const bf16_t* x_last = c->L_dec ? p.dec[c->L_dec - 1].x_out : p.dx0;
+  RC(launch_layernorm_bwd(p.gln, x_last, c->P(c->dec_ln_w), p.mean_f, p.rstd_f, nullptr, p.ga, c->G(c->dec_ln_w), c->G(c->dec_ln_b), Md, d,
+                          st));
+  RC(r.record(ev, seg++));
+  const bf16_t* dx = p.ga;
+  auto others = [&](const bf16_t* cur, bf16_t** a, bf16_t** b) {  // the two stream-gradient buffers that are not `cur`
+    bf16_t* all[3] = {p.ga, p.gb, p.gc};
+    int n = 0;
+    bf16_t* o[2] = {nullptr, nullptr};
+    for (int j = 0; j < 3; ++j)
+      if (all[j] != cur && n < 2) o[n++] = all[j];
+    *a = o[0];
+    *b = o[1];
+  };
+  for (int i = c->L_dec - 1; i >= 0; --i) {
+    bf16_t *sa, *sb;
+    others(dx, &sa, &sb);
+    const bf16_t* dx_in = nullptr;
+    RC(r.block_bwd(c->dec[i], p.dec[i], p, dx, sa, sb, Md, S, true, i == c->L_dec - 1, &dx_in));
+    dx = dx_in;
+    RC(r.record(ev, seg++));
+  }
+  RC(launch_embedding_bwd(tokens, dx, c->G(c->tok_emb), c->G(c->dec_pos), B, S, d, PAD_ID, st));
+  RC(r.record(ev, seg++));  // decoder.positional_embedding
+  RC(r.record(ev, seg++));  // token embedding (arena tail)
+
+  // ---------------- backward: encoder ----------------
+  const bf16_t* xe_last = c->L_enc ? p.enc[c->L_enc - 1].x_out : p.x0;
+  if (c->L_dec == 0) OASR_CHECK_HIP(hipMemsetAsync(p.gxa, 0, (size_t)Me * d * 2, st));
+  RC(launch_layernorm_bwd(p.gxa, xe_last, c->P(c->enc_lnp_w), p.mean_p, p.rstd_p, nullptr, p.ga, c->G(c->enc_lnp_w), c->G(c->enc_lnp_b), Me,
+                          d, st));
+  RC(r.record(ev, seg++));
+  dx = p.ga;
+  for (int i = c->L_enc - 1; i >= 0; --i) {
+    bf16_t *sa, *sb;
+    others(dx, &sa, &sb);
+    const bf16_t* dx_in = nullptr;
+    RC(r.block_bwd(c->enc[i], p.enc[i], p, dx, sa, sb, Me, c->Te, false, false, &dx_in));
+    dx = dx_in;
+    RC(r.record(ev, seg++));
+  }
+  // conv stem: x0 = gelu(u2) + pos ; u2 = conv2(h1) ; h1 = gelu(u1) ; u1 = conv1(mel)
+  {
+    long n8 = Me * d / 8;
+    long nb = (n8 + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(dgelu_mul_kernel, dim3((unsigned)nb), dim3(256), 0, st, dx, p.u2, p.gln, n8);  // gln = d(u2)
+    OASR_LAUNCH_CHECK();
+    OASR_CHECK_HIP(hipMemsetAsync(p.tmp_w2p, 0, (size_t)d * 3 * d * 4, st));
+    RC(r.wgrad(p.gln, d, Me, d, r.conv2_view(p.h1), 3 * d, p.tmp_w2p, 3 * d));
+    RC(launch_unpack_conv_grad(p.tmp_w2p, c->G(c->conv2_w), d, d, 3 * d, st));
+    RC(launch_colsum_accum(p.gln, d, Me, d, c->G(c->conv2_b), st));
+    RC(r.dgrad(p.gln, Me, d, (const bf16_t*)(c->shadow + c->sh_w2p), 3 * d, nullptr, nullptr, p.gA2));
+    RC(launch_conv2_col2im_dgelu(p.gA2, p.u1, p.gu, B, c->T1, d, st));  // gu = d(u1) [B*3000, d]
+    OASR_CHECK_HIP(hipMemsetAsync(p.tmp_w1p, 0, (size_t)d * 256 * 4, st));
+    RC(r.wgrad(p.gu, d, M1, d, r.conv1_view(p.mel_tm), 256, p.tmp_w1p, 256));
+    RC(launch_unpack_conv_grad(p.tmp_w1p, c->G(c->conv1_w), d, c->dims.n_mels, 256, st));
+    RC(launch_colsum_accum(p.gu, d, M1, d, c->G(c->conv1_b), st));
+  }
+  RC(r.record(ev, seg++));
+  if (seg != (int)c->segments.size()) {
+    oasr_set_error("internal: segment count mismatch %d vs %zu", seg, c->segments.size());
+    return OASR_ESTATE;
+  }
+  return OASR_OK;
+}
+
+extern "C" int oasr_optim_step(oasr_ctx* c, float inv_loss_scale, float max_grad_norm, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, int64_t step, float* stats_out, void* scratch, void* stream) {
+  RC(check_bound(c, true));
+  OASR_REQUIRE(c->m && c->v && stats_out && scratch && step >= 1, "oasr_optim_step: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  RC(launch_grad_stats(c->grads, c->numel, (double*)scratch, stats_out, st));
+  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  const float bc2 = (float)(1.0 - pow((double)beta2, (double)step));
+  RC(launch_adamw(c->params, c->grads, c->m, c->v, (bf16_t*)(c->shadow + c->sh_flat), c->numel, stats_out, inv_loss_scale, max_grad_norm,
+                  lr, beta1, beta2, eps, weight_decay, bc1, bc2, st));
+  return refresh_packed(c, st);
+}

@@ -1,0 +1,124 @@
+// Internal launch interface between the kernel translation units and the engine (not part of the C ABI).
+#pragma once
+#include "common.h"
+
+// A row-major bf16 operand, optionally viewed as overlapping convolution windows:
+//   plain   : element (r, k) at  r*ld + k
+//   windows : rpb > 0.  r = b*rpb + t ; element (r,k) at  b*bstride + t*ld - lead + k, and it is an implicit
+//             zero when k >= kvalid, or (t == 0 && k < lead), or (t == rpb-1 && k >= trail_from).
+//             conv1 (k3,s1,p1) over time-major mel [B][3000][80]  : ld=80,  rpb=3000, lead=80, kvalid=240, trail_from=160
+//             conv2 (k3,s2,p1) over time-major h1 [B][3000][d]    : ld=2d,  rpb=1500, lead=d,  kvalid=3d,  trail_from=3d
+struct OperandView {
+  const bf16_t* ptr;
+  long ld;
+  int rpb;
+  long bstride;
+  int lead;
+  int kvalid;
+  int trail_from;
+};
+static inline OperandView plain_view(const bf16_t* p, long ld) { return OperandView{p, ld, 0, 0, 0, 0, 0}; }
+
+// C[M,N] = epilogue( alpha * sum_k A(m,k) * B(n,k) )
+//   ta == 0 : A stored [M][K] (k contiguous);  ta == 1 : A stored [K][M] (m contiguous)
+//   tb == 0 : B stored [N][K];                 tb == 1 : B stored [K][N]
+// Epilogue, in this order, every pointer optional (fp32 math on the accumulator):
+//   v = alpha*acc (+ bias[n]) ; out_pre <- bf16(v) ; if act: v = gelu(bf16(v)) ;
+//   if pos: v = bf16(v) + pos[(m % pos_period)*N + n] ; if dgelu_u: v = bf16(v) * gelu'(u[m,n]) ;
+//   if resid: v = bf16(v) + resid[m,n] ; out <- bf16(v) ; out_f32 <- (atomic ? += v : beta*out_f32 + v)
+struct GemmArgs {
+  OperandView A, B;
+  int M, N, K;
+  int ta, tb;
+  float alpha;
+  const float* bias;
+  int act;  // 0 none, 1 exact-erf GELU
+  const float* pos;
+  int pos_period;
+  const bf16_t* dgelu_u;
+  long ldu;
+  const bf16_t* resid;
+  long ldr;
+  bf16_t* out;
+  bf16_t* out_pre;
+  long ldc;
+  float* out_f32;
+  long ldc32;
+  float beta;
+  int atomic;   // out_f32 += v with hardware fp32 atomics (split-K safe)
+  int split_k;  // >= 1; > 1 requires atomic out_f32 and no other output
+};
+int launch_gemm(const GemmArgs& a, hipStream_t stream);
+static inline GemmArgs gemm_defaults() {
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.alpha = 1.0f;
+  g.split_k = 1;
+  return g;
+}
+
+// LayerNorm over the last dim (eps 1e-5, fp32 internals, bf16 in/out; reference model.py:39)
+int launch_layernorm_fwd(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y, float* mean, float* rstd,
+                         long rows, int d, hipStream_t s);
+// dx = LN'(dy) (+ dres) ; dgamma/dbeta are ACCUMULATED (atomic fp32) into the grad arena
+int launch_layernorm_bwd(const bf16_t* dy, const bf16_t* x, const float* gamma, const float* mean, const float* rstd,
+                         const bf16_t* dres, bf16_t* dx, float* dgamma, float* dbeta, long rows, int d, hipStream_t s);
+
+// Flash attention over head_dim 64.  Q/K/V are strided views [B, T, H, 64] (row strides in elements);
+// key j visible to query i iff j < kv_len[b] (nullptr -> Tk) and (!causal || j <= i).  scale = 1/8.
+struct AttnArgs {
+  const bf16_t *q, *k, *v;
+  long ldq, ldk, ldv;        // token strides
+  long bsq, bsk, bsv;        // batch strides
+  bf16_t* o;                 // [B, Tq, H*64]
+  long ldo, bso;
+  float* lse;                // [B, H, Tq] natural-log-sum-exp of scaled scores
+  const int32_t* kv_len;     // [B] or null
+  int B, H, Tq, Tk, causal;
+  // backward only
+  const bf16_t* d_o;         // [B, Tq, H*64], same strides as o
+  float* delta;              // [B, H, Tq] workspace: rowsum(dO * O)
+  bf16_t *dq, *dk, *dv;      // same strides as q/k/v
+};
+int launch_attention_fwd(const AttnArgs& a, hipStream_t s);
+int launch_attention_bwd(const AttnArgs& a, hipStream_t s);
+
+// ---- elementwise / reductions -------------------------------------------------------------------------
+int launch_cast_f32_bf16(const float* src, bf16_t* dst, long n, hipStream_t s);
+// conv weight [co][ci][3] f32 -> bf16 [co][ldk] with k = kk*ci_n + ci, zero padded to ldk
+int launch_pack_conv_weight(const float* w, bf16_t* dst, int co, int ci, int ldk, hipStream_t s);
+// grad [co][ldk] f32 (k = kk*ci_n+ci) accumulated into dw [co][ci][3]
+int launch_unpack_conv_grad(const float* g, float* dw, int co, int ci, int ldk, hipStream_t s);
+// token embedding rows f32 [rows][d] -> bf16 [rows_pad][d], rows >= rows zero
+int launch_pack_embedding(const float* e, bf16_t* dst, int rows, int rows_pad, int d, hipStream_t s);
+// mel f32 [B][80][T] -> bf16 time-major [B][T][80]
+int launch_mel_to_time_major(const float* mel, bf16_t* out, int B, int n_mels, int T, hipStream_t s);
+// x[b,s,:] = bf16(E[tok[b,s]] + pos[s])
+int launch_embedding_fwd(const int64_t* tok, const float* E, const float* pos, bf16_t* x, int B, int S, int d, hipStream_t s);
+// dE[tok] += dx (skipping pad_id), dpos[s] += sum_b dx
+int launch_embedding_bwd(const int64_t* tok, const bf16_t* dx, float* dE, float* dpos, int B, int S, int d, long pad_id,
+                         hipStream_t s);
+// out[n] += sum_m x[m, n]   (x bf16 [M, ld], columns [0, ncols))
+int launch_colsum_accum(const bf16_t* x, long ld, long M, int ncols, float* out, hipStream_t s);
+// conv2 input-gradient fold + conv1 GELU backward: dpre1[b,t,c] = gelu'(u1) * sum of the dA windows covering t
+int launch_conv2_col2im_dgelu(const bf16_t* dA /*[B*T2][3d]*/, const bf16_t* u1 /*[B*T1][d]*/, bf16_t* dpre1, int B, int T1,
+                              int d, hipStream_t s);
+// dst(f32) += src(f32) over n  (grad of the fp32 sinusoid buffer is not needed; used for misc accumulations)
+int launch_axpy_f32(const float* src, float* dst, long n, float a, hipStream_t s);
+
+// ---- loss -------------------------------------------------------------------------------------------------
+// logits bf16 [rows][ld] (first V entries valid).  Writes, in place, dlogits = (softmax - onehot) * gscale / n_valid
+// (zeros for ignored rows and pad columns), row_loss[r] = lse - logit[target] (0 for ignored rows).
+// n_valid_dev: device int32 (count of targets != ignore).  loss_out += sum(row_loss)/n_valid * loss_mul.
+int launch_count_valid(const int64_t* targets, long rows, long ignore, int32_t* n_valid_dev, hipStream_t s);
+int launch_cross_entropy(bf16_t* logits, long ld, int V, const int64_t* targets, long rows, long ignore, float gscale,
+                         const int32_t* n_valid_dev, float* row_loss, int write_grad, hipStream_t s);
+int launch_loss_reduce(const float* row_loss, long rows, const int32_t* n_valid_dev, float mul, float* loss_out, int accumulate,
+                       hipStream_t s);
+
+// ---- optimizer (flat fp32 arenas) ---------------------------------------------------------------------------
+// stats[0] = sum g^2 (of the *scaled* grads), stats[1] = found_inf flag (nonzero if any non-finite)
+int launch_grad_stats(const float* g, long n, double* partial /*[1024]*/, float* stats /*[2]*/, hipStream_t s);
+// Fused unscale + clip + AdamW (decoupled decay) + bf16 shadow emit.  Skips everything when stats[1] != 0.
+int launch_adamw(float* p, const float* g, float* m, float* v, bf16_t* shadow, long n, const float* stats, float inv_scale,
+                 float max_norm, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2, hipStream_t s);

@@ -1,0 +1,148 @@
+// Cross-entropy over the BPE vocabulary, forward + backward in one pass (gfx950, HBM-bound).
+// Reference: F.cross_entropy(logits.view(-1, V+1), text_y.view(-1), ignore_index=51864) / accumulation_steps
+// (scripts/training/train_timestamps.py:1444-1450) on logits that the reference produced in bf16 and then
+// .float()-ed (olmoasr/model.py:768-770); the gradient it back-propagates into the tied-logits matmul is bf16.
+// One 256-thread workgroup per token row: the 51865 bf16 logits (104 KB) are read ONCE into registers
+// (26 x 16 bytes per thread), softmax statistics in fp32, and (softmax - onehot) * g is written back in place
+// as bf16 -> 2 * 2 * V bytes of HBM traffic per row, no fp32 logits tensor ever exists.
+#include "kernels.h"
+
+namespace {
+
+constexpr int CE_CHUNKS = 26;  // 26 * 256 threads * 8 = 53248 >= 51968
+
+__device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  v = is_max ? wave_max(v) : wave_sum(v);
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return is_max ? fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) : (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void ce_kernel(bf16_t* __restrict__ logits, long ld, int V, const int64_t* __restrict__ targets,
+                                                 long ignore, float gscale, const int32_t* __restrict__ n_valid_dev,
+                                                 float* __restrict__ row_loss, int write_grad) {
+  __shared__ float red[4];
+  const long row = blockIdx.x;
+  bf16_t* lr = logits + row * ld;
+  const long tgt = targets[row];
+  const int nchunk = (int)(ld >> 3);
+  if (tgt == ignore) {  // ignored row: zero gradient, zero loss (uniform branch)
+    if (write_grad) {
+      const u32x4_t z = {0u, 0u, 0u, 0u};
+      for (int ch = threadIdx.x; ch < nchunk; ch += 256) *(u32x4_t*)(lr + ch * 8) = z;
+    }
+    if (threadIdx.x == 0) row_loss[row] = 0.f;
+    return;
+  }
+  u32x4_t v[CE_CHUNKS];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int c = 0; c < CE_CHUNKS; ++c) {
+    const int ch = threadIdx.x + 256 * c;
+    if (ch < nchunk) {
+      v[c] = *(const u32x4_t*)(lr + ch * 8);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int col = ch * 8 + 2 * i;
+        if (col < V) mx = fmaxf(mx, bf_lo(v[c][i]));
+        if (col + 1 < V) mx = fmaxf(mx, bf_hi(v[c][i]));
+      }
+    }
+  }
+  mx = block_reduce(mx, red, true);
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < CE_CHUNKS; ++c) {
+    const int ch = threadIdx.x + 256 * c;
+    if (ch < nchunk) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int col = ch * 8 + 2 * i;
+        if (col < V) sum += __expf(bf_lo(v[c][i]) - mx);
+        if (col + 1 < V) sum += __expf(bf_hi(v[c][i]) - mx);
+      }
+    }
+  }
+  sum = block_reduce(sum, red, false);
+  const float lse = mx + __logf(sum);
+  if (threadIdx.x == 0) row_loss[row] = lse - bf2f(lr[tgt]);
+  if (!write_grad) return;
+  __syncthreads();  // lr[tgt] read above must precede the in-place overwrite
+  const float g = gscale / (float)max(1, *n_valid_dev);
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int c = 0; c < CE_CHUNKS; ++c) {
+    const int ch = threadIdx.x + 256 * c;
+    if (ch < nchunk) {
+      u32x4_t o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int col = ch * 8 + 2 * i;
+        float a = 0.f, b = 0.f;
+        if (col < V) a = (__expf(bf_lo(v[c][i]) - mx) * inv - (col == tgt ? 1.f : 0.f)) * g;
+        if (col + 1 < V) b = (__expf(bf_hi(v[c][i]) - mx) * inv - (col + 1 == tgt ? 1.f : 0.f)) * g;
+        o[i] = pack_bf2(a, b);
+      }
+      *(u32x4_t*)(lr + ch * 8) = o;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void count_valid_kernel(const int64_t* __restrict__ t, long rows, long ignore, int32_t* out) {
+  __shared__ int red[4];
+  int c = 0;
+  for (long i = threadIdx.x; i < rows; i += 256) c += (t[i] != ignore) ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = red[0] + red[1] + red[2] + red[3];
+}
+
+// deterministic single-block reduction (rows <= a few hundred thousand)
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restrict__ row_loss, long rows,
+                                                          const int32_t* __restrict__ n_valid_dev, float mul,
+                                                          float* __restrict__ loss_out, int accumulate) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (long i = threadIdx.x; i < rows; i += 256) s += (double)row_loss[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double tot = (red[0] + red[1]) + (red[2] + red[3]);
+    const float v = (float)(tot / (double)max(1, *n_valid_dev)) * mul;
+    *loss_out = accumulate ? (*loss_out + v) : v;
+  }
+}
+
+}  // namespace
+
+int launch_count_valid(const int64_t* targets, long rows, long ignore, int32_t* n_valid_dev, hipStream_t s) {
+  OASR_REQUIRE(targets && n_valid_dev && rows > 0, "count_valid: bad args");
+  hipLaunchKernelGGL(count_valid_kernel, dim3(1), dim3(256), 0, s, targets, rows, ignore, n_valid_dev);
+  OASR_LAUNCH_CHECK();
+  return OASR_OK;
+}
+
+int launch_cross_entropy(bf16_t* logits, long ld, int V, const int64_t* targets, long rows, long ignore, float gscale,
+                         const int32_t* n_valid_dev, float* row_loss, int write_grad, hipStream_t s) {
+  OASR_REQUIRE(logits && targets && n_valid_dev && row_loss, "cross_entropy: null pointer");
+  OASR_REQUIRE(ld % 8 == 0 && V <= ld && ld <= CE_CHUNKS * 256 * 8, "cross_entropy: ld=%ld V=%d unsupported", ld, V);
+  if (rows <= 0) return OASR_OK;
+  hipLaunchKernelGGL(ce_kernel, dim3((unsigned)rows), dim3(256), 0, s, logits, ld, V, targets, ignore, gscale, n_valid_dev,
+                     row_loss, write_grad);
+  OASR_LAUNCH_CHECK();
+  return OASR_OK;
+}
+
+int launch_loss_reduce(const float* row_loss, long rows, const int32_t* n_valid_dev, float mul, float* loss_out, int accumulate,
+                       hipStream_t s) {
+  OASR_REQUIRE(row_loss && n_valid_dev && loss_out, "loss_reduce: null pointer");
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, s, row_loss, rows, n_valid_dev, mul, loss_out, accumulate);
+  OASR_LAUNCH_CHECK();
+  return OASR_OK;
+}

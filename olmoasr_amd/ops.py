@@ -1,0 +1,129 @@
+"""Thin tensor-level wrappers over the unit operators of liboasr (used by the op-level parity tests and by the
+host-side mirrors).  bf16 tensors are torch.bfloat16; everything runs on the current HIP stream."""
+import ctypes as C
+
+import torch
+
+from . import _native as N
+
+BF = torch.bfloat16
+
+
+def _op(t, ld=None, rpb=0, bstride=0, lead=0, kvalid=0, trail_from=0):
+    return N.Operand(t.data_ptr(), ld if ld is not None else t.stride(0), rpb, bstride, lead, kvalid, trail_from)
+
+
+def gemm(A, B, M, N_, K, *, ta=False, tb=False, a_view=None, b_view=None, bias=None, act=0, pos=None, pos_period=0,
+         dgelu_u=None, resid=None, out=None, out_pre=None, ldc=None, out_f32=None, beta=0.0, atomic=False, split_k=1,
+         alpha=1.0):
+    """C[M,N] = epilogue(alpha * sum_k A(m,k) B(n,k)); see olmoasr_amd/csrc/kernels.h GemmArgs."""
+    g = N.GemmArgs()
+    g.A = a_view if a_view is not None else _op(A)
+    g.B = b_view if b_view is not None else _op(B)
+    g.M, g.N, g.K, g.ta, g.tb, g.alpha = M, N_, K, int(ta), int(tb), alpha
+    g.bias = bias.data_ptr() if bias is not None else None
+    g.act = act
+    g.pos = pos.data_ptr() if pos is not None else None
+    g.pos_period = pos_period
+    g.dgelu_u = dgelu_u.data_ptr() if dgelu_u is not None else None
+    g.ldu = dgelu_u.stride(0) if dgelu_u is not None else 0
+    g.resid = resid.data_ptr() if resid is not None else None
+    g.ldr = resid.stride(0) if resid is not None else 0
+    g.out = out.data_ptr() if out is not None else None
+    g.out_pre = out_pre.data_ptr() if out_pre is not None else None
+    g.ldc = ldc if ldc is not None else (out.stride(0) if out is not None else (out_pre.stride(0) if out_pre is not None else 0))
+    g.out_f32 = out_f32.data_ptr() if out_f32 is not None else None
+    g.ldc32 = out_f32.stride(0) if out_f32 is not None else 0
+    g.beta, g.atomic, g.split_k = beta, int(atomic), split_k
+    N.check(N.lib().oasr_gemm(C.byref(g), N.stream_ptr()), "oasr_gemm")
+
+
+def layernorm_fwd(x, gamma, beta):
+    rows, d = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    N.check(N.lib().oasr_layernorm_fwd(N.ptr(x), N.ptr(gamma), N.ptr(beta), N.ptr(y), N.ptr(mean), N.ptr(rstd), rows, d,
+                                       N.stream_ptr()), "layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None):
+    rows, d = x.shape
+    dx = torch.empty_like(x)
+    dg = torch.zeros(d, device=x.device, dtype=torch.float32)
+    db = torch.zeros_like(dg)
+    N.check(N.lib().oasr_layernorm_bwd(N.ptr(dy), N.ptr(x), N.ptr(gamma), N.ptr(mean), N.ptr(rstd), N.ptr(dres), N.ptr(dx),
+                                       N.ptr(dg), N.ptr(db), rows, d, N.stream_ptr()), "layernorm_bwd")
+    return dx, dg, db
+
+
+def _attn_args(q, k, v, o, lse, kv_len, causal):
+    B, Tq, H, D = q.shape
+    Tk = k.shape[1]
+    assert D == 64 and q.stride(3) == 1 and q.stride(2) == 64
+    a = N.AttnArgs()
+    a.q, a.k, a.v = q.data_ptr(), k.data_ptr(), v.data_ptr()
+    a.ldq, a.ldk, a.ldv = q.stride(1), k.stride(1), v.stride(1)
+    a.bsq, a.bsk, a.bsv = q.stride(0), k.stride(0), v.stride(0)
+    a.o, a.ldo, a.bso = o.data_ptr(), o.stride(1), o.stride(0)
+    a.lse = lse.data_ptr()
+    a.kv_len = kv_len.data_ptr() if kv_len is not None else None
+    a.B, a.H, a.Tq, a.Tk, a.causal = B, H, Tq, Tk, int(causal)
+    return a
+
+
+def attention_fwd(q, k, v, kv_len=None, causal=False):
+    """q [B,Tq,H,64], k/v [B,Tk,H,64] (any token/batch strides) -> o [B,Tq,H*64], lse [B,H,Tq]."""
+    B, Tq, H, _ = q.shape
+    o = torch.empty(B, Tq, H * 64, device=q.device, dtype=BF)
+    lse = torch.empty(B, H, Tq, device=q.device, dtype=torch.float32)
+    a = _attn_args(q, k, v, o.view(B, Tq, H, 64), lse, kv_len, causal)
+    N.check(N.lib().oasr_attention_fwd(C.byref(a), N.stream_ptr()), "attention_fwd")
+    return o, lse
+
+
+def attention_bwd(q, k, v, o, lse, d_o, kv_len=None, causal=False):
+    B, Tq, H, _ = q.shape
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    assert dq.stride() == q.stride() and dk.stride() == k.stride()
+    delta = torch.empty(B, H, Tq, device=q.device, dtype=torch.float32)
+    a = _attn_args(q, k, v, o.view(B, Tq, H, 64), lse, kv_len, causal)
+    a.d_o, a.delta = d_o.data_ptr(), delta.data_ptr()
+    a.dq, a.dk, a.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    N.check(N.lib().oasr_attention_bwd(C.byref(a), N.stream_ptr()), "attention_bwd")
+    return dq, dk, dv
+
+
+def cross_entropy_(logits, V, targets, ignore, gscale=1.0, write_grad=True):
+    """In place on bf16 logits [rows, ld]: returns (mean loss over non-ignored rows, row_loss); logits become the gradient."""
+    rows, ld = logits.shape
+    nv = torch.zeros(1, device=logits.device, dtype=torch.int32)
+    row_loss = torch.empty(rows, device=logits.device, dtype=torch.float32)
+    loss = torch.zeros(1, device=logits.device, dtype=torch.float32)
+    N.check(N.lib().oasr_cross_entropy(N.ptr(logits), logits.stride(0), V, N.ptr(targets), rows, ignore, gscale, N.ptr(nv),
+                                       N.ptr(row_loss), N.ptr(loss), int(write_grad), N.stream_ptr()), "cross_entropy")
+    return loss, row_loss
+
+
+def cast_bf16(x):
+    out = torch.empty(x.shape, device=x.device, dtype=BF)
+    N.check(N.lib().oasr_cast_f32_bf16(N.ptr(x), N.ptr(out), x.numel(), N.stream_ptr()), "cast")
+    return out
+
+
+def log_mel(pcm):
+    """pcm int16 or float32 [B, n] on the GPU -> float32 [B, 80, n // 160]."""
+    N.require_gpu(pcm, "pcm")
+    assert pcm.dim() == 2 and pcm.is_contiguous()
+    B, n = pcm.shape
+    if pcm.dtype == torch.int16:
+        dt = 1
+    elif pcm.dtype == torch.float32:
+        dt = 0
+    else:
+        raise N.NativeError(f"log_mel: unsupported dtype {pcm.dtype}")
+    mel = torch.empty(B, 80, n // 160, device=pcm.device, dtype=torch.float32)
+    ws = torch.empty(N.lib().oasr_log_mel_workspace_bytes(B), device=pcm.device, dtype=torch.uint8)
+    N.check(N.lib().oasr_log_mel(N.ptr(pcm), dt, B, n, N.ptr(mel), N.ptr(ws), N.stream_ptr()), "oasr_log_mel")
+    return mel

@@ -1,0 +1,282 @@
+"""Op-level parity of every HIP kernel against a plain fp32 PyTorch evaluation of the same op on the same
+(bf16-rounded) inputs.  Tolerances: a bf16 output carries one rounding (rel 2^-9 = 0.2 %), fp32 accumulation
+differences are far below that -> rtol 1e-2 with an absolute floor tied to the output scale."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+DEV = "cuda"
+
+
+def ops():
+    from olmoasr_amd import ops as o
+    return o
+
+
+def close(got, ref, rtol=1e-2, atol=None, name=""):
+    got, ref = got.float(), ref.float()
+    if atol is None:
+        atol = 1e-2 * float(ref.abs().mean()) + 1e-6
+    err = (got - ref).abs()
+    bad = err > atol + rtol * ref.abs()
+    assert not bool(bad.any()), f"{name}: {int(bad.sum())}/{bad.numel()} off, max abs err {float(err.max()):.4g}, ref scale {float(ref.abs().max()):.4g}"
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF).to(DEV)
+
+
+def outdir():
+    d = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.getcwd()), "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+# ------------------------------------------------------------------------------------------------------------
+def test_probe_tr16_lane_mapping():
+    """Pins the ds_read_b64_tr_b16 semantics the GEMM/attention transposed operand reads rely on: within each
+    16-lane group, lane c's j-th result is element (c & 3) of the 8 bytes fetched by lane 4j + (c >> 2)."""
+    from olmoasr_amd import _native as N
+    src = torch.arange(16 * 64, dtype=torch.float32).to(BF).to(DEV)  # value == linear index (exact in bf16 up to 256; use ids)
+    ids = torch.arange(16 * 64, dtype=torch.int16).to(DEV)
+    dst = torch.zeros(64 * 4, dtype=torch.int16, device=DEV)
+    N.check(N.lib().oasr_probe_tr16(N.ptr(ids), N.ptr(dst), N.stream_ptr()), "probe")
+    torch.cuda.synchronize()
+    got = dst.cpu().view(64, 4).numpy()
+    exp = np.zeros((64, 4), dtype=np.int16)
+    for l in range(64):
+        g, c = l >> 4, l & 15
+        for j in range(4):
+            src_lane = 4 * j + (c >> 2)
+            row = g * 4 + (src_lane >> 2)
+            col = (src_lane & 3) * 4 + (c & 3)
+            exp[l, j] = row * 64 + col
+    with open(os.path.join(outdir(), "probe_tr16.json"), "w") as f:
+        json.dump({"got": got.tolist(), "expected": exp.tolist()}, f)
+    assert (got == exp).all(), "ds_read_b64_tr_b16 lane mapping differs from the assumed one; see gpurun_out/probe_tr16.json"
+    del src
+
+
+# ------------------------------------------------------------------------------------------------------------
+def test_log_mel_matches_oracle():
+    from oracle import mel_oracle as me
+    from oracle import model_oracle as mo
+    pcm, *_ = mo.synthetic_batch([0, 1, 2])
+    ref = me.log_mel_batch(pcm.numpy())
+    got = ops().log_mel(pcm.to(DEV)).cpu().numpy()
+    assert got.shape == (3, 80, 3000)
+    err = np.abs(got - ref)
+    # fp32 DFT vs float64 oracle: the error is relative to the frame energy; bins near the -8 floor carry the most
+    assert err.max() < 2e-3, f"max err {err.max()}"
+    assert err.mean() < 2e-5, f"mean err {err.mean()}"
+    # float32 waveform input is the same thing as int16/32768
+    got_f = ops().log_mel((pcm.float() / 32768.0).to(DEV)).cpu().numpy()
+    assert np.array_equal(got_f, got)
+
+
+def test_log_mel_edge_cases():
+    from oracle import mel_oracle as me
+    z = torch.zeros(2, 480000, dtype=torch.int16)
+    got = ops().log_mel(z.to(DEV)).cpu().numpy()
+    assert np.allclose(got, -1.5)  # (log10(1e-10) + 4) / 4
+    g = torch.Generator().manual_seed(5)
+    short = (torch.randn(1, 16000, generator=g) * 0.3).clamp(-1, 1)
+    ref = me.log_mel_spectrogram(short[0].numpy())
+    got = ops().log_mel(short.to(DEV)).cpu().numpy()[0]
+    assert got.shape == ref.shape == (80, 100)
+    assert np.abs(got - ref).max() < 2e-3
+    # a pure tone: 80 dB of dynamic range between bins must survive (this is what rules out a bf16 DFT)
+    t = torch.arange(480000) / 16000.0
+    tone = (0.5 * torch.sin(2 * math.pi * 1000.0 * t))[None]
+    ref = me.log_mel_spectrogram(tone[0].numpy())
+    got = ops().log_mel(tone.to(DEV)).cpu().numpy()[0]
+    assert np.abs(got - ref).max() < 5e-2 and np.abs(got - ref).mean() < 2e-3
+
+
+# ------------------------------------------------------------------------------------------------------------
+GEMM_SHAPES = [(256, 256, 128), (384, 128, 512), (300, 136, 200), (128, 1024, 64), (1000, 384, 1536)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+def test_gemm_layouts(M, N, K, ta, tb):
+    A = rnd(K, M, seed=1) if ta else rnd(M, K, seed=1)
+    B = rnd(K, N, seed=2) if tb else rnd(N, K, seed=2)
+    out = torch.full((M, N), float("nan"), device=DEV, dtype=BF)
+    ops().gemm(A, B, M, N, K, ta=ta, tb=tb, out=out)
+    Af = A.float().t() if ta else A.float()
+    Bf = B.float().t() if tb else B.float()
+    close(out, Af @ Bf.t(), name=f"gemm {M}x{N}x{K} ta={ta} tb={tb}")
+
+
+def test_gemm_epilogues():
+    M, N, K = 300, 256, 192
+    A, B = rnd(M, K, seed=3), rnd(N, K, seed=4, scale=0.1)
+    bias = torch.randn(N, device=DEV)
+    resid = rnd(M, N, seed=5)
+    ref = A.float() @ B.float().t() + bias
+    out, pre = torch.empty(M, N, device=DEV, dtype=BF), torch.empty(M, N, device=DEV, dtype=BF)
+    ops().gemm(A, B, M, N, K, bias=bias, act=1, out=out, out_pre=pre)
+    close(pre, ref, name="pre-activation")
+    close(out, F.gelu(pre.float()), name="gelu(out_pre)")
+    ops().gemm(A, B, M, N, K, bias=bias, resid=resid, out=out)
+    close(out, ref.to(BF).float() + resid.float(), name="residual")
+    pos = torch.randn(100, N, device=DEV)
+    ops().gemm(A, B, M, N, K, bias=bias, act=1, pos=pos, pos_period=100, out=out)
+    close(out, F.gelu(ref.to(BF).float()).to(BF).float() + pos[torch.arange(M, device=DEV) % 100], name="gelu+pos")
+    u = rnd(M, N, seed=6)
+    ops().gemm(A, B, M, N, K, dgelu_u=u, out=out)
+    uf = u.float().cpu().requires_grad_(True)
+    F.gelu(uf).sum().backward()
+    close(out, (A.float() @ B.float().t()).to(BF).float() * uf.grad.to(DEV), name="dgelu")
+    c32 = torch.ones(M, N, device=DEV)
+    ops().gemm(A, B, M, N, K, out_f32=c32, beta=1.0)
+    close(c32, A.float() @ B.float().t() + 1.0, rtol=1e-4, atol=1e-3, name="f32 beta=1")
+    c32.zero_()
+    ops().gemm(A, B, M, N, K, out_f32=c32, atomic=True, split_k=3)
+    close(c32, A.float() @ B.float().t(), rtol=1e-4, atol=1e-3, name="split-k atomic")
+
+
+def test_gemm_wgrad_shape():
+    """dW[N,K] += dY[M,N]^T X[M,K] with a long ragged token dimension and split-K atomics (TN layout)."""
+    Mtok, N, K = 3000, 384, 256
+    dY, X = rnd(Mtok, N, seed=7, scale=0.05), rnd(Mtok, K, seed=8)
+    dW = torch.zeros(N, K, device=DEV)
+    ops().gemm(dY, X, N, K, Mtok, ta=True, tb=True, out_f32=dW, atomic=True, split_k=4)
+    close(dW, dY.float().t() @ X.float(), rtol=1e-3, atol=1e-2, name="wgrad")
+
+
+@pytest.mark.parametrize("which", ["conv1", "conv2"])
+def test_gemm_conv_windows(which):
+    """Conv1d(k=3,p=1[,s=2]) as a window GEMM over a time-major activation, against F.conv1d."""
+    from olmoasr_amd import _native as N_
+    o = ops()
+    B_ = 2
+    if which == "conv1":
+        ci, co, T, stride = 80, 128, 3000, 1
+    else:
+        ci, co, T, stride = 128, 128, 3000, 2
+    x = rnd(B_, T, ci, seed=9)  # time-major
+    w = (torch.randn(co, ci, 3, generator=torch.Generator().manual_seed(10)) * 0.05).to(BF)
+    ldk = 256 if which == "conv1" else 3 * ci
+    wp = torch.zeros(co, ldk, dtype=BF)
+    wp[:, :3 * ci] = w.permute(0, 2, 1).reshape(co, 3 * ci)  # k = kk*ci + c
+    wp = wp.to(DEV)
+    Tout = T // stride
+    view = N_.Operand(x.data_ptr(), ci * stride, Tout, T * ci, ci, 3 * ci, (2 * ci) if stride == 1 else 3 * ci)
+    out = torch.empty(B_ * Tout, co, device=DEV, dtype=BF)
+    o.gemm(None, wp, B_ * Tout, co, ldk, a_view=view, out=out)
+    ref = F.conv1d(x.float().permute(0, 2, 1), w.float().to(DEV), stride=stride, padding=1).permute(0, 2, 1).reshape(B_ * Tout, co)
+    close(out, ref, name=which)
+    # wgrad through the same window view: dWp[co, ldk] = dY^T . windows
+    dY = rnd(B_ * Tout, co, seed=11, scale=0.1)
+    dWp = torch.zeros(co, ldk, device=DEV)
+    o.gemm(dY, None, co, ldk, B_ * Tout, ta=True, tb=True, b_view=view, out_f32=dWp, atomic=True, split_k=2)
+    xf = x.float().permute(0, 2, 1).detach().requires_grad_(False)
+    wf = w.float().to(DEV).requires_grad_(True)
+    y = F.conv1d(xf, wf, stride=stride, padding=1)
+    y.backward(dY.float().view(B_, Tout, co).permute(0, 2, 1))
+    ref_w = wf.grad.permute(0, 2, 1).reshape(co, 3 * ci)
+    close(dWp[:, :3 * ci], ref_w, rtol=1e-3, atol=2e-2 * float(ref_w.abs().mean()) + 1e-6, name=which + " wgrad")
+
+
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,d", [(1000, 384), (37, 512), (4096, 1024), (130, 1280)])
+def test_layernorm(rows, d):
+    x = rnd(rows, d, seed=12, scale=2.0)
+    gamma = (1 + 0.1 * torch.randn(d)).to(DEV)
+    beta = (0.1 * torch.randn(d)).to(DEV)
+    y, mean, rstd = ops().layernorm_fwd(x, gamma, beta)
+    xf = x.float().detach().requires_grad_(True)
+    gf, bf_ = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = F.layer_norm(xf, (d,), gf, bf_, 1e-5)
+    close(y, ref, name="ln fwd")
+    close(mean, xf.mean(-1), rtol=1e-4, atol=1e-5, name="mean")
+    dy, dres = rnd(rows, d, seed=13), rnd(rows, d, seed=14)
+    dx, dg, db = ops().layernorm_bwd(dy, x, gamma, mean, rstd, dres)
+    ref.backward(dy.float())
+    close(dx, xf.grad.to(BF).float() + dres.float(), name="ln dx")
+    close(dg, gf.grad, rtol=2e-3, atol=2e-3 * float(gf.grad.abs().mean()) + 1e-4, name="dgamma")
+    close(db, bf_.grad, rtol=2e-3, atol=2e-3 * float(bf_.grad.abs().mean()) + 1e-4, name="dbeta")
+
+
+# ------------------------------------------------------------------------------------------------------------
+def ref_attention(q, k, v, kv_len, causal):
+    B, Tq, H, D = q.shape
+    Tk = k.shape[1]
+    qf, kf, vf = (t.float().permute(0, 2, 1, 3) for t in (q, k, v))
+    s = qf @ kf.transpose(-1, -2) / 8.0
+    mask = torch.zeros(B, 1, Tq, Tk, device=q.device, dtype=torch.bool)
+    if causal:
+        mask |= torch.ones(Tq, Tk, device=q.device, dtype=torch.bool).triu(1)
+    if kv_len is not None:
+        mask |= torch.arange(Tk, device=q.device)[None, None, None, :] >= kv_len[:, None, None, None]
+    s = s.masked_fill(mask, float("-inf"))
+    p = torch.softmax(s, -1)
+    o = (p @ vf).permute(0, 2, 1, 3).reshape(B, Tq, H * D)
+    return o, torch.logsumexp(s, -1)
+
+
+ATTN_CASES = [
+    dict(B=2, H=3, Tq=1500, Tk=1500, causal=False, kv=False),   # encoder self-attention
+    dict(B=3, H=2, Tq=448, Tk=448, causal=True, kv=True),       # decoder self-attention with key padding
+    dict(B=2, H=2, Tq=448, Tk=1500, causal=False, kv=False),    # cross-attention
+    dict(B=1, H=1, Tq=70, Tk=70, causal=True, kv=False),        # ragged small
+    dict(B=2, H=2, Tq=5, Tk=200, causal=False, kv=False),       # decode-like
+]
+
+
+@pytest.mark.parametrize("case", ATTN_CASES)
+def test_attention_fwd_bwd(case):
+    B, H, Tq, Tk = case["B"], case["H"], case["Tq"], case["Tk"]
+    d = H * 64
+    # fused-qkv style strided views, exactly as the engine lays them out
+    if Tq == Tk:
+        qkv = rnd(B, Tq, 3 * d, seed=15)
+        q, k, v = (qkv[:, :, i * d:(i + 1) * d].unflatten(2, (H, 64)) for i in range(3))
+    else:
+        qb, kvb = rnd(B, Tq, d, seed=16), rnd(B, Tk, 2 * d, seed=17)
+        q = qb.unflatten(2, (H, 64))
+        k, v = (kvb[:, :, i * d:(i + 1) * d].unflatten(2, (H, 64)) for i in range(2))
+    kv_len = None
+    if case["kv"]:
+        kv_len = torch.tensor([7, 220, 448][:B], dtype=torch.int32, device=DEV)
+    o, lse = ops().attention_fwd(q, k, v, kv_len, case["causal"])
+    qr, kr, vr = (t.detach().float().requires_grad_(True) for t in (q, k, v))
+    ro, rlse = ref_attention(qr, kr, vr, kv_len, case["causal"])
+    close(o, ro, atol=2e-3 + 1e-2 * float(ro.abs().mean()), name="attn o")
+    close(lse, rlse, rtol=1e-3, atol=2e-3, name="lse")
+    d_o = rnd(B, Tq, d, seed=18, scale=0.5)
+    dq, dk, dv = ops().attention_bwd(q, k, v, o, lse, d_o, kv_len, case["causal"])
+    ro.backward(d_o.float())
+    for nm, got, ref in (("dq", dq, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
+        close(got, ref, rtol=2e-2, atol=3e-2 * float(ref.abs().mean()) + 1e-3, name=nm)
+
+
+# ------------------------------------------------------------------------------------------------------------
+def test_cross_entropy():
+    rows, V, ld, ignore = 300, 51865, 51968, 51864
+    g = torch.Generator().manual_seed(19)
+    logits = torch.zeros(rows, ld, dtype=BF)
+    logits[:, :V] = (torch.randn(rows, V, generator=g) * 3).to(BF)
+    tgt = torch.randint(0, 50257, (rows,), generator=g)
+    tgt[::7] = ignore
+    tgt[5] = 51863
+    lf = logits[:, :V].float().to(DEV).requires_grad_(True)
+    ref = F.cross_entropy(lf, tgt.to(DEV), ignore_index=ignore)
+    (ref * 4.0).backward()
+    lg = logits.to(DEV)
+    loss, row_loss = ops().cross_entropy_(lg, V, tgt.to(DEV), ignore, gscale=4.0)
+    assert abs(float(loss) - float(ref)) < 1e-4 * abs(float(ref))
+    close(lg[:, :V], lf.grad, rtol=1e-2, atol=1e-7, name="dlogits")
+    assert float(lg[:, V:].float().abs().max()) == 0.0
+    assert float(lg[::7].float().abs().max()) == 0.0
