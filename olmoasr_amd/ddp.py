@@ -1,0 +1,99 @@
+"""Data-parallel gradient exchange over the flat gradient arena.
+
+Replaces ``DistributedDataParallel(model, device_ids=[local_rank])`` of the reference
+(scripts/training/train_timestamps.py:2330) and its reducer:
+
+  * C2  init-time parameter broadcast      -> one ``broadcast`` of the flat fp32 parameter arena
+  * C3  per-forward buffer broadcast       -> dropped: the sinusoid buffer is a pure function of the dims
+  * C4  bucketed gradient all-reduce       -> buckets are CONTIGUOUS RANGES of the flat gradient arena in the order the
+        engine finishes them (``OLMoASR.grad_segments``).  The engine records one HIP event per segment while the
+        backward is being enqueued; each bucket's all-reduce waits for its last segment's event on a side stream, so
+        RCCL traffic overlaps the remaining backward.  It fires once per accumulation window (the reference fires on
+        every micro-batch because it never uses ``no_sync``; sum-of-means == mean-of-sums up to rounding order).
+        xGMI is point-to-point (7 links/GPU), so buckets are large (default 128 MiB) to amortise RCCL launch cost and
+        let RCCL spread one collective over all links; the SUM is turned into the reference's mean by folding
+        1/world_size into the optimizer's unscale factor (no extra pass over the gradients).
+
+Works with any ``torch.distributed`` backend: "nccl" (= RCCL on ROCm) on GPUs, "gloo" on CPU for the unit tests.
+"""
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def plan_buckets(segments: Sequence[Tuple[int, int]], cap_elems: int) -> List[Tuple[int, int, int]]:
+    """Merge gradient segments (offset, numel), given in completion order, into buckets (offset, numel, last_segment)
+    of at most ``cap_elems`` elements (a single larger segment becomes its own bucket).  Only arena-contiguous
+    neighbours are merged, so every bucket is one contiguous range."""
+    buckets = []
+    cur = None
+    for i, (off, n) in enumerate(segments):
+        if n == 0:
+            continue
+        if cur is not None and cur[0] + cur[1] == off and cur[1] + n <= cap_elems:
+            cur = (cur[0], cur[1] + n, i)
+        else:
+            if cur is not None:
+                buckets.append(cur)
+            cur = (off, n, i)
+    if cur is not None:
+        buckets.append(cur)
+    return buckets
+
+
+class GradReducer:
+    def __init__(self, flat_grads: torch.Tensor, segments: Sequence[Tuple[int, int]], bucket_cap_mb: float = 128.0,
+                 group: Optional[dist.ProcessGroup] = None):
+        self.flat = flat_grads
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.segments = list(segments)
+        self.buckets = plan_buckets(self.segments, int(bucket_cap_mb * (1 << 20) // flat_grads.element_size()))
+        covered = sum(n for _, n, _ in self.buckets)
+        assert covered == flat_grads.numel(), "gradient segments must tile the arena"
+        self.cuda = flat_grads.is_cuda
+        self.comm_stream = torch.cuda.Stream(flat_grads.device) if self.cuda else None
+        self.events = [torch.cuda.Event() for _ in self.segments] if self.cuda else None
+
+    @property
+    def grad_divisor(self) -> float:
+        """Gradients hold the SUM over ranks after ``reduce``; divide by this (fold it into the unscale factor)."""
+        return float(self.world)
+
+    def segment_events(self):
+        """Pass to ``OLMoASR.loss_and_backward(segment_events=...)`` on the LAST micro-batch of a window."""
+        return self.events
+
+    def reduce(self, use_events: bool = True):
+        """All-reduce (SUM) every bucket.  With events: bucket k starts as soon as its gradients are final."""
+        if self.world == 1:
+            return
+        if not self.cuda:
+            for off, n, _ in self.buckets:
+                dist.all_reduce(self.flat[off:off + n], op=dist.ReduceOp.SUM, group=self.group)
+            return
+        main = torch.cuda.current_stream(self.flat.device)
+        if not use_events:
+            self.comm_stream.wait_stream(main)
+        with torch.cuda.stream(self.comm_stream):
+            for off, n, last in self.buckets:
+                if use_events:
+                    self.comm_stream.wait_event(self.events[last])
+                dist.all_reduce(self.flat[off:off + n], op=dist.ReduceOp.SUM, group=self.group)
+        main.wait_stream(self.comm_stream)
+
+
+def broadcast_parameters(flat_params: torch.Tensor, src: int = 0, group: Optional[dist.ProcessGroup] = None):
+    """DDP constructor's ``_sync_module_states`` (C2) on the flat arena."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(flat_params, src=src, group=group)
+
+
+def shard_indices(n_samples: int, rank: int, world: int) -> List[int]:
+    """DistributedSampler(shuffle=False, drop_last=False) partition (train_timestamps.py:633-638): pad by wrapping to
+    a multiple of world, then indices[rank::world]."""
+    idx = list(range(n_samples))
+    total = (n_samples + world - 1) // world * world
+    idx += idx[: total - n_samples]
+    return idx[rank:total:world]

@@ -1,0 +1,406 @@
+"""Host-side mirror of the reference's ``olmoasr/model.py`` for the MI355X-native path.
+
+Same class names, constructor arguments, attribute tree and state_dict keys as the reference
+(``LayerNorm`` model.py:14, ``Linear`` :42, ``Conv1d`` :104, ``sinusoids`` :199, ``MultiHeadAttention`` :233,
+``ResidualAttentionBlock`` :445, ``AudioEncoder`` :531, ``TextDecoder`` :626, ``OLMoASR`` :778), so checkpoints
+round-trip (``load_state_dict`` / ``state_dict``; DDP's ``module.`` prefix is stripped by ``load_model``).
+
+What differs is *where the numbers live and who computes*:
+  * every parameter is a view into ONE flat fp32 arena laid out in gradient-ready order (see
+    ``oasr_param_info``); ``.grad`` of every parameter is a view into a second flat arena.  That is what the
+    fused AdamW and the bucketed RCCL reduction operate on.
+  * ``OLMoASR.forward`` / ``embed_audio`` / ``logits`` call the C++ engine in ``liboasr.so`` (hand-written HIP
+    kernels).  ``OLMoASR.loss_and_backward`` is the fused training micro-step (forward + CE + backward) that
+    replaces ``logits = model(...); loss = F.cross_entropy(...); scaler.scale(loss).backward()``
+    (train_timestamps.py:1440-1454) without materialising fp32 logits or a [B,448,448] mask.
+There is no CPU fallback: constructing the model without a HIP device raises.
+"""
+import ctypes as C
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+from torch import Tensor, nn
+
+from . import _native as N
+from .config.model_dims import ModelDimensions
+
+PAD_ID = 51864
+
+
+def sinusoids(length, channels, max_timescale=10000):
+    """Returns sinusoids for positional embedding (reference model.py:199-230, same op sequence so the buffer is
+    bit-identical)."""
+    assert channels % 2 == 0
+    log_timescale_increment = np.log(max_timescale) / (channels // 2 - 1)
+    inv_timescales = torch.exp(-log_timescale_increment * torch.arange(channels // 2))
+    scaled_time = torch.arange(length)[:, np.newaxis] * inv_timescales[np.newaxis, :]
+    return torch.cat([torch.sin(scaled_time), torch.cos(scaled_time)], dim=1)
+
+
+class _ParamModule(nn.Module):
+    """Leaf holder: parameters are attached later as views of the flat arena."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise N.NativeError(f"{type(self).__name__}.forward: sub-module calls are not part of the native hot path; "
+                            "call OLMoASR.forward / embed_audio / logits / loss_and_backward")
+
+
+class LayerNorm(_ParamModule):
+    def __init__(self, n_state: int):
+        super().__init__()
+        self.normalized_shape = (n_state,)
+        self.eps = 1e-5
+
+
+class Linear(_ParamModule):
+    def __init__(self, in_features: int, out_features: int, bias: bool = True):
+        super().__init__()
+        self.in_features, self.out_features, self.has_bias = in_features, out_features, bias
+
+
+class Conv1d(_ParamModule):
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int, stride: int = 1, padding: int = 0):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = (kernel_size,), (stride,), (padding,)
+
+
+class Embedding(_ParamModule):
+    def __init__(self, num_embeddings: int, embedding_dim: int, padding_idx: int):
+        super().__init__()
+        self.num_embeddings, self.embedding_dim, self.padding_idx = num_embeddings, embedding_dim, padding_idx
+
+
+class MultiHeadAttention(_ParamModule):
+    def __init__(self, n_state: int, n_head: int):
+        super().__init__()
+        self.n_head = n_head
+        self.query = Linear(n_state, n_state)
+        self.key = Linear(n_state, n_state, bias=False)
+        self.value = Linear(n_state, n_state)
+        self.out = Linear(n_state, n_state)
+
+
+class _Sequential(nn.Module):
+    """Index-addressable container giving the reference's ``mlp.0`` / ``mlp.2`` state_dict keys."""
+
+    def __init__(self, mods: dict):
+        super().__init__()
+        for k, v in mods.items():
+            self.add_module(k, v)
+
+
+class ResidualAttentionBlock(_ParamModule):
+    def __init__(self, n_state: int, n_head: int, cross_attention: bool = False):
+        super().__init__()
+        self.attn = MultiHeadAttention(n_state, n_head)
+        self.attn_ln = LayerNorm(n_state)
+        self.cross_attn = MultiHeadAttention(n_state, n_head) if cross_attention else None
+        self.cross_attn_ln = LayerNorm(n_state) if cross_attention else None
+        self.mlp = _Sequential({"0": Linear(n_state, 4 * n_state), "2": Linear(4 * n_state, n_state)})
+        self.mlp_ln = LayerNorm(n_state)
+
+
+class AudioEncoder(_ParamModule):
+    def __init__(self, n_mels: int, n_ctx: int, n_state: int, n_head: int, n_layer: int):
+        super().__init__()
+        self.conv1 = Conv1d(n_mels, n_state, kernel_size=3, padding=1)
+        self.conv2 = Conv1d(n_state, n_state, kernel_size=3, stride=2, padding=1)
+        self.register_buffer("positional_embedding", sinusoids(n_ctx, n_state))
+        self.blocks = nn.ModuleList([ResidualAttentionBlock(n_state, n_head) for _ in range(n_layer)])
+        self.ln_post = LayerNorm(n_state)
+
+
+class TextDecoder(_ParamModule):
+    def __init__(self, n_vocab: int, n_ctx: int, n_state: int, n_head: int, n_layer: int):
+        super().__init__()
+        self.token_embedding = Embedding(n_vocab + 1, n_state, padding_idx=51864 if n_vocab == 51864 else 51865)
+        self.blocks = nn.ModuleList([ResidualAttentionBlock(n_state, n_head, cross_attention=True) for _ in range(n_layer)])
+        self.ln = LayerNorm(n_state)
+
+
+def _reference_init_(name: str, t: Tensor, gen: Optional[torch.Generator]):
+    """Init distributions of the reference: kaiming_normal_(fan_in, relu) on every Linear/Conv1d weight, the token
+    embedding (incl. the pad row) and the decoder positional embedding (model.py:81,171,258-264,665-675); biases
+    torch's default U(-1/sqrt(fan_in), 1/sqrt(fan_in)); LayerNorm ones/zeros."""
+    if "_ln" in name or ".ln." in name or name.endswith("ln.weight") or name.endswith("ln.bias") or "ln_post" in name:
+        t.fill_(1.0 if name.endswith("weight") else 0.0)
+        return
+    if name.endswith(".bias"):
+        fan_in = _FAN_IN_OF_BIAS[name]
+        bound = 1.0 / math.sqrt(fan_in)
+        t.uniform_(-bound, bound, generator=gen)
+        return
+    fan_in = 1
+    for s in t.shape[1:]:
+        fan_in *= s
+    t.normal_(0.0, math.sqrt(2.0 / fan_in), generator=gen)
+
+
+_FAN_IN_OF_BIAS = {}
+
+
+class OLMoASR(nn.Module):
+    """MI355X-native ``olmoasr.model.OLMoASR`` (reference model.py:778-968)."""
+
+    def __init__(self, dims: ModelDimensions, device=None, seed: Optional[int] = None):
+        super().__init__()
+        lib = N.lib()
+        if device is None:
+            device = "cuda"
+        device = torch.device(device)
+        if device.type != "cuda" or not torch.cuda.is_available():
+            raise N.NativeError("olmoasr_amd.model.OLMoASR needs a HIP device (MI355X); there is no CPU fallback")
+        self.dims = dims
+        self.encoder = AudioEncoder(dims.n_mels, dims.n_audio_ctx, dims.n_audio_state, dims.n_audio_head, dims.n_audio_layer)
+        self.decoder = TextDecoder(dims.n_vocab, dims.n_text_ctx, dims.n_text_state, dims.n_text_head, dims.n_text_layer)
+        cd = N.Dims(*[getattr(dims, f[0]) for f in N.Dims._fields_])
+        self._ctx = lib.oasr_create(C.byref(cd))
+        if not self._ctx:
+            raise N.NativeError("oasr_create: " + lib.oasr_last_error().decode())
+        self._numel = lib.oasr_param_numel(self._ctx)
+        self._table = []
+        for i in range(lib.oasr_param_count(self._ctx)):
+            name = C.create_string_buffer(128)
+            off, numel, ndim = C.c_int64(), C.c_int64(), C.c_int()
+            shape = (C.c_int64 * 4)()
+            N.check(lib.oasr_param_info(self._ctx, i, name, 128, C.byref(off), C.byref(numel), C.byref(ndim), shape), "param_info")
+            self._table.append((name.value.decode(), off.value, numel.value, tuple(shape[j] for j in range(ndim.value))))
+        self._segments = []
+        for i in range(lib.oasr_segment_count(self._ctx)):
+            o, m = C.c_int64(), C.c_int64()
+            N.check(lib.oasr_segment_info(self._ctx, i, C.byref(o), C.byref(m)), "segment_info")
+            self._segments.append((o.value, m.value))
+        # ---- flat arenas -----------------------------------------------------------------------------------
+        gen = torch.Generator().manual_seed(seed) if seed is not None else None
+        flat = torch.empty(self._numel, dtype=torch.float32)
+        d = dims.n_audio_state
+        for name, off, numel, shape in self._table:
+            if name.endswith(".bias"):
+                if "conv1" in name:
+                    _FAN_IN_OF_BIAS[name] = dims.n_mels * 3
+                elif "conv2" in name:
+                    _FAN_IN_OF_BIAS[name] = d * 3
+                elif "mlp.2" in name:
+                    _FAN_IN_OF_BIAS[name] = 4 * d
+                else:
+                    _FAN_IN_OF_BIAS[name] = d
+            _reference_init_(name, flat[off:off + numel].view(shape), gen)
+        self._flat = flat.to(device)
+        self._gflat = None
+        self._shadow = torch.zeros(lib.oasr_shadow_bytes(self._ctx), dtype=torch.uint8, device=device)
+        self._workspace = None
+        self._attach_views()
+        self.to(device)  # moves the sinusoid buffer; parameters are already there (see _apply)
+        self._bind()
+        self.refresh_shadow()
+
+    # ---- arena plumbing --------------------------------------------------------------------------------------
+    def _module_and_attr(self, name):
+        parts = name.split(".")
+        mod = self
+        for p in parts[:-1]:
+            mod = getattr(mod, p) if not p.isdigit() else mod[int(p)] if isinstance(mod, nn.ModuleList) else getattr(mod, p)
+        return mod, parts[-1]
+
+    def _attach_views(self):
+        for name, off, numel, shape in self._table:
+            mod, attr = self._module_and_attr(name)
+            view = self._flat[off:off + numel].view(shape)
+            if attr in mod._parameters and mod._parameters[attr] is not None:
+                mod._parameters[attr].data = view
+            else:
+                mod.register_parameter(attr, nn.Parameter(view))
+        if self._gflat is not None:
+            for name, off, numel, shape in self._table:
+                mod, attr = self._module_and_attr(name)
+                mod._parameters[attr].grad = self._gflat[off:off + numel].view(shape)
+
+    def _apply(self, fn, recurse=True):
+        """.to()/.cuda()/.float(): move the flat arenas, then re-point every parameter view (nn.Module._apply would
+        otherwise give each parameter private storage and break the arena)."""
+        new_flat = fn(self._flat)
+        if new_flat.dtype != torch.float32 or new_flat.device.type != "cuda":
+            raise N.NativeError("the native model keeps fp32 master weights on a HIP device")
+        self._flat = new_flat.contiguous()
+        if self._gflat is not None:
+            self._gflat = fn(self._gflat).contiguous()
+        self._shadow = self._shadow.to(self._flat.device)
+        self._workspace = None
+        for m in self.modules():  # buffers only
+            for k, b in m._buffers.items():
+                if b is not None:
+                    m._buffers[k] = fn(b)
+        self._attach_views()
+        if hasattr(self, "_ctx"):
+            self._bind()
+        return self
+
+    def _bind(self):
+        lib = N.lib()
+        pos = self.encoder.positional_embedding
+        if pos.dtype != torch.float32 or not pos.is_contiguous():
+            self.encoder._buffers["positional_embedding"] = pos.float().contiguous()
+            pos = self.encoder.positional_embedding
+        opt = getattr(self, "_opt_state", None)
+        N.check(lib.oasr_bind(self._ctx, N.ptr(self._flat), N.ptr(self._gflat), N.ptr(opt[0]) if opt else None,
+                              N.ptr(opt[1]) if opt else None, N.ptr(pos)), "oasr_bind")
+        N.check(lib.oasr_bind_shadow(self._ctx, N.ptr(self._shadow)), "oasr_bind_shadow")
+
+    def refresh_shadow(self):
+        """Re-derive the bf16 compute copies after the fp32 parameters changed outside ``optim_step``."""
+        with torch.cuda.device(self._flat.device):
+            N.check(N.lib().oasr_refresh_shadow(self._ctx, N.stream_ptr()), "oasr_refresh_shadow")
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+        res = super().load_state_dict(sd, strict=strict, assign=False)
+        self._bind()
+        self.refresh_shadow()
+        return res
+
+    def enable_grad_arena(self):
+        if self._gflat is None:
+            self._gflat = torch.zeros_like(self._flat)
+            self._attach_views()
+            self._bind()
+        return self._gflat
+
+    @property
+    def flat_params(self) -> Tensor:
+        return self._flat
+
+    @property
+    def flat_grads(self) -> Tensor:
+        return self.enable_grad_arena()
+
+    @property
+    def grad_segments(self):
+        """[(offset, numel)] arena ranges in the order their gradients become final during backward."""
+        return list(self._segments)
+
+    def _ws(self, B, S, mode):
+        need = N.lib().oasr_workspace_bytes(self._ctx, B, S, mode)
+        if self._workspace is None or self._workspace.numel() < need:
+            self._workspace = None
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=self._flat.device)
+        return self._workspace
+
+    # ---- reference API ---------------------------------------------------------------------------------------
+    @staticmethod
+    def _text_len_from_mask(padding_mask: Tensor) -> Tensor:
+        """The reference's padding mask is column-only (train_timestamps.py:314-315): zeros with [:, len:] = -inf.
+        Recover len[b] = number of finite columns in row 0."""
+        return torch.isfinite(padding_mask[:, 0, :]).sum(-1).to(torch.int32)
+
+    def _forward_impl(self, mel, tokens, text_len, want_logits=True, want_xa=False):
+        N.require_gpu(mel, "mel")
+        N.require_gpu(tokens, "tokens")
+        B, S = tokens.shape
+        assert mel.shape == (B, self.dims.n_mels, 2 * self.dims.n_audio_ctx), "incorrect audio shape"
+        mel = mel.float().contiguous()
+        tokens = tokens.to(torch.int64).contiguous()
+        ws = self._ws(B, S, 0)
+        logits = torch.empty(B, S, self.dims.n_vocab + 1, device=mel.device, dtype=torch.float32) if want_logits else None
+        xa = torch.empty(B, self.dims.n_audio_ctx, self.dims.n_audio_state, device=mel.device, dtype=torch.bfloat16) if want_xa else None
+        with torch.cuda.device(mel.device):
+            N.check(N.lib().oasr_forward(self._ctx, N.ptr(mel), N.ptr(tokens), N.ptr(text_len), B, S, N.ptr(logits), N.ptr(xa),
+                                         N.ptr(ws), ws.numel(), N.stream_ptr()), "oasr_forward")
+        return logits, xa
+
+    @torch.no_grad()
+    def forward(self, mel: Tensor, tokens: Tensor, padding_mask: Optional[Tensor] = None, verbose: bool = False) -> Tensor:
+        """logits fp32 [B, S, n_vocab+1] (reference model.py:856-887).  ``padding_mask`` is the reference's
+        [B,S,S] additive mask (or an int32 [B] text_len tensor)."""
+        text_len = None
+        if padding_mask is not None:
+            text_len = padding_mask.to(torch.int32) if padding_mask.dim() == 1 else self._text_len_from_mask(padding_mask)
+            text_len = text_len.to(mel.device).contiguous()
+        return self._forward_impl(mel, tokens, text_len)[0]
+
+    @torch.no_grad()
+    def embed_audio(self, mel: Tensor) -> Tensor:
+        B = mel.shape[0]
+        tok = torch.zeros(B, 1, dtype=torch.int64, device=mel.device)
+        return self._forward_impl(mel, tok, None, want_logits=False, want_xa=True)[1]
+
+    @torch.no_grad()
+    def logits(self, tokens: Tensor, audio_features: Tensor, padding_mask: Tensor = None):
+        raise N.NativeError("OLMoASR.logits(tokens, audio_features) needs the decoder-only entry point (next round); "
+                            "use forward(mel, tokens, padding_mask)")
+
+    @property
+    def device(self):
+        return self._flat.device
+
+    @property
+    def is_multilingual(self):
+        return self.dims.n_vocab >= 51865
+
+    @property
+    def num_languages(self):
+        return self.dims.n_vocab - 51765 - int(self.is_multilingual)
+
+    # ---- fused training micro-step ---------------------------------------------------------------------------
+    def zero_grad(self, set_to_none: bool = False):
+        g = self.enable_grad_arena()
+        with torch.cuda.device(g.device):
+            N.check(N.lib().oasr_zero_grad(self._ctx, N.stream_ptr()), "oasr_zero_grad")
+
+    def loss_and_backward(self, mel: Tensor, tokens: Tensor, targets: Tensor, text_len: Tensor, *, loss_scale: float = 1.0,
+                          accumulation_steps: int = 1, loss_out: Optional[Tensor] = None, accumulate_loss: bool = False,
+                          return_logits: bool = False, segment_events=None):
+        """forward + F.cross_entropy(ignore_index=51864)/accumulation_steps + backward of (loss * loss_scale)
+        (train_timestamps.py:1440-1454).  Gradients accumulate into ``flat_grads``.  Returns (loss tensor [1], logits|None)."""
+        for t, nm in ((mel, "mel"), (tokens, "tokens"), (targets, "targets"), (text_len, "text_len")):
+            N.require_gpu(t, nm)
+        self.enable_grad_arena()
+        B, S = tokens.shape
+        assert S == self.dims.n_text_ctx, "training feeds the full padded context (train_timestamps.py:318-329)"
+        mel = mel.float().contiguous()
+        tokens = tokens.to(torch.int64).contiguous()
+        targets = targets.to(torch.int64).contiguous()
+        text_len = text_len.to(torch.int32).contiguous()
+        ws = self._ws(B, S, 1)
+        if loss_out is None:
+            loss_out = torch.zeros(1, device=mel.device, dtype=torch.float32)
+        logits = torch.empty(B, S, self.dims.n_vocab + 1, device=mel.device, dtype=torch.float32) if return_logits else None
+        ev = None
+        if segment_events is not None:
+            assert len(segment_events) == len(self._segments)
+            ev = (C.c_void_p * len(segment_events))(*[e.cuda_event for e in segment_events])
+        with torch.cuda.device(mel.device):
+            N.check(N.lib().oasr_train_fwd_bwd(self._ctx, N.ptr(mel), N.ptr(tokens), N.ptr(targets), N.ptr(text_len), B,
+                                               float(loss_scale), 1.0 / accumulation_steps, N.ptr(loss_out), int(accumulate_loss),
+                                               N.ptr(logits), ev, N.ptr(ws), ws.numel(), N.stream_ptr()), "oasr_train_fwd_bwd")
+        return loss_out, logits
+
+    def init_optimizer_state(self):
+        if getattr(self, "_opt_state", None) is None:
+            self._opt_state = (torch.zeros_like(self._flat), torch.zeros_like(self._flat))
+            self._opt_stats = torch.zeros(2, device=self._flat.device, dtype=torch.float32)
+            self._opt_scratch = torch.zeros(8192, device=self._flat.device, dtype=torch.uint8)
+            self.enable_grad_arena()
+            self._bind()
+        return self._opt_state
+
+    def optim_step(self, *, step: int, lr: float, inv_loss_scale: float = 1.0, max_grad_norm: float = 1.0, betas=(0.9, 0.98),
+                   eps: float = 1e-6, weight_decay: float = 0.1):
+        """scaler.unscale_ + clip_grad_norm_ + AdamW.step (train_timestamps.py:1509-1512), fused, plus the bf16 shadow
+        refresh.  Returns the device stats tensor [sum g^2 (scaled), found_inf]."""
+        self.init_optimizer_state()
+        with torch.cuda.device(self._flat.device):
+            N.check(N.lib().oasr_optim_step(self._ctx, float(inv_loss_scale), float(max_grad_norm), float(lr), float(betas[0]),
+                                            float(betas[1]), float(eps), float(weight_decay), int(step), N.ptr(self._opt_stats),
+                                            N.ptr(self._opt_scratch), N.stream_ptr()), "oasr_optim_step")
+        return self._opt_stats
+
+    def __del__(self):
+        try:
+            if getattr(self, "_ctx", None):
+                N.lib().oasr_destroy(self._ctx)
+                self._ctx = None
+        except Exception:
+            pass

@@ -85,8 +85,8 @@ def attention_fwd(q, k, v, kv_len=None, causal=False):
 
 def attention_bwd(q, k, v, o, lse, d_o, kv_len=None, causal=False):
     B, Tq, H, _ = q.shape
-    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-    assert dq.stride() == q.stride() and dk.stride() == k.stride()
+    # gradients use the operands' own (possibly fused-qkv) strides
+    dq, dk, dv = (torch.empty_strided(t.shape, t.stride(), device=t.device, dtype=t.dtype) for t in (q, k, v))
     delta = torch.empty(B, H, Tq, device=q.device, dtype=torch.float32)
     a = _attn_args(q, k, v, o.view(B, Tq, H, 64), lse, kv_len, causal)
     a.d_o, a.delta = d_o.data_ptr(), delta.data_ptr()

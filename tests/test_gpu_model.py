@@ -1,0 +1,203 @@
+"""Model-level parity of the HIP engine against the CPU oracle (oracle/model_oracle.py, itself pinned to the
+unmodified reference by tests/test_oracle_model.py and tests/golden/ref_tiny_b2.npz).
+
+Tolerances.  BASELINE.json asks for "logits within 1e-3 bf16 tolerance".  The reference itself, evaluated under
+torch.autocast(bfloat16) on CPU, differs from its own fp32 evaluation by ~7.5e-2 abs on these inputs (recorded in
+the golden file as bf16_vs_fp32_maxabs; logit scale ~7, one bf16 ulp there is 3.1e-2).  A bf16-compute engine can
+only be held to that envelope, which is what these tests do: the native logits must be as close to the fp32
+reference as the reference's own bf16 evaluation is (factor 1.5), i.e. ~1e-2 RELATIVE to the logit scale; the 1e-3
+figure is met relative to that scale only by the fp32 accumulators (op-level tests), not end to end in bf16.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+POS = [0, 1, 2, 7, 50, 100, 219, 447]
+
+
+def _dims(mo_dims):
+    from olmoasr_amd.config.model_dims import ModelDimensions
+    return ModelDimensions(**{k: getattr(mo_dims, k) for k in ModelDimensions.__dataclass_fields__})
+
+
+@pytest.fixture(scope="module")
+def native_tiny(tiny_case):
+    from olmoasr_amd.model import OLMoASR
+    net = OLMoASR(_dims(tiny_case["dims"]), device=DEV, seed=0)
+    missing = net.load_state_dict(tiny_case["sd"], strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return net
+
+
+@pytest.fixture(scope="module")
+def oracle_tiny(tiny_case):
+    from oracle import model_oracle as mo
+    c = tiny_case
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    loss, grads, logits = mo.loss_and_grads(c["sd"], c["dims"], c["mel"], c["tokens"], c["targets"], c["text_len"])
+    return dict(loss=loss, grads=grads, logits=logits)
+
+
+def test_state_dict_roundtrip(native_tiny, tiny_case):
+    sd = native_tiny.state_dict()
+    assert set(sd.keys()) == set(tiny_case["sd"].keys())
+    for k, v in tiny_case["sd"].items():
+        assert torch.equal(sd[k].cpu(), v), k
+
+
+def test_forward_logits_vs_oracle_and_golden(native_tiny, oracle_tiny, tiny_case, golden_dir):
+    c = tiny_case
+    g = np.load(os.path.join(golden_dir, "ref_tiny_b2.npz"))
+    envelope = float(g["bf16_vs_fp32_maxabs"])  # reference-bf16 vs reference-fp32 on the same inputs
+    from oracle import model_oracle as mo
+    pm = mo.build_padding_mask(c["text_len"])
+    logits = native_tiny(c["mel"].to(DEV), c["tokens"].to(DEV), pm.to(DEV)).cpu()
+    assert logits.shape == (2, 448, 51865) and logits.dtype == torch.float32
+    ref = oracle_tiny["logits"]
+    err = (logits - ref).abs()
+    scale = float(ref.abs().max())
+    print(f"native-vs-fp32-oracle max abs {float(err.max()):.4f} mean {float(err.mean()):.5f}; envelope {envelope:.4f}; scale {scale:.2f}")
+    assert float(err.max()) <= 1.5 * envelope
+    assert float(err.mean()) <= 0.012  # bf16 output rounding alone is ~0.25 * ulp(7) = 0.008
+    # against the committed reference fixtures (fp32 reference slices)
+    s = logits[:, POS, :]
+    assert np.abs(s[..., :512].numpy() - g["fp32_head"]).max() <= 1.5 * envelope
+    # argmax agreement wherever the fp32 reference's top-2 margin clears the bf16 envelope
+    top2 = ref.topk(2, -1).values
+    safe = (top2[..., 0] - top2[..., 1]) > 2 * envelope
+    assert (logits.argmax(-1)[safe] == ref.argmax(-1)[safe]).all()
+    # text_len tensor form of the mask gives identical results
+    l2 = native_tiny(c["mel"].to(DEV), c["tokens"].to(DEV), c["text_len"].to(DEV)).cpu()
+    assert torch.equal(l2, logits)
+
+
+def test_loss_and_grads_vs_oracle(native_tiny, oracle_tiny, tiny_case):
+    c = tiny_case
+    from oracle import model_oracle as mo
+    native_tiny.zero_grad()
+    loss, logits = native_tiny.loss_and_backward(c["mel"].to(DEV), c["tokens"].to(DEV), c["targets"].to(DEV), c["text_len"].to(DEV),
+                                                 return_logits=True)
+    torch.cuda.synchronize()
+    ref_loss = float(oracle_tiny["loss"])
+    print(f"loss native {float(loss):.5f} oracle {ref_loss:.5f}")
+    assert abs(float(loss) - ref_loss) < 2e-2
+    # the bf16 mirror of the oracle gives the envelope for gradient error of a bf16 evaluation
+    _, gb, _ = mo.loss_and_grads(c["sd"], c["dims"], c["mel"], c["tokens"], c["targets"], c["text_len"], autocast_bf16=True)
+    worst = []
+    for name, p in native_tiny.named_parameters():
+        gn = p.grad.detach().cpu()
+        gr = oracle_tiny["grads"][name]
+        rel = float((gn - gr).norm() / (gr.norm() + 1e-12))
+        env = float((gb[name].float() - gr).norm() / (gr.norm() + 1e-12))
+        worst.append((rel / max(env, 1e-3), rel, env, name))
+        cos = float((gn * gr).sum() / (gn.norm() * gr.norm() + 1e-20))
+        assert cos > 0.99, f"{name}: cosine {cos:.4f} (rel {rel:.4f}, bf16-oracle envelope {env:.4f})"
+        assert rel <= max(3.0 * env, 0.05), f"{name}: rel err {rel:.4f} vs bf16-oracle envelope {env:.4f}"
+    worst.sort(reverse=True)
+    print("worst grad rel-err / envelope:", [(round(a, 2), round(b, 4), round(e, 4), n) for a, b, e, n in worst[:5]])
+    # global norm (what clip_grad_norm_ sees)
+    gnorm = float(native_tiny.flat_grads.double().norm())
+    rnorm = float(torch.sqrt(sum((g.double() ** 2).sum() for g in oracle_tiny["grads"].values())))
+    assert abs(gnorm - rnorm) / rnorm < 2e-2
+
+
+def test_loss_scale_and_accumulation_are_linear(native_tiny, tiny_case):
+    c = tiny_case
+    args = (c["mel"].to(DEV), c["tokens"].to(DEV), c["targets"].to(DEV), c["text_len"].to(DEV))
+    native_tiny.zero_grad()
+    native_tiny.loss_and_backward(*args)
+    g1 = native_tiny.flat_grads.clone()
+    native_tiny.zero_grad()
+    l2, _ = native_tiny.loss_and_backward(*args, loss_scale=65536.0, accumulation_steps=2)
+    native_tiny.loss_and_backward(*args, loss_scale=65536.0, accumulation_steps=2, loss_out=l2, accumulate_loss=True)
+    g2 = native_tiny.flat_grads.clone() / 65536.0
+    rel = float((g2 - g1).norm() / g1.norm())
+    assert rel < 2e-2, rel  # two half-weight micro-steps == one step (bf16 rounding + atomics order differ)
+    assert not torch.isnan(g2).any()
+
+
+def test_optim_step_matches_adamw(native_tiny, tiny_case):
+    """Fused unscale+clip+AdamW against the oracle's AdamW applied to the SAME (native) gradients."""
+    from oracle import model_oracle as mo
+    c = tiny_case
+    net = native_tiny
+    net.load_state_dict(c["sd"])
+    net.init_optimizer_state()
+    for t in net._opt_state:
+        t.zero_()
+    net.zero_grad()
+    scale = 1024.0
+    net.loss_and_backward(c["mel"].to(DEV), c["tokens"].to(DEV), c["targets"].to(DEV), c["text_len"].to(DEV), loss_scale=scale)
+    names = [n for n, _ in net.named_parameters()]
+    grads = {n: (p.grad.detach().cpu() / scale) for n, p in net.named_parameters()}
+    params = {n: c["sd"][n].clone() for n in names}
+    total, coef = mo.clip_coef(grads, 1.0)
+    for n in names:
+        grads[n] = grads[n] * coef
+    m = {n: torch.zeros_like(params[n]) for n in names}
+    v = {n: torch.zeros_like(params[n]) for n in names}
+    mo.adamw_step(params, grads, m, v, step=1, lr=1.5e-3)
+    stats = net.optim_step(step=1, lr=1.5e-3, inv_loss_scale=1.0 / scale)
+    torch.cuda.synchronize()
+    assert float(stats[1]) == 0.0
+    assert abs(float(stats[0].sqrt()) / scale - float(total)) / float(total) < 1e-4
+    for n, p in net.named_parameters():
+        diff = float((p.detach().cpu() - params[n]).abs().max())
+        assert diff < 2e-6, f"{n}: {diff}"
+    # a non-finite gradient skips the step (GradScaler semantics)
+    before = net.flat_params.clone()
+    net.flat_grads[12345] = float("inf")
+    stats = net.optim_step(step=2, lr=1.5e-3)
+    assert float(stats[1]) != 0.0 and torch.equal(before, net.flat_params)
+    net.load_state_dict(c["sd"])
+
+
+def test_training_memorises_and_greedy_tokens_match_oracle(tiny_case):
+    """End to end: train a 2-layer model on 4 fixed synthetic clips until it is confident, then decode greedily on
+    both sides (cache-less loop in the style of notebooks/ow_decoding.py:42-72) -- token ids must be identical."""
+    from olmoasr_amd.model import OLMoASR
+    from olmoasr_amd import ops
+    from oracle import model_oracle as mo
+    dims = mo.Dims(80, 1500, 384, 6, 2, 51864, 448, 384, 6, 2)
+    net = OLMoASR(_dims(dims), device=DEV, seed=1)
+    g = torch.Generator().manual_seed(7)
+    B, L = 4, 10
+    pcm = torch.stack([mo.synthetic_sample(100 + i)[0] for i in range(B)])
+    mel = ops.log_mel(pcm.to(DEV))
+    body = torch.randint(1000, 20000, (B, L - 3), generator=g)
+    toks = torch.cat([torch.tensor([[50257, 50362]] * B), body, torch.full((B, 1), 50256)], 1)
+    ti = torch.full((B, 448), mo.PAD_ID, dtype=torch.long)
+    ty = ti.clone()
+    ti[:, :L - 1] = toks[:, :-1]
+    ty[:, :L - 1] = toks[:, 1:]
+    tl = torch.full((B,), L - 1, dtype=torch.int32)
+    losses = []
+    steps = 150
+    for step in range(1, steps + 1):
+        net.zero_grad()
+        loss, _ = net.loss_and_backward(mel, ti.to(DEV), ty.to(DEV), tl.to(DEV), loss_scale=65536.0)
+        lr = 1e-3 * min(1.0, step / 10) * mo.lr_lambda(max(step, 1), 10 ** 9) if False else 1e-3 * min(1.0, step / 10)
+        net.optim_step(step=step, lr=lr, inv_loss_scale=1.0 / 65536.0)
+        if step % 10 == 0 or step == 1:
+            losses.append(float(loss))
+    print("loss trajectory:", [round(x, 3) for x in losses])
+    assert losses[-1] < 0.1 * losses[0] and losses[-1] < 0.5
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    ref = mo.greedy_decode(sd, dims, mel.cpu(), [50257, 50362], max_new=L)
+    # native cache-less greedy
+    out = torch.tensor([[50257, 50362]] * B, device=DEV)
+    done = torch.zeros(B, dtype=torch.bool, device=DEV)
+    for _ in range(L):
+        lg = net(mel, out)[:, -1, :dims.n_vocab]
+        nxt = lg.argmax(-1)
+        nxt = torch.where(done, torch.full_like(nxt, 50256), nxt)
+        out = torch.cat([out, nxt[:, None]], 1)
+        done |= nxt == 50256
+        if bool(done.all()):
+            break
+    assert torch.equal(out.cpu(), ref), f"native {out.cpu().tolist()} vs oracle {ref.tolist()}"
+    assert torch.equal(out.cpu()[:, :L], toks[:, :L])  # and both reproduce the memorised transcripts
