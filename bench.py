@@ -1,0 +1,235 @@
+#!/usr/bin/env python
+"""bench.py -- OLMoASR DDP training step on MI355X (BASELINE.json metric: audio-seconds/sec/node, train step).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one optimizer step of the reference's train() loop (scripts/training/train_timestamps.py:1405-1549) on a
+per-GPU batch of 256 synthetic 30 s clips (BASELINE.json configs[2]: medium, global 2048 on 8 GPUs = 256/GPU; weak
+scaling), executed as micro-batches with gradient accumulation exactly like `accumulation_steps` there:
+  int16 PCM (resident in HBM) -> log-mel (HIP) -> encoder/decoder forward -> CE(ignore pad)/accum -> backward
+  (-> bucketed RCCL all-reduce of the flat fp32 gradient arena, overlapped with the backward of the last micro-batch)
+  -> fused unscale + clip_grad_norm_(1.0) + AdamW.
+Prints ONE JSON line on rank 0 (driver contract) with `roofline` (dominant kernel = the bf16 MFMA GEMM, measured with
+HIP events on its own stream in one extra, identical step) and `cpu_baseline` (the CPU oracle on the host cores,
+bounded sample, N=1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16, MI355X_MICROARCH.md "Chip-level parameters"
+PAD_ID = 51864
+
+
+def train_flops_per_sample(d, L, T=1500, S=448, V=51865, F=3000, n_mels=80):
+    """Algorithmic dense FLOPs of one training sample = 3 x forward (SURVEY.md section 2.2 / BASELINE.md section 2)."""
+    conv = 2 * F * n_mels * 3 * d + 2 * T * d * 3 * d
+    enc_layer = 24 * T * d * d + 4 * T * T * d
+    dec_layer = (8 * S * d * d + 4 * S * S * d) + (4 * S * d * d + 4 * T * d * d + 4 * S * T * d) + 16 * S * d * d
+    logits = 2 * S * d * V
+    return 3 * (conv + L * enc_layer + L * dec_layer + logits)
+
+
+def synth_batch(n, device, seed):
+    """Synthetic clips in the layout of SURVEY.md section 8(d), generated on the device: int16 PCM ~ N(0, 0.1) with a silent
+    tail, tokens [sot, notimestamps, body..., eot] padded with 51864 to 448."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    pcm = (torch.randn(n, 480000, generator=g, device=device) * 0.1).clamp_(-1, 1).mul_(32767).round_().to(torch.int16)
+    sil = torch.randint(0, 240001, (n,), generator=g, device=device)
+    idx = torch.arange(480000, device=device)[None, :]
+    pcm.masked_fill_(idx >= (480000 - sil)[:, None], 0)
+    L = torch.randint(8, 221, (n,), generator=g, device=device)
+    body = torch.randint(0, 50256, (n, 449), generator=g, device=device)
+    pos = torch.arange(449, device=device)[None, :]
+    toks = torch.where(pos == 0, torch.full_like(body, 50257), body)
+    toks = torch.where(pos == 1, torch.full_like(body, 50362), toks)
+    toks = torch.where(pos == (L - 1)[:, None], torch.full_like(body, 50256), toks)
+    toks = torch.where(pos >= L[:, None], torch.full_like(body, PAD_ID), toks)
+    text_input = toks[:, :448].clone()
+    text_input = torch.where(pos[:, :448] >= (L - 1)[:, None], torch.full_like(text_input, PAD_ID), text_input)
+    text_y = toks[:, 1:449].contiguous()
+    return pcm, text_input.contiguous(), text_y, (L - 1).to(torch.int32)
+
+
+def host_cores():
+    """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(p))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(variant, seconds_budget=30.0):
+    """The CPU oracle (oracle/model_oracle.py == the reference's algorithm, pinned by tests/golden) timed on this host:
+    ONE clip through the full step (forward + CE + backward + clip + AdamW), fp32, all host cores."""
+    import numpy as np
+    from oracle import mel_oracle as me
+    from oracle import model_oracle as mo
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    dims = mo.VARIANTS[variant]
+    sd = mo.init_state_dict(dims, seed=0)
+    pcm, ti, ty, tl = mo.synthetic_batch([0])
+    t0 = time.time()
+    mel = torch.from_numpy(me.log_mel_batch(pcm.numpy(), dtype=np.float32))
+    loss, grads, _ = mo.loss_and_grads(sd, dims, mel, ti, ty, tl)
+    _, coef = mo.clip_coef(grads, 1.0)
+    names = list(grads)
+    for n in names:
+        grads[n].mul_(coef)
+    m = {n: torch.zeros_like(sd[n]) for n in names}
+    v = {n: torch.zeros_like(sd[n]) for n in names}
+    mo.adamw_step(sd, grads, m, v, step=1, lr=1.5e-3)
+    dt = time.time() - t0
+    return {"value": round(30.0 / dt, 3), "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
+            "sample": f"1 clip x 30 s, OLMoASR-{variant} fp32 full step (log-mel + fwd + CE + bwd + clip + AdamW) in {dt:.1f} s, "
+                      f"torch {torch.get_num_threads()} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--variant", default="medium")
+    ap.add_argument("--per-gpu-batch", type=int, default=256)
+    ap.add_argument("--micro-batch", type=int, default=32)
+    ap.add_argument("--bucket-mb", type=float, default=128.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    from olmoasr_amd import _native as N
+    from olmoasr_amd import ddp, ops
+    from olmoasr_amd.config.model_dims import VARIANT_TO_DIMS
+    from olmoasr_amd.model import OLMoASR
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+
+    dims = VARIANT_TO_DIMS[args.variant]
+    net = OLMoASR(dims, device=dev, seed=0)
+    ddp.broadcast_parameters(net.flat_params)
+    net.refresh_shadow()
+    net.init_optimizer_state()
+    reducer = ddp.GradReducer(net.flat_grads, net.grad_segments, bucket_cap_mb=args.bucket_mb) if world > 1 else None
+
+    B, mb = args.per_gpu_batch, min(args.micro_batch, args.per_gpu_batch)
+    assert B % mb == 0
+    accum = B // mb
+    # sample i of the global batch goes to rank i % world (DistributedSampler rule): seed per rank
+    pcm, ti, ty, tl = synth_batch(B, dev, seed=1234 + rank)
+    loss_buf = torch.zeros(1, device=dev)
+    loss_scale = 65536.0  # GradScaler() initial scale; the reference keeps it enabled for bf16 (train_timestamps.py:2349)
+    state = {"step": 0}
+
+    def one_step():
+        state["step"] += 1
+        net.zero_grad()
+        for i in range(accum):
+            sl = slice(i * mb, (i + 1) * mb)
+            mel = ops.log_mel(pcm[sl])
+            last = i == accum - 1
+            net.loss_and_backward(mel, ti[sl], ty[sl], tl[sl], loss_scale=loss_scale, accumulation_steps=accum, loss_out=loss_buf,
+                                  accumulate_loss=i > 0, segment_events=reducer.segment_events() if (reducer and last) else None)
+        div = 1.0
+        if reducer:
+            reducer.reduce()
+            div = reducer.grad_divisor
+        net.optim_step(step=state["step"], lr=1.5e-4, inv_loss_scale=1.0 / (loss_scale * div), max_grad_norm=1.0)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    final_loss = float(loss_buf)
+    found_inf = float(net._opt_stats[1])
+
+    # ---- live roofline of the dominant kernel: one more identical step with every GEMM launch bracketed by HIP events
+    roof = None
+    if not args.no_profile:
+        lib = N.lib()
+        lib.oasr_profile_gemm(1)
+        one_step()
+        ms = (ctypes.c_double * 4)()
+        fl = (ctypes.c_double * 4)()
+        cnt = (ctypes.c_int64 * 4)()
+        N.check(lib.oasr_profile_gemm_collect(ms, fl, cnt), "profile_collect")
+        lib.oasr_profile_gemm(0)
+        names = {0: "gemm_kernel<false,false> (NT: forward)", 1: "gemm_kernel<false,true> (NN: dgrad)",
+                 2: "gemm_kernel<true,false>", 3: "gemm_kernel<true,true> (TN: wgrad)"}
+        per = {names[k]: {"launches": int(cnt[k]), "ms": round(ms[k], 3), "tflops": round(fl[k] / ms[k] / 1e9, 1) if ms[k] > 0 else 0.0}
+               for k in range(4) if cnt[k]}
+        dom = max(range(4), key=lambda k: ms[k])
+        achieved = fl[dom] / ms[dom] / 1e9 if ms[dom] > 0 else 0.0
+        roof = {"bound": "mfma", "kernel": names[dom], "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "avg_launch_us": round(1000.0 * ms[dom] / max(1, cnt[dom]), 2), "launches_per_step": int(cnt[dom]),
+                "all_gemm_variants": per,
+                "gemm_ms_per_step": round(sum(ms), 2)}
+
+    if rank == 0:
+        ms_per_step = 1000.0 * elapsed / args.steps
+        value = world * B * 30.0 * args.steps / elapsed
+        fl_sample = train_flops_per_sample(dims.n_audio_state, dims.n_audio_layer)
+        step_tflops = B * fl_sample / (elapsed / args.steps) / 1e12
+        out = {
+            "metric": "audio-seconds/sec/node (train step)", "value": round(value, 1), "unit": "audio-seconds/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"OLMoASR-{args.variant} bf16 train step, {B} x 30 s synthetic clips per GPU "
+                                   f"({accum} micro-batches of {mb}, grad accumulation), global batch {world * B}",
+                       "global_batch": world * B, "micro_batch": mb, "parallelism": f"dp{world}",
+                       "optimizer": "AdamW fused (unscale+clip+step), loss scale 65536"},
+            "step_model_tflops_per_gpu": round(step_tflops, 1),
+            "step_frac_of_mfma_peak": round(step_tflops / PEAK_BF16_TFLOPS, 4),
+            "final_loss": round(final_loss, 4), "found_inf": found_inf,
+        }
+        if roof:
+            out["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.variant)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -114,6 +114,11 @@ int oasr_attention_bwd(const oasr_attn_args*, void* stream);
 int oasr_cross_entropy(void* logits_bf16, int64_t ld, int V, const int64_t* targets, int64_t rows, int64_t ignore, float gscale,
                        int32_t* n_valid_dev, float* row_loss, float* loss_out, int write_grad, void* stream);
 int oasr_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* bench.py's live roofline measurement: when enabled every GEMM launch is bracketed by HIP events on ITS stream;
+ * collect() synchronises and returns, per kernel variant (index 2*ta+tb: 0 = NT forward, 1 = NN dgrad, 3 = TN wgrad),
+ * summed milliseconds, summed algorithmic flops (2*M*N*K, conv windows at their real width) and launch count. */
+int oasr_profile_gemm(int enable);
+int oasr_profile_gemm_collect(double* ms4, double* flops4, int64_t* count4);
 int oasr_probe_tr16(const void* src_bf16 /*[16][64]*/, void* dst_bf16 /*[64 lanes][4]*/, void* stream);
 
 #ifdef __cplusplus

@@ -52,6 +52,18 @@ extern "C" int oasr_gemm(const oasr_gemm_args* a, void* stream) {
   return launch_gemm(g, (hipStream_t)stream);
 }
 
+extern "C" int oasr_profile_gemm(int enable) {
+  gemm_profile_enable(enable);
+  return OASR_OK;
+}
+extern "C" int oasr_profile_gemm_collect(double* ms4, double* flops4, int64_t* count4) {
+  OASR_REQUIRE(ms4 && flops4 && count4, "profile_collect: null");
+  long c[4];
+  int rc = gemm_profile_collect(ms4, flops4, c);
+  for (int i = 0; i < 4; ++i) count4[i] = c[i];
+  return rc;
+}
+
 extern "C" int oasr_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int64_t rows,
                                   int d, void* stream) {
   return launch_layernorm_fwd((const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, d, (hipStream_t)stream);

@@ -13,9 +13,23 @@
 // LDS images are XOR-swizzled so both ds_read_b128 (k-contiguous tiles) and the transpose reads are
 // bank-conflict free.  The MFMA is issued with swapped operands (D'[n][m]) so each lane ends up holding 4
 // consecutive columns of one output row -> 8-byte bf16 / 16-byte fp32 row-contiguous stores.
+#include <vector>
+
 #include "kernels.h"
 
 namespace {
+
+// ---- optional per-launch timing (bench.py's live roofline measurement): HIP events on the launch stream --------
+struct GemmProfile {
+  bool on = false;
+  std::vector<hipEvent_t> events;  // pairs (start, stop)
+  struct Rec {
+    int kind;
+    double flops;
+  };
+  std::vector<Rec> recs;
+};
+GemmProfile g_prof;
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = 128 * 64 * 2;
@@ -281,8 +295,25 @@ int launch_t(const GemmArgs& a, hipStream_t stream) {
   }
   const int tiles = cdiv(a.M, BM) * cdiv(a.N, BN);
   dim3 grid(tiles, a.split_k);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (g_prof.on) {
+    const size_t idx = g_prof.recs.size();
+    while (g_prof.events.size() < 2 * (idx + 1)) {
+      hipEvent_t e;
+      OASR_CHECK_HIP(hipEventCreate(&e));
+      g_prof.events.push_back(e);
+    }
+    e0 = g_prof.events[2 * idx];
+    e1 = g_prof.events[2 * idx + 1];
+    // algorithmic flops: conv windows count their real kernel width, not the zero padding
+    const double kk = a.A.rpb ? (double)(a.ta ? a.K : a.A.kvalid) : (double)a.K;
+    const double nn = (a.B.rpb && a.tb) ? (double)a.B.kvalid : (double)a.N;
+    g_prof.recs.push_back({(TA ? 2 : 0) + (TB ? 1 : 0), 2.0 * (double)a.M * nn * kk});
+    OASR_CHECK_HIP(hipEventRecord(e0, stream));
+  }
   hipLaunchKernelGGL((gemm_kernel<TA, TB>), grid, dim3(256), lds, stream, a);
   OASR_LAUNCH_CHECK();
+  if (e1) OASR_CHECK_HIP(hipEventRecord(e1, stream));
   return OASR_OK;
 }
 
@@ -302,4 +333,29 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   if (!a.ta && a.tb) return launch_t<false, true>(a, stream);
   if (a.ta && !a.tb) return launch_t<true, false>(a, stream);
   return launch_t<true, true>(a, stream);
+}
+
+void gemm_profile_enable(int on) {
+  g_prof.on = on != 0;
+  if (on) g_prof.recs.clear();
+}
+
+// Sums elapsed ms / algorithmic flops / launch count per kernel variant (index = 2*ta + tb).  Synchronises.
+int gemm_profile_collect(double ms[4], double flops[4], long count[4]) {
+  for (int i = 0; i < 4; ++i) {
+    ms[i] = 0;
+    flops[i] = 0;
+    count[i] = 0;
+  }
+  for (size_t i = 0; i < g_prof.recs.size(); ++i) {
+    OASR_CHECK_HIP(hipEventSynchronize(g_prof.events[2 * i + 1]));
+    float t = 0.f;
+    OASR_CHECK_HIP(hipEventElapsedTime(&t, g_prof.events[2 * i], g_prof.events[2 * i + 1]));
+    const int k = g_prof.recs[i].kind;
+    ms[k] += t;
+    flops[k] += g_prof.recs[i].flops;
+    count[k] += 1;
+  }
+  g_prof.recs.clear();
+  return OASR_OK;
 }

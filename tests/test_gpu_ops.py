@@ -259,7 +259,8 @@ def test_attention_fwd_bwd(case):
     dq, dk, dv = ops().attention_bwd(q, k, v, o, lse, d_o, kv_len, case["causal"])
     ro.backward(d_o.float())
     for nm, got, ref in (("dq", dq, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
-        close(got, ref, rtol=2e-2, atol=3e-2 * float(ref.abs().mean()) + 1e-3, name=nm)
+        # dS/P are rounded to bf16 before the second MFMA: error is relative to the largest entries of a row
+        close(got, ref, rtol=2e-2, atol=5e-3 * float(ref.abs().max()) + 1e-3, name=nm)
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -75,3 +75,48 @@ def test_null_context_is_rejected_loudly(native):
     assert b"null dims" in lib.oasr_last_error()
     with pytest.raises(native.NativeError):
         native.require_gpu(__import__("torch").zeros(1), "x")
+
+
+def test_host_side_audio_mirror(native):
+    """Host logic of the whisper.audio mirror (no GPU): constants, pad_or_trim on arrays/tensors, and the library's
+    slaney filterbank against the oracle's (and thereby against transformers' WhisperFeatureExtractor)."""
+    import numpy as np
+    import torch
+    import olmoasr_amd
+    from olmoasr_amd import audio
+    from oracle import mel_oracle as me
+    assert (audio.SAMPLE_RATE, audio.N_FFT, audio.HOP_LENGTH, audio.N_SAMPLES, audio.N_FRAMES, audio.FRAMES_PER_SECOND) == \
+        (16000, 400, 160, 480000, 3000, 100)
+    x = np.arange(10, dtype=np.float32)
+    for L in (4, 10, 16):
+        assert np.array_equal(audio.pad_or_trim(x, L), me.pad_or_trim(x, L))
+        assert torch.equal(audio.pad_or_trim(torch.from_numpy(x), L), torch.from_numpy(me.pad_or_trim(x, L)))
+    y = np.ones((3, 5), np.float32)
+    assert audio.pad_or_trim(y, 7, axis=0).shape == (7, 5)
+    assert np.array_equal(audio.mel_filters().numpy(), me.mel_filters())
+    assert olmoasr_amd.N_FRAMES == 3000 and olmoasr_amd.ModelDimensions is not None
+    with pytest.raises(native.NativeError):
+        audio.log_mel_spectrogram("clip.wav")
+
+
+def test_train_script_host_logic():
+    """Accumulation rule, LR schedule and GradScaler bookkeeping of the torchrun entry vs the oracle's restatement of
+    train_timestamps.py:764-781 and torch's GradScaler defaults."""
+    import importlib.util
+    from oracle import model_oracle as mo
+    spec = importlib.util.spec_from_file_location("tt", os.path.join(ROOT, "scripts", "training", "train_timestamps.py"))
+    tt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tt)
+    for eff, w, b in ((512, 8, 64), (2048, 8, 32), (4096, 8, 64), (8, 1, 8), (7, 2, 8)):
+        assert tt.accumulation_steps(eff, w, b) == mo.accumulation_steps(eff, w, b)
+    for n in (10, 1000, 524288):
+        for s in (0, 1, 2, 5, n // 2, n - 1, n):
+            assert tt.lr_lambda(s, n) == mo.lr_lambda(s, n)
+    sc = tt.GradScalerState()
+    sc.update(True)
+    assert sc.scale == 32768.0
+    for _ in range(2000):
+        sc.update(False)
+    assert sc.scale == 65536.0 and sc.growth_tracker == 0
+    a = tt.parse_args(["--model_variant", "medium", "--betas", "(0.9, 0.98)", "--eff_batch_size", "2048"])
+    assert a.model_variant == "medium" and a.eff_batch_size == 2048

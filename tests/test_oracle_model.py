@@ -16,7 +16,7 @@ POS = [0, 1, 2, 7, 50, 100, 219, 447]
 @pytest.fixture(scope="module")
 def ora(tiny_case):
     c = tiny_case
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    torch.set_num_threads(min(32, len(os.sched_getaffinity(0))))
     loss, grads, logits = mo.loss_and_grads(c["sd"], c["dims"], c["mel"], c["tokens"], c["targets"], c["text_len"])
     return dict(loss=loss, grads=grads, logits=logits)
 
