@@ -118,7 +118,9 @@ int oasr_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
  * collect() synchronises and returns, per kernel variant (index 2*ta+tb: 0 = NT forward, 1 = NN dgrad, 3 = TN wgrad),
  * summed milliseconds, summed algorithmic flops (2*M*N*K, conv windows at their real width) and launch count. */
 int oasr_profile_gemm(int enable);
+int oasr_gemm_force_general(int on); /* tests: route every GEMM through the register-staged general kernel */
 int oasr_profile_gemm_collect(double* ms4, double* flops4, int64_t* count4);
+int oasr_probe_lds_oob(const void* src_u16 /*[512]*/, void* dst_u16 /*[512]*/, void* stream);
 int oasr_probe_tr16(const void* src_bf16 /*[16][64]*/, void* dst_bf16 /*[64 lanes][4]*/, void* stream);
 
 #ifdef __cplusplus

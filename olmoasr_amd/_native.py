@@ -73,7 +73,9 @@ def _declare(lib):
         "oasr_cross_entropy": (i32, [vp, i64, i32, vp, i64, i64, f32, vp, vp, vp, i32, vp]),
         "oasr_cast_f32_bf16": (i32, [vp, vp, i64, vp]),
         "oasr_probe_tr16": (i32, [vp, vp, vp]),
+        "oasr_probe_lds_oob": (i32, [vp, vp, vp]),
         "oasr_profile_gemm": (i32, [i32]),
+        "oasr_gemm_force_general": (i32, [i32]),
         "oasr_profile_gemm_collect": (i32, [vp, vp, vp]),
     }
     for name, (res, args) in sig.items():

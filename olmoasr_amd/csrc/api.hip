@@ -56,6 +56,10 @@ extern "C" int oasr_profile_gemm(int enable) {
   gemm_profile_enable(enable);
   return OASR_OK;
 }
+extern "C" int oasr_gemm_force_general(int on) {
+  gemm_force_general(on);
+  return OASR_OK;
+}
 extern "C" int oasr_profile_gemm_collect(double* ms4, double* flops4, int64_t* count4) {
   OASR_REQUIRE(ms4 && flops4 && count4, "profile_collect: null");
   long c[4];
@@ -138,6 +142,25 @@ __global__ void probe_tr16_kernel(const bf16_t* __restrict__ src, bf16_t* __rest
   const int row = (l >> 4) * 4 + ((l & 15) >> 2), col = ((l & 15) & 3) * 4;
   const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(tile + row * 64 + col));
   for (int j = 0; j < 4; ++j) dst[l * 4 + j] = (bf16_t)v[j];
+}
+// One wave: LDS pre-filled with 0xAAAA; lanes < 32 issue an in-range 16-byte buffer_load..lds, lanes >= 32 an
+// out-of-range one (offset beyond num_records).  dst[64*8] u16 shows what the hardware writes for OOB lanes.
+typedef __attribute__((address_space(3))) void* lds_void_ptr_t;
+__global__ void probe_lds_oob_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst) {
+  __shared__ __attribute__((aligned(16))) bf16_t tile[64 * 8];
+  const int l = threadIdx.x;
+  for (int i = l; i < 64 * 8; i += 64) tile[i] = 0xAAAA;
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(src), 0, 64 * 16, 0x00020000);
+  const unsigned off = l < 32 ? l * 16 : 0x80000000u;
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_ptr_t)tile, 16, off, 0, 0, 0);
+  __syncthreads();
+  for (int i = l; i < 64 * 8; i += 64) dst[i] = tile[i];
+}
+extern "C" int oasr_probe_lds_oob(const void* src, void* dst, void* stream) {
+  hipLaunchKernelGGL(probe_lds_oob_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst);
+  OASR_LAUNCH_CHECK();
+  return OASR_OK;
 }
 extern "C" int oasr_probe_tr16(const void* src, void* dst, void* stream) {
   hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst);

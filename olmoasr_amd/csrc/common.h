@@ -55,19 +55,46 @@ __host__ __device__ __forceinline__ bf16_t f2bf(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return (bf16_t)(u >> 16);
 }
-__device__ __forceinline__ float bf_round(float f) { return bf2f(f2bf(f)); }
+typedef __attribute__((ext_vector_type(2))) float oasr_f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 oasr_bf16x2_t;
+#if defined(__HIP_DEVICE_COMPILE__)
+// gfx950 has a hardware RNE converter (v_cvt_pk_bf16_f32, 2 values per instruction); the bit-twiddling f2bf above is
+// the host-side / reference definition and costs ~6 VALU per value on the device.
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  const oasr_f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, oasr_bf16x2_t));
 }
+__device__ __forceinline__ float bf_round(float f) { return (float)(__bf16)f; }
+__device__ __forceinline__ bf16_t f2bf_dev(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+#else
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+__device__ __forceinline__ float bf_round(float f) { return bf2f(f2bf(f)); }
+__device__ __forceinline__ bf16_t f2bf_dev(float f) { return f2bf(f); }
+#endif
 __device__ __forceinline__ float bf_lo(uint32_t p) { return __uint_as_float(p << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }
 
-// exact (erf) GELU and its derivative, fp32
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// exact-erf GELU (nn.GELU() default) and its derivative.  erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below
+// the bf16 rounding every consumer applies) on v_rcp_f32 / v_exp_f32: ~15 VALU per value instead of libm erff's 34,
+// and GELU' reuses the same exponential (pdf = exp(-x^2/2)/sqrt(2 pi)).
+struct GeluParts {
+  float cdf, e;  // Phi(x), exp(-x^2/2)
+};
+__device__ __forceinline__ GeluParts gelu_parts(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f);
+  const float half_erfc = 0.5f * poly * e;  // 0.5 * erfc(|x|/sqrt2)
+  GeluParts g;
+  g.cdf = x >= 0.f ? 1.0f - half_erfc : half_erfc;
+  g.e = e;
+  return g;
+}
+__device__ __forceinline__ float gelu_f(float x) { return x * gelu_parts(x).cdf; }
 __device__ __forceinline__ float dgelu_f(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  const GeluParts g = gelu_parts(x);
+  return g.cdf + x * g.e * 0.3989422804014327f;
 }
 
 // ---- wave64 reductions ---------------------------------------------------------------------------

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src
     ((u32x4_t*)dst)[i] = o;
   }
   if (blockIdx.x == 0)
-    for (long i = (n8 << 3) + threadIdx.x; i < n; i += 256) dst[i] = f2bf(src[i]);
+    for (long i = (n8 << 3) + threadIdx.x; i < n; i += 256) dst[i] = f2bf_dev(src[i]);
 }
 
 // w [co][ci][3] -> dst [co][ldk], k = kk*ci_n + ci
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict_
       const int kk = k / ci, c = k - kk * ci;
       v = w[((long)o * ci + c) * 3 + kk];
     }
-    dst[i] = f2bf(v);
+    dst[i] = f2bf_dev(v);
   }
 }
 
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void mel_tm_kernel(const float* __restrict__ m
   bf16_t* dst = out + ((long)b * T + t0) * C;
   for (int i = threadIdx.x; i < C * 32; i += 256) {
     const int tt = i / C, c = i - tt * C;
-    if (t0 + tt < T) dst[(long)tt * C + c] = f2bf(tile[c][tt]);
+    if (t0 + tt < T) dst[(long)tt * C + c] = f2bf_dev(tile[c][tt]);
   }
 }
 

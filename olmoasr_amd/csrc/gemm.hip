@@ -13,6 +13,8 @@
 // LDS images are XOR-swizzled so both ds_read_b128 (k-contiguous tiles) and the transpose reads are
 // bank-conflict free.  The MFMA is issued with swapped operands (D'[n][m]) so each lane ends up holding 4
 // consecutive columns of one output row -> 8-byte bf16 / 16-byte fp32 row-contiguous stores.
+#include <stdlib.h>
+
 #include <vector>
 
 #include "kernels.h"
@@ -30,6 +32,8 @@ struct GemmProfile {
   std::vector<Rec> recs;
 };
 GemmProfile g_prof;
+bool g_force_general = false;
+int g_fast_geometry = 0;  // 0 = heuristic, 1 = force 256x128 (4 waves), 2 = force 256x256 (8 waves, 2 stages)  // tests: run the register-staged general kernel even where the fast path applies
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = 128 * 64 * 2;
@@ -141,6 +145,70 @@ __device__ __forceinline__ bf16x8_t read_frag(const char* lds, int sub, int ks, 
   }
 }
 
+// Fused epilogue for 4 consecutive columns n..n+3 of output row m (see GemmArgs in kernels.h for the order of ops).
+__device__ __forceinline__ void epilogue_store(const GemmArgs& p, int m, int n, int pos_row, float (&v)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] *= p.alpha;
+        if (p.bias) {
+          const f32x4_t b4 = *(const f32x4_t*)(p.bias + n);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] += b4[i];
+        }
+        if (p.out_pre) {
+          u32x2_t o;
+          o[0] = pack_bf2(v[0], v[1]);
+          o[1] = pack_bf2(v[2], v[3]);
+          *(u32x2_t*)(p.out_pre + (long)m * p.ldc + n) = o;
+        }
+        if (p.act == 1) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = gelu_f(bf_round(v[i]));
+        }
+        if (p.pos) {
+          const f32x4_t p4 = *(const f32x4_t*)(p.pos + (long)pos_row * p.N + n);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = bf_round(v[i]) + p4[i];
+        }
+        if (p.dgelu_u) {
+          const u32x2_t u = *(const u32x2_t*)(p.dgelu_u + (long)m * p.ldu + n);
+          v[0] = bf_round(v[0]) * dgelu_f(bf_lo(u[0]));
+          v[1] = bf_round(v[1]) * dgelu_f(bf_hi(u[0]));
+          v[2] = bf_round(v[2]) * dgelu_f(bf_lo(u[1]));
+          v[3] = bf_round(v[3]) * dgelu_f(bf_hi(u[1]));
+        }
+        if (p.resid) {
+          const u32x2_t r = *(const u32x2_t*)(p.resid + (long)m * p.ldr + n);
+          v[0] = bf_round(v[0]) + bf_lo(r[0]);
+          v[1] = bf_round(v[1]) + bf_hi(r[0]);
+          v[2] = bf_round(v[2]) + bf_lo(r[1]);
+          v[3] = bf_round(v[3]) + bf_hi(r[1]);
+        }
+        if (p.out) {
+          u32x2_t o;
+          o[0] = pack_bf2(v[0], v[1]);
+          o[1] = pack_bf2(v[2], v[3]);
+          *(u32x2_t*)(p.out + (long)m * p.ldc + n) = o;
+        }
+        if (p.out_f32) {
+          float* dst = p.out_f32 + (long)m * p.ldc32 + n;
+          if (p.atomic) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) unsafeAtomicAdd(dst + i, v[i]);
+          } else {
+            f32x4_t c4;
+            if (p.beta != 0.f) {
+              c4 = *(const f32x4_t*)dst;
+#pragma unroll
+              for (int i = 0; i < 4; ++i) c4[i] = p.beta * c4[i] + v[i];
+            } else {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) c4[i] = v[i];
+            }
+            *(f32x4_t*)dst = c4;
+          }
+        }
+}
+
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -221,68 +289,259 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         if (n >= p.N) continue;
         float v[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = p.alpha * acc[mt][nt][q * 4 + i];
-        if (p.bias) {
-          const f32x4_t b4 = *(const f32x4_t*)(p.bias + n);
+        for (int i = 0; i < 4; ++i) v[i] = acc[mt][nt][q * 4 + i];
+        epilogue_store(p, m, n, pos_row, v);
+      }
+    }
+  }
+}
+
+
+// ====================================================================================================================
+// Fast path (plain operands, K % 64 == 0): operand tiles go L2/HBM -> LDS directly with buffer_load_dwordx4 ... lds
+// (no VGPR staging, no ds_write).  The LDS image is lane-linear per wave instruction, so the bank-conflict swizzle is
+// applied to the per-lane SOURCE address and undone by the same XOR on the fragment read.  Every wave owns a
+// 128x64 sub-tile = 4x2 MFMA 32x32x16 blocks (128 accumulator VGPRs).  Two geometries:
+//   * 256x256x64, 8 waves (2x4), two LDS stages (128 KiB): the next K-tile streams in while this one is multiplied;
+//     one barrier per K-tile, one workgroup per CU, two waves per SIMD.                       (large problems)
+//   * 256x128x64, 4 waves (2x2), one LDS stage (48 KiB): 2-3 workgroups per CU hide each other's load latency.
+// M/N tails are handled by clamping source rows (garbage only reaches output rows/cols that are never stored).
+// SWAP: MFMA issued as D'[n][m] (lane owns one output row, 4 consecutive columns -> vector stores); !SWAP: D[m][n]
+// (lane owns one output column -> a wave's fp32 atomics hit 2 x 128 contiguous bytes): used for split-K wgrad.
+constexpr int FBM = 256;
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+template <bool TRANS, int ROWS, int NI, int NW>
+__device__ __forceinline__ void fast_offsets(const OperandView& v, int R, int row0, int lane, int wave, unsigned (&off)[NI]) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] += b4[i];
-        }
-        if (p.out_pre) {
-          u32x2_t o;
-          o[0] = pack_bf2(v[0], v[1]);
-          o[1] = pack_bf2(v[2], v[3]);
-          *(u32x2_t*)(p.out_pre + (long)m * p.ldc + n) = o;
-        }
-        if (p.act == 1) {
+  for (int j = 0; j < NI; ++j) {
+    const int q = j * NW + wave;  // 1 KiB chunk index inside the tile image
+    if (!TRANS) {
+      const int row = q * 8 + (lane >> 3), phys = lane & 7;
+      const int c16 = phys ^ ((row >> 1) & 7);
+      int gr = row0 + row;
+      gr = gr < R ? gr : R - 1;
+      off[j] = (unsigned)(((long)(gr - row0) * v.ld + c16 * 8) * 2);
+    } else {
+      constexpr int CPR = ROWS / 8;  // 16-byte pieces per k-row
+      constexpr int KPC = 64 / CPR;  // k-rows per 1 KiB chunk
+      const int krow = q * KPC + lane / CPR, phys = lane % CPR;
+      const int c16 = phys ^ ((krow & 3) << 2);
+      int col = row0 + c16 * 8;
+      col = col + 8 <= R ? col : R - 8;
+      off[j] = (unsigned)(((long)krow * v.ld + (col - row0)) * 2);
+    }
+  }
+}
+
+template <bool TRANS, int RB /*row bytes of a transposed tile*/>
+__device__ __forceinline__ bf16x8_t fast_frag(const char* lds, int sub, int ks, int lane) {
+  if (!TRANS) {
+    const int row = sub + (lane & 31);
+    const int c16 = ks * 2 + (lane >> 5);
+    return *(const bf16x8_t*)(lds + row * 128 + ((c16 ^ ((row >> 1) & 7)) << 4));
+  } else {
+    const int G = lane >> 4, i = lane & 15;
+    const int krow = ks * 16 + (G >> 1) * 8 + (i >> 2);
+    const int col = sub + (G & 1) * 16 + (i & 3) * 4;
+    const int addr = krow * RB + ((((col >> 3)) ^ ((krow & 3) << 2)) << 4) + (col & 7) * 2;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds + addr));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds + addr + 4 * RB));
+    const s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, v);
+  }
+}
+
+// 16 bytes per lane straight into LDS at (wave-uniform) dst + lane*16.  Kept in a non-template __device__ function:
+// hipcc 7.2 silently drops the host-side kernel handle when this builtin appears in a template-dependent expression.
+__device__ __forceinline__ void glds16(const __amdgpu_buffer_rsrc_t rs, char* dst, unsigned voff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_ptr)dst, 16, voff, 0, 0, 0);
+}
+
+// Issue this wave's share of one K-tile: NIA + NIB direct-to-LDS 1 KiB pieces (A image first, B image behind it).
+#define OASR_STAGE_TILE(KT, DST)                                                                                          \
+  do {                                                                                                                    \
+    const __amdgpu_buffer_rsrc_t ra_ = make_rsrc(baseA + (KT) * stepA);                                                   \
+    const __amdgpu_buffer_rsrc_t rb_ = make_rsrc(baseB + (KT) * stepB);                                                   \
+    char* dst_ = (DST);                                                                                                   \
+    _Pragma("unroll") for (int j_ = 0; j_ < NIA; ++j_)                                                                    \
+        glds16(ra_, dst_ + (j_ * NW + wave) * 1024, offA[j_]);                                               \
+    _Pragma("unroll") for (int j_ = 0; j_ < NIB; ++j_)                                                                    \
+        glds16(rb_, dst_ + A_BYTES + (j_ * NW + wave) * 1024, offB[j_]);                                     \
+  } while (0)
+
+}  // namespace
+
+// (external linkage: hipcc 7.2 drops the host-side handle of this instantiation set when it has internal linkage)
+template <bool TA, bool TB, int FBN, int NWN, int NSTAGE, bool SWAP>
+__global__ __launch_bounds__(512) void oasr_gemm_fast_kernel(GemmArgs p) {
+  constexpr int NW = 2 * NWN;                     // waves per workgroup
+  constexpr int A_BYTES = FBM * 64 * 2, B_BYTES = FBN * 64 * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int NIA = (A_BYTES / 1024) / NW, NIB = (B_BYTES / 1024) / NW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / NWN, wn = wave % NWN;
+  const int tiles_m = (p.M + FBM - 1) / FBM, tiles_n = (p.N + FBN - 1) / FBN;
+  // XCD-aware + grouped rasterisation: each XCD walks 8(m) x tiles_n(n) super-rows column by column, so the
+  // workgroups resident on one XCD cover a compact block of tiles and share A/B panels through that XCD's L2.
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  constexpr int GM = 8;
+  const int per_group = GM * tiles_n;
+  const int group = bid / per_group, in_group = bid - group * per_group;
+  const int first_m = group * GM;
+  const int gsz = min(GM, tiles_m - first_m);
+  const int tm = first_m + in_group % gsz, tn = in_group / gsz;
+  const int m0 = tm * FBM, n0 = tn * FBN;
+
+  const int kt_total = p.K / BK;
+  const int per = (kt_total + p.split_k - 1) / p.split_k;
+  const int kt0 = blockIdx.y * per;
+  const int kt1 = min(kt_total, kt0 + per);
+  if (kt0 >= kt1) return;
+
+  unsigned offA[NIA], offB[NIB];
+  fast_offsets<TA, FBM, NIA, NW>(p.A, p.M, m0, lane, wave, offA);
+  fast_offsets<TB, FBN, NIB, NW>(p.B, p.N, n0, lane, wave, offB);
+  const bf16_t* baseA = TA ? p.A.ptr + m0 : p.A.ptr + (long)m0 * p.A.ld;
+  const bf16_t* baseB = TB ? p.B.ptr + n0 : p.B.ptr + (long)n0 * p.B.ld;
+  const long stepA = TA ? (long)BK * p.A.ld : BK, stepB = TB ? (long)BK * p.B.ld : BK;
+
+  f32x16_t acc[4][2];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = gelu_f(bf_round(v[i]));
-        }
-        if (p.pos) {
-          const f32x4_t p4 = *(const f32x4_t*)(p.pos + (long)pos_row * p.N + n);
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = bf_round(v[i]) + p4[i];
-        }
-        if (p.dgelu_u) {
-          const u32x2_t u = *(const u32x2_t*)(p.dgelu_u + (long)m * p.ldu + n);
-          v[0] = bf_round(v[0]) * dgelu_f(bf_lo(u[0]));
-          v[1] = bf_round(v[1]) * dgelu_f(bf_hi(u[0]));
-          v[2] = bf_round(v[2]) * dgelu_f(bf_lo(u[1]));
-          v[3] = bf_round(v[3]) * dgelu_f(bf_hi(u[1]));
-        }
-        if (p.resid) {
-          const u32x2_t r = *(const u32x2_t*)(p.resid + (long)m * p.ldr + n);
-          v[0] = bf_round(v[0]) + bf_lo(r[0]);
-          v[1] = bf_round(v[1]) + bf_hi(r[0]);
-          v[2] = bf_round(v[2]) + bf_lo(r[1]);
-          v[3] = bf_round(v[3]) + bf_hi(r[1]);
-        }
-        if (p.out) {
-          u32x2_t o;
-          o[0] = pack_bf2(v[0], v[1]);
-          o[1] = pack_bf2(v[2], v[3]);
-          *(u32x2_t*)(p.out + (long)m * p.ldc + n) = o;
-        }
-        if (p.out_f32) {
-          float* dst = p.out_f32 + (long)m * p.ldc32 + n;
-          if (p.atomic) {
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) unsafeAtomicAdd(dst + i, v[i]);
-          } else {
-            f32x4_t c4;
-            if (p.beta != 0.f) {
-              c4 = *(const f32x4_t*)dst;
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (NSTAGE == 2) {
+    OASR_STAGE_TILE(kt0, smem);
+    __syncthreads();
+  }
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const char* cur;
+    if (NSTAGE == 2) {
+      cur = smem + ((kt - kt0) & 1) * STAGE;
+      if (kt + 1 < kt1)
+        OASR_STAGE_TILE(kt + 1, smem + (((kt - kt0) & 1) ^ 1) * STAGE);
+    } else {
+      cur = smem;
+      OASR_STAGE_TILE(kt, smem);
+      __syncthreads();  // hipcc drains vmcnt(0) for the LDS-DMA before the barrier
+    }
+    const char* sA = cur;
+    const char* sB = cur + A_BYTES;
 #pragma unroll
-              for (int i = 0; i < 4; ++i) c4[i] = p.beta * c4[i] + v[i];
-            } else {
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8_t af[4], bfr[2];
 #pragma unroll
-              for (int i = 0; i < 4; ++i) c4[i] = v[i];
-            }
-            *(f32x4_t*)dst = c4;
-          }
+      for (int t = 0; t < 4; ++t) af[t] = fast_frag<TA, FBM * 2>(sA, wm * 128 + t * 32, ks, lane);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) bfr[t] = fast_frag<TB, FBN * 2>(sB, wn * 64 + t * 32, ks, lane);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          if (SWAP)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[nt], af[mt], acc[mt][nt], 0, 0, 0);
+          else
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
+        }
+    }
+    __syncthreads();  // stage fully consumed (and, with two stages, the prefetched tile has landed)
+  }
+
+  const int h = lane >> 5;
+  if (SWAP) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int m = m0 + wm * 128 + mt * 32 + (lane & 31);
+      if (m >= p.M) continue;
+      const int pos_row = p.pos ? (m % p.pos_period) : 0;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = n0 + wn * 64 + nt * 32 + 8 * q + 4 * h;
+          if (n >= p.N) continue;
+          float v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = acc[mt][nt][q * 4 + i];
+          epilogue_store(p, m, n, pos_row, v);
+        }
+      }
+    }
+  } else {
+    // D[m][n]: lane owns column n = .. + (lane & 31), rows (r & 3) + 8*(r >> 2) + 4*h.  fp32 atomic accumulate only.
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int n = n0 + wn * 64 + nt * 32 + (lane & 31);
+      if (n >= p.N) continue;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * 128 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (m < p.M) unsafeAtomicAdd(p.out_f32 + (long)m * p.ldc32 + n, p.alpha * acc[mt][nt][r]);
         }
       }
     }
   }
+}
+
+namespace {
+
+template <bool TA, bool TB, int FBN, int NWN, int NSTAGE, bool SWAP>
+int launch_fast_cfg(const GemmArgs& a, hipStream_t stream) {
+  static bool attr = false;
+  const int lds = NSTAGE * (FBM * 64 * 2 + FBN * 64 * 2);
+  if (!attr) {
+    OASR_CHECK_HIP(hipFuncSetAttribute((const void*)oasr_gemm_fast_kernel<TA, TB, FBN, NWN, NSTAGE, SWAP>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr = true;
+  }
+  const int tiles = cdiv(a.M, FBM) * cdiv(a.N, FBN);
+  dim3 grid(tiles, a.split_k);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (g_prof.on) {
+    const size_t idx = g_prof.recs.size();
+    while (g_prof.events.size() < 2 * (idx + 1)) {
+      hipEvent_t e;
+      OASR_CHECK_HIP(hipEventCreate(&e));
+      g_prof.events.push_back(e);
+    }
+    e0 = g_prof.events[2 * idx];
+    e1 = g_prof.events[2 * idx + 1];
+    g_prof.recs.push_back({(TA ? 2 : 0) + (TB ? 1 : 0), 2.0 * (double)a.M * (double)a.N * (double)a.K});
+    OASR_CHECK_HIP(hipEventRecord(e0, stream));
+  }
+  hipLaunchKernelGGL((oasr_gemm_fast_kernel<TA, TB, FBN, NWN, NSTAGE, SWAP>), grid, dim3(128 * NWN), lds, stream, a);
+  OASR_LAUNCH_CHECK();
+  if (e1) OASR_CHECK_HIP(hipEventRecord(e1, stream));
+  return OASR_OK;
+}
+
+template <bool TA, bool TB>
+int launch_fast_t(const GemmArgs& a, hipStream_t stream) {
+  const bool atomic_only = a.atomic && a.out_f32 && !a.out && !a.out_pre;
+  const long big_tiles = (long)cdiv(a.M, FBM) * cdiv(a.N, 256) * a.split_k;
+  // Heuristic: the 1-workgroup-per-CU 256x256 geometry wins when the epilogue is light (split-K wgrad: atomics only);
+  // with a fused bias/GELU/residual epilogue the 256x128 geometry's 2-3 co-resident workgroups overlap one
+  // workgroup's VALU-heavy epilogue with another's MFMA main loop.  OASR_GEMM_GEOM=1|2 overrides (experiments).
+  static const int env_geom = [] {
+    const char* e = getenv("OASR_GEMM_GEOM");
+    return e ? atoi(e) : 0;
+  }();
+  const int geom = g_fast_geometry ? g_fast_geometry : env_geom;
+  const bool big = geom == 2 || (geom == 0 && atomic_only && big_tiles >= 256);
+  if (atomic_only) {
+    if (big) return launch_fast_cfg<TA, TB, 256, 4, 2, false>(a, stream);
+    return launch_fast_cfg<TA, TB, 128, 2, 1, false>(a, stream);
+  }
+  if (big) return launch_fast_cfg<TA, TB, 256, 4, 2, true>(a, stream);
+  return launch_fast_cfg<TA, TB, 128, 2, 1, true>(a, stream);
 }
 
 template <bool TA, bool TB>
@@ -329,6 +588,14 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   OASR_REQUIRE(a.split_k >= 1, "gemm: split_k");
   OASR_REQUIRE(a.split_k == 1 || (a.atomic && a.out_f32 && !a.out && !a.out_pre), "gemm: split_k > 1 needs atomic fp32 output only");
   OASR_REQUIRE(a.out || a.out_f32 || a.out_pre, "gemm: no output");
+  const bool fast = !a.A.rpb && !a.B.rpb && (a.K % BK) == 0 && (!a.ta || (a.M % 8) == 0) && (!a.tb || (a.N % 8) == 0) &&
+                    a.M >= 8 && a.N >= 8 && !g_force_general;
+  if (fast) {
+    if (!a.ta && !a.tb) return launch_fast_t<false, false>(a, stream);
+    if (!a.ta && a.tb) return launch_fast_t<false, true>(a, stream);
+    if (a.ta && !a.tb) return launch_fast_t<true, false>(a, stream);
+    return launch_fast_t<true, true>(a, stream);
+  }
   if (!a.ta && !a.tb) return launch_t<false, false>(a, stream);
   if (!a.ta && a.tb) return launch_t<false, true>(a, stream);
   if (a.ta && !a.tb) return launch_t<true, false>(a, stream);
@@ -358,4 +625,9 @@ int gemm_profile_collect(double ms[4], double flops[4], long count[4]) {
   }
   g_prof.recs.clear();
   return OASR_OK;
+}
+
+void gemm_force_general(int on) {
+  g_force_general = (on == 1);
+  g_fast_geometry = on >= 2 ? on - 1 : 0;  // 2 -> force 256x128, 3 -> force 256x256
 }
