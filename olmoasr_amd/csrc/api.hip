@@ -94,6 +94,7 @@ static AttnArgs to_attn(const oasr_attn_args* a) {
   r.ldo = a->ldo;
   r.bso = a->bso;
   r.lse = a->lse;
+  r.o32 = a->o32;
   r.kv_len = a->kv_len;
   r.B = a->B;
   r.H = a->H;

@@ -191,6 +191,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         o[1] = pack_bf2(oT[dt][4 * g4 + 2] * inv, oT[dt][4 * g4 + 3] * inv);
         *(u32x2_t*)(op + dt * 32 + 8 * g4 + 4 * hh) = o;
       }
+    if (a.o32) {  // unrounded O for the backward's delta term (bf16 O loses it when mean(V) dominates V's variation)
+      float* o32p = a.o32 + (long)b * a.bso + (long)myq * a.ldo + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+          *(f32x4_t*)(o32p + dt * 32 + 8 * g4 + 4 * hh) =
+              (f32x4_t){oT[dt][4 * g4] * inv, oT[dt][4 * g4 + 1] * inv, oT[dt][4 * g4 + 2] * inv, oT[dt][4 * g4 + 3] * inv};
+    }
     if (hh == 0 && a.lse) a.lse[((long)b * a.H + h) * a.Tq + myq] = (m_run + __builtin_amdgcn_logf(l_tot)) * LN2;
   }
 }
@@ -209,16 +218,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   const bf16_t* qp = a.q + (long)b * a.bsq + (long)myq_c * a.ldq + h * 64;
   const bf16_t* dop = a.d_o + (long)b * a.bso + (long)myq_c * a.ldo + h * 64;
   const bf16_t* op = a.o + (long)b * a.bso + (long)myq_c * a.ldo + h * 64;
+  const float* o32p = a.o32 ? a.o32 + (long)b * a.bso + (long)myq_c * a.ldo + h * 64 : nullptr;
   bf16x8_t qf[4], dof[4];
   float dpart = 0.f;
 #pragma unroll
   for (int ds = 0; ds < 4; ++ds) {
     qf[ds] = ld_frag_global(qp + ds * 16 + hh * 8);
     const u32x4_t d4 = *(const u32x4_t*)(dop + ds * 16 + hh * 8);
-    const u32x4_t o4 = *(const u32x4_t*)(op + ds * 16 + hh * 8);
     dof[ds] = __builtin_bit_cast(bf16x8_t, d4);
+    if (o32p) {
+      const f32x4_t oa = *(const f32x4_t*)(o32p + ds * 16 + hh * 8), ob = *(const f32x4_t*)(o32p + ds * 16 + hh * 8 + 4);
+      dpart += bf_lo(d4[0]) * oa[0] + bf_hi(d4[0]) * oa[1] + bf_lo(d4[1]) * oa[2] + bf_hi(d4[1]) * oa[3];
+      dpart += bf_lo(d4[2]) * ob[0] + bf_hi(d4[2]) * ob[1] + bf_lo(d4[3]) * ob[2] + bf_hi(d4[3]) * ob[3];
+    } else {
+      const u32x4_t o4 = *(const u32x4_t*)(op + ds * 16 + hh * 8);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dpart += bf_lo(d4[i]) * bf_lo(o4[i]) + bf_hi(d4[i]) * bf_hi(o4[i]);
+      for (int i = 0; i < 4; ++i) dpart += bf_lo(d4[i]) * bf_lo(o4[i]) + bf_hi(d4[i]) * bf_hi(o4[i]);
+    }
   }
   const float delta = dpart + __shfl_xor(dpart, 32, 64);
   const long stat_idx = ((long)b * a.H + h) * a.Tq + myq_c;

@@ -104,13 +104,16 @@ def test_loss_and_grads_vs_oracle(native_tiny, oracle_tiny, tiny_case):
         print(f"   {rel:.4f} {env:.4f} {cos:.5f} {name}")
     glob = (num / den) ** 0.5
     print(f"global grad rel-L2-err {glob:.4f}")
-    # Tolerances for a bf16 backward against the fp32 reference gradients.  The CPU mirror keeps softmax-backward in
-    # fp32, so it under-estimates what a bf16 flash-attention backward (bf16 P/dS, delta from the bf16-rounded O) does
-    # to attention-internal gradients of a random-init model (near-uniform attention over 1500 keys -> tiny dS signal):
-    # per tensor <= 10 % relative L2 and cosine > 0.99, whole gradient <= 3 %.
-    assert all(cos > 0.99 for _, _, cos, _ in worst), worst[:3]
-    assert worst[0][0] <= 0.10, worst[:3]
-    assert glob <= 0.03
+    # Tolerances for a bf16 backward against the fp32 reference gradients: every tensor must be as close as the CPU
+    # bf16 mirror of the reference is (measured: both ~2.5 % worst case on attention projections of this random-init
+    # model), i.e. <= max(2 x mirror, 3 %) per tensor, cosine > 0.999, and <= 2 % over the whole gradient.
+    # (Needs the fp32 copy of the attention output for the backward's delta term: with delta taken from the
+    # bf16-rounded O the cross-attention gradients were 7-9 % off -- see tests/test_gpu_ops.py::
+    # test_attention_bwd_delta_precision.)
+    assert all(cos > 0.999 for _, _, cos, _ in worst), worst[:3]
+    for rel, env, cos, name in worst:
+        assert rel <= max(2.0 * env, 0.03), (name, rel, env)
+    assert glob <= 0.02
     # global norm (what clip_grad_norm_ sees)
     gnorm = float(native_tiny.flat_grads.double().norm())
     rnorm = float(torch.sqrt(sum((g.double() ** 2).sum() for g in oracle_tiny["grads"].values())))
