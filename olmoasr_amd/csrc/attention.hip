@@ -30,16 +30,32 @@ typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
 
 __device__ __forceinline__ int tile_addr(int row, int c16) { return row * 128 + ((c16 ^ ((row >> 1) & 7)) << 4); }
 
-// cooperative 64x64 tile: each of 256 threads moves 2 x 16 bytes
-__device__ __forceinline__ void tile_issue(const bf16_t* base, long ld, int row0, int rmax, int tid, u32x4_t (&r)[2]) {
+// cooperative 64x64 tile: each of 256 threads moves 2 x 16 bytes.  Bounds-checked buffer loads: the descriptor covers
+// rows [0, rmax) of this (batch, head) slice, so rows past the end read as zeros (their scores are masked, and zero V
+// rows keep 0 * V finite); the per-thread offsets are loop invariants and the tile advance is a scalar offset, so the
+// loop carries no vector address arithmetic.
+struct TileSrc {
+  __amdgpu_buffer_rsrc_t rs;
+  unsigned voff[2];
+  unsigned row_bytes;
+};
+__device__ __forceinline__ TileSrc tile_src(const bf16_t* base, long ld, int rmax, int tid) {
+  TileSrc t;
+  // last valid byte: row (rmax-1), 64 columns
+  t.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base), 0, (int)(((long)(rmax - 1) * ld + 64) * 2), 0x00020000);
+  t.row_bytes = (unsigned)(ld * 2);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int id = tid + 256 * i;
-    const int row = id >> 3, c16 = id & 7;
-    int gr = row0 + row;
-    gr = gr < rmax ? gr : rmax - 1;  // clamp: rows past the end are masked by the caller, data stays finite
-    r[i] = *(const u32x4_t*)(base + (long)gr * ld + c16 * 8);
+    t.voff[i] = (unsigned)((id >> 3) * ld * 2 + (id & 7) * 16);
   }
+  return t;
+}
+__device__ __forceinline__ void tile_issue(const TileSrc& t, int row0, u32x4_t (&r)[2]) {
+  const unsigned soff = (unsigned)row0 * t.row_bytes;
+#pragma unroll
+  // the tile offset goes into the VGPR offset: on gfx9-class raw buffers the range check does not cover soffset
+  for (int i = 0; i < 2; ++i) r[i] = __builtin_amdgcn_raw_buffer_load_b128(t.rs, t.voff[i] + soff, 0, 0);
 }
 __device__ __forceinline__ void tile_commit(char* lds, int tid, const u32x4_t (&r)[2]) {
 #pragma unroll
@@ -79,11 +95,16 @@ __device__ __forceinline__ int acc_row(int r, int hh) { return (r & 3) + 8 * (r 
 
 // ------------------------------------------------------------------------------------------------------------
 template <bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE];  // stage s: K at 2s*TILE, V at (2s+1)*TILE
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
-  const int b = blockIdx.y / a.H, h = blockIdx.y - b * a.H;
-  const int q0 = blockIdx.x * 128;
+  // 1-D grid, XCD-aware: all query blocks of one (batch, head) run on the same XCD so K/V are filled into that XCD's
+  // L2 once and re-used by the other query blocks (round-robin dispatch would fetch them through all 8 L2s).
+  const int nqb = (a.Tq + 127) >> 7;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = bid / nqb;
+  const int b = bh / a.H, h = bh - b * a.H;
+  const int q0 = (bid - bh * nqb) * 128;
   const int myq = q0 + wave * 32 + (lane & 31);
   const int myq_c = myq < a.Tq ? myq : a.Tq - 1;
 
@@ -98,8 +119,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   if (CAUSAL) kv_end = kv_end < q0 + 128 ? kv_end : q0 + 128;
   const int ntiles = (kv_end + 63) >> 6;
 
-  const bf16_t* kbase = a.k + (long)b * a.bsk + h * 64;
-  const bf16_t* vbase = a.v + (long)b * a.bsv + h * 64;
+  const TileSrc ksrc = tile_src(a.k + (long)b * a.bsk + h * 64, a.ldk, a.Tk, tid);
+  const TileSrc vsrc = tile_src(a.v + (long)b * a.bsv + h * 64, a.ldv, a.Tk, tid);
 
   f32x16_t oT[2];
 #pragma unroll
@@ -110,8 +131,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 
   u32x4_t rk[2], rv[2];
   if (ntiles > 0) {
-    tile_issue(kbase, a.ldk, 0, a.Tk, tid, rk);
-    tile_issue(vbase, a.ldv, 0, a.Tk, tid, rv);
+    tile_issue(ksrc, 0, rk);
+    tile_issue(vsrc, 0, rv);
     tile_commit(smem, tid, rk);
     tile_commit(smem + TILE, tid, rv);
   }
@@ -122,8 +143,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     const char* vb = kb + TILE;
     const bool more = t + 1 < ntiles;
     if (more) {
-      tile_issue(kbase, a.ldk, (t + 1) * 64, a.Tk, tid, rk);
-      tile_issue(vbase, a.ldv, (t + 1) * 64, a.Tk, tid, rv);
+      tile_issue(ksrc, (t + 1) * 64, rk);
+      tile_issue(vsrc, (t + 1) * 64, rv);
     }
     f32x16_t sT[2];
 #pragma unroll
@@ -133,26 +154,38 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
       for (int ds = 0; ds < 4; ++ds) sT[kt] = MFMA(frag_rows(kb, kt * 32, ds, lane), qf[ds], sT[kt]);
     }
+    // Only boundary tiles need the per-element mask (wave-uniform test): last partial tile of kv_len, and for the
+    // causal case the tiles that cross this wave's diagonal.  Scores stay raw; the softmax scale rides in the fma.
+    constexpr float C = SCALE * LOG2E;
+    const int q_lo = q0 + wave * 32;  // smallest query row of this wave
+    const bool full = (t * 64 + 64 <= kv_len) && (!CAUSAL || (t * 64 + 63 <= q_lo));
     float m_tile = NEG;
+    if (full) {
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+      for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = t * 64 + kt * 32 + acc_row(r, hh);
-        const bool ok = (key < kv_len) && (!CAUSAL || key <= myq);
-        const float s = ok ? sT[kt][r] * (SCALE * LOG2E) : NEG;
-        sT[kt][r] = s;
-        m_tile = fmaxf(m_tile, s);
-      }
+        for (int r = 0; r < 16; ++r) m_tile = fmaxf(m_tile, sT[kt][r]);
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = t * 64 + kt * 32 + acc_row(r, hh);
+          const bool ok = (key < kv_len) && (!CAUSAL || key <= myq);
+          const float sv = ok ? sT[kt][r] : NEG;
+          sT[kt][r] = sv;
+          m_tile = fmaxf(m_tile, sv);
+        }
+    }
     m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
-    const float m_new = fmaxf(m_run, m_tile);
+    const float m_new = fmaxf(m_run, m_tile * C);  // NEG * C stays hugely negative
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     float psum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(sT[kt][r] - m_new);
+        const float p = __builtin_amdgcn_exp2f(fmaf(sT[kt][r], C, -m_new));
         sT[kt][r] = p;
         psum += p;
       }
@@ -210,8 +243,13 @@ template <bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
-  const int b = blockIdx.y / a.H, h = blockIdx.y - b * a.H;
-  const int q0 = blockIdx.x * 128;
+  // 1-D grid, XCD-aware: all query blocks of one (batch, head) run on the same XCD so K/V are filled into that XCD's
+  // L2 once and re-used by the other query blocks (round-robin dispatch would fetch them through all 8 L2s).
+  const int nqb = (a.Tq + 127) >> 7;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = bid / nqb;
+  const int b = bh / a.H, h = bh - b * a.H;
+  const int q0 = (bid - bh * nqb) * 128;
   const int myq = q0 + wave * 32 + (lane & 31);
   const int myq_c = myq < a.Tq ? myq : a.Tq - 1;
 
@@ -246,8 +284,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   int kv_end = kv_len;
   if (CAUSAL) kv_end = kv_end < q0 + 128 ? kv_end : q0 + 128;
   const int ntiles = (kv_end + 63) >> 6;
-  const bf16_t* kbase = a.k + (long)b * a.bsk + h * 64;
-  const bf16_t* vbase = a.v + (long)b * a.bsv + h * 64;
+  const TileSrc ksrc = tile_src(a.k + (long)b * a.bsk + h * 64, a.ldk, a.Tk, tid);
+  const TileSrc vsrc = tile_src(a.v + (long)b * a.bsv + h * 64, a.ldv, a.Tk, tid);
 
   f32x16_t dqT[2];
 #pragma unroll
@@ -257,8 +295,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 
   u32x4_t rk[2], rv[2];
   if (ntiles > 0) {
-    tile_issue(kbase, a.ldk, 0, a.Tk, tid, rk);
-    tile_issue(vbase, a.ldv, 0, a.Tk, tid, rv);
+    tile_issue(ksrc, 0, rk);
+    tile_issue(vsrc, 0, rv);
     tile_commit(smem, tid, rk);
     tile_commit(smem + TILE, tid, rv);
   }
@@ -268,8 +306,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     const char* vb = kb + TILE;
     const bool more = t + 1 < ntiles;
     if (more) {
-      tile_issue(kbase, a.ldk, (t + 1) * 64, a.Tk, tid, rk);
-      tile_issue(vbase, a.ldv, (t + 1) * 64, a.Tk, tid, rv);
+      tile_issue(ksrc, (t + 1) * 64, rk);
+      tile_issue(vsrc, (t + 1) * 64, rv);
     }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
@@ -284,12 +322,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         sT = MFMA(frag_rows(kb, kt * 32, ds, lane), qf[ds], sT);
         dpT = MFMA(frag_rows(vb, kt * 32, ds, lane), dof[ds], dpT);
       }
+      const bool full = (t * 64 + kt * 32 + 32 <= kv_len) && (!CAUSAL || (t * 64 + kt * 32 + 31 <= q0 + wave * 32));
+      if (full) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = t * 64 + kt * 32 + acc_row(r, hh);
-        const bool ok = (key < kv_len) && (!CAUSAL || key <= myq);
-        const float p = ok ? __builtin_amdgcn_exp2f(sT[r] * (SCALE * LOG2E) - lse2) : 0.f;
-        sT[r] = p * (dpT[r] - delta);
+        for (int r = 0; r < 16; ++r) {
+          const float p = __builtin_amdgcn_exp2f(fmaf(sT[r], SCALE * LOG2E, -lse2));
+          sT[r] = p * (dpT[r] - delta);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = t * 64 + kt * 32 + acc_row(r, hh);
+          const bool ok = (key < kv_len) && (!CAUSAL || key <= myq);
+          const float p = ok ? __builtin_amdgcn_exp2f(fmaf(sT[r], SCALE * LOG2E, -lse2)) : 0.f;
+          sT[r] = p * (dpT[r] - delta);
+        }
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -327,8 +374,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
   constexpr int STAGE = 2 * TILE + 512;
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
-  const int b = blockIdx.y / a.H, h = blockIdx.y - b * a.H;
-  const int k0 = blockIdx.x * 128;
+  const int nkb = (a.Tk + 127) >> 7;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = bid / nkb;
+  const int b = bh / a.H, h = bh - b * a.H;
+  const int k0 = (bid - bh * nkb) * 128;
   const int mykey = k0 + wave * 32 + (lane & 31);
   const int mykey_c = mykey < a.Tk ? mykey : a.Tk - 1;
 
@@ -352,8 +402,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
       dvT[i][r] = 0.f;
     }
 
-  const bf16_t* qbase = a.q + (long)b * a.bsq + h * 64;
-  const bf16_t* dobase = a.d_o + (long)b * a.bso + h * 64;
+  const TileSrc qsrc = tile_src(a.q + (long)b * a.bsq + h * 64, a.ldq, a.Tq, tid);
+  const TileSrc dosrc = tile_src(a.d_o + (long)b * a.bso + h * 64, a.ldo, a.Tq, tid);
   const float* lse_b = a.lse + ((long)b * a.H + h) * a.Tq;
   const float* delta_b = a.delta + ((long)b * a.H + h) * a.Tq;
 
@@ -364,8 +414,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
   u32x4_t rq[2], rd[2];
   float rstat = 0.f;
   auto issue = [&](int t) {
-    tile_issue(qbase, a.ldq, t * 64, a.Tq, tid, rq);
-    tile_issue(dobase, a.ldo, t * 64, a.Tq, tid, rd);
+    tile_issue(qsrc, t * 64, rq);
+    tile_issue(dosrc, t * 64, rd);
     if (tid < 128) {
       int qi = t * 64 + (tid & 63);
       qi = qi < a.Tq ? qi : a.Tq - 1;
@@ -403,6 +453,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
         s = MFMA(frag_rows(qb, qt * 32, ds, lane), kf[ds], s);
         dp = MFMA(frag_rows(dob, qt * 32, ds, lane), vf[ds], dp);
       }
+      const int key_hi = k0 + wave * 32 + 31;  // largest key of this wave
+      const bool full = (t * 64 + qt * 32 + 32 <= a.Tq) && (key_hi < kv_len) && (!CAUSAL || key_hi <= t * 64 + qt * 32);
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const int ql = qt * 32 + 8 * g4 + 4 * hh;
@@ -411,9 +463,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int r = 4 * g4 + i;
-          const int qg = t * 64 + ql + i;
-          const bool ok = (qg < a.Tq) && (mykey < kv_len) && (!CAUSAL || mykey <= qg);
-          const float p = ok ? __builtin_amdgcn_exp2f(s[r] * (SCALE * LOG2E) - l4[i]) : 0.f;
+          float p = __builtin_amdgcn_exp2f(fmaf(s[r], SCALE * LOG2E, -l4[i]));
+          if (!full) {
+            const int qg = t * 64 + ql + i;
+            const bool ok = (qg < a.Tq) && (mykey < kv_len) && (!CAUSAL || mykey <= qg);
+            p = ok ? p : 0.f;
+          }
           s[r] = p;
           dp[r] = p * (dp[r] - d4[i]);
         }
@@ -464,7 +519,7 @@ int check_args(const AttnArgs& a, bool bwd) {
 int launch_attention_fwd(const AttnArgs& a, hipStream_t s) {
   int rc = check_args(a, false);
   if (rc) return rc;
-  dim3 grid(cdiv(a.Tq, 128), a.B * a.H);
+  dim3 grid(cdiv(a.Tq, 128) * a.B * a.H);
   if (a.causal)
     hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, s, a);
   else
@@ -476,7 +531,7 @@ int launch_attention_fwd(const AttnArgs& a, hipStream_t s) {
 int launch_attention_bwd(const AttnArgs& a, hipStream_t s) {
   int rc = check_args(a, true);
   if (rc) return rc;
-  dim3 gq(cdiv(a.Tq, 128), a.B * a.H), gk(cdiv(a.Tk, 128), a.B * a.H);
+  dim3 gq(cdiv(a.Tq, 128) * a.B * a.H), gk(cdiv(a.Tk, 128) * a.B * a.H);
   if (a.causal) {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, gq, dim3(256), 0, s, a);
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, gk, dim3(256), 0, s, a);

@@ -299,9 +299,9 @@ struct Runner {
     g.out_f32 = dW;
     g.ldc32 = ldw;
     g.atomic = 1;
-    const long tiles = (long)cdiv(N, 128) * cdiv(K, 128);
+    const long tiles = (long)cdiv(N, 256) * cdiv(K, 128);
     const long kt = cdiv(M, 64);
-    long split = (1024 + tiles - 1) / tiles;
+    long split = (512 + tiles - 1) / tiles;  // ~2 workgroups per CU; every extra split costs a full atomic epilogue
     if (split > kt / 8) split = kt / 8;
     if (split < 1) split = 1;
     g.split_k = (int)split;

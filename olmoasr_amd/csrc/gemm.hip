@@ -145,68 +145,73 @@ __device__ __forceinline__ bf16x8_t read_frag(const char* lds, int sub, int ks, 
   }
 }
 
-// Fused epilogue for 4 consecutive columns n..n+3 of output row m (see GemmArgs in kernels.h for the order of ops).
+// Fused epilogue math for 4 consecutive columns n..n+3 of output row m (see GemmArgs in kernels.h for the order of
+// ops): returns the pre-activation and the final value packed to bf16; v[] holds the final fp32 values on return.
+__device__ __forceinline__ void epilogue_math(const GemmArgs& p, int m, int n, int pos_row, float (&v)[4], u32x2_t& pre, u32x2_t& fin) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] *= p.alpha;
+  if (p.bias) {
+    const f32x4_t b4 = *(const f32x4_t*)(p.bias + n);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] += b4[i];
+  }
+  pre[0] = pack_bf2(v[0], v[1]);
+  pre[1] = pack_bf2(v[2], v[3]);
+  if (p.act == 1) {
+    v[0] = gelu_f(bf_lo(pre[0]));
+    v[1] = gelu_f(bf_hi(pre[0]));
+    v[2] = gelu_f(bf_lo(pre[1]));
+    v[3] = gelu_f(bf_hi(pre[1]));
+  }
+  if (p.pos) {
+    const f32x4_t p4 = *(const f32x4_t*)(p.pos + (long)pos_row * p.N + n);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = bf_round(v[i]) + p4[i];
+  }
+  if (p.dgelu_u) {
+    const u32x2_t u = *(const u32x2_t*)(p.dgelu_u + (long)m * p.ldu + n);
+    v[0] = bf_round(v[0]) * dgelu_f(bf_lo(u[0]));
+    v[1] = bf_round(v[1]) * dgelu_f(bf_hi(u[0]));
+    v[2] = bf_round(v[2]) * dgelu_f(bf_lo(u[1]));
+    v[3] = bf_round(v[3]) * dgelu_f(bf_hi(u[1]));
+  }
+  if (p.resid) {
+    const u32x2_t r = *(const u32x2_t*)(p.resid + (long)m * p.ldr + n);
+    v[0] = bf_round(v[0]) + bf_lo(r[0]);
+    v[1] = bf_round(v[1]) + bf_hi(r[0]);
+    v[2] = bf_round(v[2]) + bf_lo(r[1]);
+    v[3] = bf_round(v[3]) + bf_hi(r[1]);
+  }
+  fin[0] = pack_bf2(v[0], v[1]);
+  fin[1] = pack_bf2(v[2], v[3]);
+}
+
+__device__ __forceinline__ void epilogue_f32(const GemmArgs& p, int m, int n, const float (&v)[4]) {
+  float* dst = p.out_f32 + (long)m * p.ldc32 + n;
+  if (p.atomic) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) unsafeAtomicAdd(dst + i, v[i]);
+  } else {
+    f32x4_t c4;
+    if (p.beta != 0.f) {
+      c4 = *(const f32x4_t*)dst;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) c4[i] = p.beta * c4[i] + v[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) c4[i] = v[i];
+    }
+    *(f32x4_t*)dst = c4;
+  }
+}
+
+// direct (8-byte) stores: general kernel
 __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int m, int n, int pos_row, float (&v)[4]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] *= p.alpha;
-        if (p.bias) {
-          const f32x4_t b4 = *(const f32x4_t*)(p.bias + n);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] += b4[i];
-        }
-        if (p.out_pre) {
-          u32x2_t o;
-          o[0] = pack_bf2(v[0], v[1]);
-          o[1] = pack_bf2(v[2], v[3]);
-          *(u32x2_t*)(p.out_pre + (long)m * p.ldc + n) = o;
-        }
-        if (p.act == 1) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = gelu_f(bf_round(v[i]));
-        }
-        if (p.pos) {
-          const f32x4_t p4 = *(const f32x4_t*)(p.pos + (long)pos_row * p.N + n);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = bf_round(v[i]) + p4[i];
-        }
-        if (p.dgelu_u) {
-          const u32x2_t u = *(const u32x2_t*)(p.dgelu_u + (long)m * p.ldu + n);
-          v[0] = bf_round(v[0]) * dgelu_f(bf_lo(u[0]));
-          v[1] = bf_round(v[1]) * dgelu_f(bf_hi(u[0]));
-          v[2] = bf_round(v[2]) * dgelu_f(bf_lo(u[1]));
-          v[3] = bf_round(v[3]) * dgelu_f(bf_hi(u[1]));
-        }
-        if (p.resid) {
-          const u32x2_t r = *(const u32x2_t*)(p.resid + (long)m * p.ldr + n);
-          v[0] = bf_round(v[0]) + bf_lo(r[0]);
-          v[1] = bf_round(v[1]) + bf_hi(r[0]);
-          v[2] = bf_round(v[2]) + bf_lo(r[1]);
-          v[3] = bf_round(v[3]) + bf_hi(r[1]);
-        }
-        if (p.out) {
-          u32x2_t o;
-          o[0] = pack_bf2(v[0], v[1]);
-          o[1] = pack_bf2(v[2], v[3]);
-          *(u32x2_t*)(p.out + (long)m * p.ldc + n) = o;
-        }
-        if (p.out_f32) {
-          float* dst = p.out_f32 + (long)m * p.ldc32 + n;
-          if (p.atomic) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) unsafeAtomicAdd(dst + i, v[i]);
-          } else {
-            f32x4_t c4;
-            if (p.beta != 0.f) {
-              c4 = *(const f32x4_t*)dst;
-#pragma unroll
-              for (int i = 0; i < 4; ++i) c4[i] = p.beta * c4[i] + v[i];
-            } else {
-#pragma unroll
-              for (int i = 0; i < 4; ++i) c4[i] = v[i];
-            }
-            *(f32x4_t*)dst = c4;
-          }
-        }
+  u32x2_t pre, fin;
+  epilogue_math(p, m, n, pos_row, v, pre, fin);
+  if (p.out_pre) *(u32x2_t*)(p.out_pre + (long)m * p.ldc + n) = pre;
+  if (p.out) *(u32x2_t*)(p.out + (long)m * p.ldc + n) = fin;
+  if (p.out_f32) epilogue_f32(p, m, n, v);
 }
 
 template <bool TA, bool TB>
@@ -375,7 +380,7 @@ __device__ __forceinline__ void glds16(const __amdgpu_buffer_rsrc_t rs, char* ds
 
 // (external linkage: hipcc 7.2 drops the host-side handle of this instantiation set when it has internal linkage)
 template <bool TA, bool TB, int FBN, int NWN, int NSTAGE, bool SWAP>
-__global__ __launch_bounds__(512) void oasr_gemm_fast_kernel(GemmArgs p) {
+__global__ __launch_bounds__(128 * NWN, NWN == 2 ? 3 : 2) void oasr_gemm_fast_kernel(GemmArgs p) {
   constexpr int NW = 2 * NWN;                     // waves per workgroup
   constexpr int A_BYTES = FBM * 64 * 2, B_BYTES = FBN * 64 * 2, STAGE = A_BYTES + B_BYTES;
   constexpr int NIA = (A_BYTES / 1024) / NW, NIB = (B_BYTES / 1024) / NW;
@@ -455,22 +460,58 @@ __global__ __launch_bounds__(512) void oasr_gemm_fast_kernel(GemmArgs p) {
 
   const int h = lane >> 5;
   if (SWAP) {
+    // bf16 outputs leave through a per-wave 8 KiB LDS staging tile ([64 rows][128 B], 16-byte chunks XOR-swizzled
+    // by row) so that global stores are 16 bytes per lane and 128 contiguous bytes per output row, instead of 8-byte
+    // pieces scattered over 32 rows.  All LDS is free here: the main loop ended on a barrier.
+    char* stg = smem + wave * 8192;  // [0,4K): pre-activation rows, [4K,8K): final rows; 32 rows x 128 B each
+    const bool vec_ok = (p.N % 8) == 0 && (p.ldc % 8) == 0;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       const int m = m0 + wm * 128 + mt * 32 + (lane & 31);
-      if (m >= p.M) continue;
-      const int pos_row = p.pos ? (m % p.pos_period) : 0;
+      const int mc = m < p.M ? m : p.M - 1;  // clamp: loads stay in range, stores are masked below
+      const int pos_row = p.pos ? (mc % p.pos_period) : 0;
+      const int row = lane & 31;
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int n = n0 + wn * 64 + nt * 32 + 8 * q + 4 * h;
-          if (n >= p.N) continue;
+          int n = n0 + wn * 64 + nt * 32 + 8 * q + 4 * h;
+          const bool n_ok = n < p.N;
+          n = n_ok ? n : 0;
           float v[4];
 #pragma unroll
           for (int i = 0; i < 4; ++i) v[i] = acc[mt][nt][q * 4 + i];
-          epilogue_store(p, m, n, pos_row, v);
+          u32x2_t pre, fin;
+          epilogue_math(p, mc, n, pos_row, v, pre, fin);
+          if (p.out_f32 && m < p.M && n_ok) epilogue_f32(p, m, n, v);
+          if (!vec_ok) {
+            if (m < p.M && n_ok) {
+              if (p.out_pre) *(u32x2_t*)(p.out_pre + (long)m * p.ldc + n) = pre;
+              if (p.out) *(u32x2_t*)(p.out + (long)m * p.ldc + n) = fin;
+            }
+          } else {
+            const int a = row * 128 + (((nt * 4 + q) ^ (row & 7)) << 4) + h * 8;
+            if (p.out_pre) *(u32x2_t*)(stg + a) = pre;
+            if (p.out) *(u32x2_t*)(stg + 4096 + a) = fin;
+          }
         }
+      }
+      if (vec_ok) {
+        __builtin_amdgcn_wave_barrier();  // wave-private staging: LDS ops of one wave execute in order
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+          bf16_t* dst = pass == 0 ? p.out_pre : p.out;
+          if (!dst) continue;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int r2 = i * 8 + (lane >> 3), ch = lane & 7;
+            const u32x4_t val = *(const u32x4_t*)(stg + pass * 4096 + r2 * 128 + ((ch ^ (r2 & 7)) << 4));
+            const int mm = m0 + wm * 128 + mt * 32 + r2;
+            const int nn = n0 + wn * 64 + ch * 8;
+            if (mm < p.M && nn < p.N) *(u32x4_t*)(dst + (long)mm * p.ldc + nn) = val;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
       }
     }
   } else {
@@ -527,15 +568,16 @@ template <bool TA, bool TB>
 int launch_fast_t(const GemmArgs& a, hipStream_t stream) {
   const bool atomic_only = a.atomic && a.out_f32 && !a.out && !a.out_pre;
   const long big_tiles = (long)cdiv(a.M, FBM) * cdiv(a.N, 256) * a.split_k;
-  // Heuristic: the 1-workgroup-per-CU 256x256 geometry wins when the epilogue is light (split-K wgrad: atomics only);
-  // with a fused bias/GELU/residual epilogue the 256x128 geometry's 2-3 co-resident workgroups overlap one
-  // workgroup's VALU-heavy epilogue with another's MFMA main loop.  OASR_GEMM_GEOM=1|2 overrides (experiments).
+  // Geometry: measured on the OLMoASR-medium shapes (scripts/gemm_bench.py) the 256x128 / 3-workgroups-per-CU
+  // geometry is at least as fast as the 1-workgroup-per-CU 256x256 one everywhere except very small split-K outputs;
+  // co-resident workgroups overlap one's VALU-heavy epilogue with another's MFMA main loop.
+  // OASR_GEMM_GEOM=1|2 overrides (experiments).
   static const int env_geom = [] {
     const char* e = getenv("OASR_GEMM_GEOM");
     return e ? atoi(e) : 0;
   }();
   const int geom = g_fast_geometry ? g_fast_geometry : env_geom;
-  const bool big = geom == 2 || (geom == 0 && atomic_only && big_tiles >= 256);
+  const bool big = geom == 2 || (geom == 0 && atomic_only && (long)cdiv(a.M, FBM) * cdiv(a.N, 128) <= 32 && big_tiles >= 128);
   if (atomic_only) {
     if (big) return launch_fast_cfg<TA, TB, 256, 4, 2, false>(a, stream);
     return launch_fast_cfg<TA, TB, 128, 2, 1, false>(a, stream);
