@@ -47,6 +47,7 @@ extern "C" int oasr_gemm(const oasr_gemm_args* a, void* stream) {
   g.out_f32 = a->out_f32;
   g.ldc32 = a->ldc32;
   g.beta = a->beta;
+  g.colsum = a->colsum;
   g.atomic = a->atomic;
   g.split_k = a->split_k < 1 ? 1 : a->split_k;
   return launch_gemm(g, (hipStream_t)stream);
@@ -75,7 +76,7 @@ extern "C" int oasr_layernorm_fwd(const void* x, const float* gamma, const float
 extern "C" int oasr_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                   const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int d, void* stream) {
   return launch_layernorm_bwd((const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, dgamma, dbeta,
-                              rows, d, (hipStream_t)stream);
+                              nullptr, rows, d, (hipStream_t)stream);
 }
 
 static AttnArgs to_attn(const oasr_attn_args* a) {

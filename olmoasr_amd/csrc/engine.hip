@@ -270,7 +270,8 @@ struct Runner {
     return launch_gemm(g, st);
   }
   // dx[M,K] = dy[M,N] . W[N,K]  (* gelu'(u))  (+ resid)
-  int dgrad(const bf16_t* dy, long M, int N, const bf16_t* W, int K, const bf16_t* dgelu_u, const bf16_t* resid, bf16_t* dx) {
+  int dgrad(const bf16_t* dy, long M, int N, const bf16_t* W, int K, const bf16_t* dgelu_u, const bf16_t* resid, bf16_t* dx,
+            float* colsum = nullptr) {
     GemmArgs g = gemm_defaults();
     g.A = plain_view(dy, N);
     g.B = plain_view(W, K);
@@ -284,6 +285,7 @@ struct Runner {
     g.ldr = K;
     g.out = dx;
     g.ldc = K;
+    g.colsum = colsum;
     return launch_gemm(g, st);
   }
   // dW[N,K] += dy[M,N]^T . x[M,K]   (fp32 atomics, split over the token dimension)
@@ -436,26 +438,27 @@ struct Runner {
   }
 
   // dx_out (grad of the block output) -> returns grad of the block input in *dx_in_out (ping-pong ga/gb)
+  // Bias gradients of Linears that write into the residual stream (mlp.2, attn.out, cross_attn.out) are column sums of a
+  // residual-stream gradient, and every such gradient is produced by a LayerNorm backward -> that kernel accumulates
+  // them (its `dsum` output).  The caller's LN backward already filled this block's mlp.2.bias gradient from dx_out;
+  // `dsum_next` is the bias gradient the produced dx_in belongs to (previous block's mlp.2.bias, or null).
   int block_bwd(const BlockP& bp, const BlockSave& s, Plan& p, const bf16_t* dx_out, bf16_t* scratch_a, bf16_t* scratch_b, long M,
-                long Tq, bool causal, bool first_cross, const bf16_t** dx_in) {
+                long Tq, bool causal, bool first_cross, float* dsum_next, const bf16_t** dx_in) {
     const int d = c->d;
     const bf16_t* xm = bp.cross ? s.x_mid2 : s.x_mid;
     // ---- MLP -----------------------------------------------------------------------------------------------
     RC(wgrad(dx_out, d, M, d, plain_view(s.hg, 4 * d), 4 * d, c->G(bp.w2), 4 * d));
-    RC(launch_colsum_accum(dx_out, d, M, d, c->G(bp.b2), st));
-    RC(dgrad(dx_out, M, d, c->W(bp.w2), 4 * d, s.u, nullptr, p.gu));
+    RC(dgrad(dx_out, M, d, c->W(bp.w2), 4 * d, s.u, nullptr, p.gu, c->G(bp.b1)));  // + fused mlp.0.bias gradient
     RC(wgrad(p.gu, 4 * d, M, 4 * d, plain_view(s.ln2, d), d, c->G(bp.w1), d));
-    RC(launch_colsum_accum(p.gu, 4 * d, M, 4 * d, c->G(bp.b1), st));
     RC(dgrad(p.gu, M, 4 * d, c->W(bp.w1), d, nullptr, nullptr, p.gln));
-    RC(launch_layernorm_bwd(p.gln, xm, c->P(bp.mlp_ln_w), s.mean2, s.rstd2, dx_out, scratch_a, c->G(bp.mlp_ln_w), c->G(bp.mlp_ln_b), M,
-                            d, st));
+    RC(launch_layernorm_bwd(p.gln, xm, c->P(bp.mlp_ln_w), s.mean2, s.rstd2, dx_out, scratch_a, c->G(bp.mlp_ln_w), c->G(bp.mlp_ln_b),
+                            c->G(bp.cross ? bp.cattn.ob : bp.attn.ob), M, d, st));
     const bf16_t* dx = scratch_a;
     bf16_t* nxt = scratch_b;
     // ---- cross attention ---------------------------------------------------------------------------------------
     if (bp.cross) {
       const long Mkv = (long)B * c->Te;
       RC(wgrad(dx, d, M, d, plain_view(s.ca.o, d), d, c->G(bp.cattn.ow), d));
-      RC(launch_colsum_accum(dx, d, M, d, c->G(bp.cattn.ob), st));
       RC(dgrad(dx, M, d, c->W(bp.cattn.ow), d, nullptr, nullptr, p.go));
       AttnArgs a;
       attn_args(a, s.ca, true, Tq, c->Te, false);
@@ -472,14 +475,14 @@ struct Runner {
       // d(xa) accumulates over the decoder layers (bf16, like autograd's accumulation into xa.grad)
       RC(dgrad(p.gkv, Mkv, 2 * d, c->W(bp.cattn.kw), d, nullptr, first_cross ? nullptr : p.gxa, p.gxa));
       RC(dgrad(p.gq, M, d, c->W(bp.cattn.qw), d, nullptr, nullptr, p.gln));
-      RC(launch_layernorm_bwd(p.gln, s.x_mid, c->P(bp.cln_w), s.ca.mean, s.ca.rstd, dx, nxt, c->G(bp.cln_w), c->G(bp.cln_b), M, d, st));
+      RC(launch_layernorm_bwd(p.gln, s.x_mid, c->P(bp.cln_w), s.ca.mean, s.ca.rstd, dx, nxt, c->G(bp.cln_w), c->G(bp.cln_b),
+                              c->G(bp.attn.ob), M, d, st));
       const bf16_t* t = dx;
       dx = nxt;
       nxt = const_cast<bf16_t*>(t);
     }
     // ---- self attention ----------------------------------------------------------------------------------------
     RC(wgrad(dx, d, M, d, plain_view(s.sa.o, d), d, c->G(bp.attn.ow), d));
-    RC(launch_colsum_accum(dx, d, M, d, c->G(bp.attn.ob), st));
     RC(dgrad(dx, M, d, c->W(bp.attn.ow), d, nullptr, nullptr, p.go));
     AttnArgs a;
     attn_args(a, s.sa, false, Tq, Tq, causal);
@@ -493,8 +496,8 @@ struct Runner {
     RC(launch_colsum_accum(p.gqkv, 3 * d, M, d, c->G(bp.attn.qb), st));
     RC(launch_colsum_accum(p.gqkv + 2 * d, 3 * d, M, d, c->G(bp.attn.vb), st));
     RC(dgrad(p.gqkv, M, 3 * d, c->W(bp.attn.qw), d, nullptr, nullptr, p.gln));
-    RC(launch_layernorm_bwd(p.gln, s.x_in, c->P(bp.attn_ln_w), s.sa.mean, s.sa.rstd, dx, nxt, c->G(bp.attn_ln_w), c->G(bp.attn_ln_b), M, d,
-                            st));
+    RC(launch_layernorm_bwd(p.gln, s.x_in, c->P(bp.attn_ln_w), s.sa.mean, s.sa.rstd, dx, nxt, c->G(bp.attn_ln_w), c->G(bp.attn_ln_b),
+                            dsum_next, M, d, st));
     *dx_in = nxt;
     return OASR_OK;
   }
@@ -744,8 +747,8 @@ extern "C" int oasr_train_fwd_bwd(oasr_ctx* c, const float* mel, const int64_t* 
   RC(r.wgrad(p.logits, c->Vp, Md, c->V, plain_view(p.lnf, d), d, c->G(c->tok_emb), d));
   RC(r.dgrad(p.logits, Md, c->Vp, c->W(c->tok_emb), d, nullptr, nullptr, p.gln));
   const bf16_t* x_last = c->L_dec ? p.dec[c->L_dec - 1].x_out : p.dx0;
-  RC(launch_layernorm_bwd(p.gln, x_last, c->P(c->dec_ln_w), p.mean_f, p.rstd_f, nullptr, p.ga, c->G(c->dec_ln_w), c->G(c->dec_ln_b), Md, d,
-                          st));
+  RC(launch_layernorm_bwd(p.gln, x_last, c->P(c->dec_ln_w), p.mean_f, p.rstd_f, nullptr, p.ga, c->G(c->dec_ln_w), c->G(c->dec_ln_b),
+                          c->L_dec ? c->G(c->dec[c->L_dec - 1].b2) : nullptr, Md, d, st));
   RC(r.record(ev, seg++));
   const bf16_t* dx = p.ga;
   auto others = [&](const bf16_t* cur, bf16_t** a, bf16_t** b) {  // the two stream-gradient buffers that are not `cur`
@@ -761,7 +764,7 @@ extern "C" int oasr_train_fwd_bwd(oasr_ctx* c, const float* mel, const int64_t* 
     bf16_t *sa, *sb;
     others(dx, &sa, &sb);
     const bf16_t* dx_in = nullptr;
-    RC(r.block_bwd(c->dec[i], p.dec[i], p, dx, sa, sb, Md, S, true, i == c->L_dec - 1, &dx_in));
+    RC(r.block_bwd(c->dec[i], p.dec[i], p, dx, sa, sb, Md, S, true, i == c->L_dec - 1, i > 0 ? c->G(c->dec[i - 1].b2) : nullptr, &dx_in));
     dx = dx_in;
     RC(r.record(ev, seg++));
   }
@@ -772,15 +775,15 @@ extern "C" int oasr_train_fwd_bwd(oasr_ctx* c, const float* mel, const int64_t* 
   // ---------------- backward: encoder ----------------
   const bf16_t* xe_last = c->L_enc ? p.enc[c->L_enc - 1].x_out : p.x0;
   if (c->L_dec == 0) OASR_CHECK_HIP(hipMemsetAsync(p.gxa, 0, (size_t)Me * d * 2, st));
-  RC(launch_layernorm_bwd(p.gxa, xe_last, c->P(c->enc_lnp_w), p.mean_p, p.rstd_p, nullptr, p.ga, c->G(c->enc_lnp_w), c->G(c->enc_lnp_b), Me,
-                          d, st));
+  RC(launch_layernorm_bwd(p.gxa, xe_last, c->P(c->enc_lnp_w), p.mean_p, p.rstd_p, nullptr, p.ga, c->G(c->enc_lnp_w), c->G(c->enc_lnp_b),
+                          c->L_enc ? c->G(c->enc[c->L_enc - 1].b2) : nullptr, Me, d, st));
   RC(r.record(ev, seg++));
   dx = p.ga;
   for (int i = c->L_enc - 1; i >= 0; --i) {
     bf16_t *sa, *sb;
     others(dx, &sa, &sb);
     const bf16_t* dx_in = nullptr;
-    RC(r.block_bwd(c->enc[i], p.enc[i], p, dx, sa, sb, Me, c->Te, false, false, &dx_in));
+    RC(r.block_bwd(c->enc[i], p.enc[i], p, dx, sa, sb, Me, c->Te, false, false, i > 0 ? c->G(c->enc[i - 1].b2) : nullptr, &dx_in));
     dx = dx_in;
     RC(r.record(ev, seg++));
   }

@@ -379,7 +379,7 @@ __device__ __forceinline__ void glds16(const __amdgpu_buffer_rsrc_t rs, char* ds
 }  // namespace
 
 // (external linkage: hipcc 7.2 drops the host-side handle of this instantiation set when it has internal linkage)
-template <bool TA, bool TB, int FBN, int NWN, int NSTAGE, bool SWAP>
+template <bool TA, bool TB, int FBN, int NWN, int NSTAGE, bool SWAP, bool CSUM>
 __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 3 : 2) void oasr_gemm_fast_kernel(GemmArgs p) {
   constexpr int NW = 2 * NWN;                     // waves per workgroup
   constexpr int A_BYTES = FBM * 64 * 2, B_BYTES = FBN * 64 * 2, STAGE = A_BYTES + B_BYTES;
@@ -465,6 +465,7 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 3 : 2) void oasr_gemm_fast_ke
     // pieces scattered over 32 rows.  All LDS is free here: the main loop ended on a barrier.
     char* stg = smem + wave * 8192;  // [0,4K): pre-activation rows, [4K,8K): final rows; 32 rows x 128 B each
     const bool vec_ok = (p.N % 8) == 0 && (p.ldc % 8) == 0;
+    float ctot = 0.f;  // CSUM: this lane's column (n0 + wn*64 + lane) summed over the wave's 128 rows
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       const int m = m0 + wm * 128 + mt * 32 + (lane & 31);
@@ -498,6 +499,14 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 3 : 2) void oasr_gemm_fast_ke
       }
       if (vec_ok) {
         __builtin_amdgcn_wave_barrier();  // wave-private staging: LDS ops of one wave execute in order
+        if (CSUM) {  // fused bias gradient: column sums of the staged (bf16) output rows, valid rows only
+          const int mrow0 = m0 + wm * 128 + mt * 32;
+#pragma unroll
+          for (int r2 = 0; r2 < 32; ++r2) {
+            const bf16_t e = *(const bf16_t*)(stg + 4096 + r2 * 128 + (((lane >> 3) ^ (r2 & 7)) << 4) + (lane & 7) * 2);
+            if (mrow0 + r2 < p.M) ctot += bf2f(e);
+          }
+        }
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
           bf16_t* dst = pass == 0 ? p.out_pre : p.out;
@@ -513,6 +522,10 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 3 : 2) void oasr_gemm_fast_ke
         }
         __builtin_amdgcn_wave_barrier();
       }
+    }
+    if (CSUM) {
+      const int n = n0 + wn * 64 + lane;
+      if (n < p.N) unsafeAtomicAdd(p.colsum + n, ctot);
     }
   } else {
     // D[m][n]: lane owns column n = .. + (lane & 31), rows (r & 3) + 8*(r >> 2) + 4*h.  fp32 atomic accumulate only.
@@ -534,12 +547,12 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 3 : 2) void oasr_gemm_fast_ke
 
 namespace {
 
-template <bool TA, bool TB, int FBN, int NWN, int NSTAGE, bool SWAP>
+template <bool TA, bool TB, int FBN, int NWN, int NSTAGE, bool SWAP, bool CSUM = false>
 int launch_fast_cfg(const GemmArgs& a, hipStream_t stream) {
   static bool attr = false;
   const int lds = NSTAGE * (FBM * 64 * 2 + FBN * 64 * 2);
   if (!attr) {
-    OASR_CHECK_HIP(hipFuncSetAttribute((const void*)oasr_gemm_fast_kernel<TA, TB, FBN, NWN, NSTAGE, SWAP>,
+    OASR_CHECK_HIP(hipFuncSetAttribute((const void*)oasr_gemm_fast_kernel<TA, TB, FBN, NWN, NSTAGE, SWAP, CSUM>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr = true;
   }
@@ -558,7 +571,7 @@ int launch_fast_cfg(const GemmArgs& a, hipStream_t stream) {
     g_prof.recs.push_back({(TA ? 2 : 0) + (TB ? 1 : 0), 2.0 * (double)a.M * (double)a.N * (double)a.K});
     OASR_CHECK_HIP(hipEventRecord(e0, stream));
   }
-  hipLaunchKernelGGL((oasr_gemm_fast_kernel<TA, TB, FBN, NWN, NSTAGE, SWAP>), grid, dim3(128 * NWN), lds, stream, a);
+  hipLaunchKernelGGL((oasr_gemm_fast_kernel<TA, TB, FBN, NWN, NSTAGE, SWAP, CSUM>), grid, dim3(128 * NWN), lds, stream, a);
   OASR_LAUNCH_CHECK();
   if (e1) OASR_CHECK_HIP(hipEventRecord(e1, stream));
   return OASR_OK;
@@ -582,7 +595,15 @@ int launch_fast_t(const GemmArgs& a, hipStream_t stream) {
     if (big) return launch_fast_cfg<TA, TB, 256, 4, 2, false>(a, stream);
     return launch_fast_cfg<TA, TB, 128, 2, 1, false>(a, stream);
   }
-  if (big) return launch_fast_cfg<TA, TB, 256, 4, 2, true>(a, stream);
+  if (big) {
+    const int rc = launch_fast_cfg<TA, TB, 256, 4, 2, true>(a, stream);
+    return (rc || !a.colsum) ? rc : launch_colsum_accum(a.out, a.ldc, a.M, a.N, a.colsum, stream);
+  }
+  if (a.colsum) {
+    if (!TA && TB) return launch_fast_cfg<false, true, 128, 2, 1, true, true>(a, stream);  // dgrad + fused bias gradient
+    const int rc = launch_fast_cfg<TA, TB, 128, 2, 1, true>(a, stream);
+    return rc ? rc : launch_colsum_accum(a.out, a.ldc, a.M, a.N, a.colsum, stream);
+  }
   return launch_fast_cfg<TA, TB, 128, 2, 1, true>(a, stream);
 }
 
@@ -630,6 +651,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   OASR_REQUIRE(a.split_k >= 1, "gemm: split_k");
   OASR_REQUIRE(a.split_k == 1 || (a.atomic && a.out_f32 && !a.out && !a.out_pre), "gemm: split_k > 1 needs atomic fp32 output only");
   OASR_REQUIRE(a.out || a.out_f32 || a.out_pre, "gemm: no output");
+  OASR_REQUIRE(!a.colsum || (a.out && (a.N % 8) == 0 && a.split_k == 1), "gemm: colsum needs a bf16 `out`, N % 8 == 0, split_k == 1");
   const bool fast = !a.A.rpb && !a.B.rpb && (a.K % BK) == 0 && (!a.ta || (a.M % 8) == 0) && (!a.tb || (a.N % 8) == 0) &&
                     a.M >= 8 && a.N >= 8 && !g_force_general;
   if (fast) {
@@ -638,10 +660,13 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     if (a.ta && !a.tb) return launch_fast_t<true, false>(a, stream);
     return launch_fast_t<true, true>(a, stream);
   }
-  if (!a.ta && !a.tb) return launch_t<false, false>(a, stream);
-  if (!a.ta && a.tb) return launch_t<false, true>(a, stream);
-  if (a.ta && !a.tb) return launch_t<true, false>(a, stream);
-  return launch_t<true, true>(a, stream);
+  int rc;
+  if (!a.ta && !a.tb) rc = launch_t<false, false>(a, stream);
+  else if (!a.ta && a.tb) rc = launch_t<false, true>(a, stream);
+  else if (a.ta && !a.tb) rc = launch_t<true, false>(a, stream);
+  else rc = launch_t<true, true>(a, stream);
+  if (rc == OASR_OK && a.colsum) rc = launch_colsum_accum(a.out, a.ldc, a.M, a.N, a.colsum, stream);  // unfused fallback
+  return rc;
 }
 
 void gemm_profile_enable(int on) {

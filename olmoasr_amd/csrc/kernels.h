@@ -45,6 +45,7 @@ struct GemmArgs {
   float* out_f32;
   long ldc32;
   float beta;
+  float* colsum;  // optional [N]: += column sums of the bf16 values stored to `out` (fused bias gradient)
   int atomic;   // out_f32 += v with hardware fp32 atomics (split-K safe)
   int split_k;  // >= 1; > 1 requires atomic out_f32 and no other output
 };
@@ -64,9 +65,10 @@ static inline GemmArgs gemm_defaults() {
 // LayerNorm over the last dim (eps 1e-5, fp32 internals, bf16 in/out; reference model.py:39)
 int launch_layernorm_fwd(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y, float* mean, float* rstd,
                          long rows, int d, hipStream_t s);
-// dx = LN'(dy) (+ dres) ; dgamma/dbeta are ACCUMULATED (atomic fp32) into the grad arena
+// dx = LN'(dy) (+ dres) ; dgamma/dbeta are ACCUMULATED (atomic fp32) into the grad arena; dsum (optional) += column
+// sums of the produced dx (= the bias gradient of the Linear whose output this residual-stream gradient belongs to)
 int launch_layernorm_bwd(const bf16_t* dy, const bf16_t* x, const float* gamma, const float* mean, const float* rstd,
-                         const bf16_t* dres, bf16_t* dx, float* dgamma, float* dbeta, long rows, int d, hipStream_t s);
+                         const bf16_t* dres, bf16_t* dx, float* dgamma, float* dbeta, float* dsum, long rows, int d, hipStream_t s);
 
 // Flash attention over head_dim 64.  Q/K/V are strided views [B, T, H, 64] (row strides in elements);
 // key j visible to query i iff j < kv_len[b] (nullptr -> Tk) and (!causal || j <= i).  scale = 1/8.

@@ -81,11 +81,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const bf16_t* __restrict__ dres,
                                                      bf16_t* __restrict__ dx, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, long rows, int d) {
+                                                     float* __restrict__ dbeta, float* __restrict__ dsum, long rows, int d) {
   __shared__ float red[4][2048];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = d >> 3;
-  float gw[MAXC][8], dg[MAXC][8], db[MAXC][8];
+  float gw[MAXC][8], dg[MAXC][8], db[MAXC][8], dsx[MAXC][8];
 #pragma unroll
   for (int c = 0; c < MAXC; ++c) {
     const int ch = lane + 64 * c;
@@ -93,6 +93,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     for (int i = 0; i < 8; ++i) {
       dg[c][i] = 0.f;
       db[c][i] = 0.f;
+      dsx[c][i] = 0.f;
       gw[c][i] = (ch < nchunk) ? gamma[ch * 8 + i] : 0.f;
     }
   }
@@ -134,22 +135,30 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 #pragma unroll
           for (int i = 0; i < 8; ++i) o[i] = bf_round(o[i]) + rv[i];
         }
-        *(u32x4_t*)(dx + row * d + ch * 8) = pack8(o);
+        const u32x4_t packed = pack8(o);
+        *(u32x4_t*)(dx + row * d + ch * 8) = packed;
+        if (dsum) {  // column sum of the stored (bf16) gradient = bias gradient of the Linear that produced this stream
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            dsx[c][2 * i] += bf_lo(packed[i]);
+            dsx[c][2 * i + 1] += bf_hi(packed[i]);
+          }
+        }
       }
     }
   }
   // block reduction of the column partials, then one atomic per column per block
-  for (int pass = 0; pass < 2; ++pass) {
+  for (int pass = 0; pass < (dsum ? 3 : 2); ++pass) {
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
       const int ch = lane + 64 * c;
       if (ch < nchunk) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) red[wave][ch * 8 + i] = pass == 0 ? dg[c][i] : db[c][i];
+        for (int i = 0; i < 8; ++i) red[wave][ch * 8 + i] = pass == 0 ? dg[c][i] : (pass == 1 ? db[c][i] : dsx[c][i]);
       }
     }
     __syncthreads();
-    float* dst = pass == 0 ? dgamma : dbeta;
+    float* dst = pass == 0 ? dgamma : (pass == 1 ? dbeta : dsum);
     for (int j = threadIdx.x; j < d; j += 256) {
       const float t = red[0][j] + red[1][j] + red[2][j] + red[3][j];
       unsafeAtomicAdd(dst + j, t);
@@ -171,14 +180,14 @@ int launch_layernorm_fwd(const bf16_t* x, const float* gamma, const float* beta,
 }
 
 int launch_layernorm_bwd(const bf16_t* dy, const bf16_t* x, const float* gamma, const float* mean, const float* rstd,
-                         const bf16_t* dres, bf16_t* dx, float* dgamma, float* dbeta, long rows, int d, hipStream_t s) {
+                         const bf16_t* dres, bf16_t* dx, float* dgamma, float* dbeta, float* dsum, long rows, int d, hipStream_t s) {
   OASR_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "layernorm_bwd: null pointer");
   OASR_REQUIRE(d % 8 == 0 && d <= 2048 && d > 0, "layernorm: d=%d must be a multiple of 8 and <= 2048", d);
   if (rows <= 0) return OASR_OK;
   long blocks = (rows + 3) / 4;
   if (blocks > 512) blocks = 512;
   hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta,
-                     rows, d);
+                     dsum, rows, d);
   OASR_LAUNCH_CHECK();
   return OASR_OK;
 }

@@ -44,8 +44,9 @@ def plan_buckets(segments: Sequence[Tuple[int, int]], cap_elems: int) -> List[Tu
 
 class GradReducer:
     def __init__(self, flat_grads: torch.Tensor, segments: Sequence[Tuple[int, int]], bucket_cap_mb: float = 128.0,
-                 group: Optional[dist.ProcessGroup] = None):
+                 group: Optional[dist.ProcessGroup] = None, force: bool = False):
         self.flat = flat_grads
+        self.force = force  # run the collectives even at world_size 1 (single-GPU test of the event/stream path)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.segments = list(segments)
@@ -67,7 +68,7 @@ class GradReducer:
 
     def reduce(self, use_events: bool = True):
         """All-reduce (SUM) every bucket.  With events: bucket k starts as soon as its gradients are final."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         if not self.cuda:
             for off, n, _ in self.buckets:

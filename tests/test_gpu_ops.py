@@ -337,3 +337,16 @@ def test_cross_entropy():
     close(lg[:, :V], lf.grad, rtol=1e-2, atol=1e-7, name="dlogits")
     assert float(lg[:, V:].float().abs().max()) == 0.0
     assert float(lg[::7].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("tb", [False, True])
+def test_gemm_fused_column_sum(tb, gemm_path):
+    """Bias gradient fused into the dgrad epilogue (NN fast path) and its unfused fallback (other layouts / kernels)."""
+    M, N, K = 1000, 384, 256
+    A = rnd(M, K, seed=31)
+    B = rnd(K, N, seed=32, scale=0.1) if tb else rnd(N, K, seed=32, scale=0.1)
+    u = rnd(M, N, seed=33)
+    out = torch.empty(M, N, device=DEV, dtype=BF)
+    cs = torch.full((N,), 0.5, device=DEV)
+    ops().gemm(A, B, M, N, K, tb=tb, dgelu_u=u, out=out, colsum=cs)
+    close(cs, out.float().sum(0) + 0.5, rtol=1e-4, atol=1e-3, name="fused colsum == column sums of the stored output")
