@@ -108,7 +108,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--variant", default="medium")
     ap.add_argument("--per-gpu-batch", type=int, default=256)
-    ap.add_argument("--micro-batch", type=int, default=32)
+    ap.add_argument("--micro-batch", type=int, default=64)
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic.json"),
+                    help="per-symbol HBM bytes per launch from the rocprofv3 PMC passes (scripts/pmc_traffic.py)")
     ap.add_argument("--bucket-mb", type=float, default=128.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -182,6 +184,8 @@ def main():
     found_inf = float(net._opt_stats[1])
 
     # ---- live roofline of the dominant kernel: one more identical step with every GEMM launch bracketed by HIP events
+    # on the launch stream (olmoasr_amd/csrc/gemm.hip); aggregated by kernel SYMBOL so it can be compared line by line
+    # with `rocprofv3 --kernel-trace --stats` of this same command (profiles/).
     roof = None
     if not args.no_profile:
         lib = N.lib()
@@ -190,18 +194,28 @@ def main():
         ms = (ctypes.c_double * 4)()
         fl = (ctypes.c_double * 4)()
         cnt = (ctypes.c_int64 * 4)()
-        N.check(lib.oasr_profile_gemm_collect(ms, fl, cnt), "profile_collect")
+        buf = ctypes.create_string_buffer(16384)
+        N.check(lib.oasr_profile_gemm_collect(ms, fl, cnt, buf, 16384), "profile_collect")
         lib.oasr_profile_gemm(0)
-        names = {0: "gemm_kernel<false,false> (NT: forward)", 1: "gemm_kernel<false,true> (NN: dgrad)",
-                 2: "gemm_kernel<true,false>", 3: "gemm_kernel<true,true> (TN: wgrad)"}
-        per = {names[k]: {"launches": int(cnt[k]), "ms": round(ms[k], 3), "tflops": round(fl[k] / ms[k] / 1e9, 1) if ms[k] > 0 else 0.0}
-               for k in range(4) if cnt[k]}
-        dom = max(range(4), key=lambda k: ms[k])
-        achieved = fl[dom] / ms[dom] / 1e9 if ms[dom] > 0 else 0.0
-        roof = {"bound": "mfma", "kernel": names[dom], "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                "avg_launch_us": round(1000.0 * ms[dom] / max(1, cnt[dom]), 2), "launches_per_step": int(cnt[dom]),
-                "all_gemm_variants": per,
+        sym = {}
+        for line in buf.value.decode().strip().split("\n"):
+            if line:
+                name, n, t, f = line.split("\t")
+                sym[name] = {"launches": int(n), "ms": float(t), "flops": float(f)}
+        dom = max(sym, key=lambda k: sym[k]["ms"])
+        dsym = sym[dom]
+        achieved = dsym["flops"] / dsym["ms"] / 1e9
+        traffic = None
+        if args.traffic_json and os.path.exists(args.traffic_json):  # HBM bytes per launch from the PMC passes (profiles/)
+            traffic = json.load(open(args.traffic_json)).get(dom, {}).get("hbm_bytes_per_launch")
+        layouts = {0: "NT (forward)", 1: "NN (dgrad)", 2: "TN", 3: "TN (wgrad)"}
+        roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                "avg_launch_us": round(1000.0 * dsym["ms"] / dsym["launches"], 2), "launches_per_step": dsym["launches"],
+                "alg_flops_per_launch": round(dsym["flops"] / dsym["launches"], 1),
+                "by_symbol": {k: {"launches": v["launches"], "avg_us": round(1000.0 * v["ms"] / v["launches"], 2),
+                                  "tflops": round(v["flops"] / v["ms"] / 1e9, 1)} for k, v in sorted(sym.items(), key=lambda kv: -kv[1]["ms"])},
+                "by_layout_tflops": {layouts[k]: round(fl[k] / ms[k] / 1e9, 1) for k in range(4) if cnt[k]},
                 "gemm_ms_per_step": round(sum(ms), 2)}
 
     if rank == 0:

@@ -76,7 +76,7 @@ def _declare(lib):
         "oasr_probe_lds_oob": (i32, [vp, vp, vp]),
         "oasr_profile_gemm": (i32, [i32]),
         "oasr_gemm_force_general": (i32, [i32]),
-        "oasr_profile_gemm_collect": (i32, [vp, vp, vp]),
+        "oasr_profile_gemm_collect": (i32, [vp, vp, vp, C.c_char_p, i32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -61,10 +61,10 @@ extern "C" int oasr_gemm_force_general(int on) {
   gemm_force_general(on);
   return OASR_OK;
 }
-extern "C" int oasr_profile_gemm_collect(double* ms4, double* flops4, int64_t* count4) {
+extern "C" int oasr_profile_gemm_collect(double* ms4, double* flops4, int64_t* count4, char* by_symbol, int cap) {
   OASR_REQUIRE(ms4 && flops4 && count4, "profile_collect: null");
   long c[4];
-  int rc = gemm_profile_collect(ms4, flops4, c);
+  int rc = gemm_profile_collect(ms4, flops4, c, by_symbol, cap);
   for (int i = 0; i < 4; ++i) count4[i] = c[i];
   return rc;
 }

@@ -15,6 +15,8 @@
 // consecutive columns of one output row -> 8-byte bf16 / 16-byte fp32 row-contiguous stores.
 #include <stdlib.h>
 
+#include <map>
+#include <string>
 #include <vector>
 
 #include "kernels.h"
@@ -28,6 +30,7 @@ struct GemmProfile {
   struct Rec {
     int kind;
     double flops;
+    const char* name;  // kernel symbol as rocprofv3 prints it (template arguments included)
   };
   std::vector<Rec> recs;
 };
@@ -568,7 +571,10 @@ int launch_fast_cfg(const GemmArgs& a, hipStream_t stream) {
     }
     e0 = g_prof.events[2 * idx];
     e1 = g_prof.events[2 * idx + 1];
-    g_prof.recs.push_back({(TA ? 2 : 0) + (TB ? 1 : 0), 2.0 * (double)a.M * (double)a.N * (double)a.K});
+    auto tf = [](bool b) { return b ? "true" : "false"; };
+    static const std::string name = std::string("oasr_gemm_fast_kernel<") + tf(TA) + ", " + tf(TB) + ", " + std::to_string(FBN) + ", " +
+                                    std::to_string(NWN) + ", " + std::to_string(NSTAGE) + ", " + tf(SWAP) + ", " + tf(CSUM) + ">";
+    g_prof.recs.push_back({(TA ? 2 : 0) + (TB ? 1 : 0), 2.0 * (double)a.M * (double)a.N * (double)a.K, name.c_str()});
     OASR_CHECK_HIP(hipEventRecord(e0, stream));
   }
   hipLaunchKernelGGL((oasr_gemm_fast_kernel<TA, TB, FBN, NWN, NSTAGE, SWAP, CSUM>), grid, dim3(128 * NWN), lds, stream, a);
@@ -630,7 +636,8 @@ int launch_t(const GemmArgs& a, hipStream_t stream) {
     // algorithmic flops: conv windows count their real kernel width, not the zero padding
     const double kk = a.A.rpb ? (double)(a.ta ? a.K : a.A.kvalid) : (double)a.K;
     const double nn = (a.B.rpb && a.tb) ? (double)a.B.kvalid : (double)a.N;
-    g_prof.recs.push_back({(TA ? 2 : 0) + (TB ? 1 : 0), 2.0 * (double)a.M * nn * kk});
+    static const std::string name = std::string("gemm_kernel<") + (TA ? "true" : "false") + ", " + (TB ? "true" : "false") + ">";
+    g_prof.recs.push_back({(TA ? 2 : 0) + (TB ? 1 : 0), 2.0 * (double)a.M * nn * kk, name.c_str()});
     OASR_CHECK_HIP(hipEventRecord(e0, stream));
   }
   hipLaunchKernelGGL((gemm_kernel<TA, TB>), grid, dim3(256), lds, stream, a);
@@ -674,13 +681,20 @@ void gemm_profile_enable(int on) {
   if (on) g_prof.recs.clear();
 }
 
-// Sums elapsed ms / algorithmic flops / launch count per kernel variant (index = 2*ta + tb).  Synchronises.
-int gemm_profile_collect(double ms[4], double flops[4], long count[4]) {
+// Sums elapsed ms / algorithmic flops / launch count per operand layout (index = 2*ta + tb) and, as text
+// "symbol\tlaunches\tms\tflops\n", per kernel symbol (so bench.py can be checked against rocprofv3's per-kernel
+// averages).  Synchronises.
+int gemm_profile_collect(double ms[4], double flops[4], long count[4], char* by_symbol, int cap) {
   for (int i = 0; i < 4; ++i) {
     ms[i] = 0;
     flops[i] = 0;
     count[i] = 0;
   }
+  struct Agg {
+    long n = 0;
+    double ms = 0, flops = 0;
+  };
+  std::map<std::string, Agg> agg;
   for (size_t i = 0; i < g_prof.recs.size(); ++i) {
     OASR_CHECK_HIP(hipEventSynchronize(g_prof.events[2 * i + 1]));
     float t = 0.f;
@@ -689,6 +703,19 @@ int gemm_profile_collect(double ms[4], double flops[4], long count[4]) {
     ms[k] += t;
     flops[k] += g_prof.recs[i].flops;
     count[k] += 1;
+    Agg& a = agg[g_prof.recs[i].name];
+    a.n += 1;
+    a.ms += t;
+    a.flops += g_prof.recs[i].flops;
+  }
+  if (by_symbol && cap > 0) {
+    std::string out;
+    for (auto& kv : agg) {
+      char line[512];
+      snprintf(line, sizeof(line), "%s\t%ld\t%.6f\t%.6e\n", kv.first.c_str(), kv.second.n, kv.second.ms, kv.second.flops);
+      out += line;
+    }
+    snprintf(by_symbol, cap, "%s", out.c_str());
   }
   g_prof.recs.clear();
   return OASR_OK;

@@ -53,7 +53,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream);
 // bench-only: time every GEMM launch with HIP events on its stream; collect() sums per variant (2*ta+tb)
 void gemm_profile_enable(int on);
 void gemm_force_general(int on);  // tests: disable the direct-to-LDS fast path
-int gemm_profile_collect(double ms[4], double flops[4], long count[4]);
+int gemm_profile_collect(double ms[4], double flops[4], long count[4], char* by_symbol, int cap);
 static inline GemmArgs gemm_defaults() {
   GemmArgs g;
   memset(&g, 0, sizeof(g));
