@@ -303,9 +303,17 @@ struct Runner {
     g.atomic = 1;
     const long tiles = (long)cdiv(N, 256) * cdiv(K, 128);
     const long kt = cdiv(M, 64);
-    long split = (512 + tiles - 1) / tiles;  // ~2 workgroups per CU; every extra split costs a full atomic epilogue
-    if (split > kt / 8) split = kt / 8;
-    if (split < 1) split = 1;
+    // ~2-3 workgroups per CU; a multiple of 8 so every XCD owns whole K-ranges (L2 locality, see gemm.hip); every
+    // extra split costs one more atomic epilogue per tile.
+    long split = (512 + tiles - 1) / tiles;
+    if (split >= 4) {
+      split = (split + 7) / 8 * 8;
+      while (split > 8 && split > kt / 8) split -= 8;
+      if (split > kt / 2) split = 1;
+    } else {
+      split = split > kt / 8 ? 1 : split;
+      if (split < 1) split = 1;
+    }
     g.split_k = (int)split;
     return launch_gemm(g, st);
   }

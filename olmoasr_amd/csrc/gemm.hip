@@ -392,20 +392,42 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 3 : 2) void oasr_gemm_fast_ke
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / NWN, wn = wave % NWN;
   const int tiles_m = (p.M + FBM - 1) / FBM, tiles_n = (p.N + FBN - 1) / FBN;
-  // XCD-aware + grouped rasterisation: each XCD walks 8(m) x tiles_n(n) super-rows column by column, so the
-  // workgroups resident on one XCD cover a compact block of tiles and share A/B panels through that XCD's L2.
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  constexpr int GM = 8;
-  const int per_group = GM * tiles_n;
-  const int group = bid / per_group, in_group = bid - group * per_group;
-  const int first_m = group * GM;
-  const int gsz = min(GM, tiles_m - first_m);
-  const int tm = first_m + in_group % gsz, tn = in_group / gsz;
+  // Rasterisation (speed only; any mapping is correct).  Block b runs on XCD b % 8, each XCD has a private 4 MiB L2.
+  //  * split-K (SWAP == false, wgrad): the K-range index is tied to the XCD -- XCD x owns splits [x*S/8, (x+1)*S/8) for
+  //    every output tile, walking all tiles of one split before the next.  The token slab a split streams is then
+  //    fetched from HBM by exactly one L2 and shared by all concurrently running tiles (instead of once per XCD).
+  //  * otherwise: XCD-contiguous chunks of the tile list, grouped GM rows of tiles x all column tiles with GM chosen so
+  //    one group is resident on the XCD at once: the group's A panels stream through L2 once while every column tile
+  //    consumes them, weights (small) are re-read from L2/MALL.
+  int tm, tn, ksplit;
+  {
+    const int ntile = tiles_m * tiles_n;
+    if (!SWAP && (p.split_k & 7) == 0 && gridDim.y == 1) {
+      const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;  // j-th block dispatched to this XCD
+      const int s8 = p.split_k >> 3;
+      const int t = j % ntile;
+      ksplit = xcd * s8 + j / ntile;
+      tm = t / tiles_n;
+      tn = t - tm * tiles_n;
+    } else {
+      const int bid = xcd_remap(blockIdx.x, gridDim.x);
+      constexpr int RESIDENT = 32 * (NWN == 2 ? 3 : 1);  // workgroups resident per XCD
+      int gm = p.raster_gm > 0 ? p.raster_gm : RESIDENT / tiles_n;
+      gm = gm < 1 ? 1 : (gm > 16 ? 16 : gm);
+      const int per_group = gm * tiles_n;
+      const int group = bid / per_group, in_group = bid - group * per_group;
+      const int first_m = group * gm;
+      const int gsz = min(gm, tiles_m - first_m);
+      tm = first_m + in_group % gsz;
+      tn = in_group / gsz;
+      ksplit = blockIdx.y;
+    }
+  }
   const int m0 = tm * FBM, n0 = tn * FBN;
 
   const int kt_total = p.K / BK;
   const int per = (kt_total + p.split_k - 1) / p.split_k;
-  const int kt0 = blockIdx.y * per;
+  const int kt0 = ksplit * per;
   const int kt1 = min(kt_total, kt0 + per);
   if (kt0 >= kt1) return;
 
@@ -561,6 +583,7 @@ int launch_fast_cfg(const GemmArgs& a, hipStream_t stream) {
   }
   const int tiles = cdiv(a.M, FBM) * cdiv(a.N, FBN);
   dim3 grid(tiles, a.split_k);
+  if (!SWAP && (a.split_k & 7) == 0) grid = dim3(tiles * a.split_k, 1);  // split index tied to the XCD (see kernel)
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (g_prof.on) {
     const size_t idx = g_prof.recs.size();
@@ -659,6 +682,15 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   OASR_REQUIRE(a.split_k == 1 || (a.atomic && a.out_f32 && !a.out && !a.out_pre), "gemm: split_k > 1 needs atomic fp32 output only");
   OASR_REQUIRE(a.out || a.out_f32 || a.out_pre, "gemm: no output");
   OASR_REQUIRE(!a.colsum || (a.out && (a.N % 8) == 0 && a.split_k == 1), "gemm: colsum needs a bf16 `out`, N % 8 == 0, split_k == 1");
+  static const int env_gm = [] {
+    const char* e = getenv("OASR_GEMM_GM");
+    return e ? atoi(e) : 0;
+  }();
+  if (a.raster_gm == 0 && env_gm > 0) {
+    GemmArgs b = a;
+    b.raster_gm = env_gm;
+    return launch_gemm(b, stream);
+  }
   const bool fast = !a.A.rpb && !a.B.rpb && (a.K % BK) == 0 && (!a.ta || (a.M % 8) == 0) && (!a.tb || (a.N % 8) == 0) &&
                     a.M >= 8 && a.N >= 8 && !g_force_general;
   if (fast) {

@@ -48,6 +48,7 @@ struct GemmArgs {
   float* colsum;  // optional [N]: += column sums of the bf16 values stored to `out` (fused bias gradient)
   int atomic;   // out_f32 += v with hardware fp32 atomics (split-K safe)
   int split_k;  // >= 1; > 1 requires atomic out_f32 and no other output
+  int raster_gm;  // fast path: tile rows per L2 group (0 = choose from residency)
 };
 int launch_gemm(const GemmArgs& a, hipStream_t stream);
 // bench-only: time every GEMM launch with HIP events on its stream; collect() sums per variant (2*ta+tb)

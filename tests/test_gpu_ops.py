@@ -179,6 +179,10 @@ def test_gemm_wgrad_shape(gemm_path):
     dW = torch.zeros(N, K, device=DEV)
     ops().gemm(dY, X, N, K, Mtok, ta=True, tb=True, out_f32=dW, atomic=True, split_k=4)
     close(dW, dY.float().t() @ X.float(), rtol=1e-3, atol=1e-2, name="wgrad")
+    for split in (8, 16):  # multiples of 8 take the XCD-owned K-range mapping
+        dW.zero_()
+        ops().gemm(dY, X, N, K, Mtok, ta=True, tb=True, out_f32=dW, atomic=True, split_k=split)
+        close(dW, dY.float().t() @ X.float(), rtol=1e-3, atol=1e-2, name=f"wgrad split {split}")
 
 
 @pytest.mark.parametrize("which", ["conv1", "conv2"])
