@@ -44,7 +44,9 @@ int oasr_log_mel(const void* pcm, int pcm_dtype, int B, int n_samples, float* me
 int oasr_mel_filterbank(float* out_host);
 
 /* ---- model context: olmoasr.model.OLMoASR(dims) (olmoasr/model.py:778-813) -------------------------------------------- */
-oasr_ctx* oasr_create(const oasr_dims* dims);
+oasr_ctx* oasr_create(const oasr_dims* dims); /* training model: n_vocab + 1 embedding rows (pad row, model.py:665-667) */
+/* embed_rows = n_vocab selects olmoasr.inf_model.OLMoASR's layout (inf_model.py:302; scripts/eval/gen_inf_ckpt.py) */
+oasr_ctx* oasr_create_ex(const oasr_dims* dims, int embed_rows);
 void oasr_destroy(oasr_ctx*);
 
 /* Parameter table: one flat fp32 arena in gradient-ready (reverse-backward) order; the Python modules expose
@@ -74,6 +76,13 @@ size_t oasr_workspace_bytes(const oasr_ctx*, int B, int S, int mode);
  * NULL = no padding mask (causal only).  logits_out f32 [B,S,n_vocab+1] (or NULL); xa_out bf16 [B,n_audio_ctx,d] (or NULL). */
 int oasr_forward(oasr_ctx*, const float* mel, const int64_t* tokens, const int32_t* text_len, int B, int S, float* logits_out,
                  void* xa_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* OLMoASR.embed_audio(mel) (model.py:815): xa_out bf16 [B, n_audio_ctx, d]. */
+int oasr_encode(oasr_ctx*, const float* mel, int B, void* xa_out, void* workspace, size_t workspace_bytes, void* stream);
+/* OLMoASR.logits(tokens, audio_features) (model.py:818-854): decoder on given xa.  last_only != 0 -> logits_out f32
+ * [B, rows] of position S-1 only (the greedy step of whisper.decoding / notebooks/ow_decoding.py:50-72). */
+int oasr_decode_logits(oasr_ctx*, const int64_t* tokens, const void* xa, const int32_t* text_len, int B, int S, int last_only,
+                       float* logits_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* One micro-step of train() (train_timestamps.py:1440-1454): forward, CE(ignore_index=pad)/accum, backward.
  * Gradients of the loss scaled by loss_scale are ACCUMULATED into the bound grad arena (zero it with oasr_zero_grad

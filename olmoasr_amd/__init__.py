@@ -15,7 +15,10 @@ def __getattr__(name):
     if name == "OLMoASR":
         from .model import OLMoASR
         return OLMoASR
-    if name in ("model", "audio", "ddp", "ops", "synth"):
+    if name in ("load_model", "gen_inf_ckpt", "MODEL2LINK"):
+        from . import hub
+        return getattr(hub, name)
+    if name in ("model", "audio", "ddp", "ops", "synth", "decoding", "transcribe", "hub"):
         import importlib
         return importlib.import_module(f"{__name__}.{name}")
     raise AttributeError(name)

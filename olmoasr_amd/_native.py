@@ -50,6 +50,9 @@ def _declare(lib):
         "oasr_log_mel": (i32, [vp, i32, i32, i32, vp, vp, vp]),
         "oasr_mel_filterbank": (i32, [vp]),
         "oasr_create": (vp, [C.POINTER(Dims)]),
+        "oasr_create_ex": (vp, [C.POINTER(Dims), i32]),
+        "oasr_encode": (i32, [vp, vp, i32, vp, vp, sz, vp]),
+        "oasr_decode_logits": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, sz, vp]),
         "oasr_destroy": (None, [vp]),
         "oasr_param_count": (i32, [vp]),
         "oasr_param_info": (i32, [vp, i32, C.c_char_p, i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(i32), C.POINTER(i64)]),

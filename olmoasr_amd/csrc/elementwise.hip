@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void mel_tm_kernel(const float* __restrict__ m
 
 __global__ __launch_bounds__(256) void embedding_fwd_kernel(const int64_t* __restrict__ tok, const float* __restrict__ E,
                                                             const float* __restrict__ pos, bf16_t* __restrict__ x, int S, int d,
-                                                            long rows) {
+                                                            long rows, long n_embed) {
   const int cpr = d >> 3;  // 8-element chunks per row
   const long total = rows * cpr;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -95,7 +95,11 @@ __global__ __launch_bounds__(256) void embedding_fwd_kernel(const int64_t* __res
     const int ch = (int)(i - r * cpr);
     const long t = tok[r];
     const int s = (int)(r % S);
-    const f32x4_t a0 = *(const f32x4_t*)(E + t * d + ch * 8), a1 = *(const f32x4_t*)(E + t * d + ch * 8 + 4);
+    // ids outside the table (nn.Embedding would raise; e.g. the pad id fed to the pad-row-less inference model) read as
+    // a zero row instead of out-of-bounds memory
+    const bool ok = t >= 0 && t < n_embed;
+    const f32x4_t z4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4_t a0 = ok ? *(const f32x4_t*)(E + t * d + ch * 8) : z4, a1 = ok ? *(const f32x4_t*)(E + t * d + ch * 8 + 4) : z4;
     const f32x4_t p0 = *(const f32x4_t*)(pos + (long)s * d + ch * 8), p1 = *(const f32x4_t*)(pos + (long)s * d + ch * 8 + 4);
     u32x4_t o;
     o[0] = pack_bf2(a0[0] + p0[0], a0[1] + p0[1]);
@@ -225,10 +229,11 @@ int launch_mel_to_time_major(const float* mel, bf16_t* out, int B, int n_mels, i
   OASR_LAUNCH_CHECK();
   return OASR_OK;
 }
-int launch_embedding_fwd(const int64_t* tok, const float* E, const float* pos, bf16_t* x, int B, int S, int d, hipStream_t s) {
+int launch_embedding_fwd(const int64_t* tok, const float* E, const float* pos, bf16_t* x, int B, int S, int d, long n_embed,
+                         hipStream_t s) {
   OASR_REQUIRE(tok && E && pos && x && d % 8 == 0, "embedding_fwd: bad args");
   const long rows = (long)B * S;
-  hipLaunchKernelGGL(embedding_fwd_kernel, dim3(grid_for(rows * (d / 8))), dim3(256), 0, s, tok, E, pos, x, S, d, rows);
+  hipLaunchKernelGGL(embedding_fwd_kernel, dim3(grid_for(rows * (d / 8))), dim3(256), 0, s, tok, E, pos, x, S, d, rows, n_embed);
   OASR_LAUNCH_CHECK();
   return OASR_OK;
 }

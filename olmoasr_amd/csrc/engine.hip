@@ -426,16 +426,27 @@ struct Runner {
     return OASR_OK;
   }
 
-  int decoder_fwd(Plan& p, const int64_t* tokens) {
+  int decoder_fwd(Plan& p, const int64_t* tokens, bool last_only = false) {
     const int d = c->d;
     const long Md = (long)B * S;
-    RC(launch_embedding_fwd(tokens, c->P(c->tok_emb), c->P(c->dec_pos), p.dx0, B, S, d, st));
+    RC(launch_embedding_fwd(tokens, c->P(c->tok_emb), c->P(c->dec_pos), p.dx0, B, S, d, c->V, st));
     const bf16_t* x = p.dx0;
     for (int i = 0; i < c->L_dec; ++i) {
       RC(block_fwd(c->dec[i], p.dec[i], x, Md, S, p.xa, true));
       x = p.dec[i].x_out;
     }
     RC(launch_layernorm_fwd(x, c->P(c->dec_ln_w), c->P(c->dec_ln_b), p.lnf, p.mean_f, p.rstd_f, Md, d, st));
+    if (last_only) {  // greedy decoding only needs position S-1 of every sequence: M = B rows, row stride S*d
+      GemmArgs g = gemm_defaults();
+      g.A = plain_view(p.lnf + (long)(S - 1) * d, (long)S * d);
+      g.B = plain_view(c->W(c->tok_emb), d);
+      g.M = B;
+      g.N = c->Vp;
+      g.K = d;
+      g.out = p.logits;
+      g.ldc = c->Vp;
+      return launch_gemm(g, st);
+    }
     RC(linear(p.lnf, Md, d, c->W(c->tok_emb), c->Vp, nullptr, 0, nullptr, p.logits, nullptr));
     return OASR_OK;
   }
@@ -560,9 +571,18 @@ int check_bound(const oasr_ctx* c, bool need_grads) {
 }  // namespace
 
 // ================================================ C ABI ============================================================
-extern "C" oasr_ctx* oasr_create(const oasr_dims* dm) {
+extern "C" oasr_ctx* oasr_create_ex(const oasr_dims* dm, int embed_rows);
+extern "C" oasr_ctx* oasr_create(const oasr_dims* dm) { return oasr_create_ex(dm, dm ? dm->n_vocab + 1 : 0); }
+
+// embed_rows: rows of decoder.token_embedding -- n_vocab + 1 for the training model (pad row, olmoasr/model.py:665-667),
+// n_vocab for the inference model (olmoasr/inf_model.py:302; checkpoints written by scripts/eval/gen_inf_ckpt.py)
+extern "C" oasr_ctx* oasr_create_ex(const oasr_dims* dm, int embed_rows) {
   if (!dm) {
     oasr_set_error("oasr_create: null dims");
+    return nullptr;
+  }
+  if (embed_rows != dm->n_vocab && embed_rows != dm->n_vocab + 1) {
+    oasr_set_error("oasr_create_ex: embed_rows must be n_vocab or n_vocab + 1");
     return nullptr;
   }
   const int d = dm->n_audio_state;
@@ -580,7 +600,7 @@ extern "C" oasr_ctx* oasr_create(const oasr_dims* dm) {
   c->Te = dm->n_audio_ctx;
   c->T1 = 2 * dm->n_audio_ctx;
   c->S_max = dm->n_text_ctx;
-  c->V = dm->n_vocab + 1;  // training model carries the pad row (olmoasr/model.py:665-667)
+  c->V = embed_rows;
   c->Vp = (c->V + 127) / 128 * 128;
   c->aux_floats = 0;
   Builder b{c};
@@ -718,6 +738,36 @@ extern "C" int oasr_forward(oasr_ctx* c, const float* mel, const int64_t* tokens
     OASR_CHECK_HIP(hipMemcpyAsync(xa_out, p.xa, (size_t)B * c->Te * c->d * 2, hipMemcpyDeviceToDevice, r.st));
   if (logits_out) RC(write_logits_f32(p.logits, c->Vp, (long)B * S, c->V, logits_out, r.st));
   return OASR_OK;
+}
+
+// AudioEncoder.forward (olmoasr/model.py:571-623): mel -> xa bf16 [B, n_audio_ctx, d]
+extern "C" int oasr_encode(oasr_ctx* c, const float* mel, int B, void* xa_out, void* workspace, size_t workspace_bytes, void* stream) {
+  RC(check_bound(c, false));
+  OASR_REQUIRE(mel && xa_out && workspace && B > 0, "oasr_encode: bad args");
+  OASR_REQUIRE(workspace_bytes >= oasr_workspace_bytes(c, B, 1, OASR_MODE_INFER), "oasr_encode: workspace too small");
+  Arena A(workspace, workspace_bytes);
+  Plan p;
+  make_plan(c, A, p, B, 1, false);
+  Runner r{c, (hipStream_t)stream, B, 1, nullptr};
+  RC(r.encoder_fwd(p, mel));
+  OASR_CHECK_HIP(hipMemcpyAsync(xa_out, p.xa, (size_t)B * c->Te * c->d * 2, hipMemcpyDeviceToDevice, r.st));
+  return OASR_OK;
+}
+
+// TextDecoder.forward without kv_cache (olmoasr/model.py:688-775) on given audio features: OLMoASR.logits(tokens, xa).
+// last_only != 0: logits_out is f32 [B, rows] for position S-1 only (greedy decode step); else f32 [B, S, rows].
+extern "C" int oasr_decode_logits(oasr_ctx* c, const int64_t* tokens, const void* xa, const int32_t* text_len, int B, int S,
+                                  int last_only, float* logits_out, void* workspace, size_t workspace_bytes, void* stream) {
+  RC(check_bound(c, false));
+  OASR_REQUIRE(tokens && xa && logits_out && workspace && B > 0 && S > 0 && S <= c->S_max, "oasr_decode_logits: bad args");
+  OASR_REQUIRE(workspace_bytes >= oasr_workspace_bytes(c, B, S, OASR_MODE_INFER), "oasr_decode_logits: workspace too small");
+  Arena A(workspace, workspace_bytes);
+  Plan p;
+  make_plan(c, A, p, B, S, false);
+  Runner r{c, (hipStream_t)stream, B, S, text_len};
+  OASR_CHECK_HIP(hipMemcpyAsync(p.xa, xa, (size_t)B * c->Te * c->d * 2, hipMemcpyDeviceToDevice, r.st));
+  RC(r.decoder_fwd(p, tokens, last_only != 0));
+  return write_logits_f32(p.logits, c->Vp, last_only ? (long)B : (long)B * S, c->V, logits_out, r.st);
 }
 
 extern "C" int oasr_zero_grad(oasr_ctx* c, void* stream) {

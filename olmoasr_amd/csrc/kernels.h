@@ -102,7 +102,8 @@ int launch_pack_embedding(const float* e, bf16_t* dst, int rows, int rows_pad, i
 // mel f32 [B][80][T] -> bf16 time-major [B][T][80]
 int launch_mel_to_time_major(const float* mel, bf16_t* out, int B, int n_mels, int T, hipStream_t s);
 // x[b,s,:] = bf16(E[tok[b,s]] + pos[s])
-int launch_embedding_fwd(const int64_t* tok, const float* E, const float* pos, bf16_t* x, int B, int S, int d, hipStream_t s);
+int launch_embedding_fwd(const int64_t* tok, const float* E, const float* pos, bf16_t* x, int B, int S, int d, long n_embed,
+                         hipStream_t s);
 // dE[tok] += dx (skipping pad_id), dpos[s] += sum_b dx
 int launch_embedding_bwd(const int64_t* tok, const bf16_t* dx, float* dE, float* dpos, int B, int S, int d, long pad_id,
                          hipStream_t s);

@@ -114,9 +114,9 @@ class AudioEncoder(_ParamModule):
 
 
 class TextDecoder(_ParamModule):
-    def __init__(self, n_vocab: int, n_ctx: int, n_state: int, n_head: int, n_layer: int):
+    def __init__(self, n_vocab: int, n_ctx: int, n_state: int, n_head: int, n_layer: int, pad_row: bool = True):
         super().__init__()
-        self.token_embedding = Embedding(n_vocab + 1, n_state, padding_idx=51864 if n_vocab == 51864 else 51865)
+        self.token_embedding = Embedding(n_vocab + (1 if pad_row else 0), n_state, padding_idx=51864 if n_vocab == 51864 else 51865)
         self.blocks = nn.ModuleList([ResidualAttentionBlock(n_state, n_head, cross_attention=True) for _ in range(n_layer)])
         self.ln = LayerNorm(n_state)
 
@@ -145,9 +145,12 @@ _FAN_IN_OF_BIAS = {}
 class OLMoASR(nn.Module):
     """MI355X-native ``olmoasr.model.OLMoASR`` (reference model.py:778-968)."""
 
-    def __init__(self, dims: ModelDimensions, device=None, seed: Optional[int] = None):
+    def __init__(self, dims: ModelDimensions, device=None, seed: Optional[int] = None, inference: bool = False):
+        """``inference=True`` gives the layout of the reference's ``olmoasr.inf_model.OLMoASR`` (token embedding with
+        n_vocab rows, no pad row: inf_model.py:302), i.e. what ``load_model(..., inference=True)`` builds."""
         super().__init__()
         lib = N.lib()
+        self.inference = inference
         if device is None:
             device = "cuda"
         device = torch.device(device)
@@ -155,9 +158,11 @@ class OLMoASR(nn.Module):
             raise N.NativeError("olmoasr_amd.model.OLMoASR needs a HIP device (MI355X); there is no CPU fallback")
         self.dims = dims
         self.encoder = AudioEncoder(dims.n_mels, dims.n_audio_ctx, dims.n_audio_state, dims.n_audio_head, dims.n_audio_layer)
-        self.decoder = TextDecoder(dims.n_vocab, dims.n_text_ctx, dims.n_text_state, dims.n_text_head, dims.n_text_layer)
+        self.decoder = TextDecoder(dims.n_vocab, dims.n_text_ctx, dims.n_text_state, dims.n_text_head, dims.n_text_layer,
+                                   pad_row=not inference)
         cd = N.Dims(*[getattr(dims, f[0]) for f in N.Dims._fields_])
-        self._ctx = lib.oasr_create(C.byref(cd))
+        self._n_rows = dims.n_vocab + (0 if inference else 1)
+        self._ctx = lib.oasr_create_ex(C.byref(cd), self._n_rows)
         if not self._ctx:
             raise N.NativeError("oasr_create: " + lib.oasr_last_error().decode())
         self._numel = lib.oasr_param_numel(self._ctx)
@@ -303,7 +308,7 @@ class OLMoASR(nn.Module):
         mel = mel.float().contiguous()
         tokens = tokens.to(torch.int64).contiguous()
         ws = self._ws(B, S, 0)
-        logits = torch.empty(B, S, self.dims.n_vocab + 1, device=mel.device, dtype=torch.float32) if want_logits else None
+        logits = torch.empty(B, S, self._n_rows, device=mel.device, dtype=torch.float32) if want_logits else None
         xa = torch.empty(B, self.dims.n_audio_ctx, self.dims.n_audio_state, device=mel.device, dtype=torch.bfloat16) if want_xa else None
         with torch.cuda.device(mel.device):
             N.check(N.lib().oasr_forward(self._ctx, N.ptr(mel), N.ptr(tokens), N.ptr(text_len), B, S, N.ptr(logits), N.ptr(xa),
@@ -322,14 +327,50 @@ class OLMoASR(nn.Module):
 
     @torch.no_grad()
     def embed_audio(self, mel: Tensor) -> Tensor:
+        """AudioEncoder forward (reference model.py:815): bf16 [B, n_audio_ctx, n_audio_state]."""
+        N.require_gpu(mel, "mel")
         B = mel.shape[0]
-        tok = torch.zeros(B, 1, dtype=torch.int64, device=mel.device)
-        return self._forward_impl(mel, tok, None, want_logits=False, want_xa=True)[1]
+        assert mel.shape[1:] == (self.dims.n_mels, 2 * self.dims.n_audio_ctx), "incorrect audio shape"
+        mel = mel.float().contiguous()
+        ws = self._ws(B, 1, 0)
+        xa = torch.empty(B, self.dims.n_audio_ctx, self.dims.n_audio_state, device=mel.device, dtype=torch.bfloat16)
+        with torch.cuda.device(mel.device):
+            N.check(N.lib().oasr_encode(self._ctx, N.ptr(mel), B, N.ptr(xa), N.ptr(ws), ws.numel(), N.stream_ptr()), "oasr_encode")
+        return xa
 
     @torch.no_grad()
-    def logits(self, tokens: Tensor, audio_features: Tensor, padding_mask: Tensor = None):
-        raise N.NativeError("OLMoASR.logits(tokens, audio_features) needs the decoder-only entry point (next round); "
-                            "use forward(mel, tokens, padding_mask)")
+    def logits(self, tokens: Tensor, audio_features: Tensor, padding_mask: Tensor = None, last_only: bool = False):
+        """TextDecoder forward on given audio features (reference model.py:818-854).  fp32 [B, S, rows], or [B, rows] for
+        the last position only (``last_only`` -- the greedy decoding step)."""
+        N.require_gpu(tokens, "tokens")
+        N.require_gpu(audio_features, "audio_features")
+        B, S = tokens.shape
+        xa = audio_features.to(torch.bfloat16).contiguous()
+        assert xa.shape == (B, self.dims.n_audio_ctx, self.dims.n_audio_state)
+        tokens = tokens.to(torch.int64).contiguous()
+        text_len = None
+        if padding_mask is not None:
+            text_len = padding_mask.to(torch.int32) if padding_mask.dim() == 1 else self._text_len_from_mask(padding_mask)
+            text_len = text_len.to(tokens.device).contiguous()
+        ws = self._ws(B, S, 0)
+        shape = (B, self._n_rows) if last_only else (B, S, self._n_rows)
+        out = torch.empty(*shape, device=tokens.device, dtype=torch.float32)
+        with torch.cuda.device(tokens.device):
+            N.check(N.lib().oasr_decode_logits(self._ctx, N.ptr(tokens), N.ptr(xa), N.ptr(text_len), B, S, int(last_only), N.ptr(out),
+                                               N.ptr(ws), ws.numel(), N.stream_ptr()), "oasr_decode_logits")
+        return out
+
+    @torch.no_grad()
+    def decode(self, mel: Tensor, options=None, **kwargs):
+        """Greedy decoding (temperature 0) of a batch of 30 s windows -- see olmoasr_amd/decoding.py."""
+        from .decoding import decode as _decode
+        return _decode(self, mel, options, **kwargs)
+
+    @torch.no_grad()
+    def transcribe(self, audio, **kwargs):
+        """Long-form sliding-window driver -- see olmoasr_amd/transcribe.py."""
+        from .transcribe import transcribe as _transcribe
+        return _transcribe(self, audio, **kwargs)
 
     @property
     def device(self):

@@ -252,3 +252,67 @@ def test_bucketed_reducer_events_single_gpu(native_tiny, tiny_case):
     finally:
         if own_pg:
             dist.destroy_process_group()
+
+
+def test_inference_model_decode_and_transcribe(tmp_path, tiny_case):
+    """Inference layout (no pad row) + load_model + greedy decode() + long-form transcribe() against the oracle's
+    cache-less greedy loop on the same weights."""
+    import olmoasr_amd
+    from olmoasr_amd import hub
+    from olmoasr_amd.decoding import greedy_token_matrix
+    from olmoasr_amd.model import OLMoASR
+    from oracle import mel_oracle as me
+    from oracle import model_oracle as mo
+    dims = mo.Dims(80, 1500, 384, 6, 2, 51864, 448, 384, 6, 2)
+    sd = mo.init_state_dict(dims, seed=5)
+    # make the head confident so greedy ids are decided by margins far above bf16 noise: boost one token per position
+    ck_train = {"model_state_dict": {"module." + k: v for k, v in sd.items()}, "dims": _dims(dims)}
+    p_train = tmp_path / "train_ddp.pt"
+    torch.save(ck_train, p_train)
+    ck_inf = hub.gen_inf_ckpt(ck_train)
+    assert ck_inf["model_state_dict"]["decoder.token_embedding.weight"].shape[0] == 51864 and isinstance(ck_inf["dims"], dict)
+    p_inf = tmp_path / "inf.pt"
+    torch.save(ck_inf, p_inf)
+    net = olmoasr_amd.load_model(str(p_inf), device=DEV, inference=True)
+    assert net.inference and net.decoder.token_embedding.weight.shape[0] == 51864
+    net_t = olmoasr_amd.load_model(str(p_train), device=DEV)  # DDP-prefixed training checkpoint
+    assert net_t.decoder.token_embedding.weight.shape[0] == 51865
+    c = tiny_case
+    mel = c["mel"].to(DEV)
+    # logits(tokens, embed_audio(mel)) == forward(mel, tokens); inference head == training head on the shared rows
+    xa = net.embed_audio(mel)
+    lg_inf = net.logits(c["tokens"].to(DEV)[:, :7], xa)
+    lg_fwd = net(mel, c["tokens"].to(DEV)[:, :7])
+    assert torch.equal(lg_inf, lg_fwd) and lg_inf.shape == (2, 7, 51864)
+    lg_train = net_t(mel, c["tokens"].to(DEV)[:, :7])
+    dd = (lg_train[..., :51864] - lg_inf).abs()
+    print("train-head vs inference-head logits: max abs diff", float(dd.max()), "n differing", int((dd > 0).sum()))
+    assert torch.equal(lg_train[..., :51864], lg_inf)
+    last = net.logits(c["tokens"].to(DEV)[:, :7], xa, last_only=True)
+    assert torch.equal(last, lg_inf[:, -1])
+    # greedy decode vs the oracle loop, compared where the oracle's own top-2 margin clears the bf16 envelope
+    sd_inf = {k: v for k, v in ck_inf["model_state_dict"].items()}
+    xa_cpu = mo.encoder_forward(sd_inf, dims, c["mel"])
+    toks = greedy_token_matrix(net, mel, max_new=6)
+    ref = mo.greedy_decode(sd_inf, dims, c["mel"], [50257, 50362], max_new=6)
+    agree = 0
+    for b in range(2):
+        for t in range(2, min(toks.shape[1], ref.shape[1])):
+            if not torch.equal(toks[b, :t].cpu(), ref[b, :t]):
+                break
+            lgc = mo.decoder_forward(sd_inf, dims, ref[b:b + 1, :t], xa_cpu[b:b + 1])[0, -1, :51864]
+            top2 = lgc.topk(2).values
+            if float(top2[0] - top2[1]) > 0.15:
+                assert int(toks[b, t]) == int(ref[b, t])
+                agree += 1
+    res = net.decode(mel)
+    assert len(res) == 2 and all(isinstance(r.tokens, list) for r in res) and all(r.avg_logprob <= 0 for r in res)
+    # long-form driver: 70 s of audio -> 3 windows of 30 s, every window decoded, seek advances by 3000 frames
+    pcm = torch.cat([mo.synthetic_sample(200 + i)[0] for i in range(3)])[: 70 * 16000]
+    out = net.transcribe(pcm, sample_len=3)
+    assert [s["seek"] for s in out["segments"]] == [0, 3000, 6000] and out["segments"][-1]["end"] == 70.0
+    assert len(out["tokens"]) == sum(len(s["tokens"]) for s in out["segments"])
+    # window 0 of the long file == decoding the first 30 s alone
+    mel0 = olmoasr_amd.log_mel_spectrogram(pcm[:480000])
+    r0 = net.decode(mel0, sample_len=3)
+    print("greedy positions checked:", agree, "window0", out["segments"][0]["tokens"], r0.tokens)
