@@ -84,6 +84,16 @@ int oasr_encode(oasr_ctx*, const float* mel, int B, void* xa_out, void* workspac
 int oasr_decode_logits(oasr_ctx*, const int64_t* tokens, const void* xa, const int32_t* text_len, int B, int S, int last_only,
                        float* logits_out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Cached greedy decoding = the reference's install_kv_cache_hooks (model.py:925-964 / inf_model.py:422-453) + one
+ * TextDecoder step per token.  kv_cache: oasr_kv_cache_bytes(B) bytes, caller owned, valid for one 30 s window batch.
+ * decode_begin computes the cross-attention K/V of every layer from xa (bf16 [B, n_audio_ctx, d]); decode_step consumes
+ * the token at position `pos` of each sequence (tokens_last i64 [B]) and returns f32 logits [B, rows] for position pos+1. */
+size_t oasr_kv_cache_bytes(const oasr_ctx*, int B);
+size_t oasr_decode_step_workspace_bytes(const oasr_ctx*, int B);
+int oasr_decode_begin(oasr_ctx*, const void* xa, int B, void* kv_cache, void* stream);
+int oasr_decode_step(oasr_ctx*, const int64_t* tokens_last, int B, int pos, void* kv_cache, float* logits_out, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
 /* One micro-step of train() (train_timestamps.py:1440-1454): forward, CE(ignore_index=pad)/accum, backward.
  * Gradients of the loss scaled by loss_scale are ACCUMULATED into the bound grad arena (zero it with oasr_zero_grad
  * at the start of an accumulation window).  loss_out (device f32): unscaled loss/accum, overwritten or accumulated.

@@ -52,6 +52,10 @@ def _declare(lib):
         "oasr_create": (vp, [C.POINTER(Dims)]),
         "oasr_create_ex": (vp, [C.POINTER(Dims), i32]),
         "oasr_encode": (i32, [vp, vp, i32, vp, vp, sz, vp]),
+        "oasr_kv_cache_bytes": (sz, [vp, i32]),
+        "oasr_decode_step_workspace_bytes": (sz, [vp, i32]),
+        "oasr_decode_begin": (i32, [vp, vp, i32, vp, vp]),
+        "oasr_decode_step": (i32, [vp, vp, i32, i32, vp, vp, vp, sz, vp]),
         "oasr_decode_logits": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, sz, vp]),
         "oasr_destroy": (None, [vp]),
         "oasr_param_count": (i32, [vp]),

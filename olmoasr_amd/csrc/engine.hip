@@ -770,6 +770,131 @@ extern "C" int oasr_decode_logits(oasr_ctx* c, const int64_t* tokens, const void
   return write_logits_f32(p.logits, c->Vp, last_only ? (long)B : (long)B * S, c->V, logits_out, r.st);
 }
 
+// ---- cached greedy decoding (OLMoASR.install_kv_cache_hooks, olmoasr/model.py:925-964 / inf_model.py:422-453) -----------
+// The reference caches every key/value Linear output in a dict via forward hooks (self-attention K/V grow by torch.cat per
+// token, cross-attention K/V are computed once per window).  Here the cache is one caller-owned buffer:
+//   per decoder layer: self K [B, n_text_ctx, d] | self V [B, n_text_ctx, d] | cross KV [B, n_audio_ctx, 2d]   (bf16)
+// oasr_decode_begin fills the cross K/V of all layers from xa; oasr_decode_step runs the decoder on ONE new token per
+// sequence at position `pos`, the K/V projections write straight into the cache rows (GEMM output row stride = one
+// sequence's cache), attention reads the first pos+1 cached keys.
+extern "C" size_t oasr_kv_cache_bytes(const oasr_ctx* c, int B) {
+  if (!c || B <= 0) return 0;
+  const size_t per_layer = ((size_t)2 * B * c->S_max * c->d + (size_t)B * c->Te * 2 * c->d) * 2;
+  return per_layer * c->L_dec + 256;
+}
+namespace {
+struct KvLayer {
+  bf16_t *k, *v, *ckv;
+};
+KvLayer kv_layer(const oasr_ctx* c, void* cache, int B, int layer) {
+  const size_t per_layer = (size_t)2 * B * c->S_max * c->d + (size_t)B * c->Te * 2 * c->d;
+  bf16_t* base = (bf16_t*)cache + per_layer * layer;
+  return KvLayer{base, base + (size_t)B * c->S_max * c->d, base + (size_t)2 * B * c->S_max * c->d};
+}
+}  // namespace
+
+extern "C" size_t oasr_decode_step_workspace_bytes(const oasr_ctx* c, int B) {
+  if (!c || B <= 0) return 0;
+  // x, ln, q, o, x2 (5 * B*d) + u, hg (2 * B*4d) + logits (B*Vp) bf16 + stats
+  return ((size_t)B * c->d * 6 + (size_t)B * 8 * c->d + (size_t)B * c->Vp) * 2 + (size_t)B * c->H * 8 + (size_t)B * 16 + 8192;
+}
+
+extern "C" int oasr_decode_begin(oasr_ctx* c, const void* xa, int B, void* kv_cache, void* stream) {
+  RC(check_bound(c, false));
+  OASR_REQUIRE(xa && kv_cache && B > 0, "oasr_decode_begin: bad args");
+  Runner r{c, (hipStream_t)stream, B, 1, nullptr};
+  const int d = c->d;
+  for (int i = 0; i < c->L_dec; ++i) {
+    const BlockP& bp = c->dec[i];
+    KvLayer kl = kv_layer(c, kv_cache, B, i);
+    RC(r.linear((const bf16_t*)xa, (long)B * c->Te, d, c->W(bp.cattn.kw), 2 * d, c->aux(bp.cattn.fused_bias) + d, 0, nullptr, kl.ckv, nullptr));
+  }
+  return OASR_OK;
+}
+
+// tokens_last i64 [B]: the token at position pos of every sequence.  logits_out f32 [B, rows] for the NEXT position.
+extern "C" int oasr_decode_step(oasr_ctx* c, const int64_t* tokens_last, int B, int pos, void* kv_cache, float* logits_out,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  RC(check_bound(c, false));
+  OASR_REQUIRE(tokens_last && kv_cache && logits_out && workspace && B > 0 && pos >= 0 && pos < c->S_max, "oasr_decode_step: bad args");
+  OASR_REQUIRE(workspace_bytes >= oasr_decode_step_workspace_bytes(c, B), "oasr_decode_step: workspace too small");
+  const int d = c->d, S_max = c->S_max;
+  hipStream_t st = (hipStream_t)stream;
+  Runner r{c, st, B, 1, nullptr};
+  Arena A(workspace, workspace_bytes);
+  bf16_t* x = A.bf((size_t)B * d);
+  bf16_t* ln = A.bf((size_t)B * d);
+  bf16_t* q = A.bf((size_t)B * d);
+  bf16_t* o = A.bf((size_t)B * d);
+  bf16_t* x2 = A.bf((size_t)B * d);
+  bf16_t* x3 = A.bf((size_t)B * d);
+  bf16_t* u = A.bf((size_t)B * 4 * d);
+  bf16_t* hg = A.bf((size_t)B * 4 * d);
+  bf16_t* logits = A.bf((size_t)B * c->Vp);
+  float* lse = A.f32((size_t)B * c->H);
+  float* mean = A.f32(B);
+  float* rstd = A.f32(B);
+  // token + positional embedding of position pos: S = 1 per sequence, positional row offset by pos
+  RC(launch_embedding_fwd(tokens_last, c->P(c->tok_emb), c->P(c->dec_pos) + (size_t)pos * d, x, B, 1, d, c->V, st));
+  bf16_t* cur = x;
+  for (int i = 0; i < c->L_dec; ++i) {
+    const BlockP& bp = c->dec[i];
+    KvLayer kl = kv_layer(c, kv_cache, B, i);
+    RC(launch_layernorm_fwd(cur, c->P(bp.attn_ln_w), c->P(bp.attn_ln_b), ln, mean, rstd, B, d, st));
+    RC(r.linear(ln, B, d, c->W(bp.attn.qw), d, c->P(bp.attn.qb), 0, nullptr, q, nullptr));
+    {  // K and V rows of this position go straight into the cache: output row b lands at [b, pos, :]
+      GemmArgs g = gemm_defaults();
+      g.A = plain_view(ln, d);
+      g.M = B;
+      g.N = d;
+      g.K = d;
+      g.ldc = (long)S_max * d;
+      g.B = plain_view(c->W(bp.attn.kw), d);
+      g.out = kl.k + (size_t)pos * d;
+      RC(launch_gemm(g, st));
+      g.B = plain_view(c->W(bp.attn.vw), d);
+      g.bias = c->P(bp.attn.vb);
+      g.out = kl.v + (size_t)pos * d;
+      RC(launch_gemm(g, st));
+    }
+    AttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.q = q;
+    a.ldq = d;
+    a.bsq = d;
+    a.k = kl.k;
+    a.v = kl.v;
+    a.ldk = a.ldv = d;
+    a.bsk = a.bsv = (long)S_max * d;
+    a.o = o;
+    a.ldo = d;
+    a.bso = d;
+    a.lse = lse;
+    a.B = B;
+    a.H = c->H;
+    a.Tq = 1;
+    a.Tk = pos + 1;
+    RC(launch_attention_fwd(a, st));
+    RC(r.linear(o, B, d, c->W(bp.attn.ow), d, c->P(bp.attn.ob), 0, cur, x2, nullptr));
+    RC(launch_layernorm_fwd(x2, c->P(bp.cln_w), c->P(bp.cln_b), ln, mean, rstd, B, d, st));
+    RC(r.linear(ln, B, d, c->W(bp.cattn.qw), d, c->P(bp.cattn.qb), 0, nullptr, q, nullptr));
+    a.k = kl.ckv;
+    a.v = kl.ckv + d;
+    a.ldk = a.ldv = 2 * d;
+    a.bsk = a.bsv = (long)c->Te * 2 * d;
+    a.Tk = c->Te;
+    RC(launch_attention_fwd(a, st));
+    RC(r.linear(o, B, d, c->W(bp.cattn.ow), d, c->P(bp.cattn.ob), 0, x2, x3, nullptr));
+    RC(launch_layernorm_fwd(x3, c->P(bp.mlp_ln_w), c->P(bp.mlp_ln_b), ln, mean, rstd, B, d, st));
+    RC(r.linear(ln, B, d, c->W(bp.w1), 4 * d, c->P(bp.b1), 1, nullptr, hg, u));
+    RC(r.linear(hg, B, 4 * d, c->W(bp.w2), d, c->P(bp.b2), 0, x3, cur == x ? x2 : x, nullptr));
+    cur = (cur == x) ? x2 : x;
+  }
+  RC(launch_layernorm_fwd(cur, c->P(c->dec_ln_w), c->P(c->dec_ln_b), ln, mean, rstd, B, d, st));
+  RC(r.linear(ln, B, d, c->W(c->tok_emb), c->Vp, nullptr, 0, nullptr, logits, nullptr));
+  return write_logits_f32(logits, c->Vp, B, c->V, logits_out, st);
+}
+
 extern "C" int oasr_zero_grad(oasr_ctx* c, void* stream) {
   RC(check_bound(c, true));
   OASR_CHECK_HIP(hipMemsetAsync(c->grads, 0, (size_t)c->numel * 4, (hipStream_t)stream));

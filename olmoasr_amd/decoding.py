@@ -14,9 +14,10 @@ the caller:
       next = argmax(logits); rows that already emitted eot keep emitting eot; stop when every row has.
   sum_logprobs accumulates log_softmax(logits)[next] of the sampled (non-eot-padding) tokens -> avg_logprob, as whisper.
 
-The decoder is re-run without a kv-cache each step (the reference-internal pattern of notebooks/ow_decoding.py:42-72);
-only the last position's logits are computed (one [B, d] x [d, V] GEMM).  Cached-KV step kernels are the next step
-(SURVEY.md K19).
+Two step engines: (default) the KV-cached one -- ``OLMoASR.kv_cache_begin/kv_cache_step`` = the reference's
+``install_kv_cache_hooks`` (model.py:925-964) + a one-token decoder step, cross-attention K/V computed once per window;
+and, for cross-checking, the cache-less one that re-runs the decoder on the whole prefix (the reference-internal pattern
+of notebooks/ow_decoding.py:42-72), computing only the last position's logits.
 """
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
@@ -40,6 +41,7 @@ class DecodingOptions:
     beam_size: Optional[int] = None
     best_of: Optional[int] = None
     fp16: bool = True
+    use_kv_cache: bool = True  # False: re-run the decoder on the whole prefix every step (ow_decoding.py style)
 
 
 @dataclass
@@ -77,8 +79,16 @@ def decode(model, mel: torch.Tensor, options: Optional[DecodingOptions] = None, 
     sum_logprobs = torch.zeros(B, device=xa.device)
     n_sampled = torch.zeros(B, device=xa.device)
     sup = options.suppress_mask.to(xa.device) if options.suppress_mask is not None else None
+    state = None
+    if options.use_kv_cache:
+        state = model.kv_cache_begin(xa)
+        for p in range(len(init) - 1):  # prefill the prompt; the last prompt token is fed by the first loop iteration
+            model.kv_cache_step(state, toks[:, p])
     for _ in range(sample_len):
-        lg = model.logits(toks, xa, last_only=True)[:, :dims.n_vocab]
+        if state is not None:
+            lg = model.kv_cache_step(state, toks[:, -1])[:, :dims.n_vocab]
+        else:
+            lg = model.logits(toks, xa, last_only=True)[:, :dims.n_vocab]
         if sup is not None:
             lg = lg + sup
         logp = torch.log_softmax(lg.float(), dim=-1)

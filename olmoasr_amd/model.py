@@ -360,6 +360,36 @@ class OLMoASR(nn.Module):
                                                N.ptr(ws), ws.numel(), N.stream_ptr()), "oasr_decode_logits")
         return out
 
+    # ---- cached decoding (the reference's install_kv_cache_hooks + one decoder step per token) ------------------------
+    @torch.no_grad()
+    def kv_cache_begin(self, audio_features: Tensor):
+        """Allocates the KV cache for this batch of windows and fills the cross-attention K/V of every decoder layer."""
+        N.require_gpu(audio_features, "audio_features")
+        xa = audio_features.to(torch.bfloat16).contiguous()
+        B = xa.shape[0]
+        lib = N.lib()
+        cache = torch.empty(lib.oasr_kv_cache_bytes(self._ctx, B), dtype=torch.uint8, device=xa.device)
+        ws = torch.empty(lib.oasr_decode_step_workspace_bytes(self._ctx, B), dtype=torch.uint8, device=xa.device)
+        with torch.cuda.device(xa.device):
+            N.check(lib.oasr_decode_begin(self._ctx, N.ptr(xa), B, N.ptr(cache), N.stream_ptr()), "oasr_decode_begin")
+        return {"cache": cache, "ws": ws, "B": B, "pos": 0}
+
+    @torch.no_grad()
+    def kv_cache_step(self, state, tokens_last: Tensor) -> Tensor:
+        """Feeds the token at position state['pos'] of every sequence; returns fp32 logits [B, rows] for the next one."""
+        B = state["B"]
+        tokens_last = tokens_last.to(torch.int64).contiguous()
+        assert tokens_last.shape == (B,)
+        out = torch.empty(B, self._n_rows, device=tokens_last.device, dtype=torch.float32)
+        with torch.cuda.device(tokens_last.device):
+            N.check(N.lib().oasr_decode_step(self._ctx, N.ptr(tokens_last), B, state["pos"], N.ptr(state["cache"]), N.ptr(out),
+                                             N.ptr(state["ws"]), state["ws"].numel(), N.stream_ptr()), "oasr_decode_step")
+        state["pos"] += 1
+        return out
+
+    def install_kv_cache_hooks(self, cache=None):
+        raise N.NativeError("the native engine owns the KV cache: use kv_cache_begin()/kv_cache_step() (or decode(), which does)")
+
     @torch.no_grad()
     def decode(self, mel: Tensor, options=None, **kwargs):
         """Greedy decoding (temperature 0) of a batch of 30 s windows -- see olmoasr_amd/decoding.py."""

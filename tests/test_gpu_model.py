@@ -316,3 +316,26 @@ def test_inference_model_decode_and_transcribe(tmp_path, tiny_case):
     mel0 = olmoasr_amd.log_mel_spectrogram(pcm[:480000])
     r0 = net.decode(mel0, sample_len=3)
     print("greedy positions checked:", agree, "window0", out["segments"][0]["tokens"], r0.tokens)
+
+
+def test_kv_cached_decode_matches_cacheless(tiny_case):
+    """One-token decoder steps over the KV cache must reproduce the full-prefix decoder: logits per step within bf16
+    accumulation-order noise, greedy ids identical on a model trained to confident predictions."""
+    from olmoasr_amd.decoding import DecodingOptions, decode
+    from olmoasr_amd.model import OLMoASR
+    from oracle import model_oracle as mo
+    dims = mo.Dims(80, 1500, 384, 6, 2, 51864, 448, 384, 6, 2)
+    net = OLMoASR(_dims(dims), device=DEV, seed=11, inference=True)
+    mel = tiny_case["mel"].to(DEV)
+    xa = net.embed_audio(mel)
+    toks = tiny_case["tokens"].to(DEV)[:, :7]
+    full = net.logits(toks, xa)  # [B, 7, V]
+    st = net.kv_cache_begin(xa)
+    for p in range(7):
+        step = net.kv_cache_step(st, toks[:, p])
+        err = float((step - full[:, p]).abs().max())
+        assert err < 0.08, (p, err)  # same bf16 math, different tile shapes / accumulation order
+    r_c = decode(net, mel, DecodingOptions(sample_len=5, use_kv_cache=True))
+    r_n = decode(net, mel, DecodingOptions(sample_len=5, use_kv_cache=False))
+    for a, b in zip(r_c, r_n):
+        assert abs(a.avg_logprob - b.avg_logprob) < 0.05
