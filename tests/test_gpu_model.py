@@ -339,3 +339,29 @@ def test_kv_cached_decode_matches_cacheless(tiny_case):
     r_n = decode(net, mel, DecodingOptions(sample_len=5, use_kv_cache=False))
     for a, b in zip(r_c, r_n):
         assert abs(a.avg_logprob - b.avg_logprob) < 0.05
+
+
+def test_train_script_end_to_end(tmp_path):
+    """The torchrun entry (world_size 1): a few optimizer steps on the seeded synthetic shard, loss goes down, the
+    checkpoint pair is written with the reference's keys and loads back through load_model (DDP prefix included)."""
+    import importlib.util
+    import olmoasr_amd
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("tt_gpu", os.path.join(root, "scripts", "training", "train_timestamps.py"))
+    tt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tt)
+    log = tt.main(["--model_variant", "tiny", "--eff_batch_size", "8", "--train_batch_size", "4", "--train_steps", "12",
+                   "--lr", "1e-3", "--train_log_freq", "1", "--n_synthetic", "8", "--ckpt_freq", "12", "--ckpt_dir", str(tmp_path),
+                   "--exp_name", "t"])
+    assert len(log) == 12 and all(not r["found_inf"] for r in log)
+    assert log[0]["lr"] == 0.0 and log[1]["lr"] == 1e-3  # warmup = ceil(0.002 * 12) = 1 step
+    assert log[-1]["train_loss"] < log[0]["train_loss"] - 1.0
+    assert log[-1]["audio_min_per_GPU_second"] > 0
+    files = sorted(os.listdir(tmp_path / "t"))
+    assert len(files) == 2 and files[0].endswith("_ddp.pt") and files[1].endswith("_non_ddp.pt")
+    ck = torch.load(tmp_path / "t" / files[0], weights_only=False)
+    assert {"global_step", "local_step", "epoch", "best_eval_wer", "model_state_dict", "optimizer_state_dict", "scaler_state_dict",
+            "scheduler_state_dict", "dims"} <= set(ck)
+    assert all(k.startswith("module.") for k in ck["model_state_dict"]) and ck["global_step"] == 12
+    net = olmoasr_amd.load_model(str(tmp_path / "t" / files[0]), device=DEV)
+    assert net.dims.n_audio_state == 384 and torch.isfinite(net.flat_params).all()
