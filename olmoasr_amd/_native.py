@@ -6,7 +6,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liboasr.so")
+# OASR_LIB: A/B a differently built library of the SAME ABI (kernel experiments); never a fallback.
+LIB_PATH = os.environ.get("OASR_LIB") or os.path.join(_HERE, "liboasr.so")
 _lib = None
 
 

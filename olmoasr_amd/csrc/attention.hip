@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
   kv_len = kv_len < a.Tk ? kv_len : a.Tk;
   int kv_end = kv_len;
   if (CAUSAL) kv_end = kv_end < q0 + 128 ? kv_end : q0 + 128;
-  const int ntiles = (kv_end + 63) >> 6;
+  const int ntiles = kv_end > 0 ? (kv_end + 63) >> 6 : 1;  // >= 1: a fully masked tile yields l = 0 -> O = 0
 
   const TileSrc ksrc = tile_src(a.k + (long)b * a.bsk + h * 64, a.ldk, a.Tk, tid);
   const TileSrc vsrc = tile_src(a.v + (long)b * a.bsv + h * 64, a.ldv, a.Tk, tid);
@@ -129,13 +129,14 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
     for (int r = 0; r < 16; ++r) oT[i][r] = 0.f;
   float m_run = NEG, l_run = 0.f;
 
+  // Unconditional prologue (ntiles >= 1 by construction): a guarded one leaves "Q/dO fragment loads may be pending" in
+  // the compiler's wait-count state at the loop header, and hipcc then re-waits vmcnt(3..0) in front of the first MFMAs
+  // of EVERY iteration -- i.e. for the K/V prefetch it has just issued -- serialising the load latency into the loop.
   u32x4_t rk[2], rv[2];
-  if (ntiles > 0) {
-    tile_issue(ksrc, 0, rk);
-    tile_issue(vsrc, 0, rv);
-    tile_commit(smem, tid, rk);
-    tile_commit(smem + TILE, tid, rv);
-  }
+  tile_issue(ksrc, 0, rk);
+  tile_issue(vsrc, 0, rv);
+  tile_commit(smem, tid, rk);
+  tile_commit(smem + TILE, tid, rv);
   __syncthreads();
 
   for (int t = 0; t < ntiles; ++t) {
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   kv_len = kv_len < a.Tk ? kv_len : a.Tk;
   int kv_end = kv_len;
   if (CAUSAL) kv_end = kv_end < q0 + 128 ? kv_end : q0 + 128;
-  const int ntiles = (kv_end + 63) >> 6;
+  const int ntiles = kv_end > 0 ? (kv_end + 63) >> 6 : 1;  // >= 1: a fully masked tile yields l = 0 -> O = 0
   const TileSrc ksrc = tile_src(a.k + (long)b * a.bsk + h * 64, a.ldk, a.Tk, tid);
   const TileSrc vsrc = tile_src(a.v + (long)b * a.bsv + h * 64, a.ldv, a.Tk, tid);
 
@@ -293,13 +294,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) dqT[i][r] = 0.f;
 
+  // Unconditional prologue (ntiles >= 1 by construction): a guarded one leaves "Q/dO fragment loads may be pending" in
+  // the compiler's wait-count state at the loop header, and hipcc then re-waits vmcnt(3..0) in front of the first MFMAs
+  // of EVERY iteration -- i.e. for the K/V prefetch it has just issued -- serialising the load latency into the loop.
   u32x4_t rk[2], rv[2];
-  if (ntiles > 0) {
-    tile_issue(ksrc, 0, rk);
-    tile_issue(vsrc, 0, rv);
-    tile_commit(smem, tid, rk);
-    tile_commit(smem + TILE, tid, rv);
-  }
+  tile_issue(ksrc, 0, rk);
+  tile_issue(vsrc, 0, rv);
+  tile_commit(smem, tid, rk);
+  tile_commit(smem + TILE, tid, rv);
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const char* kb = smem + (t & 1) * 2 * TILE;
@@ -427,12 +429,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
     tile_commit(st + TILE, tid, rd);
     if (tid < 128) ((float*)(st + 2 * TILE))[tid] = rstat;
   };
-  if (any && t_begin < nqt) {
-    issue(t_begin);
-    commit(smem);
+  if (!any) {  // every key of this block is padding: dK = dV = 0 (uniform early exit, before any load is issued)
+    if (mykey < a.Tk) {
+      bf16_t* dkp0 = a.dk + (long)b * a.bsk + (long)mykey * a.ldk + h * 64;
+      bf16_t* dvp0 = a.dv + (long)b * a.bsv + (long)mykey * a.ldv + h * 64;
+      const u32x4_t z = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        *(u32x4_t*)(dkp0 + hh * 32 + i * 8) = z;
+        *(u32x4_t*)(dvp0 + hh * 32 + i * 8) = z;
+      }
+    }
+    return;
   }
+  // unconditional prologue: see attn_fwd_kernel (a guarded one makes hipcc re-wait the prefetch at the loop top)
+  issue(t_begin);
+  commit(smem);
   __syncthreads();
-  for (int t = t_begin; any && t < nqt; ++t) {
+  for (int t = t_begin; t < nqt; ++t) {
     const int cur = (t - t_begin) & 1;
     const char* st = smem + cur * STAGE;
     const char* qb = st;

@@ -4,15 +4,23 @@
 // :104-195 Conv1d as window GEMMs, :768-770 logits) and their autograd backward (dgrad, wgrad), SURVEY.md §2.3
 // K2,K3,K5,K9,K12,K14.
 //
-// Tiling: 128x128x64 per 256-thread workgroup, 2x2 waves, each wave a 64x64 sub-tile as 2x2
-// v_mfma_f32_32x32x16_bf16 blocks (64 accumulator VGPRs).  Operands are staged HBM -> VGPR -> LDS with
-// bounds-checked buffer loads (out-of-range rows / conv padding read as zero) and double-buffered in LDS (64 KiB,
-// two workgroups per CU), one barrier per K-tile.  Operands whose reduction index is NOT contiguous in memory
-// (dgrad's W[N][K], wgrad's dY[M][N] and X[M][K]) are kept in their natural layout and transposed on the way
-// into the matrix core with ds_read_b64_tr_b16, so no transposed copies of weights or activations exist in HBM.
-// LDS images are XOR-swizzled so both ds_read_b128 (k-contiguous tiles) and the transpose reads are
-// bank-conflict free.  The MFMA is issued with swapped operands (D'[n][m]) so each lane ends up holding 4
-// consecutive columns of one output row -> 8-byte bf16 / 16-byte fp32 row-contiguous stores.
+// Three kernels share the operand views, LDS images and fragment readers:
+//  * oasr_gemm_pp_kernel   256x256x64 "ping-pong": 8 waves, one workgroup per CU, direct-to-LDS (buffer_load ... lds)
+//    staging that is never drained inside the K loop (one counted vmcnt per K-tile), two wave groups one barrier
+//    apart so one of them is always inside an MFMA section.  Default for every bf16-output GEMM with more than half
+//    a wave of tiles (all Linear forward / dgrad GEMMs of the training step).
+//  * oasr_gemm_fast_kernel 256x128x64 (4 waves; 3 workgroups per CU for the split-K / atomic wgrad variant, 2 for
+//    bf16 outputs) and 256x256x64 (8 waves, 2 stages): direct-to-LDS staging, one stage drained per barrier;
+//    co-resident workgroups hide each other's drains.  wgrad (fp32 atomics, XCD-owned K ranges) and small problems.
+//  * gemm_kernel           128x128x64, register-staged with bounds-checked buffer loads: conv window views (rpb != 0),
+//    K not a multiple of 64, fp32 / positional-embedding / odd-stride outputs.
+// Operands whose reduction index is NOT contiguous in memory (dgrad's W[N][K], wgrad's dY[M][N] and X[M][K]) are kept
+// in their natural layout and transposed on the way into the matrix core with ds_read_b64_tr_b16, so no transposed
+// copies of weights or activations exist in HBM.  LDS images are XOR-swizzled so both ds_read_b128 (k-contiguous
+// tiles) and the transpose reads are bank-conflict free.  For bf16 outputs the MFMA is issued with swapped operands
+// (D'[n][m]) so each lane holds 4 consecutive columns of one output row; results leave through a wave-private LDS
+// tile so that every global access of the epilogue (stores, residual / dGELU-input reads) is 16 bytes per lane.
+#include <math.h>
 #include <stdlib.h>
 
 #include <map>
@@ -319,9 +327,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 constexpr int FBM = 256;
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef __attribute__((address_space(3))) u32x2_t* lds_u32x2_ptr;
+typedef __attribute__((address_space(3))) u32x4_t* lds_u32x4_ptr;
 
+// Byte offsets (from the tile's base row/column `rel0`, default row0) of this lane's 16-byte pieces of the operand
+// image that starts at row/column row0.
 template <bool TRANS, int ROWS, int NI, int NW>
-__device__ __forceinline__ void fast_offsets(const OperandView& v, int R, int row0, int lane, int wave, unsigned (&off)[NI]) {
+__device__ __forceinline__ void fast_offsets(const OperandView& v, int R, int row0, int lane, int wave, unsigned (&off)[NI],
+                                             int rel0 = -1) {
+  rel0 = rel0 < 0 ? row0 : rel0;
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     const int q = j * NW + wave;  // 1 KiB chunk index inside the tile image
@@ -330,7 +344,7 @@ __device__ __forceinline__ void fast_offsets(const OperandView& v, int R, int ro
       const int c16 = phys ^ ((row >> 1) & 7);
       int gr = row0 + row;
       gr = gr < R ? gr : R - 1;
-      off[j] = (unsigned)(((long)(gr - row0) * v.ld + c16 * 8) * 2);
+      off[j] = (unsigned)(((long)(gr - rel0) * v.ld + c16 * 8) * 2);
     } else {
       constexpr int CPR = ROWS / 8;  // 16-byte pieces per k-row
       constexpr int KPC = 64 / CPR;  // k-rows per 1 KiB chunk
@@ -338,7 +352,7 @@ __device__ __forceinline__ void fast_offsets(const OperandView& v, int R, int ro
       const int c16 = phys ^ ((krow & 3) << 2);
       int col = row0 + c16 * 8;
       col = col + 8 <= R ? col : R - 8;
-      off[j] = (unsigned)(((long)krow * v.ld + (col - row0)) * 2);
+      off[j] = (unsigned)(((long)krow * v.ld + (col - rel0)) * 2);
     }
   }
 }
@@ -379,11 +393,189 @@ __device__ __forceinline__ void glds16(const __amdgpu_buffer_rsrc_t rs, char* ds
         glds16(rb_, dst_ + A_BYTES + (j_ * NW + wave) * 1024, offB[j_]);                                     \
   } while (0)
 
+// The common bf16-output epilogues (everything but fp32 / positional-embedding / odd-stride outputs), organised so that
+// every runtime option is one wave-uniform branch per 32-row block and all global traffic is 16 bytes per lane:
+//   pass A  acc * alpha (+ bias) -> bf16 (the autocast rounding point of the Linear) -> wave-private LDS tile
+//           ([32 rows][128 B], 16-byte chunks XOR-swizzled by row);
+//   pass B  each lane takes 8 consecutive columns of one row back out of LDS and applies what follows the rounding
+//           point in GemmArgs order (GELU, x dGELU(u), + residual; u and the residual are read with the same
+//           coalesced 16-byte accesses as the stores and are prefetched before pass A), accumulates the fused
+//           bias-gradient column sums, and stores out_pre / out.
+// Bit-identical to epilogue_math(): every later op starts from the bf16-rounded pre-activation.
+__host__ __device__ __forceinline__ bool fast_rows_ok(const GemmArgs& p) {
+  const unsigned long al = (unsigned long)p.out | (unsigned long)p.out_pre | (unsigned long)p.resid | (unsigned long)p.dgelu_u;
+  return !p.out_f32 && !p.pos && (p.N % 8) == 0 && (p.ldc % 8) == 0 && (al & 15) == 0 && (!p.resid || (p.ldr % 8) == 0) &&
+         (!p.dgelu_u || (p.ldu % 8) == 0) && !(p.resid && p.dgelu_u);
+}
+
+// stg: this wave's staging tile, 8-row groups of 1 KiB placed GS bytes apart; bias_lds: 64 floats of wave-private LDS.
+template <bool CSUM, int GS = 1024, bool PF = true>
+__device__ __forceinline__ void fast_epilogue_rows(const GemmArgs& p, f32x16_t (&acc)[4][2], char* stg, float* bias_lds,
+                                                   int mrow0, int ncol0, int lane) {
+  const int h = lane >> 5, row = lane & 31;
+  const bool has_bias = p.bias != nullptr, has_side = p.dgelu_u != nullptr || p.resid != nullptr, has_u = p.dgelu_u != nullptr;
+  const bool has_pre = p.out_pre != nullptr, has_out = p.out != nullptr, gelu = p.act == 1;
+  const bf16_t* side = has_u ? p.dgelu_u : p.resid;  // at most one of the two (fast_rows_ok)
+  const long lds_ = has_u ? p.ldu : p.ldr;
+  const int ch = lane & 7, nn = ncol0 + ch * 8;
+  const bool n_ok = nn < p.N;
+  if (has_bias) bias_lds[lane] = (ncol0 + lane < p.N) ? p.bias[ncol0 + lane] : 0.f;
+  float cs[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) cs[e] = 0.f;
+  u32x4_t sd[4];
+  if (has_side && PF) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int mm = mrow0 + i * 8 + (lane >> 3);
+      if (n_ok && mm < p.M) sd[i] = *(const u32x4_t*)(side + (long)mm * lds_ + nn);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  // staging addresses: the swizzle XOR only touches bits 4-6, so every chunk address is (lane base) ^ (chunk << 4)
+  unsigned wbase = (unsigned)(size_t)stg + (row >> 3) * GS + (row & 7) * 128 + h * 8 + ((row & 7) << 4);
+  unsigned rbase = (unsigned)(size_t)stg + (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4);
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    // (opaque re-definition per block: otherwise hipcc keeps all derived addresses of all four blocks live and spills)
+    asm volatile("" : "+v"(wbase), "+v"(rbase));
+    // pass A
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = acc[mt][nt][q * 4 + i] * p.alpha;
+        if (has_bias) {
+          const f32x4_t b4 = *(const f32x4_t*)(bias_lds + nt * 32 + 8 * q + 4 * h);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] += b4[i];
+        }
+        u32x2_t pk;
+        pk[0] = pack_bf2(v[0], v[1]);
+        pk[1] = pack_bf2(v[2], v[3]);
+        *(lds_u32x2_ptr)(size_t)(wbase ^ ((nt * 4 + q) << 4)) = pk;
+      }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_sched_barrier(0);  // keep the blocks apart: hipcc otherwise hoists work across them and spills
+    // side inputs of the next 32-row block (its accumulators' predecessors are dead now)
+    // (PF == false, register-capped kernels: this block's own side inputs, right after its accumulators died)
+    u32x4_t sn[4];
+    if (has_side && (mt < 3 || !PF)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int mm = mrow0 + (mt + (PF ? 1 : 0)) * 32 + i * 8 + (lane >> 3);
+        if (n_ok && mm < p.M) sn[i] = *(const u32x4_t*)(side + (long)mm * lds_ + nn);
+      }
+    }
+    // pass B
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r2 = i * 8 + (lane >> 3);
+      const int mm = mrow0 + mt * 32 + r2;
+      const bool ok = n_ok && mm < p.M;
+      const u32x4_t pre = *(lds_u32x4_ptr)(size_t)(rbase + i * GS);  // rows r2 = i*8 + (lane >> 3): (r2 & 7) == lane >> 3
+      if (has_pre && ok) *(u32x4_t*)(p.out_pre + (long)mm * p.ldc + nn) = pre;
+      u32x4_t fin = pre;
+      if (gelu || has_side) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          x[2 * e] = bf_lo(pre[e]);
+          x[2 * e + 1] = bf_hi(pre[e]);
+        }
+        if (gelu) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = gelu_f(x[e]);
+        }
+        if (has_side) {
+          const u32x4_t sv = PF ? sd[i] : sn[i];
+          if (has_u) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              x[2 * e] = bf_round(x[2 * e]) * dgelu_f(bf_lo(sv[e]));
+              x[2 * e + 1] = bf_round(x[2 * e + 1]) * dgelu_f(bf_hi(sv[e]));
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              x[2 * e] = bf_round(x[2 * e]) + bf_lo(sv[e]);
+              x[2 * e + 1] = bf_round(x[2 * e + 1]) + bf_hi(sv[e]);
+            }
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) fin[e] = pack_bf2(x[2 * e], x[2 * e + 1]);
+      }
+      if (CSUM && ok) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          cs[2 * e] += bf_lo(fin[e]);
+          cs[2 * e + 1] += bf_hi(fin[e]);
+        }
+      }
+      if (has_out && ok) *(u32x4_t*)(p.out + (long)mm * p.ldc + nn) = fin;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (PF) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sd[i] = sn[i];
+    }
+  }
+  if (CSUM) {  // lanes sharing (lane & 7) hold partial sums of the same 8 columns
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = cs[e];
+      t += __shfl_xor(t, 8);
+      t += __shfl_xor(t, 16);
+      t += __shfl_xor(t, 32);
+      cs[e] = t;
+    }
+    if (lane < 8 && n_ok) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) unsafeAtomicAdd(p.colsum + nn + e, cs[e]);
+    }
+  }
+}
+
+// Epilogue shared by the direct-to-LDS kernels: each wave owns a 128 x 64 block of the output tile as acc[4][2]
+// 32x32 MFMA blocks (rows m0 + wm*128 + mt*32, columns n0 + wn*64 + nt*32).  All waves of the workgroup must be past
+// their last main-loop LDS read (the staging tiles alias the operand images).
+template <bool SWAP, bool CSUM, bool PF = true>
+__device__ __forceinline__ void fast_epilogue(const GemmArgs& p, f32x16_t (&acc)[4][2], char* smem, int m0, int n0, int wm,
+                                              int wn, int wave, int lane) {
+  if (SWAP) {  // bf16 outputs (the host routes anything fast_rows_ok() rejects to the general kernel)
+    fast_epilogue_rows<CSUM, 1024, PF>(p, acc, smem + wave * 8192, (float*)(smem + wave * 8192 + 4096), m0 + wm * 128,
+                                       n0 + wn * 64, lane);
+    return;
+  }
+  const int h = lane >> 5;
+  {
+    // D[m][n]: lane owns column n = .. + (lane & 31), rows (r & 3) + 8*(r >> 2) + 4*h.  fp32 atomic accumulate only.
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int n = n0 + wn * 64 + nt * 32 + (lane & 31);
+      if (n >= p.N) continue;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * 128 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (m < p.M) unsafeAtomicAdd(p.out_f32 + (long)m * p.ldc32 + n, p.alpha * acc[mt][nt][r]);
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // (external linkage: hipcc 7.2 drops the host-side handle of this instantiation set when it has internal linkage)
 template <bool TA, bool TB, int FBN, int NWN, int NSTAGE, bool SWAP, bool CSUM>
-__global__ __launch_bounds__(128 * NWN, NWN == 2 ? 3 : 2) void oasr_gemm_fast_kernel(GemmArgs p) {
+// (3 workgroups per CU only for the split-K / atomic variant: its epilogue needs no registers beyond the accumulators)
+__global__ __launch_bounds__(128 * NWN, (NWN == 2 && !SWAP) ? 3 : 2) void oasr_gemm_fast_kernel(GemmArgs p) {
   constexpr int NW = 2 * NWN;                     // waves per workgroup
   constexpr int A_BYTES = FBM * 64 * 2, B_BYTES = FBN * 64 * 2, STAGE = A_BYTES + B_BYTES;
   constexpr int NIA = (A_BYTES / 1024) / NW, NIB = (B_BYTES / 1024) / NW;
@@ -411,7 +603,7 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 3 : 2) void oasr_gemm_fast_ke
       tn = t - tm * tiles_n;
     } else {
       const int bid = xcd_remap(blockIdx.x, gridDim.x);
-      constexpr int RESIDENT = 32 * (NWN == 2 ? 3 : 1);  // workgroups resident per XCD
+      constexpr int RESIDENT = 32 * (NWN == 2 ? (SWAP ? 2 : 3) : 1);  // workgroups resident per XCD
       int gm = p.raster_gm > 0 ? p.raster_gm : RESIDENT / tiles_n;
       gm = gm < 1 ? 1 : (gm > 16 ? 16 : gm);
       const int per_group = gm * tiles_n;
@@ -483,92 +675,177 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 3 : 2) void oasr_gemm_fast_ke
     __syncthreads();  // stage fully consumed (and, with two stages, the prefetched tile has landed)
   }
 
-  const int h = lane >> 5;
-  if (SWAP) {
-    // bf16 outputs leave through a per-wave 8 KiB LDS staging tile ([64 rows][128 B], 16-byte chunks XOR-swizzled
-    // by row) so that global stores are 16 bytes per lane and 128 contiguous bytes per output row, instead of 8-byte
-    // pieces scattered over 32 rows.  All LDS is free here: the main loop ended on a barrier.
-    char* stg = smem + wave * 8192;  // [0,4K): pre-activation rows, [4K,8K): final rows; 32 rows x 128 B each
-    const bool vec_ok = (p.N % 8) == 0 && (p.ldc % 8) == 0;
-    float ctot = 0.f;  // CSUM: this lane's column (n0 + wn*64 + lane) summed over the wave's 128 rows
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      const int m = m0 + wm * 128 + mt * 32 + (lane & 31);
-      const int mc = m < p.M ? m : p.M - 1;  // clamp: loads stay in range, stores are masked below
-      const int pos_row = p.pos ? (mc % p.pos_period) : 0;
-      const int row = lane & 31;
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          int n = n0 + wn * 64 + nt * 32 + 8 * q + 4 * h;
-          const bool n_ok = n < p.N;
-          n = n_ok ? n : 0;
-          float v[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = acc[mt][nt][q * 4 + i];
-          u32x2_t pre, fin;
-          epilogue_math(p, mc, n, pos_row, v, pre, fin);
-          if (p.out_f32 && m < p.M && n_ok) epilogue_f32(p, m, n, v);
-          if (!vec_ok) {
-            if (m < p.M && n_ok) {
-              if (p.out_pre) *(u32x2_t*)(p.out_pre + (long)m * p.ldc + n) = pre;
-              if (p.out) *(u32x2_t*)(p.out + (long)m * p.ldc + n) = fin;
-            }
-          } else {
-            const int a = row * 128 + (((nt * 4 + q) ^ (row & 7)) << 4) + h * 8;
-            if (p.out_pre) *(u32x2_t*)(stg + a) = pre;
-            if (p.out) *(u32x2_t*)(stg + 4096 + a) = fin;
-          }
-        }
-      }
-      if (vec_ok) {
-        __builtin_amdgcn_wave_barrier();  // wave-private staging: LDS ops of one wave execute in order
-        if (CSUM) {  // fused bias gradient: column sums of the staged (bf16) output rows, valid rows only
-          const int mrow0 = m0 + wm * 128 + mt * 32;
-#pragma unroll
-          for (int r2 = 0; r2 < 32; ++r2) {
-            const bf16_t e = *(const bf16_t*)(stg + 4096 + r2 * 128 + (((lane >> 3) ^ (r2 & 7)) << 4) + (lane & 7) * 2);
-            if (mrow0 + r2 < p.M) ctot += bf2f(e);
-          }
-        }
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-          bf16_t* dst = pass == 0 ? p.out_pre : p.out;
-          if (!dst) continue;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int r2 = i * 8 + (lane >> 3), ch = lane & 7;
-            const u32x4_t val = *(const u32x4_t*)(stg + pass * 4096 + r2 * 128 + ((ch ^ (r2 & 7)) << 4));
-            const int mm = m0 + wm * 128 + mt * 32 + r2;
-            const int nn = n0 + wn * 64 + ch * 8;
-            if (mm < p.M && nn < p.N) *(u32x4_t*)(dst + (long)mm * p.ldc + nn) = val;
-          }
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
-    }
-    if (CSUM) {
-      const int n = n0 + wn * 64 + lane;
-      if (n < p.N) unsafeAtomicAdd(p.colsum + n, ctot);
-    }
-  } else {
-    // D[m][n]: lane owns column n = .. + (lane & 31), rows (r & 3) + 8*(r >> 2) + 4*h.  fp32 atomic accumulate only.
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int n = n0 + wn * 64 + nt * 32 + (lane & 31);
-      if (n >= p.N) continue;
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wm * 128 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (m < p.M) unsafeAtomicAdd(p.out_f32 + (long)m * p.ldc32 + n, p.alpha * acc[mt][nt][r]);
-        }
-      }
+  fast_epilogue<SWAP, CSUM, true>(p, acc, smem, m0, n0, wm, wn, wave, lane);
+}
+
+
+// ---- 256 x 256 x 64 "ping-pong" kernel ---------------------------------------------------------------------------
+// 8 waves (2 along M x 4 along N, 128 x 64 outputs each), one workgroup per CU, 128 KiB of LDS = two K-tile buffers of
+// four 16 KiB half-tile images (A rows 0-127 / 128-255, B columns 0-127 / 128-255; each image is laid out exactly like
+// a 128-row operand tile of the kernel above, so the fragment readers are shared).
+//
+// A K-tile is consumed in four phases, one 64 x 32 output quadrant (8 MFMAs) each:
+//     phase  LDS -> VGPR          MFMA        direct-to-LDS staging issued (2 x 1 KiB pieces per wave)
+//       0    B0 (4), A0 (8)       A0 x B0     A rows   0-127 of tile t+1 -> other buffer
+//       1    B1 (4)               A0 x B1     A rows 128-255 of tile t+1 -> other buffer
+//       2    A1 (8)               A1 x B1     B cols   0-127 of tile t+2 -> THIS buffer (its B images are dead)
+//       3    -                    A1 x B0     B cols 128-255 of tile t+2 -> THIS buffer;  s_waitcnt vmcnt(4)
+// Every phase is  { ds_reads; staging; s_barrier; MFMAs; s_barrier }.  The waves of the upper M half run one barrier
+// behind the lower half, so on every SIMD one wave is in its MFMA section while the other issues LDS reads and DMA:
+// the matrix pipe never waits for a barrier-drained staging step (the 1-workgroup-per-CU failure mode of the
+// kernel above).  The DMA queue is never drained inside the loop: the single counted wait per K-tile (phase 3) leaves
+// the two newest half-tiles (tile t+2's B) in flight across the barriers.
+// Hazards (DMA writes are ordered with LDS reads only by the issuing wave's vmcnt wait followed by a barrier):
+//   RAW  tile t+1 is complete after phase 3's wait of tile t + the barriers up to the first read in phase 0 of t+1
+//        (two barrier events later even for the trailing wave group);
+//   WAR  an image is re-staged >= 2 phases after its last ds_read, or in the next phase when the reading phase
+//        retired its reads (lgkmcnt(0)) before its first barrier (B1 in phase 1 -> B restaged in phase 2).
+#define OASR_PP_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+template <bool TA, bool TB, bool SWAP, bool CSUM>
+__global__ __launch_bounds__(512, 2) void oasr_gemm_pp_kernel(GemmArgs p) {
+  constexpr int HALF = 128 * 64 * 2, BUF = 4 * HALF;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
+  int tm, tn, ksplit;
+  {
+    const int ntile = tiles_m * tiles_n;
+    if (!SWAP && (p.split_k & 7) == 0 && gridDim.y == 1) {  // split-K range tied to the XCD (see the kernel above)
+      const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+      const int s8 = p.split_k >> 3;
+      const int t = j % ntile;
+      ksplit = xcd * s8 + j / ntile;
+      tm = t / tiles_n;
+      tn = t - tm * tiles_n;
+    } else {
+      const int bid = xcd_remap(blockIdx.x, gridDim.x);
+      int gm = p.raster_gm > 0 ? p.raster_gm : 32 / tiles_n;  // one group of tile rows resident per XCD (32 CUs)
+      gm = gm < 1 ? 1 : (gm > 16 ? 16 : gm);
+      const int per_group = gm * tiles_n;
+      const int group = bid / per_group, in_group = bid - group * per_group;
+      const int first_m = group * gm;
+      const int gsz = min(gm, tiles_m - first_m);
+      tm = first_m + in_group % gsz;
+      tn = in_group / gsz;
+      ksplit = blockIdx.y;
     }
   }
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int kt_total = p.K / BK;
+  const int per = (kt_total + p.split_k - 1) / p.split_k;
+  const int kt0 = ksplit * per;
+  const int nt = min(kt_total, kt0 + per) - kt0;  // K-tiles of this workgroup
+  if (nt <= 0) return;
+
+  // staging offsets: image i (0,1 = A halves; 2,3 = B halves), 2 pieces per wave
+  unsigned off[4][2];
+  fast_offsets<TA, 128, 2, 8>(p.A, p.M, m0, lane, wave, off[0], m0);
+  fast_offsets<TA, 128, 2, 8>(p.A, p.M, m0 + 128, lane, wave, off[1], m0);
+  fast_offsets<TB, 128, 2, 8>(p.B, p.N, n0, lane, wave, off[2], n0);
+  fast_offsets<TB, 128, 2, 8>(p.B, p.N, n0 + 128, lane, wave, off[3], n0);
+  const bf16_t* baseA = (TA ? p.A.ptr + m0 : p.A.ptr + (long)m0 * p.A.ld) + (long)kt0 * (TA ? (long)BK * p.A.ld : BK);
+  const bf16_t* baseB = (TB ? p.B.ptr + n0 : p.B.ptr + (long)n0 * p.B.ld) + (long)kt0 * (TB ? (long)BK * p.B.ld : BK);
+  const long stepA = TA ? (long)BK * p.A.ld : BK, stepB = TB ? (long)BK * p.B.ld : BK;
+
+#define OASR_PP_STAGE(IMG, T, BUFP)                                                                          \
+  do {                                                                                                       \
+    const __amdgpu_buffer_rsrc_t rs_ = make_rsrc((IMG) < 2 ? baseA + (T) * stepA : baseB + (T) * stepB);     \
+    char* d_ = (BUFP) + (IMG) * HALF + wave * 1024;                                                          \
+    glds16(rs_, d_, off[IMG][0]);                                                                            \
+    glds16(rs_, d_ + 8192, off[IMG][1]);                                                                     \
+  } while (0)
+
+  f32x16_t acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // prologue: all of tile 0, B of tile 1
+  OASR_PP_STAGE(0, 0, smem);
+  OASR_PP_STAGE(1, 0, smem);
+  OASR_PP_STAGE(2, 0, smem);
+  OASR_PP_STAGE(3, 0, smem);
+  if (nt > 1) {
+    OASR_PP_STAGE(2, 1, smem + BUF);
+    OASR_PP_STAGE(3, 1, smem + BUF);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  OASR_PP_BARRIER();
+  if (wm == 1) OASR_PP_BARRIER();  // the upper half trails by one barrier from here on
+
+  const int aoff = wm * HALF, boff = (2 + (wn >> 1)) * HALF, bsub = (wn & 1) * 64;
+  bf16x8_t fa[2][4], fb0[4], fb1[4];
+#define OASR_PP_MMA(MT0, NT, FB)                                                                             \
+  do {                                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    __builtin_amdgcn_s_setprio(1);                                                                           \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_) {   \
+      if (SWAP)                                                                                              \
+        acc[MT0 + t_][NT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FB[ks_], fa[t_][ks_], acc[MT0 + t_][NT], 0, 0, 0); \
+      else                                                                                                   \
+        acc[MT0 + t_][NT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t_][ks_], FB[ks_], acc[MT0 + t_][NT], 0, 0, 0); \
+    }                                                                                                        \
+    __builtin_amdgcn_s_setprio(0);                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+  } while (0)
+
+  for (int t = 0; t < nt; ++t) {
+    char* cur = smem + (t & 1) * BUF;
+    char* oth = smem + ((t & 1) ^ 1) * BUF;
+    const bool next1 = t + 1 < nt, next2 = t + 2 < nt;
+    // ---- phase 0
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fb0[ks] = fast_frag<TB, 256>(cur + boff, bsub, ks, lane);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i][ks] = fast_frag<TA, 256>(cur + aoff, i * 32, ks, lane);
+    if (next1) OASR_PP_STAGE(0, t + 1, oth);
+    OASR_PP_BARRIER();
+    OASR_PP_MMA(0, 0, fb0);
+    OASR_PP_BARRIER();
+    // ---- phase 1
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fb1[ks] = fast_frag<TB, 256>(cur + boff, bsub + 32, ks, lane);
+    if (next1) OASR_PP_STAGE(1, t + 1, oth);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // B images of `cur` are dead before this phase's barrier
+    OASR_PP_BARRIER();
+    OASR_PP_MMA(0, 1, fb1);
+    OASR_PP_BARRIER();
+    // ---- phase 2
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i][ks] = fast_frag<TA, 256>(cur + aoff, 64 + i * 32, ks, lane);
+    if (next2) OASR_PP_STAGE(2, t + 2, cur);
+    OASR_PP_BARRIER();
+    OASR_PP_MMA(2, 1, fb1);
+    OASR_PP_BARRIER();
+    // ---- phase 3
+    if (next2) {
+      OASR_PP_STAGE(3, t + 2, cur);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // everything but tile t+2's B has landed (this wave's pieces)
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    OASR_PP_BARRIER();
+    OASR_PP_MMA(2, 0, fb0);
+    OASR_PP_BARRIER();
+  }
+  if (wm == 0) OASR_PP_BARRIER();  // re-join: the trailing half has finished its LDS reads after this
+#undef OASR_PP_STAGE
+#undef OASR_PP_MMA
+  fast_epilogue<SWAP, CSUM>(p, acc, smem, m0, n0, wm, wn, wave, lane);
 }
+
 
 namespace {
 
@@ -606,6 +883,48 @@ int launch_fast_cfg(const GemmArgs& a, hipStream_t stream) {
   return OASR_OK;
 }
 
+template <bool TA, bool TB, bool SWAP, bool CSUM = false>
+int launch_pp_cfg(const GemmArgs& a, hipStream_t stream) {
+  static bool attr = false;
+  const int lds = 2 * 4 * 128 * 64 * 2;
+  if (!attr) {
+    OASR_CHECK_HIP(hipFuncSetAttribute((const void*)oasr_gemm_pp_kernel<TA, TB, SWAP, CSUM>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr = true;
+  }
+  const int tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
+  dim3 grid(tiles, a.split_k);
+  if (!SWAP && (a.split_k & 7) == 0) grid = dim3(tiles * a.split_k, 1);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (g_prof.on) {
+    const size_t idx = g_prof.recs.size();
+    while (g_prof.events.size() < 2 * (idx + 1)) {
+      hipEvent_t e;
+      OASR_CHECK_HIP(hipEventCreate(&e));
+      g_prof.events.push_back(e);
+    }
+    e0 = g_prof.events[2 * idx];
+    e1 = g_prof.events[2 * idx + 1];
+    auto tf = [](bool b) { return b ? "true" : "false"; };
+    static const std::string name =
+        std::string("oasr_gemm_pp_kernel<") + tf(TA) + ", " + tf(TB) + ", " + tf(SWAP) + ", " + tf(CSUM) + ">";
+    g_prof.recs.push_back({(TA ? 2 : 0) + (TB ? 1 : 0), 2.0 * (double)a.M * (double)a.N * (double)a.K, name.c_str()});
+    OASR_CHECK_HIP(hipEventRecord(e0, stream));
+  }
+  hipLaunchKernelGGL((oasr_gemm_pp_kernel<TA, TB, SWAP, CSUM>), grid, dim3(512), lds, stream, a);
+  OASR_LAUNCH_CHECK();
+  if (e1) OASR_CHECK_HIP(hipEventRecord(e1, stream));
+  return OASR_OK;
+}
+
+// Geometry choice for bf16-output GEMMs, from interleaved A/B runs on the OLMoASR-medium shapes (scripts/gemm_ab.py,
+// encoder M = 96000 and decoder M = 28672 tokens): the ping-pong kernel is faster on every layer shape (+4..20 % on
+// the encoder, +4..43 % on the decoder where 256 x 128 tiles quantise badly) except the dGELU-epilogue dgrad (-3 %).
+// Below ~half a wave of 256 x 256 tiles the 256 x 128 geometry keeps more CUs busy.
+bool prefer_pingpong(const GemmArgs& a) {
+  return a.K >= 2 * BK && (long)cdiv(a.M, 256) * cdiv(a.N, 256) > 128;
+}
+
 template <bool TA, bool TB>
 int launch_fast_t(const GemmArgs& a, hipStream_t stream) {
   const bool atomic_only = a.atomic && a.out_f32 && !a.out && !a.out_pre;
@@ -620,6 +939,12 @@ int launch_fast_t(const GemmArgs& a, hipStream_t stream) {
   }();
   const int geom = g_fast_geometry ? g_fast_geometry : env_geom;
   const bool big = geom == 2 || (geom == 0 && atomic_only && (long)cdiv(a.M, FBM) * cdiv(a.N, 128) <= 32 && big_tiles >= 128);
+  if (geom == 3 || (geom == 0 && !atomic_only && prefer_pingpong(a))) {  // 256x256 ping-pong kernel
+    if (atomic_only) return launch_pp_cfg<TA, TB, false>(a, stream);
+    if (a.colsum && !TA && TB) return launch_pp_cfg<false, true, true, true>(a, stream);
+    const int rc = launch_pp_cfg<TA, TB, true>(a, stream);
+    return (rc || !a.colsum) ? rc : launch_colsum_accum(a.out, a.ldc, a.M, a.N, a.colsum, stream);
+  }
   if (atomic_only) {
     if (big) return launch_fast_cfg<TA, TB, 256, 4, 2, false>(a, stream);
     return launch_fast_cfg<TA, TB, 128, 2, 1, false>(a, stream);
@@ -691,8 +1016,9 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     b.raster_gm = env_gm;
     return launch_gemm(b, stream);
   }
+  const bool atomic_only = a.atomic && a.out_f32 && !a.out && !a.out_pre;
   const bool fast = !a.A.rpb && !a.B.rpb && (a.K % BK) == 0 && (!a.ta || (a.M % 8) == 0) && (!a.tb || (a.N % 8) == 0) &&
-                    a.M >= 8 && a.N >= 8 && !g_force_general;
+                    a.M >= 8 && a.N >= 8 && !g_force_general && (atomic_only || fast_rows_ok(a));
   if (fast) {
     if (!a.ta && !a.tb) return launch_fast_t<false, false>(a, stream);
     if (!a.ta && a.tb) return launch_fast_t<false, true>(a, stream);
@@ -755,5 +1081,5 @@ int gemm_profile_collect(double ms[4], double flops[4], long count[4], char* by_
 
 void gemm_force_general(int on) {
   g_force_general = (on == 1);
-  g_fast_geometry = on >= 2 ? on - 1 : 0;  // 2 -> force 256x128, 3 -> force 256x256
+  g_fast_geometry = on >= 2 ? on - 1 : 0;  // 2 -> force 256x128, 3 -> force 256x256 (2-stage), 4 -> force 256x256 ping-pong
 }

@@ -26,7 +26,7 @@ def timeit(fn, iters=10):
 
 
 def main():
-    geoms = [int(a) for a in sys.argv[1:]] or [0, 2, 3]
+    geoms = [int(a) for a in sys.argv[1:]] or [0, 2, 4]
     M, d = 48000, 1024
     x = torch.randn(M, 4 * d, device=DEV).to(BF)
     w = (torch.randn(4 * d, 4 * d, device=DEV) * 0.02).to(BF)

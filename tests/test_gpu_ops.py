@@ -107,7 +107,7 @@ GEMM_SHAPES = [(256, 256, 128), (384, 128, 512), (296, 136, 200), (128, 1024, 64
                (3000, 1152, 384)]
 
 
-@pytest.fixture(params=[0, 1, 2, 3], ids=["auto", "general", "fast256x128", "fast256x256"])
+@pytest.fixture(params=[0, 1, 2, 3, 4], ids=["auto", "general", "fast256x128", "fast256x256", "pingpong256"])
 def gemm_path(request):
     """Run GEMM tests through both kernels: the direct-to-LDS fast path (where it applies) and the general one."""
     from olmoasr_amd import _native as N
