@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic.json"),
                     help="per-symbol HBM bytes per launch from the rocprofv3 PMC passes (scripts/pmc_traffic.py)")
     ap.add_argument("--bucket-mb", type=float, default=128.0)
+    ap.add_argument("--trim-padding", action="store_true",
+                    help="opt-in, NOT the reference's computation shape: run the decoder over ceil16(max text_len) of each "
+                         "micro-batch instead of the padded 448 positions (same loss and gradients; see DESIGN.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
@@ -147,6 +150,11 @@ def main():
     loss_scale = 65536.0  # GradScaler() initial scale; the reference keeps it enabled for bf16 (train_timestamps.py:2349)
     state = {"step": 0}
 
+    # (the data loader knows the token counts on the host; one sync here, outside the timed region)
+    ctx = [None] * accum
+    if args.trim_padding:
+        ctx = [min(448, (int(tl[i * mb:(i + 1) * mb].max()) + 15) // 16 * 16) for i in range(accum)]
+
     def one_step():
         state["step"] += 1
         net.zero_grad()
@@ -155,7 +163,8 @@ def main():
             mel = ops.log_mel(pcm[sl])
             last = i == accum - 1
             net.loss_and_backward(mel, ti[sl], ty[sl], tl[sl], loss_scale=loss_scale, accumulation_steps=accum, loss_out=loss_buf,
-                                  accumulate_loss=i > 0, segment_events=reducer.segment_events() if (reducer and last) else None)
+                                  accumulate_loss=i > 0, segment_events=reducer.segment_events() if (reducer and last) else None,
+                                  text_ctx=ctx[i])
         div = 1.0
         if reducer:
             reducer.reduce()
@@ -221,7 +230,7 @@ def main():
     if rank == 0:
         ms_per_step = 1000.0 * elapsed / args.steps
         value = world * B * 30.0 * args.steps / elapsed
-        fl_sample = train_flops_per_sample(dims.n_audio_state, dims.n_audio_layer)
+        fl_sample = sum(train_flops_per_sample(dims.n_audio_state, dims.n_audio_layer, S=(c or 448)) for c in ctx) / len(ctx)  # executed flops
         step_tflops = B * fl_sample / (elapsed / args.steps) / 1e12
         out = {
             "metric": "audio-seconds/sec/node (train step)", "value": round(value, 1), "unit": "audio-seconds/sec",
@@ -230,7 +239,9 @@ def main():
             "config": {"workload": f"OLMoASR-{args.variant} bf16 train step, {B} x 30 s synthetic clips per GPU "
                                    f"({accum} micro-batches of {mb}, grad accumulation), global batch {world * B}",
                        "global_batch": world * B, "micro_batch": mb, "parallelism": f"dp{world}",
-                       "optimizer": "AdamW fused (unscale+clip+step), loss scale 65536"},
+                       "optimizer": "AdamW fused (unscale+clip+step), loss scale 65536",
+                       "decoder_positions": ("trimmed to ceil16(max text_len) per micro-batch: %s (opt-in, not the reference shape)" % ctx)
+                       if args.trim_padding else "448 (padded, as the reference)"},
             "step_model_tflops_per_gpu": round(step_tflops, 1),
             "step_frac_of_mfma_peak": round(step_tflops / PEAK_BF16_TFLOPS, 4),
             "final_loss": round(final_loss, 4), "found_inf": found_inf,

@@ -102,6 +102,12 @@ int oasr_decode_step(oasr_ctx*, const int64_t* tokens_last, int B, int pos, void
 int oasr_train_fwd_bwd(oasr_ctx*, const float* mel, const int64_t* tokens, const int64_t* targets, const int32_t* text_len, int B,
                        float loss_scale, float inv_accum, float* loss_out, int accumulate_loss, float* logits_out,
                        void** seg_events, void* workspace, size_t workspace_bytes, void* stream);
+/* The same step over the first S <= n_text_ctx decoder positions (tokens/targets [B,S]; logits_out [B,S,n_vocab+1]).
+ * For S >= max(text_len) the loss and all gradients equal the full-context ones (the trimmed positions are pure
+ * padding: ignore_index targets, never attended to by a real query) -- an opt-in the reference does not have. */
+int oasr_train_fwd_bwd_s(oasr_ctx*, const float* mel, const int64_t* tokens, const int64_t* targets, const int32_t* text_len, int B,
+                         int S, float loss_scale, float inv_accum, float* loss_out, int accumulate_loss, float* logits_out,
+                         void** seg_events, void* workspace, size_t workspace_bytes, void* stream);
 int oasr_zero_grad(oasr_ctx*, void* stream);
 
 /* scaler.unscale_ + clip_grad_norm_(max_norm) + AdamW.step + bf16 shadow refresh (train_timestamps.py:1509-1512).

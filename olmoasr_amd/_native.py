@@ -71,6 +71,7 @@ def _declare(lib):
         "oasr_workspace_bytes": (sz, [vp, i32, i32, i32]),
         "oasr_forward": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, sz, vp]),
         "oasr_train_fwd_bwd": (i32, [vp, vp, vp, vp, vp, i32, f32, f32, vp, i32, vp, vp, vp, sz, vp]),
+        "oasr_train_fwd_bwd_s": (i32, [vp, vp, vp, vp, vp, i32, i32, f32, f32, vp, i32, vp, vp, vp, sz, vp]),
         "oasr_zero_grad": (i32, [vp, vp]),
         "oasr_optim_step": (i32, [vp, f32, f32, f32, f32, f32, f32, f32, i64, vp, vp, vp]),
         "oasr_gemm": (i32, [C.POINTER(GemmArgs), vp]),

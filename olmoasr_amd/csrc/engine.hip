@@ -904,8 +904,20 @@ extern "C" int oasr_zero_grad(oasr_ctx* c, void* stream) {
 extern "C" int oasr_train_fwd_bwd(oasr_ctx* c, const float* mel, const int64_t* tokens, const int64_t* targets, const int32_t* text_len,
                                   int B, float loss_scale, float inv_accum, float* loss_out, int accumulate_loss, float* logits_out,
                                   void** ev, void* workspace, size_t workspace_bytes, void* stream) {
+  return oasr_train_fwd_bwd_s(c, mel, tokens, targets, text_len, B, c ? c->S_max : 0, loss_scale, inv_accum, loss_out, accumulate_loss,
+                              logits_out, ev, workspace, workspace_bytes, stream);
+}
+
+// Same step over a decoder context of S <= n_text_ctx positions (tokens / targets are [B, S]).  With S >= max(text_len)
+// rounded up, the loss, every gradient and therefore the optimizer step are those of the full padded context: positions
+// past the last real token only ever see ignore_index targets, and no real query attends to them (causal mask), so
+// the reference spends their share of the decoder on exact zeros (train_timestamps.py:318-329 pads every sample to 448).
+extern "C" int oasr_train_fwd_bwd_s(oasr_ctx* c, const float* mel, const int64_t* tokens, const int64_t* targets,
+                                    const int32_t* text_len, int B, int S, float loss_scale, float inv_accum, float* loss_out,
+                                    int accumulate_loss, float* logits_out, void** ev, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
   RC(check_bound(c, true));
-  const int S = c->S_max;
+  OASR_REQUIRE(S > 0 && S <= c->S_max, "oasr_train_fwd_bwd: S=%d outside (0, n_text_ctx=%d]", S, c->S_max);
   OASR_REQUIRE(mel && tokens && targets && text_len && loss_out && workspace && B > 0, "oasr_train_fwd_bwd: bad args");
   OASR_REQUIRE(workspace_bytes >= oasr_workspace_bytes(c, B, S, OASR_MODE_TRAIN), "oasr_train_fwd_bwd: workspace too small");
   const int d = c->d;

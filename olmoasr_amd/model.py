@@ -422,14 +422,21 @@ class OLMoASR(nn.Module):
 
     def loss_and_backward(self, mel: Tensor, tokens: Tensor, targets: Tensor, text_len: Tensor, *, loss_scale: float = 1.0,
                           accumulation_steps: int = 1, loss_out: Optional[Tensor] = None, accumulate_loss: bool = False,
-                          return_logits: bool = False, segment_events=None):
+                          return_logits: bool = False, segment_events=None, text_ctx: Optional[int] = None):
         """forward + F.cross_entropy(ignore_index=51864)/accumulation_steps + backward of (loss * loss_scale)
-        (train_timestamps.py:1440-1454).  Gradients accumulate into ``flat_grads``.  Returns (loss tensor [1], logits|None)."""
+        (train_timestamps.py:1440-1454).  Gradients accumulate into ``flat_grads``.  Returns (loss tensor [1], logits|None).
+
+        ``text_ctx`` (opt-in, not in the reference): run the decoder over the first ``text_ctx`` positions only.  With
+        ``text_ctx >= max(text_len)`` the loss and gradients equal the full-context ones (the rest is padding the
+        reference computes and then ignores); logits are returned for those positions only."""
         for t, nm in ((mel, "mel"), (tokens, "tokens"), (targets, "targets"), (text_len, "text_len")):
             N.require_gpu(t, nm)
         self.enable_grad_arena()
         B, S = tokens.shape
         assert S == self.dims.n_text_ctx, "training feeds the full padded context (train_timestamps.py:318-329)"
+        if text_ctx is not None:
+            S = max(1, min(int(text_ctx), S))
+            tokens, targets = tokens[:, :S], targets[:, :S]
         mel = mel.float().contiguous()
         tokens = tokens.to(torch.int64).contiguous()
         targets = targets.to(torch.int64).contiguous()
@@ -443,9 +450,9 @@ class OLMoASR(nn.Module):
             assert len(segment_events) == len(self._segments)
             ev = (C.c_void_p * len(segment_events))(*[e.cuda_event for e in segment_events])
         with torch.cuda.device(mel.device):
-            N.check(N.lib().oasr_train_fwd_bwd(self._ctx, N.ptr(mel), N.ptr(tokens), N.ptr(targets), N.ptr(text_len), B,
-                                               float(loss_scale), 1.0 / accumulation_steps, N.ptr(loss_out), int(accumulate_loss),
-                                               N.ptr(logits), ev, N.ptr(ws), ws.numel(), N.stream_ptr()), "oasr_train_fwd_bwd")
+            N.check(N.lib().oasr_train_fwd_bwd_s(self._ctx, N.ptr(mel), N.ptr(tokens), N.ptr(targets), N.ptr(text_len), B, S,
+                                                 float(loss_scale), 1.0 / accumulation_steps, N.ptr(loss_out), int(accumulate_loss),
+                                                 N.ptr(logits), ev, N.ptr(ws), ws.numel(), N.stream_ptr()), "oasr_train_fwd_bwd")
         return loss_out, logits
 
     def init_optimizer_state(self):

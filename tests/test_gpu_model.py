@@ -135,6 +135,33 @@ def test_loss_scale_and_accumulation_are_linear(native_tiny, tiny_case):
     assert not torch.isnan(g2).any()
 
 
+def test_trimmed_text_context_gives_the_full_context_step(native_tiny, tiny_case):
+    """oasr_train_fwd_bwd_s: running the decoder over ceil(max(text_len)) positions instead of the padded 448 must give
+    the same loss, the same logits on those positions and the same gradients (padding rows contribute exact zeros)."""
+    c = tiny_case
+    args = (c["mel"].to(DEV), c["tokens"].to(DEV), c["targets"].to(DEV), c["text_len"].to(DEV))
+    native_tiny.zero_grad()
+    l_full, lg_full = native_tiny.loss_and_backward(*args, return_logits=True)
+    g_full = native_tiny.flat_grads.clone()
+    S = int(c["text_len"].max())
+    S = (S + 15) // 16 * 16
+    assert S < c["tokens"].shape[1]
+    native_tiny.zero_grad()
+    l_trim, lg_trim = native_tiny.loss_and_backward(*args, return_logits=True, text_ctx=S)
+    g_trim = native_tiny.flat_grads.clone()
+    assert lg_trim.shape[1] == S
+    assert abs(float(l_full) - float(l_trim)) < 1e-5 * max(1.0, abs(float(l_full)))
+    valid = (torch.arange(S, device=DEV)[None, :] < args[3][:, None])
+    assert torch.equal(lg_trim[valid], lg_full[:, :S][valid])  # same kernels, same rows -> same bits
+    rel = float((g_trim - g_full).norm() / g_full.norm())
+    print(f"trimmed S={S}: grad rel diff {rel:.2e}")
+    assert rel < 1e-4  # only the fp32 summation order of the split-K weight gradients differs
+    # an S shorter than the longest sample is still well defined (teacher forcing on a truncated context)
+    native_tiny.zero_grad()
+    l_short, _ = native_tiny.loss_and_backward(*args, text_ctx=8)
+    assert torch.isfinite(l_short).all() and not torch.isnan(native_tiny.flat_grads).any()
+
+
 def test_optim_step_matches_adamw(native_tiny, tiny_case):
     """Fused unscale+clip+AdamW against the oracle's AdamW applied to the SAME (native) gradients."""
     from oracle import model_oracle as mo
