@@ -10,6 +10,8 @@
 #include <vector>
 
 #include "../../include/oasr.h"
+#include <math.h>
+
 #include "kernels.h"
 
 namespace {
@@ -303,16 +305,21 @@ struct Runner {
     g.atomic = 1;
     const long tiles = (long)cdiv(N, 256) * cdiv(K, 128);
     const long kt = cdiv(M, 64);
-    // ~2-3 workgroups per CU; a multiple of 8 so every XCD owns whole K-ranges (L2 locality, see gemm.hip); every
-    // extra split costs one more atomic epilogue per tile.
-    long split = (512 + tiles - 1) / tiles;
-    if (split >= 4) {
-      split = (split + 7) / 8 * 8;
-      while (split > 8 && split > kt / 8) split -= 8;
-      if (split > kt / 2) split = 1;
-    } else {
-      split = split > kt / 8 ? 1 : split;
-      if (split < 1) split = 1;
+    // Split-K choice (scripts/wgrad_sweep.py): 768 workgroups are resident at once (3 per CU); what matters is how the
+    // tiles x split grid quantises onto them (1.33 waves is the worst case), the ~32 K-tiles' worth of atomic epilogue
+    // every extra split adds, and that multiples of 8 let every XCD own whole K-ranges (gemm.hip).
+    long split = 1;
+    double best = 1e30;
+    static const int cand[] = {1, 2, 4, 8, 16, 24, 32};
+    for (int s_ : cand) {
+      if (s_ > 1 && (kt / s_ < 8 || tiles >= 768)) break;
+      const double w = (double)tiles * s_, per = (double)kt / s_ + 32.0;
+      const double waves = w <= 768.0 ? 0.55 + 0.45 * w / 768.0 : ceil(w / 768.0);
+      const double score = per * waves;
+      if (score < 0.97 * best) {
+        best = score;
+        split = s_;
+      }
     }
     g.split_k = (int)split;
     return launch_gemm(g, st);
