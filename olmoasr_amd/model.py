@@ -464,6 +464,40 @@ class OLMoASR(nn.Module):
             self._bind()
         return self._opt_state
 
+    # ---- optimizer state in torch.optim.AdamW's own layout (checkpoint compatibility) ------------
+    def _param_slices(self):
+        """(name, offset, numel, shape) in ``named_parameters()`` order == the reference model's ``parameters()`` order, the
+        index space of ``AdamW.state_dict()['state']``."""
+        table = {name: (off, numel, shape) for name, off, numel, shape in self._table}
+        return [(name,) + table[name] for name, _ in self.named_parameters()]
+
+    def optimizer_state_dict(self, *, step: int, lr: float, betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.1):
+        """What ``torch.optim.AdamW(model.parameters(), ...).state_dict()`` holds after ``step`` steps
+        (train_timestamps.py:727-733, saved at :949): the reference can ``optimizer.load_state_dict`` it."""
+        m, v = self.init_optimizer_state()
+        state = {}
+        for i, (_, off, numel, shape) in enumerate(self._param_slices()):
+            state[i] = {"step": torch.tensor(float(step)), "exp_avg": m[off:off + numel].view(shape).detach().cpu().clone(),
+                        "exp_avg_sq": v[off:off + numel].view(shape).detach().cpu().clone()}
+        group = {"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": weight_decay, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(state)))}
+        return {"state": state if step > 0 else {}, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, sd) -> int:
+        """Inverse of ``optimizer_state_dict`` (also accepts a checkpoint written by the reference).  Returns the step count."""
+        m, v = self.init_optimizer_state()
+        m.zero_()
+        v.zero_()
+        step = 0
+        slices = self._param_slices()
+        for i, st in sd.get("state", {}).items():
+            _, off, numel, shape = slices[int(i)]
+            assert tuple(st["exp_avg"].shape) == tuple(shape), (slices[int(i)][0], st["exp_avg"].shape, shape)
+            m[off:off + numel].copy_(st["exp_avg"].reshape(-1).to(m.device, torch.float32))
+            v[off:off + numel].copy_(st["exp_avg_sq"].reshape(-1).to(v.device, torch.float32))
+            step = max(step, int(float(st["step"])))
+        return step
+
     def optim_step(self, *, step: int, lr: float, inv_loss_scale: float = 1.0, max_grad_norm: float = 1.0, betas=(0.9, 0.98),
                    eps: float = 1e-6, weight_decay: float = 0.1):
         """scaler.unscale_ + clip_grad_norm_ + AdamW.step (train_timestamps.py:1509-1512), fused, plus the bf16 shadow

@@ -17,6 +17,7 @@ HIP engine (olmoasr_amd).  Data is int16 PCM on the device; log-mel runs on the 
 """
 import argparse
 import ast
+import glob
 import json
 import math
 import os
@@ -61,7 +62,8 @@ def parse_args(argv=None):
     ap.add_argument("--n_synthetic", type=int, default=4096, help="size of the synthetic dataset (samples)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--bucket_cap_mb", type=float, default=128.0)
-    ap.add_argument("--resume", type=str2bool, default=False)
+    ap.add_argument("--resume", type=str2bool, default=False, help="continue from the latest checkpoint of --exp_name")
+    ap.add_argument("--ckpt_file_name", default="", help="checkpoint to resume from: a path, or a file-name prefix in the run dir")
     return ap.parse_args(argv)
 
 
@@ -105,16 +107,19 @@ def lr_lambda(global_step, train_steps):
     return max(0.0, float(train_steps - global_step) / float(max(1, train_steps - warmup)))
 
 
-def save_ckpt(net, opt_state, scaler, global_step, local_step, epoch, args, dims, rank):
-    """Checkpoint dict with the reference's keys (train_timestamps.py:930-972); ``_ddp`` file has ``module.`` keys."""
+def save_ckpt(net, opt_state, scaler, global_step, local_step, epoch, args, dims, rank, cursor=0, lr=0.0, betas=(0.9, 0.98)):
+    """Checkpoint dict with the reference's keys (train_timestamps.py:930-972); ``_ddp`` file has ``module.`` keys.  The
+    optimizer entry is torch.optim.AdamW's own state_dict layout, so either side can load the other's file."""
     if rank != 0:
         return None
     os.makedirs(os.path.join(args.ckpt_dir, args.exp_name), exist_ok=True)
     sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     base = {"global_step": global_step, "local_step": local_step, "epoch": epoch, "best_eval_wer": None,
-            "optimizer_state_dict": {"flat_exp_avg": opt_state[0].cpu(), "flat_exp_avg_sq": opt_state[1].cpu(), "step": global_step},
-            "scaler_state_dict": scaler.state_dict(), "scheduler_state_dict": {"last_epoch": global_step},
-            "dims": dims.__dict__}
+            "optimizer_state_dict": net.optimizer_state_dict(step=global_step, lr=lr, betas=betas, eps=args.eps,
+                                                             weight_decay=args.weight_decay),
+            "scaler_state_dict": scaler.state_dict(),
+            "scheduler_state_dict": {"last_epoch": global_step, "_step_count": global_step + 1, "base_lrs": [args.lr]},
+            "dims": dims.__dict__, "data_cursor": cursor}
     tag = f"latesttrain_{global_step:08d}_{args.model_variant}_" + "_".join(["ddp", "fp16"])
     paths = []
     for suffix, prefix in (("ddp", "module."), ("non_ddp", "")):
@@ -124,6 +129,29 @@ def save_ckpt(net, opt_state, scaler, global_step, local_step, epoch, args, dims
         torch.save(ck, p)
         paths.append(p)
     return paths
+
+
+def find_ckpt(args):
+    """File selection of the reference's load_ckpt (train_timestamps.py:1012-1030): explicit path, or the latest
+    ``*_ddp.pt`` of this experiment."""
+    if args.ckpt_file_name and "/" in args.ckpt_file_name:
+        return args.ckpt_file_name
+    pat = os.path.join(args.ckpt_dir, args.exp_name, f"{args.ckpt_file_name or '*'}_*_{args.model_variant}_*_ddp.pt")
+    files = [f for f in glob.glob(pat) if not f.endswith("_non_ddp.pt")]
+    if not files:
+        raise FileNotFoundError(f"no checkpoint matches {pat}")
+    return max(files, key=lambda f: int(os.path.basename(f).split("_")[1]))
+
+
+def load_ckpt(net, scaler, path):
+    """Resume (train_timestamps.py:975-1074): model (``module.`` keys), AdamW moments, GradScaler, counters."""
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    net.load_state_dict({k[len("module."):] if k.startswith("module.") else k: v for k, v in ck["model_state_dict"].items()})
+    net.refresh_shadow()
+    opt_steps = net.load_optimizer_state_dict(ck["optimizer_state_dict"])
+    scaler.load_state_dict(ck["scaler_state_dict"])
+    assert opt_steps in (0, ck["global_step"]), (opt_steps, ck["global_step"])
+    return ck["global_step"], ck["local_step"], ck["epoch"], int(ck.get("data_cursor", 0))
 
 
 def main(argv=None):
@@ -154,6 +182,8 @@ def main(argv=None):
     mine = ddp.shard_indices(args.n_synthetic, rank, world_size)
     loss_buf = torch.zeros(1, device=dev)
     global_step, local_step, cursor, epoch = 0, 0, 0, 0
+    if args.resume or args.ckpt_file_name:
+        global_step, local_step, epoch, cursor = load_ckpt(net, scaler, find_ckpt(args))
     log = []
     if rank == 0:
         print(json.dumps({"event": "start", "world_size": world_size, "accumulation_steps": accum, "model": args.model_variant,
@@ -195,9 +225,10 @@ def main(argv=None):
                 log.append(rec)
                 print(json.dumps(rec), flush=True)
         if args.ckpt_freq and global_step % args.ckpt_freq == 0:
-            save_ckpt(net, opt_state, scaler, global_step, local_step, epoch, args, dims, rank)
+            save_ckpt(net, opt_state, scaler, global_step, local_step, epoch, args, dims, rank, cursor, lr, betas)
     if args.ckpt_freq:
-        save_ckpt(net, opt_state, scaler, global_step, local_step, epoch, args, dims, rank)
+        save_ckpt(net, opt_state, scaler, global_step, local_step, epoch, args, dims, rank, cursor,
+                  args.lr * lr_lambda(max(global_step - 1, 0), args.train_steps), betas)
     if world_size > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -392,3 +392,36 @@ def test_train_script_end_to_end(tmp_path):
     assert all(k.startswith("module.") for k in ck["model_state_dict"]) and ck["global_step"] == 12
     net = olmoasr_amd.load_model(str(tmp_path / "t" / files[0]), device=DEV)
     assert net.dims.n_audio_state == 384 and torch.isfinite(net.flat_params).all()
+
+
+def test_resume_continues_the_run_and_adamw_state_is_torch_compatible(tmp_path):
+    """load_ckpt (train_timestamps.py:975-1074): 4 steps + save + resume + 4 steps == 8 steps straight, and the optimizer
+    entry of the checkpoint is a state_dict that torch.optim.AdamW itself accepts for a module of the reference's
+    parameter shapes (so the reference can resume from our file and vice versa)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("tt_gpu_resume", os.path.join(root, "scripts", "training", "train_timestamps.py"))
+    tt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tt)
+    common = ["--model_variant", "tiny", "--eff_batch_size", "8", "--train_batch_size", "4", "--lr", "1e-3", "--train_log_freq", "1",
+              "--n_synthetic", "24", "--ckpt_dir", str(tmp_path), "--train_steps", "8"]
+    straight = tt.main(common + ["--exp_name", "a", "--ckpt_freq", "8"])
+    # same schedule (train_steps 8), stopped after 4 steps by checkpointing every 4 and resuming from step 4
+    tt.main(common + ["--exp_name", "b", "--ckpt_freq", "4"])
+    first = sorted(f for f in os.listdir(tmp_path / "b") if f.endswith("_ddp.pt") and "non_ddp" not in f)[0]
+    assert "_00000004_" in first
+    resumed = tt.main(common + ["--exp_name", "b2", "--ckpt_file_name", str(tmp_path / "b" / first)])
+    assert [r["global_step"] for r in resumed] == [5, 6, 7, 8]
+    for r, s in zip(resumed, straight[4:]):
+        assert r["lr"] == s["lr"]
+        assert abs(r["train_loss"] - s["train_loss"]) < 2e-2 * max(1.0, abs(s["train_loss"])), (r, s)  # atomics-order noise only
+    # the AdamW entry loads into torch.optim.AdamW over parameters of the same shapes and order
+    ck = torch.load(tmp_path / "b" / first, weights_only=False)
+    shapes = [v.shape for k, v in ck["model_state_dict"].items() if not k.endswith("encoder.positional_embedding")]  # (a buffer)
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+    opt = torch.optim.AdamW(params, lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.1)
+    opt.load_state_dict(ck["optimizer_state_dict"])
+    st = opt.state_dict()["state"]
+    assert len(st) == len(params) and float(st[0]["step"]) == 4.0
+    assert all(st[i]["exp_avg"].shape == params[i].shape for i in range(len(params)))
+    assert sum(float(st[i]["exp_avg_sq"].sum()) for i in range(len(params))) > 0
