@@ -5,10 +5,13 @@
 //   hann(400) STFT, hop 160, center/reflect pad, drop last frame -> |X|^2 [201, n/160]
 //   -> 80x201 slaney mel filterbank -> log10(clamp 1e-10) -> max(x, clipmax-8) -> (x+4)/4
 //
-// v1 design: one workgroup = 64 frames of one clip.  The windowed DFT is a dense
-// [64 x 400] x [400 x 416] product on the exact-f32 matrix pipe (v_mfma_f32_16x16x4_f32, k-ordered
-// fmaf chain == f32 accuracy; bf16 MFMA cannot hold the 80 dB dynamic range the -8 floor needs).
-// The hann window is folded into the basis.  Power and the mel projection stay on chip (LDS), only
+// Design: one workgroup = 64 frames of one clip.  The windowed DFT runs on the exact-f32 matrix pipe
+// (v_mfma_f32_16x16x4_f32, k-ordered fmaf chain == f32 accuracy; bf16 MFMA cannot hold the 80 dB dynamic range the
+// -8 floor needs) with the frame FOLDED about its centre first: the periodic hann window and cos are even, sin is odd
+// under n -> 400 - n, so   Re X[k] = sum_{n=0..200} w[n] c[k][n] (x[n] + x[400-n])   (n = 0 and 200 counted once),
+//                          Im X[k] = sum_{n=1..199} w[n] s[k][n] (x[n] - x[400-n]),
+// i.e. two [64 x 208] x [208 x 208] products instead of one [64 x 400] x [400 x 416]: half the MFMA work of the
+// dense DFT, same arithmetic.  The hann window is folded into the basis.  Power and the mel projection stay on chip (LDS), only
 // PCM is read and log-mel written: algorithmic HBM bytes = 2*n (i16) + 4*80*n/160 per clip.
 // The per-clip max (for the -8 floor) is an ordered-uint atomicMax; a second tiny pass applies it.
 #include "common.h"
@@ -24,6 +27,7 @@ constexpr int NS = FT * HOP + (NFFT - HOP);  // 10480 samples per workgroup
 constexpr int SLAB_LD = 432;       // basis slab row stride (floats): 432 % 32 == 16 -> conflict-free b32 reads
 constexpr int P_LD = 212;          // power row stride (floats): 53 16-B slots -> conflict-free b128 reads
 constexpr int KS = 16;             // DFT k per slab
+constexpr int NK = 208;            // folded sample index n = 0..200, padded to 13 slabs (rows > 200 of the basis are zero)
 
 __device__ __forceinline__ unsigned f2ord(float f) {
   unsigned u = __float_as_uint(f);
@@ -44,7 +48,7 @@ __device__ __forceinline__ float load_pcm<float>(const float* p, long i) { retur
 
 template <typename PCM>
 __global__ __launch_bounds__(256) void logmel_main(const PCM* __restrict__ pcm, int n_samples, int n_frames,
-                                                   const float* __restrict__ basis,    // [400][416]
+                                                   const float* __restrict__ basis,    // [208][416] folded basis: w[n] cos | w[n] sin
                                                    const float* __restrict__ melfilt,  // [208][80]
                                                    float* __restrict__ out,            // [B][80][n_frames] log10 values
                                                    unsigned* __restrict__ clipmax) {   // [B] ordered-uint max
@@ -77,21 +81,47 @@ __global__ __launch_bounds__(256) void logmel_main(const PCM* __restrict__ pcm, 
   for (int i = 0; i < 26; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   const int frame_l = wave * 16 + c;  // A-operand row of this lane
-  for (int kb = 0; kb < NFFT / KS; ++kb) {
+  // basis slabs go L2 -> registers -> LDS one slab ahead: the loads of slab kb+1 are in flight under slab kb's MFMAs
+  constexpr int SLAB_V4 = KS * (NB / 4), PER_T = (SLAB_V4 + 255) / 256;  // 1664 16-byte pieces, 7 per thread
+  f32x4_t pre[PER_T];
+  auto slab_fetch = [&](int kb) {
+#pragma unroll
+    for (int j = 0; j < PER_T; ++j) {
+      const int i = tid + j * 256;
+      if (i < SLAB_V4) pre[j] = *(const f32x4_t*)(basis + (long)(kb * KS + i / (NB / 4)) * NB + (i % (NB / 4)) * 4);
+    }
+  };
+  slab_fetch(0);
+  for (int kb = 0; kb < NK / KS; ++kb) {
     __syncthreads();  // previous slab fully consumed (and, first time, samples staged)
-    for (int i = tid; i < KS * (NB / 4); i += 256) {
-      const int r = i / (NB / 4), q = i % (NB / 4);
-      const f32x4_t v = *(const f32x4_t*)(basis + (long)(kb * KS + r) * NB + q * 4);
-      *(f32x4_t*)(slab + r * SLAB_LD + q * 4) = v;
+#pragma unroll
+    for (int j = 0; j < PER_T; ++j) {
+      const int i = tid + j * 256;
+      if (i < SLAB_V4) *(f32x4_t*)(slab + (i / (NB / 4)) * SLAB_LD + (i % (NB / 4)) * 4) = pre[j];
     }
     __syncthreads();
-    const f32x4_t a4 = *(const f32x4_t*)(samp + lds_sample_addr(frame_l * HOP + kb * KS + 4 * g));
+    if (kb + 1 < NK / KS) slab_fetch(kb + 1);
+    // this lane's 4 folded samples n0..n0+3: x[n] and its mirror x[400-n] (two aligned 16-byte reads around 400-n0)
+    const int n0 = kb * KS + 4 * g;
+    const f32x4_t xa = *(const f32x4_t*)(samp + lds_sample_addr(frame_l * HOP + n0));
+    const f32x4_t g1 = *(const f32x4_t*)(samp + lds_sample_addr(frame_l * HOP + NFFT - n0 - 4));
+    const float x_m = samp[lds_sample_addr(frame_l * HOP + NFFT - n0)];  // x[400 - n0]: outside the frame when n0 == 0
+    const bool once = n0 == 0 || n0 == NFFT / 2;                           // n = 0 and n = 200 are their own mirror
+    const float xr[4] = {once ? 0.f : x_m, g1[3], g1[2], g1[1]};
+    float ev[4], od[4];
 #pragma unroll
-    for (int nt = 0; nt < 26; ++nt) {
+    for (int i = 0; i < 4; ++i) {
+      ev[i] = xa[i] + xr[i];
+      od[i] = xa[i] - xr[i];
+    }
+#pragma unroll
+    for (int nt = 0; nt < 13; ++nt) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float bv = slab[(4 * g + i) * SLAB_LD + nt * 16 + c];
-        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i], bv, acc[nt], 0, 0, 0);
+        const float bc = slab[(4 * g + i) * SLAB_LD + nt * 16 + c];
+        const float bs = slab[(4 * g + i) * SLAB_LD + NBH + nt * 16 + c];
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ev[i], bc, acc[nt], 0, 0, 0);
+        acc[13 + nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(od[i], bs, acc[13 + nt], 0, 0, 0);
       }
     }
   }
@@ -168,7 +198,7 @@ __global__ __launch_bounds__(256) void logmel_finalize(float* __restrict__ mel, 
 
 // ---- host-built constant tables (double precision, rounded once to f32) -----------------------------
 struct MelTables {
-  float* basis = nullptr;    // [400][416]
+  float* basis = nullptr;    // [208][416] (folded)
   float* melfilt = nullptr;  // [208][80]
   int device = -1;
 };
@@ -210,7 +240,7 @@ static int ensure_tables(int device, MelTables** t_out) {
   OASR_REQUIRE(device >= 0 && device < 16, "device index %d out of range", device);
   MelTables& t = g_tables[device];
   if (t.basis == nullptr) {
-    float* hb = (float*)calloc((size_t)NFFT * NB, sizeof(float));
+    float* hb = (float*)calloc((size_t)NK * NB, sizeof(float));
     float* hf = (float*)calloc((size_t)NBH * NMEL, sizeof(float));
     float* fb = (float*)malloc(sizeof(float) * NMEL * NFREQ);
     if (!hb || !hf || !fb) {
@@ -218,21 +248,21 @@ static int ensure_tables(int device, MelTables** t_out) {
       return OASR_EHIP;
     }
     const double PI = 3.14159265358979323846;
-    for (int j = 0; j < NFFT; ++j) {
-      const double w = 0.5 - 0.5 * cos(2.0 * PI * j / NFFT);  // torch.hann_window(400), periodic
+    for (int j = 0; j <= NFFT / 2; ++j) {  // folded rows; rows 201..207 stay zero
+      const double w = 0.5 - 0.5 * cos(2.0 * PI * j / NFFT);  // torch.hann_window(400), periodic: w[400 - j] == w[j]
       for (int f = 0; f < NFREQ; ++f) {
         const int ph = (int)(((long)j * f) % NFFT);  // exact argument reduction
         const double ang = 2.0 * PI * ph / NFFT;
         hb[(size_t)j * NB + f] = (float)(w * cos(ang));
-        hb[(size_t)j * NB + NBH + f] = (float)(w * sin(ang));
+        if (j >= 1 && j < NFFT / 2) hb[(size_t)j * NB + NBH + f] = (float)(w * sin(ang));
       }
     }
     oasr_mel_filterbank(fb);
     for (int m = 0; m < NMEL; ++m)
       for (int f = 0; f < NFREQ; ++f) hf[(size_t)f * NMEL + m] = fb[m * NFREQ + f];
-    OASR_CHECK_HIP(hipMalloc((void**)&t.basis, sizeof(float) * NFFT * NB));
+    OASR_CHECK_HIP(hipMalloc((void**)&t.basis, sizeof(float) * NK * NB));
     OASR_CHECK_HIP(hipMalloc((void**)&t.melfilt, sizeof(float) * NBH * NMEL));
-    OASR_CHECK_HIP(hipMemcpy(t.basis, hb, sizeof(float) * NFFT * NB, hipMemcpyHostToDevice));
+    OASR_CHECK_HIP(hipMemcpy(t.basis, hb, sizeof(float) * NK * NB, hipMemcpyHostToDevice));
     OASR_CHECK_HIP(hipMemcpy(t.melfilt, hf, sizeof(float) * NBH * NMEL, hipMemcpyHostToDevice));
     free(hb);
     free(hf);
