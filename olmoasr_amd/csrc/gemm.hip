@@ -849,6 +849,82 @@ __global__ __launch_bounds__(512, 2) void oasr_gemm_pp_kernel(GemmArgs p) {
 
 namespace {
 
+// ---- skinny GEMM for the decode path: out[M <= 64][N] = x[M][K] . W[N][K]^T, NT layout --------------------------------
+// A decoder step multiplies a handful of token rows with every weight matrix; the 256-wide tiles above would run 3-24
+// workgroups that each walk K serially (measured 25-32 us per GEMM, 40x the time the weight bytes need).  Here one
+// workgroup owns 32 output columns, its 4 waves split K four ways and stream the weight rows straight from L2/HBM
+// into MFMA operands (16 bytes per lane, no LDS staging: every weight byte is used exactly once), x comes through
+// L1/L2.  Partial accumulators meet in LDS; the epilogue is the general kernel's.
+template <int MT>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
+  __shared__ float red[4][MT][16][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int n0 = blockIdx.x * 32;
+  int col = n0 + (lane & 31);
+  col = col < p.N ? col : p.N - 1;
+  const bf16_t* wp = p.B.ptr + (long)col * p.B.ld + h * 8;
+  const bf16_t* xp[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int row = mt * 32 + (lane & 31);
+    row = row < p.M ? row : p.M - 1;
+    xp[mt] = p.A.ptr + (long)row * p.A.ld + h * 8;
+  }
+  f32x16_t acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+  const int kq = p.K / 4;  // K % 64 == 0 (host): every wave gets a multiple of 16
+  const int k_begin = wave * kq, k_end = k_begin + kq;
+  int k = k_begin;
+  for (; k + 64 <= k_end; k += 64) {  // 4 k-steps per trip: 4 (+ 4 MT) independent 16-byte loads in flight per lane
+    u32x4_t wq[4], xq[MT][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      wq[j] = *(const u32x4_t*)(wp + k + 16 * j);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) xq[mt][j] = *(const u32x4_t*)(xp[mt] + k + 16 * j);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)  // D'[n][m]: lane owns output row m
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wq[j]), __builtin_bit_cast(bf16x8_t, xq[mt][j]),
+                                                          acc[mt], 0, 0, 0);
+  }
+  for (; k < k_end; k += 16) {
+    const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)(wp + k));
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const bf16x8_t xf = __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)(xp[mt] + k));
+      acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[mt], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][mt][r][lane] = acc[mt][r];
+  __syncthreads();
+  // wave w finishes register group q = w: columns n0 + 8w + 4h .. +3 of output row (lane & 31)
+  const int n = n0 + 8 * wave + 4 * h;
+  if (n < p.N) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = mt * 32 + (lane & 31);
+      if (m < p.M) {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          v[i] = red[0][mt][wave * 4 + i][lane] + red[1][mt][wave * 4 + i][lane] + red[2][mt][wave * 4 + i][lane] +
+                 red[3][mt][wave * 4 + i][lane];
+        epilogue_store(p, m, n, p.pos ? (m % p.pos_period) : 0, v);
+      }
+    }
+  }
+}
+
+
 template <bool TA, bool TB, int FBN, int NWN, int NSTAGE, bool SWAP, bool CSUM = false>
 int launch_fast_cfg(const GemmArgs& a, hipStream_t stream) {
   static bool attr = false;
@@ -923,6 +999,30 @@ int launch_pp_cfg(const GemmArgs& a, hipStream_t stream) {
 // Below ~half a wave of 256 x 256 tiles the 256 x 128 geometry keeps more CUs busy.
 bool prefer_pingpong(const GemmArgs& a) {
   return a.K >= 2 * BK && (long)cdiv(a.M, 256) * cdiv(a.N, 256) > 128;
+}
+
+int launch_skinny(const GemmArgs& a, hipStream_t stream) {
+  const dim3 grid(cdiv(a.N, 32));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (g_prof.on) {
+    const size_t idx = g_prof.recs.size();
+    while (g_prof.events.size() < 2 * (idx + 1)) {
+      hipEvent_t e;
+      OASR_CHECK_HIP(hipEventCreate(&e));
+      g_prof.events.push_back(e);
+    }
+    e0 = g_prof.events[2 * idx];
+    e1 = g_prof.events[2 * idx + 1];
+    g_prof.recs.push_back({0, 2.0 * (double)a.M * (double)a.N * (double)a.K, a.M <= 32 ? "gemm_skinny_kernel<1>" : "gemm_skinny_kernel<2>"});
+    OASR_CHECK_HIP(hipEventRecord(e0, stream));
+  }
+  if (a.M <= 32)
+    hipLaunchKernelGGL(gemm_skinny_kernel<1>, grid, dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL(gemm_skinny_kernel<2>, grid, dim3(256), 0, stream, a);
+  OASR_LAUNCH_CHECK();
+  if (e1) OASR_CHECK_HIP(hipEventRecord(e1, stream));
+  return OASR_OK;
 }
 
 template <bool TA, bool TB>
@@ -1016,6 +1116,10 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     b.raster_gm = env_gm;
     return launch_gemm(b, stream);
   }
+  // decode-sized problems: a few token rows against a whole weight matrix
+  if (a.M <= 64 && !a.ta && !a.tb && !a.A.rpb && !a.B.rpb && (a.K % BK) == 0 && a.split_k == 1 && !a.atomic && !a.colsum &&
+      !g_force_general && g_fast_geometry == 0)
+    return launch_skinny(a, stream);
   const bool atomic_only = a.atomic && a.out_f32 && !a.out && !a.out_pre;
   const bool fast = !a.A.rpb && !a.B.rpb && (a.K % BK) == 0 && (!a.ta || (a.M % 8) == 0) && (!a.tb || (a.N % 8) == 0) &&
                     a.M >= 8 && a.N >= 8 && !g_force_general && (atomic_only || fast_rows_ok(a));

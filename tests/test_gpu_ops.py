@@ -354,3 +354,25 @@ def test_gemm_fused_column_sum(tb, gemm_path):
     cs = torch.full((N,), 0.5, device=DEV)
     ops().gemm(A, B, M, N, K, tb=tb, dgelu_u=u, out=out, colsum=cs)
     close(cs, out.float().sum(0) + 0.5, rtol=1e-4, atol=1e-3, name="fused colsum == column sums of the stored output")
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 768, 768), (20, 2304, 768), (33, 776, 3072), (64, 51864, 384), (8, 40, 64)])
+def test_gemm_skinny_decode_shapes(M, N, K):
+    """Decode-sized GEMMs (a few token rows x a whole weight matrix) take the skinny kernel: plain, bias + GELU (+pre),
+    bias + residual, and fp32 output, against fp32 torch with the autocast rounding points."""
+    A, B = rnd(M, K, seed=11), rnd(N, K, seed=12, scale=0.05)
+    bias = torch.randn(N, device=DEV)
+    ref = A.float() @ B.float().t()
+    out = torch.full((M, N), float("nan"), device=DEV, dtype=BF)
+    ops().gemm(A, B, M, N, K, out=out)
+    close(out, ref, name="skinny plain")
+    pre = torch.empty_like(out)
+    ops().gemm(A, B, M, N, K, bias=bias, act=1, out=out, out_pre=pre)
+    close(pre, ref + bias, name="skinny pre-activation")
+    close(out, F.gelu(pre.float()), name="skinny gelu")
+    resid = rnd(M, N, seed=13)
+    ops().gemm(A, B, M, N, K, bias=bias, resid=resid, out=out)
+    close(out, (ref + bias).to(BF).float() + resid.float(), name="skinny residual")
+    o32 = torch.full((M, N), float("nan"), device=DEV)
+    ops().gemm(A, B, M, N, K, out_f32=o32)
+    close(o32, ref, rtol=2e-3, atol=2e-3, name="skinny fp32 out")
