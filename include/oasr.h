@@ -131,7 +131,7 @@ int oasr_layernorm_fwd(const void* x, const float* gamma, const float* beta, voi
 int oasr_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dres,
                        void* dx, float* dgamma, float* dbeta, int64_t rows, int d, void* stream);
 typedef struct oasr_attn_args {
-  const void *q, *k, *v; int64_t ldq, ldk, ldv, bsq, bsk, bsv; void* o; int64_t ldo, bso; float* lse; float* o32; const int32_t* kv_len;
+  const void *q, *k, *v; int64_t ldq, ldk, ldv, bsq, bsk, bsv; void* o; int64_t ldo, bso; float* lse; void* o_lo; const int32_t* kv_len;
   int B, H, Tq, Tk, causal; const void* d_o; float* delta; void *dq, *dk, *dv;
 } oasr_attn_args;
 int oasr_attention_fwd(const oasr_attn_args*, void* stream);

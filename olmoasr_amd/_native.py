@@ -37,7 +37,7 @@ class GemmArgs(C.Structure):
 class AttnArgs(C.Structure):
     _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("ldq", C.c_int64), ("ldk", C.c_int64),
                 ("ldv", C.c_int64), ("bsq", C.c_int64), ("bsk", C.c_int64), ("bsv", C.c_int64), ("o", C.c_void_p),
-                ("ldo", C.c_int64), ("bso", C.c_int64), ("lse", C.c_void_p), ("o32", C.c_void_p), ("kv_len", C.c_void_p), ("B", C.c_int),
+                ("ldo", C.c_int64), ("bso", C.c_int64), ("lse", C.c_void_p), ("o_lo", C.c_void_p), ("kv_len", C.c_void_p), ("B", C.c_int),
                 ("H", C.c_int), ("Tq", C.c_int), ("Tk", C.c_int), ("causal", C.c_int), ("d_o", C.c_void_p),
                 ("delta", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p)]
 

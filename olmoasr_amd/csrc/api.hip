@@ -95,7 +95,7 @@ static AttnArgs to_attn(const oasr_attn_args* a) {
   r.ldo = a->ldo;
   r.bso = a->bso;
   r.lse = a->lse;
-  r.o32 = a->o32;
+  r.o_lo = (bf16_t*)a->o_lo;
   r.kv_len = a->kv_len;
   r.B = a->B;
   r.H = a->H;

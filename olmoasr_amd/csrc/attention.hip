@@ -91,6 +91,34 @@ __device__ __forceinline__ bf16x8_t pack_half(const f32x16_t& p, int u) {
 __device__ __forceinline__ bf16x8_t ld_frag_global(const bf16_t* p) { return __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)p); }
 __device__ __forceinline__ int acc_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
+// ---- row-coalesced output stores --------------------------------------------------------------------------------------
+// The kernels hold their results transposed, T[dt][r] = out[row = lane & 31][col = dt*32 + acc_row(r, lane >> 5)]: a lane owns
+// one output row but only 4 consecutive columns per register group, so direct stores are 8-byte pieces scattered over
+// 32 rows per instruction (measured: the forward kernel spends 14 % of its time issuing them).  Instead each wave
+// transposes through a private LDS tile and every lane stores 16 contiguous bytes, 8 lanes covering one 128-byte row
+// segment.  `stg`: wave-private, 4 KiB; all waves must be done with the operand tiles.
+__device__ __forceinline__ void store_rows_bf16(char* stg, const f32x16_t (&T)[2], float scale, bf16_t* gbase, long ld, int rows_valid,
+                                                int lane) {
+  const int row = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      u32x2_t o;
+      o[0] = pack_bf2(T[dt][4 * g4] * scale, T[dt][4 * g4 + 1] * scale);
+      o[1] = pack_bf2(T[dt][4 * g4 + 2] * scale, T[dt][4 * g4 + 3] * scale);
+      *(u32x2_t*)(stg + row * 128 + (((dt * 4 + g4) ^ (row & 7)) << 4) + hh * 8) = o;
+    }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r2 = i * 8 + (lane >> 3), ch = lane & 7;
+    const u32x4_t v = *(const u32x4_t*)(stg + r2 * 128 + ((ch ^ (r2 & 7)) << 4));
+    if (r2 < rows_valid) *(u32x4_t*)(gbase + (long)r2 * ld + ch * 8) = v;
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
 // ------------------------------------------------------------------------------------------------------------
@@ -214,27 +242,25 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-  if (myq < a.Tq) {
-    bf16_t* op = a.o + (long)b * a.bso + (long)myq * a.ldo + h * 64;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        u32x2_t o;
-        o[0] = pack_bf2(oT[dt][4 * g4] * inv, oT[dt][4 * g4 + 1] * inv);
-        o[1] = pack_bf2(oT[dt][4 * g4 + 2] * inv, oT[dt][4 * g4 + 3] * inv);
-        *(u32x2_t*)(op + dt * 32 + 8 * g4 + 4 * hh) = o;
-      }
-    if (a.o32) {  // unrounded O for the backward's delta term (bf16 O loses it when mean(V) dominates V's variation)
-      float* o32p = a.o32 + (long)b * a.bso + (long)myq * a.ldo + h * 64;
+  {
+    // (the loop ended on a barrier: the K/V stages are free; 4 KiB of staging per wave)
+    char* stg = smem + wave * 4096;
+    const int rows_valid = a.Tq - (q0 + wave * 32);  // may be <= 0 or > 32
+    const long row0 = (long)b * a.bso + (long)(q0 + wave * 32) * a.ldo + h * 64;
+    store_rows_bf16(stg, oT, inv, a.o + row0, a.ldo, rows_valid, lane);
+    // rounding residual of O for the backward's delta term (bf16 O alone loses it when mean(V) dominates V's variation;
+    // O + residual is fp32-grade at 4 bytes per element instead of 2 + 4)
+    if (a.o_lo) {
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4)
-          *(f32x4_t*)(o32p + dt * 32 + 8 * g4 + 4 * hh) =
-              (f32x4_t){oT[dt][4 * g4] * inv, oT[dt][4 * g4 + 1] * inv, oT[dt][4 * g4 + 2] * inv, oT[dt][4 * g4 + 3] * inv};
+        for (int r = 0; r < 16; ++r) {
+          const float v = oT[dt][r] * inv;
+          oT[dt][r] = v - bf_round(v);
+        }
+      store_rows_bf16(stg, oT, 1.0f, a.o_lo + row0, a.ldo, rows_valid, lane);
     }
-    if (hh == 0 && a.lse) a.lse[((long)b * a.H + h) * a.Tq + myq] = (m_run + __builtin_amdgcn_logf(l_tot)) * LN2;
+    if (myq < a.Tq && hh == 0 && a.lse) a.lse[((long)b * a.H + h) * a.Tq + myq] = (m_run + __builtin_amdgcn_logf(l_tot)) * LN2;
   }
 }
 
@@ -257,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   const bf16_t* qp = a.q + (long)b * a.bsq + (long)myq_c * a.ldq + h * 64;
   const bf16_t* dop = a.d_o + (long)b * a.bso + (long)myq_c * a.ldo + h * 64;
   const bf16_t* op = a.o + (long)b * a.bso + (long)myq_c * a.ldo + h * 64;
-  const float* o32p = a.o32 ? a.o32 + (long)b * a.bso + (long)myq_c * a.ldo + h * 64 : nullptr;
+  const bf16_t* olop = a.o_lo ? a.o_lo + (long)b * a.bso + (long)myq_c * a.ldo + h * 64 : nullptr;
   bf16x8_t qf[4], dof[4];
   float dpart = 0.f;
 #pragma unroll
@@ -265,12 +291,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     qf[ds] = ld_frag_global(qp + ds * 16 + hh * 8);
     const u32x4_t d4 = *(const u32x4_t*)(dop + ds * 16 + hh * 8);
     dof[ds] = __builtin_bit_cast(bf16x8_t, d4);
-    if (o32p) {
-      const f32x4_t oa = *(const f32x4_t*)(o32p + ds * 16 + hh * 8), ob = *(const f32x4_t*)(o32p + ds * 16 + hh * 8 + 4);
-      dpart += bf_lo(d4[0]) * oa[0] + bf_hi(d4[0]) * oa[1] + bf_lo(d4[1]) * oa[2] + bf_hi(d4[1]) * oa[3];
-      dpart += bf_lo(d4[2]) * ob[0] + bf_hi(d4[2]) * ob[1] + bf_lo(d4[3]) * ob[2] + bf_hi(d4[3]) * ob[3];
+    const u32x4_t o4 = *(const u32x4_t*)(op + ds * 16 + hh * 8);
+    if (olop) {  // O = bf16 O + bf16 rounding residual (an fp32-grade O in 4 bytes per element, like the forward wrote it)
+      const u32x4_t r4 = *(const u32x4_t*)(olop + ds * 16 + hh * 8);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        dpart += bf_lo(d4[i]) * (bf_lo(o4[i]) + bf_lo(r4[i])) + bf_hi(d4[i]) * (bf_hi(o4[i]) + bf_hi(r4[i]));
     } else {
-      const u32x4_t o4 = *(const u32x4_t*)(op + ds * 16 + hh * 8);
 #pragma unroll
       for (int i = 0; i < 4; ++i) dpart += bf_lo(d4[i]) * bf_lo(o4[i]) + bf_hi(d4[i]) * bf_hi(o4[i]);
     }
@@ -354,18 +381,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     }
     __syncthreads();
   }
-  if (myq < a.Tq) {
-    bf16_t* dqp = a.dq + (long)b * a.bsq + (long)myq * a.ldq + h * 64;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        u32x2_t o;
-        o[0] = pack_bf2(dqT[dt][4 * g4] * SCALE, dqT[dt][4 * g4 + 1] * SCALE);
-        o[1] = pack_bf2(dqT[dt][4 * g4 + 2] * SCALE, dqT[dt][4 * g4 + 3] * SCALE);
-        *(u32x2_t*)(dqp + dt * 32 + 8 * g4 + 4 * hh) = o;
-      }
-  }
+  // (the loop ended on a barrier: the K/V stages are free for the per-wave staging tiles)
+  store_rows_bf16(smem + wave * 4096, dqT, SCALE, a.dq + (long)b * a.bsq + (long)(q0 + wave * 32) * a.ldq + h * 64, a.ldq,
+                  a.Tq - (q0 + wave * 32), lane);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -501,21 +519,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
     if (more) commit(smem + (cur ^ 1) * STAGE);
     __syncthreads();
   }
-  if (mykey < a.Tk) {
-    bf16_t* dkp = a.dk + (long)b * a.bsk + (long)mykey * a.ldk + h * 64;
-    bf16_t* dvp = a.dv + (long)b * a.bsv + (long)mykey * a.ldv + h * 64;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        u32x2_t o;
-        o[0] = pack_bf2(dkT[dt][4 * g4] * SCALE, dkT[dt][4 * g4 + 1] * SCALE);
-        o[1] = pack_bf2(dkT[dt][4 * g4 + 2] * SCALE, dkT[dt][4 * g4 + 3] * SCALE);
-        *(u32x2_t*)(dkp + dt * 32 + 8 * g4 + 4 * hh) = o;
-        o[0] = pack_bf2(dvT[dt][4 * g4], dvT[dt][4 * g4 + 1]);
-        o[1] = pack_bf2(dvT[dt][4 * g4 + 2], dvT[dt][4 * g4 + 3]);
-        *(u32x2_t*)(dvp + dt * 32 + 8 * g4 + 4 * hh) = o;
-      }
+  {
+    char* stg = smem + wave * 4096;  // the loop ended on a barrier: both stages are free
+    const int rows_valid = a.Tk - (k0 + wave * 32);
+    store_rows_bf16(stg, dkT, SCALE, a.dk + (long)b * a.bsk + (long)(k0 + wave * 32) * a.ldk + h * 64, a.ldk, rows_valid, lane);
+    store_rows_bf16(stg, dvT, 1.0f, a.dv + (long)b * a.bsv + (long)(k0 + wave * 32) * a.ldv + h * 64, a.ldv, rows_valid, lane);
   }
 }
 

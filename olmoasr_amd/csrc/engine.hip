@@ -133,7 +133,7 @@ struct AttnSave {
   bf16_t *ln, *qkv, *o;  // self: qkv [M,3d];  cross: qkv = q [M,d]
   bf16_t* kv;            // cross only: [B*Te, 2d]
   float *mean, *rstd, *lse;
-  float* o32;  // training only: unrounded attention output for the backward's delta
+  bf16_t* o_lo;  // training only: bf16 rounding residual of the attention output (o + o_lo = fp32-grade O for the backward's delta)
 };
 struct BlockSave {
   bf16_t* x_in;  // residual stream entering the block (owned by the previous stage)
@@ -164,7 +164,7 @@ void plan_attn(Arena& A, AttnSave& s, long M, long Mkv, int d, int B, int H, lon
   s.mean = A.f32(M);
   s.rstd = A.f32(M);
   s.lse = A.f32((long)B * H * Tq);
-  s.o32 = train ? A.f32(M * d) : nullptr;
+  s.o_lo = train ? A.bf(M * d) : nullptr;
 }
 
 // In inference mode the per-layer buffers are shared between layers (allocated once); in training each layer
@@ -346,7 +346,7 @@ struct Runner {
     a.ldo = d;
     a.bso = Tq * d;
     a.lse = s.lse;
-    a.o32 = s.o32;
+    a.o_lo = s.o_lo;
     a.kv_len = causal ? text_len : nullptr;
     a.B = B;
     a.H = c->H;

@@ -80,7 +80,7 @@ struct AttnArgs {
   bf16_t* o;                 // [B, Tq, H*64]
   long ldo, bso;
   float* lse;                // [B, H, Tq] natural-log-sum-exp of scaled scores
-  float* o32;                // optional fp32 copy of o (same strides): fwd writes it, bwd reads it for delta = rowsum(dO*O)
+  bf16_t* o_lo;              // optional bf16 rounding residual of o (same strides): fwd writes it, bwd uses o + o_lo for delta = rowsum(dO*O)
   const int32_t* kv_len;     // [B] or null
   int B, H, Tq, Tk, causal;
   // backward only

@@ -74,26 +74,26 @@ def _attn_args(q, k, v, o, lse, kv_len, causal):
     return a
 
 
-def attention_fwd(q, k, v, kv_len=None, causal=False, want_o32=False):
-    """q [B,Tq,H,64], k/v [B,Tk,H,64] (any token/batch strides) -> o [B,Tq,H*64], lse [B,H,Tq] (, o32)."""
+def attention_fwd(q, k, v, kv_len=None, causal=False, want_o_lo=False):
+    """q [B,Tq,H,64], k/v [B,Tk,H,64] (any token/batch strides) -> o [B,Tq,H*64], lse [B,H,Tq] (, o_lo = bf16 rounding residual of o)."""
     B, Tq, H, _ = q.shape
     o = torch.empty(B, Tq, H * 64, device=q.device, dtype=BF)
     lse = torch.empty(B, H, Tq, device=q.device, dtype=torch.float32)
     a = _attn_args(q, k, v, o.view(B, Tq, H, 64), lse, kv_len, causal)
-    o32 = torch.empty(B, Tq, H * 64, device=q.device, dtype=torch.float32) if want_o32 else None
-    a.o32 = o32.data_ptr() if want_o32 else None
+    o_lo = torch.empty(B, Tq, H * 64, device=q.device, dtype=torch.bfloat16) if want_o_lo else None
+    a.o_lo = o_lo.data_ptr() if want_o_lo else None
     N.check(N.lib().oasr_attention_fwd(C.byref(a), N.stream_ptr()), "attention_fwd")
-    return (o, lse, o32) if want_o32 else (o, lse)
+    return (o, lse, o_lo) if want_o_lo else (o, lse)
 
 
-def attention_bwd(q, k, v, o, lse, d_o, kv_len=None, causal=False, o32=None):
+def attention_bwd(q, k, v, o, lse, d_o, kv_len=None, causal=False, o_lo=None):
     B, Tq, H, _ = q.shape
     # gradients use the operands' own (possibly fused-qkv) strides
     dq, dk, dv = (torch.empty_strided(t.shape, t.stride(), device=t.device, dtype=t.dtype) for t in (q, k, v))
     delta = torch.empty(B, H, Tq, device=q.device, dtype=torch.float32)
     a = _attn_args(q, k, v, o.view(B, Tq, H, 64), lse, kv_len, causal)
     a.d_o, a.delta = d_o.data_ptr(), delta.data_ptr()
-    a.o32 = o32.data_ptr() if o32 is not None else None
+    a.o_lo = o_lo.data_ptr() if o_lo is not None else None
     a.dq, a.dk, a.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
     N.check(N.lib().oasr_attention_bwd(C.byref(a), N.stream_ptr()), "attention_bwd")
     return dq, dk, dv

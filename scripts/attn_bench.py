@@ -38,10 +38,10 @@ def main():
             k, v = (kvb[:, :, i * d:(i + 1) * d].unflatten(2, (H, 64)) for i in range(2))
         kv_len = torch.randint(8, 221, (B,), device=DEV, dtype=torch.int32) if causal else None
         d_o = torch.randn(B, Tq, d, device=DEV).to(BF)
-        o, lse, o32 = ops.attention_fwd(q, k, v, kv_len, causal, want_o32=True)
+        o, lse, o_lo = ops.attention_fwd(q, k, v, kv_len, causal, want_o_lo=True)
         flops = 4.0 * B * H * Tq * Tk * 64 * (0.5 if causal else 1.0)
-        tf = timeit(lambda: ops.attention_fwd(q, k, v, kv_len, causal, want_o32=True), iters)
-        tb = timeit(lambda: ops.attention_bwd(q, k, v, o, lse, d_o, kv_len, causal, o32=o32), iters)
+        tf = timeit(lambda: ops.attention_fwd(q, k, v, kv_len, causal, want_o_lo=True), iters)
+        tb = timeit(lambda: ops.attention_bwd(q, k, v, o, lse, d_o, kv_len, causal, o_lo=o_lo), iters)
         print(f"{name:14s} Tq={Tq} Tk={Tk}: fwd {tf:7.3f} ms {flops / tf / 1e9:7.1f} TF/s | bwd {tb:7.3f} ms {2.5 * flops / tb / 1e9:7.1f} TF/s (algorithmic 2.5x)",
               flush=True)
 
