@@ -1028,17 +1028,15 @@ int launch_skinny(const GemmArgs& a, hipStream_t stream) {
 template <bool TA, bool TB>
 int launch_fast_t(const GemmArgs& a, hipStream_t stream) {
   const bool atomic_only = a.atomic && a.out_f32 && !a.out && !a.out_pre;
-  const long big_tiles = (long)cdiv(a.M, FBM) * cdiv(a.N, 256) * a.split_k;
-  // Geometry: measured on the OLMoASR-medium shapes (scripts/gemm_bench.py) the 256x128 / 3-workgroups-per-CU
-  // geometry is at least as fast as the 1-workgroup-per-CU 256x256 one everywhere except very small split-K outputs;
-  // co-resident workgroups overlap one's VALU-heavy epilogue with another's MFMA main loop.
-  // OASR_GEMM_GEOM=1|2 overrides (experiments).
+  // Geometry (measured: scripts/gemm_ab.py, scripts/wgrad_sweep.py): bf16 outputs -> the ping-pong kernel unless the
+  // problem has under half a wave of 256x256 tiles; split-K / atomic outputs (wgrad) -> 256x128 with 3 workgroups per
+  // CU, whose co-resident workgroups hide the atomic epilogues.  OASR_GEMM_GEOM=1|2|3 overrides (experiments).
   static const int env_geom = [] {
     const char* e = getenv("OASR_GEMM_GEOM");
     return e ? atoi(e) : 0;
   }();
   const int geom = g_fast_geometry ? g_fast_geometry : env_geom;
-  const bool big = geom == 2 || (geom == 0 && atomic_only && (long)cdiv(a.M, FBM) * cdiv(a.N, 128) <= 32 && big_tiles >= 128);
+  const bool big = geom == 2;  // (the 256x256 / 2-stage geometry lost to 256x128 on every measured shape incl. small split-K outputs: scripts/wgrad_sweep.py)
   if (geom == 3 || (geom == 0 && !atomic_only && prefer_pingpong(a))) {  // 256x256 ping-pong kernel
     if (atomic_only) return launch_pp_cfg<TA, TB, false>(a, stream);
     if (a.colsum && !TA && TB) return launch_pp_cfg<false, true, true, true>(a, stream);
