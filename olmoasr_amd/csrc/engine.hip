@@ -172,9 +172,9 @@ void plan_attn(Arena& A, AttnSave& s, long M, long Mkv, int d, int B, int H, lon
 void make_plan(const oasr_ctx* c, Arena& A, Plan& p, int B, int S, bool train) {
   const int d = c->d;
   const long Me = (long)B * c->Te, M1 = (long)B * c->T1, Md = (long)B * S;
-  p.mel_tm = A.bf(M1 * c->dims.n_mels);
+  p.mel_tm = A.bf(M1 * c->dims.n_mels + 2 * 256) + 256;  // zeroed guard rows on both sides (conv1 weight gradient windows)
   p.u1 = A.bf(M1 * d);
-  p.h1 = A.bf(M1 * d);
+  p.h1 = A.bf(M1 * d + d) + d;  // one zeroed time row in front: the conv2 weight gradient reads h1 as overlapping windows from h1 - d
   p.u2 = A.bf(Me * d);
   p.x0 = A.bf(Me * d);
   auto plan_block = [&](BlockSave& s, long M, long Tq, bool cross) {
@@ -946,7 +946,12 @@ extern "C" int oasr_train_fwd_bwd_s(oasr_ctx* c, const float* mel, const int64_t
   // ---------------- backward: decoder ----------------
   int seg = 0;
   // tied logits: dE += dlogits^T . lnf ; d(lnf) = dlogits . E
-  RC(r.wgrad(p.logits, c->Vp, Md, c->V, plain_view(p.lnf, d), d, c->G(c->tok_emb), d));
+  // (V = n_vocab + 1 is odd: the direct-to-LDS kernel wants a multiple of 8 rows, so the pad class gets its own 1-row GEMM)
+  {
+    const int v8 = c->V & ~7;
+    RC(r.wgrad(p.logits, c->Vp, Md, v8, plain_view(p.lnf, d), d, c->G(c->tok_emb), d));
+    if (v8 < c->V) RC(r.wgrad(p.logits + v8, c->Vp, Md, c->V - v8, plain_view(p.lnf, d), d, c->G(c->tok_emb) + (long)v8 * d, d));
+  }
   RC(r.dgrad(p.logits, Md, c->Vp, c->W(c->tok_emb), d, nullptr, nullptr, p.gln));
   const bf16_t* x_last = c->L_dec ? p.dec[c->L_dec - 1].x_out : p.dx0;
   RC(launch_layernorm_bwd(p.gln, x_last, c->P(c->dec_ln_w), p.mean_f, p.rstd_f, nullptr, p.ga, c->G(c->dec_ln_w), c->G(c->dec_ln_b),
@@ -997,13 +1002,56 @@ extern "C" int oasr_train_fwd_bwd_s(oasr_ctx* c, const float* mel, const int64_t
     hipLaunchKernelGGL(dgelu_mul_kernel, dim3((unsigned)nb), dim3(256), 0, st, dx, p.u2, p.gln, n8);  // gln = d(u2)
     OASR_LAUNCH_CHECK();
     OASR_CHECK_HIP(hipMemsetAsync(p.tmp_w2p, 0, (size_t)d * 3 * d * 4, st));
-    RC(r.wgrad(p.gln, d, Me, d, r.conv2_view(p.h1), 3 * d, p.tmp_w2p, 3 * d));
+    // conv2 weight gradient on the direct-to-LDS kernel: the im2col matrix [B*1500][3d] is h1 itself read as overlapping
+    // rows of 3d elements at stride 2d from h1 - d (per-sample stride 3000*d == 1500 rows * 2d, so the view is plain).
+    // Only window (b, t = 0) is wrong in its first d elements (it sees the last row of sample b-1, or the zeroed guard row,
+    // instead of the left zero padding); that rank-B term is subtracted by a second, tiny GEMM over the B first rows.
+    OASR_CHECK_HIP(hipMemsetAsync(p.h1 - d, 0, (size_t)d * 2, st));
+    RC(r.wgrad(p.gln, d, Me, d, plain_view(p.h1 - d, 2L * d), 3 * d, p.tmp_w2p, 3 * d));
+    {
+      GemmArgs g = gemm_defaults();
+      g.A = plain_view(p.gln, (long)c->Te * d);          // dY rows (b, t = 0)
+      g.ta = 1;
+      g.B = plain_view(p.h1 - d, (long)c->T1 * d);       // what those windows wrongly saw as their first tap
+      g.tb = 1;
+      g.M = d;
+      g.N = d;
+      g.K = B;
+      g.alpha = -1.0f;
+      g.out_f32 = p.tmp_w2p;
+      g.ldc32 = 3 * d;
+      g.atomic = 1;
+      RC(launch_gemm(g, st));
+    }
     RC(launch_unpack_conv_grad(p.tmp_w2p, c->G(c->conv2_w), d, d, 3 * d, st));
     RC(launch_colsum_accum(p.gln, d, Me, d, c->G(c->conv2_b), st));
     RC(r.dgrad(p.gln, Me, d, (const bf16_t*)(c->shadow + c->sh_w2p), 3 * d, nullptr, nullptr, p.gA2));
     RC(launch_conv2_col2im_dgelu(p.gA2, p.u1, p.gu, B, c->T1, d, st));  // gu = d(u1) [B*3000, d]
     OASR_CHECK_HIP(hipMemsetAsync(p.tmp_w1p, 0, (size_t)d * 256 * 4, st));
-    RC(r.wgrad(p.gu, d, M1, d, r.conv1_view(p.mel_tm), 256, p.tmp_w1p, 256));
+    // conv1 weight gradient, same trick: windows of 3*n_mels (+ junk up to 256, whose gradient columns are never
+    // unpacked) at stride n_mels from mel_tm - n_mels; the first tap of every (b, 0) and the last tap of every (b, T1-1)
+    // see the neighbouring sample (or a zeroed guard row) instead of the zero padding -> two rank-B corrections.
+    {
+      const int nm = c->dims.n_mels;
+      OASR_CHECK_HIP(hipMemsetAsync(p.mel_tm - 256, 0, 256 * 2, st));
+      OASR_CHECK_HIP(hipMemsetAsync(p.mel_tm + M1 * nm, 0, 256 * 2, st));
+      RC(r.wgrad(p.gu, d, M1, d, plain_view(p.mel_tm - nm, nm), 256, p.tmp_w1p, 256));
+      for (int side = 0; side < 2; ++side) {
+        GemmArgs g = gemm_defaults();
+        g.A = plain_view(p.gu + (side ? (long)(c->T1 - 1) * d : 0), (long)c->T1 * d);  // dU rows (b, 0) / (b, T1-1)
+        g.ta = 1;
+        g.B = plain_view(side ? p.mel_tm + (long)c->T1 * nm : p.mel_tm - nm, (long)c->T1 * nm);
+        g.tb = 1;
+        g.M = d;
+        g.N = nm;
+        g.K = B;
+        g.alpha = -1.0f;
+        g.out_f32 = p.tmp_w1p + (side ? 2 * nm : 0);
+        g.ldc32 = 256;
+        g.atomic = 1;
+        RC(launch_gemm(g, st));
+      }
+    }
     RC(launch_unpack_conv_grad(p.tmp_w1p, c->G(c->conv1_w), d, c->dims.n_mels, 256, st));
     RC(launch_colsum_accum(p.gu, d, M1, d, c->G(c->conv1_b), st));
   }
