@@ -4,7 +4,7 @@
 // :104-195 Conv1d as window GEMMs, :768-770 logits) and their autograd backward (dgrad, wgrad), SURVEY.md §2.3
 // K2,K3,K5,K9,K12,K14.
 //
-// Three kernels share the operand views, LDS images and fragment readers:
+// Four kernels; the first three share the operand views, LDS images and fragment readers:
 //  * oasr_gemm_pp_kernel   256x256x64 "ping-pong": 8 waves, one workgroup per CU, direct-to-LDS (buffer_load ... lds)
 //    staging that is never drained inside the K loop (one counted vmcnt per K-tile), two wave groups one barrier
 //    apart so one of them is always inside an MFMA section.  Default for every bf16-output GEMM with more than half
@@ -14,6 +14,8 @@
 //    co-resident workgroups hide each other's drains.  wgrad (fp32 atomics, XCD-owned K ranges) and small problems.
 //  * gemm_kernel           128x128x64, register-staged with bounds-checked buffer loads: conv window views (rpb != 0),
 //    K not a multiple of 64, fp32 / positional-embedding / odd-stride outputs.
+//  * gemm_skinny_kernel    M <= 64 rows (decode steps): 32 columns per workgroup, K split over the 4 waves, weights streamed
+//    from L2/HBM straight into MFMA operands.
 // Operands whose reduction index is NOT contiguous in memory (dgrad's W[N][K], wgrad's dY[M][N] and X[M][K]) are kept
 // in their natural layout and transposed on the way into the matrix core with ds_read_b64_tr_b16, so no transposed
 // copies of weights or activations exist in HBM.  LDS images are XOR-swizzled so both ds_read_b128 (k-contiguous
