@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic.json"),
                     help="per-symbol HBM bytes per launch from the rocprofv3 PMC passes (scripts/pmc_traffic.py)")
     ap.add_argument("--bucket-mb", type=float, default=128.0)
+    ap.add_argument("--reducer", default="allreduce", choices=["allreduce", "direct"],
+                    help="gradient exchange per bucket: one RCCL all-reduce, or reduce-scatter + all-gather as all-to-alls (all xGMI links)")
     ap.add_argument("--trim-padding", action="store_true",
                     help="opt-in, NOT the reference's computation shape: run the decoder over ceil16(max text_len) of each "
                          "micro-batch instead of the padded 448 positions (same loss and gradients; see DESIGN.md)")
@@ -139,7 +141,7 @@ def main():
     ddp.broadcast_parameters(net.flat_params)
     net.refresh_shadow()
     net.init_optimizer_state()
-    reducer = ddp.GradReducer(net.flat_grads, net.grad_segments, bucket_cap_mb=args.bucket_mb) if world > 1 else None
+    reducer = ddp.GradReducer(net.flat_grads, net.grad_segments, bucket_cap_mb=args.bucket_mb, algo=args.reducer) if world > 1 else None
 
     B, mb = args.per_gpu_batch, min(args.micro_batch, args.per_gpu_batch)
     assert B % mb == 0
@@ -238,7 +240,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"OLMoASR-{args.variant} bf16 train step, {B} x 30 s synthetic clips per GPU "
                                    f"({accum} micro-batches of {mb}, grad accumulation), global batch {world * B}",
-                       "global_batch": world * B, "micro_batch": mb, "parallelism": f"dp{world}",
+                       "global_batch": world * B, "micro_batch": mb, "parallelism": f"dp{world}" + (f" ({args.reducer} gradient exchange, {args.bucket_mb:g} MiB buckets)" if world > 1 else ""),
                        "optimizer": "AdamW fused (unscale+clip+step), loss scale 65536",
                        "decoder_positions": ("trimmed to ceil16(max text_len) per micro-batch: %s (opt-in, not the reference shape)" % ctx)
                        if args.trim_padding else "448 (padded, as the reference)"},

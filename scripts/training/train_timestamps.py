@@ -62,6 +62,7 @@ def parse_args(argv=None):
     ap.add_argument("--n_synthetic", type=int, default=4096, help="size of the synthetic dataset (samples)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--bucket_cap_mb", type=float, default=128.0)
+    ap.add_argument("--reducer", default="allreduce", choices=["allreduce", "direct"])
     ap.add_argument("--resume", type=str2bool, default=False, help="continue from the latest checkpoint of --exp_name")
     ap.add_argument("--ckpt_file_name", default="", help="checkpoint to resume from: a path, or a file-name prefix in the run dir")
     return ap.parse_args(argv)
@@ -176,7 +177,7 @@ def main(argv=None):
     ddp.broadcast_parameters(net.flat_params)  # DDP ctor _sync_module_states
     net.refresh_shadow()
     opt_state = net.init_optimizer_state()
-    reducer = ddp.GradReducer(net.flat_grads, net.grad_segments, bucket_cap_mb=args.bucket_cap_mb) if world_size > 1 else None
+    reducer = ddp.GradReducer(net.flat_grads, net.grad_segments, bucket_cap_mb=args.bucket_cap_mb, algo=args.reducer) if world_size > 1 else None
     scaler = GradScalerState()
     accum = accumulation_steps(args.eff_batch_size, world_size, args.train_batch_size)
     mine = ddp.shard_indices(args.n_synthetic, rank, world_size)

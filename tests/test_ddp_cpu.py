@@ -47,6 +47,11 @@ def _worker(rank, world, port, q):
         mean = flat / red.grad_divisor
         want = sum(torch.randn(n, generator=torch.Generator().manual_seed(r)) for r in range(world)) / world
         assert torch.allclose(mean, want, atol=1e-6)
+        # the all-links variant (reduce-scatter and all-gather as all-to-alls), ragged bucket sizes included
+        flat2 = local.clone()
+        red2 = ddp.GradReducer(flat2, [(0, 333), (333, 667)], bucket_cap_mb=400 * 4 / (1 << 20), algo="direct")
+        red2.reduce()
+        assert torch.allclose(flat2 / red2.grad_divisor, want, atol=1e-6)
         # weak-scaling data partition: every sample index is owned by exactly one rank
         mine = ddp.shard_indices(16, rank, world)
         allidx = [None] * world
