@@ -1,8 +1,6 @@
 // LayerNorm forward/backward for gfx950 (HBM-bound; one wave64 per row, 16-byte bf16 vector accesses).
 // Reference: olmoasr/model.py:14-39 -- F.layer_norm in fp32 (eps 1e-5), cast back to the input dtype.
 // d <= 2048, d % 8 == 0 (reference widths: 384, 512, 768, 1024, 1280).
-#include <stdlib.h>
-
 #include "kernels.h"
 
 namespace {
@@ -214,11 +212,7 @@ int launch_layernorm_bwd(const bf16_t* dy, const bf16_t* x, const float* gamma, 
   OASR_REQUIRE(d % 8 == 0 && d <= 2048 && d > 0, "layernorm: d=%d must be a multiple of 8 and <= 2048", d);
   if (rows <= 0) return OASR_OK;
   long blocks = (rows + 3) / 4;
-  static const long cap = [] {
-    const char* e = getenv("OASR_LNB_BLOCKS");
-    return e ? atol(e) : 512L;
-  }();
-  if (blocks > cap) blocks = cap;
+  if (blocks > 512) blocks = 512;  // 2 workgroups per CU; more only adds column atomics (measured: scripts/ln_bench.py history)
   const dim3 grid((unsigned)blocks);
   if (d <= 512)
     hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, dsum, rows, d);

@@ -33,4 +33,4 @@ def t(fn, n=20):
 tf = t(lambda: ops.layernorm_fwd(x, g, b))
 tb = t(lambda: ops.layernorm_bwd(dy, x, g, mean, rstd, dres))
 u = rows * d * 2
-print(f"blocks={os.environ.get('OASR_LNB_BLOCKS', '512')}: fwd {tf * 1e3:.1f} us = {2 * u / tf / 1e9:.2f} TB/s | bwd {tb * 1e3:.1f} us = {4 * u / tb / 1e9:.2f} TB/s")
+print(f"LayerNorm {rows}x{d}: fwd {tf * 1e3:.1f} us = {2 * u / tf / 1e9:.2f} TB/s | bwd {tb * 1e3:.1f} us = {4 * u / tb / 1e9:.2f} TB/s")
