@@ -62,7 +62,15 @@ class GradReducer:
         assert covered == flat_grads.numel(), "gradient segments must tile the arena"
         self.cuda = flat_grads.is_cuda
         self.comm_stream = torch.cuda.Stream(flat_grads.device) if self.cuda else None
-        self.events = [torch.cuda.Event() for _ in self.segments] if self.cuda else None
+        self.events = None
+        if self.cuda:
+            # torch creates the underlying HIP event lazily at the first record(); the engine needs the raw handles
+            # (Event.cuda_event), so materialise them now -- a null handle would silently turn the per-bucket waits into no-ops.
+            self.events = [torch.cuda.Event() for _ in self.segments]
+            with torch.cuda.device(flat_grads.device):
+                for e in self.events:
+                    e.record()
+            assert all(e.cuda_event for e in self.events), "HIP event handles were not created"
 
     @property
     def grad_divisor(self) -> float:

@@ -448,7 +448,10 @@ class OLMoASR(nn.Module):
         ev = None
         if segment_events is not None:
             assert len(segment_events) == len(self._segments)
-            ev = (C.c_void_p * len(segment_events))(*[e.cuda_event for e in segment_events])
+            handles = [e.cuda_event for e in segment_events]
+            if not all(handles):
+                raise N.NativeError("segment_events must be recorded-once torch.cuda.Event objects (null HIP event handle)")
+            ev = (C.c_void_p * len(segment_events))(*handles)
         with torch.cuda.device(mel.device):
             N.check(N.lib().oasr_train_fwd_bwd_s(self._ctx, N.ptr(mel), N.ptr(tokens), N.ptr(targets), N.ptr(text_len), B, S,
                                                  float(loss_scale), 1.0 / accumulation_steps, N.ptr(loss_out), int(accumulate_loss),

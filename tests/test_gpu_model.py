@@ -271,10 +271,16 @@ def test_bucketed_reducer_events_single_gpu(native_tiny, tiny_case):
     try:
         red = ddp.GradReducer(net.flat_grads, net.grad_segments, bucket_cap_mb=16.0, force=True)
         assert len(red.buckets) >= 3 and sum(n for _, n, _ in red.buckets) == net.flat_grads.numel()
+        assert all(e.cuda_event for e in red.events)  # raw handles exist (torch creates them lazily at first record)
         net.zero_grad()
+        # a marker recorded on the compute stream AFTER the backward was enqueued: if the engine really records the segment
+        # events inside the backward, each of them completes no later than this marker
         net.loss_and_backward(*args, segment_events=red.segment_events())
+        marker = torch.cuda.Event()
+        marker.record()
         red.reduce()
         torch.cuda.synchronize()
+        assert marker.query() and all(e.query() for e in red.events)
         g_red = net.flat_grads.clone()
         # deterministic pieces (everything but fp32-atomic accumulation order) must agree with a plain run closely
         net.zero_grad()
