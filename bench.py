@@ -108,7 +108,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--variant", default="medium")
     ap.add_argument("--per-gpu-batch", type=int, default=256)
-    ap.add_argument("--micro-batch", type=int, default=64)
+    ap.add_argument("--micro-batch", type=int, default=0,
+                    help="clips per micro-batch (gradient accumulation over per-gpu-batch / micro-batch); 0 = the largest of "
+                         "128/64/32/... whose saved activations fit in free HBM with 24 GiB to spare")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic.json"),
                     help="per-symbol HBM bytes per launch from the rocprofv3 PMC passes (scripts/pmc_traffic.py)")
     ap.add_argument("--bucket-mb", type=float, default=128.0)
@@ -143,7 +145,20 @@ def main():
     net.init_optimizer_state()
     reducer = ddp.GradReducer(net.flat_grads, net.grad_segments, bucket_cap_mb=args.bucket_mb, algo=args.reducer) if world > 1 else None
 
-    B, mb = args.per_gpu_batch, min(args.micro_batch, args.per_gpu_batch)
+    B = args.per_gpu_batch
+    if args.micro_batch > 0:
+        mb = min(args.micro_batch, B)
+    else:  # no-recompute training keeps ~1.9 GiB of activations per medium clip: 128 clips = 240 GiB of the 288
+        free = torch.cuda.mem_get_info(dev)[0]
+        mb = 1
+        for cand in (128, 64, 32, 16, 8, 4, 2):
+            if cand <= B and B % cand == 0 and N.lib().oasr_workspace_bytes(net._ctx, cand, dims.n_text_ctx, 1) + (24 << 30) <= free:
+                mb = cand
+                break
+        if world > 1:  # same choice on every rank
+            t = torch.tensor([mb], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            mb = int(t)
     assert B % mb == 0
     accum = B // mb
     # sample i of the global batch goes to rank i % world (DistributedSampler rule): seed per rank
