@@ -440,3 +440,39 @@ def test_resume_continues_the_run_and_adamw_state_is_torch_compatible(tmp_path):
     assert len(st) == len(params) and float(st[0]["step"]) == 4.0
     assert all(st[i]["exp_avg"].shape == params[i].shape for i in range(len(params)))
     assert sum(float(st[i]["exp_avg_sq"].sum()) for i in range(len(params))) > 0
+
+
+def test_beam_search_sampling_and_timestamp_rules(tiny_case):
+    """Token-level restatement of whisper.decoding beyond greedy: beam_size 1 == greedy; a wider beam never scores below
+    it; sampling is reproducible and ranked by best_of; timestamp rules produce well-formed streams; the fallback loop
+    of transcribe() walks the temperatures."""
+    from olmoasr_amd.decoding import EOT, TIMESTAMP_BEGIN, DecodingOptions, decode
+    from olmoasr_amd.model import OLMoASR
+    from oracle import model_oracle as mo
+    dims = mo.Dims(80, 1500, 384, 6, 2, 51864, 448, 384, 6, 2)
+    net = OLMoASR(_dims(dims), device=DEV, seed=5, inference=True)
+    mel = tiny_case["mel"].to(DEV)
+    greedy = decode(net, mel, DecodingOptions(sample_len=6, use_kv_cache=False))
+    beam1 = decode(net, mel, DecodingOptions(sample_len=6, beam_size=1))
+    beam4 = decode(net, mel, DecodingOptions(sample_len=6, beam_size=4, patience=1.0))
+    for g, b1, b4 in zip(greedy, beam1, beam4):
+        assert b1.tokens == g.tokens and abs(b1.avg_logprob - g.avg_logprob) < 2e-2
+        assert b4.avg_logprob >= b1.avg_logprob - 2e-2  # the greedy path is one of the beam's candidates
+        assert 0.0 <= g.no_speech_prob <= 1.0 and abs(g.no_speech_prob - b1.no_speech_prob) < 1e-3
+    s1 = decode(net, mel, DecodingOptions(sample_len=6, temperature=0.7, best_of=3, seed=11))
+    s2 = decode(net, mel, DecodingOptions(sample_len=6, temperature=0.7, best_of=3, seed=11))
+    assert [r.tokens for r in s1] == [r.tokens for r in s2] and all(r.temperature == 0.7 for r in s1)
+    ts = decode(net, mel, DecodingOptions(sample_len=8, without_timestamps=False))
+    for r in ts:
+        toks = r.tokens
+        assert toks and TIMESTAMP_BEGIN <= toks[0] <= TIMESTAMP_BEGIN + 50  # first token: a timestamp <= 1.0 s
+        stamps = [t for t in toks if t >= TIMESTAMP_BEGIN]
+        assert stamps == sorted(stamps) and 50362 not in toks and EOT not in toks
+        for i in range(len(toks) - 2):  # never three timestamps in a row
+            assert not (toks[i] >= TIMESTAMP_BEGIN and toks[i + 1] >= TIMESTAMP_BEGIN and toks[i + 2] >= TIMESTAMP_BEGIN)
+    # transcribe(): a random-init model is far below logprob_threshold -1.0, so every window walks all temperatures
+    audio = tiny_case["pcm"][0].float() / 32768.0
+    out = net.transcribe(audio, temperature=(0.0, 0.4), sample_len=4, logprob_threshold=-1.0, best_of=2)
+    assert len(out["segments"]) == 1 and out["segments"][0]["temperature"] == 0.4 and len(out["segments"][0]["tokens"]) <= 4
+    out0 = net.transcribe(audio, temperature=(0.0, 0.4), sample_len=4, logprob_threshold=None)
+    assert out0["segments"][0]["temperature"] == 0.0
