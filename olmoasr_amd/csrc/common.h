@@ -91,7 +91,14 @@ __device__ __forceinline__ GeluParts gelu_parts(float x) {
   g.e = e;
   return g;
 }
-__device__ __forceinline__ float gelu_f(float x) { return x * gelu_parts(x).cdf; }
+// gelu(x) = x * Phi(x) = max(x, 0) - |x| * (0.5 erfc(|x|/sqrt2)): no sign select, 3 VALU fewer than x * cdf
+__device__ __forceinline__ float gelu_f(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  const float half_poly = t * (0.127414796f + t * (-0.142248368f + t * (0.7107068705f + t * (-0.7265760135f + t * 0.5307027145f))));
+  const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f);
+  return fmaf(-fabsf(x), half_poly * e, fmaxf(x, 0.f));
+}
 __device__ __forceinline__ float dgelu_f(float x) {
   const GeluParts g = gelu_parts(x);
   return g.cdf + x * g.e * 0.3989422804014327f;

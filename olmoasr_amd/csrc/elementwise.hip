@@ -138,7 +138,21 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
   if (col < ncols) {
-    for (long m = (long)blockIdx.y * 4 + rl; m < M; m += (long)gridDim.y * 4) {
+    const long step = (long)gridDim.y * 4;
+    long m = (long)blockIdx.y * 4 + rl;
+    for (; m + 3 * step < M; m += 4 * step) {  // four independent 16-byte loads in flight per lane
+      u32x4_t p[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) p[u] = *(const u32x4_t*)(x + (m + u * step) * ld + col);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[2 * j] += bf_lo(p[u][j]);
+          acc[2 * j + 1] += bf_hi(p[u][j]);
+        }
+    }
+    for (; m < M; m += step) {
       const u32x4_t p = *(const u32x4_t*)(x + m * ld + col);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
