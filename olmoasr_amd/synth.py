@@ -40,3 +40,51 @@ def synth_samples(indices, device):
     ty = torch.stack([it[2] for it in items]).to(device, non_blocking=True)
     tl = torch.tensor([it[3] for it in items], dtype=torch.int32).to(device, non_blocking=True)
     return pcm, ti, ty, tl
+
+
+class SynthLoader:
+    """Iterator over micro-batches of the synthetic dataset with background generation -- the role the reference's
+    ``DataLoader(num_workers=..., pin_memory=True, prefetch_factor=...)`` plays (train_timestamps.py:640-660): ``workers``
+    threads materialise samples (torch's CPU RNG / rounding kernels release the GIL), ``depth`` batches are kept in flight
+    as pinned host tensors, the H2D copies are asynchronous.  ``order`` yields the sample indices of successive batches."""
+
+    def __init__(self, order, device, workers: int = 8, depth: int = 3):
+        from concurrent.futures import ThreadPoolExecutor
+        self.order = iter(order)
+        self.device = device
+        self.pool = ThreadPoolExecutor(max_workers=max(1, workers))
+        self.depth = max(1, depth)
+        self.pending = []
+        self._fill()
+
+    def _submit(self, indices):
+        return [self.pool.submit(synth_sample, int(i)) for i in indices]
+
+    def _fill(self):
+        while len(self.pending) < self.depth:
+            try:
+                idx = next(self.order)
+            except StopIteration:
+                return
+            self.pending.append(self._submit(idx))
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if not self.pending:
+            raise StopIteration
+        items = [f.result() for f in self.pending.pop(0)]
+        self._fill()
+        pin = torch.cuda.is_available()
+
+        def up(t):
+            return (t.pin_memory() if pin else t).to(self.device, non_blocking=True)
+        pcm = up(torch.stack([it[0] for it in items]))
+        ti = up(torch.stack([it[1] for it in items]))
+        ty = up(torch.stack([it[2] for it in items]))
+        tl = up(torch.tensor([it[3] for it in items], dtype=torch.int32))
+        return pcm, ti, ty, tl
+
+    def close(self):
+        self.pool.shutdown(wait=False, cancel_futures=True)

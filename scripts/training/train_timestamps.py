@@ -61,6 +61,7 @@ def parse_args(argv=None):
     ap.add_argument("--synthetic", type=str2bool, default=True)
     ap.add_argument("--n_synthetic", type=int, default=4096, help="size of the synthetic dataset (samples)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--num_workers", type=int, default=8, help="sample-generation threads (the reference's DataLoader workers)")
     ap.add_argument("--bucket_cap_mb", type=float, default=128.0)
     ap.add_argument("--reducer", default="allreduce", choices=["allreduce", "direct"])
     ap.add_argument("--resume", type=str2bool, default=False, help="continue from the latest checkpoint of --exp_name")
@@ -160,7 +161,7 @@ def main(argv=None):
     from olmoasr_amd import ddp, ops
     from olmoasr_amd.config.model_dims import VARIANT_TO_DIMS
     from olmoasr_amd.model import OLMoASR
-    from olmoasr_amd.synth import synth_samples
+    from olmoasr_amd.synth import SynthLoader
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     rank = int(os.environ.get("RANK", "0"))
@@ -189,15 +190,23 @@ def main(argv=None):
     if rank == 0:
         print(json.dumps({"event": "start", "world_size": world_size, "accumulation_steps": accum, "model": args.model_variant,
                           "params": net.flat_params.numel(), "hardware_peak_flops": HARDWARE_TO_FLOPS.get(args.hardware)}), flush=True)
+    def batch_order(start):  # the sampler: this rank's shard, cyclic, train_batch_size indices per micro-batch
+        c = start
+        while True:
+            yield [mine[(c + j) % len(mine)] for j in range(args.train_batch_size)]
+            c += args.train_batch_size
+            if c >= len(mine):
+                c = 0
+
+    loader = SynthLoader(batch_order(cursor), dev, workers=args.num_workers)
     while global_step < args.train_steps:
         start_step = time.time()
         net.zero_grad()
         for i in range(accum):
-            idx = [mine[(cursor + j) % len(mine)] for j in range(args.train_batch_size)]
             cursor += args.train_batch_size
             if cursor >= len(mine):
                 cursor, epoch = 0, epoch + 1
-            pcm, ti, ty, tl = synth_samples(idx, dev)
+            pcm, ti, ty, tl = next(loader)
             mel = ops.log_mel(pcm)
             last = i == accum - 1
             net.loss_and_backward(mel, ti, ty, tl, loss_scale=scaler.scale, accumulation_steps=accum, loss_out=loss_buf,
@@ -227,6 +236,7 @@ def main(argv=None):
                 print(json.dumps(rec), flush=True)
         if args.ckpt_freq and global_step % args.ckpt_freq == 0:
             save_ckpt(net, opt_state, scaler, global_step, local_step, epoch, args, dims, rank, cursor, lr, betas)
+    loader.close()
     if args.ckpt_freq:
         save_ckpt(net, opt_state, scaler, global_step, local_step, epoch, args, dims, rank, cursor,
                   args.lr * lr_lambda(max(global_step - 1, 0), args.train_steps), betas)
