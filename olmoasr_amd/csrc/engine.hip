@@ -306,15 +306,15 @@ struct Runner {
     const long tiles = (long)cdiv(N, 256) * cdiv(K, 128);
     const long kt = cdiv(M, 64);
     // Split-K choice (scripts/wgrad_sweep.py): 768 workgroups are resident at once (3 per CU); what matters is how the
-    // tiles x split grid quantises onto them (1.33 waves is the worst case), the ~32 K-tiles' worth of atomic epilogue
-    // every extra split adds, and that multiples of 8 let every XCD own whole K-ranges (gemm.hip).
+    // tiles x split grid quantises onto them (1.33 waves is the worst case), the (16 + split) K-tiles' worth of atomic epilogue
+    // every workgroup adds, and that multiples of 8 let every XCD own whole K-ranges (gemm.hip).
     long split = 1;
     double best = 1e30;
     static const int cand[] = {1, 2, 4, 8, 16, 24, 32};
     for (int s_ : cand) {
       if (s_ > 1 && (kt / s_ < 8 || tiles >= 768)) break;
-      const double w = (double)tiles * s_, per = (double)kt / s_ + 32.0;
-      const double waves = w <= 768.0 ? 0.55 + 0.45 * w / 768.0 : ceil(w / 768.0);
+      const double w = (double)tiles * s_, per = (double)kt / s_ + 16.0 + s_;  // atomics get slower the more splits collide
+      const double waves = w <= 768.0 ? 0.7 + 0.3 * w / 768.0 : ceil(w / 768.0);
       const double score = per * waves;
       if (score < 0.97 * best) {
         best = score;

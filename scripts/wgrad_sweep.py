@@ -17,7 +17,7 @@ def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
     d = 1024
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    for tokens in (96000, 28672):
+    for tokens in [int(a) for a in os.environ.get("TOKENS", "96000,28672").split(",")]:
         dy = (torch.randn(tokens, 4 * d, device="cuda") * 0.05).to(BF)
         x = torch.randn(tokens, 4 * d, device="cuda").to(BF)
         g32 = torch.zeros(4 * d, 4 * d, device="cuda")
