@@ -2,7 +2,6 @@
 reducer's SUM + folded 1/world mean, parameter broadcast and the DistributedSampler partition rule."""
 import os
 
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp

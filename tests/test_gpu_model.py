@@ -303,7 +303,6 @@ def test_inference_model_decode_and_transcribe(tmp_path, tiny_case):
     from olmoasr_amd import hub
     from olmoasr_amd.decoding import greedy_token_matrix
     from olmoasr_amd.model import OLMoASR
-    from oracle import mel_oracle as me
     from oracle import model_oracle as mo
     dims = mo.Dims(80, 1500, 384, 6, 2, 51864, 448, 384, 6, 2)
     sd = mo.init_state_dict(dims, seed=5)

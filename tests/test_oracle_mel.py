@@ -4,7 +4,6 @@
 import os
 
 import numpy as np
-import pytest
 import torch
 
 from oracle import mel_oracle as me
