@@ -394,34 +394,60 @@ struct Runner {
     const int d = c->d;
     const long M1 = (long)B * c->T1, Me = (long)B * c->Te;
     RC(launch_mel_to_time_major(mel, p.mel_tm, B, c->dims.n_mels, c->T1, st));
-    {
+    // Both convolutions run on the direct-to-LDS kernels: the im2col matrix is the input itself read as a PLAIN matrix of
+    // overlapping rows (row stride = conv stride * C) that starts one time row before the buffer.  That view is exact
+    // except at sample boundaries -- window (b, 0) sees the previous sample's last row (or the zeroed guard row) where
+    // the conv pads with zeros, and for conv1 window (b, T1-1) sees the next sample's first row -- so those 2B (conv1) /
+    // B (conv2) output rows are recomputed afterwards by a small GEMM over one-row-per-sample window views whose
+    // padding IS an out-of-range predicate (OperandView with rpb = 1).
+    const int nm = c->dims.n_mels;
+    OASR_CHECK_HIP(hipMemsetAsync(p.mel_tm - 256, 0, 256 * 2, st));
+    OASR_CHECK_HIP(hipMemsetAsync(p.mel_tm + M1 * nm, 0, 256 * 2, st));
+    OASR_CHECK_HIP(hipMemsetAsync(p.h1 - d, 0, (size_t)d * 2, st));
+    for (int pass = 0; pass < 3; ++pass) {  // 0: all rows through the plain view; 1: rows (b, 0); 2: rows (b, T1-1)
       GemmArgs g = gemm_defaults();
-      g.A = conv1_view(p.mel_tm);
+      long row_off = 0;
+      if (pass == 0) {
+        g.A = plain_view(p.mel_tm - nm, nm);
+        g.M = (int)M1;
+        g.ldc = d;
+      } else {
+        row_off = pass == 1 ? 0 : c->T1 - 1;
+        g.A = pass == 1 ? OperandView{p.mel_tm, nm, 1, (long)c->T1 * nm, nm, 3 * nm, 3 * nm}
+                        : OperandView{p.mel_tm + (long)(c->T1 - 2) * nm, nm, 1, (long)c->T1 * nm, 0, 3 * nm, 2 * nm};
+        g.M = B;
+        g.ldc = (long)c->T1 * d;
+      }
       g.B = plain_view((const bf16_t*)(c->shadow + c->sh_w1p), 256);
-      g.M = (int)M1;
       g.N = d;
       g.K = 256;
       g.bias = c->P(c->conv1_b);
       g.act = 1;
-      g.out = p.h1;
-      g.out_pre = p.u1;
-      g.ldc = d;
+      g.out = p.h1 + row_off * d;
+      g.out_pre = p.u1 + row_off * d;
       RC(launch_gemm(g, st));
     }
-    {
+    for (int pass = 0; pass < 2; ++pass) {  // 0: all rows; 1: rows (b, 0)
       GemmArgs g = gemm_defaults();
-      g.A = conv2_view(p.h1);
+      if (pass == 0) {
+        g.A = plain_view(p.h1 - d, 2L * d);
+        g.M = (int)Me;
+        g.ldc = d;
+        g.pos_period = c->Te;
+      } else {
+        g.A = OperandView{p.h1, 2L * d, 1, (long)c->T1 * d, d, 3 * d, 3 * d};
+        g.M = B;
+        g.ldc = (long)c->Te * d;
+        g.pos_period = 1;  // every recomputed row is position 0
+      }
       g.B = plain_view((const bf16_t*)(c->shadow + c->sh_w2p), 3 * d);
-      g.M = (int)Me;
       g.N = d;
       g.K = 3 * d;
       g.bias = c->P(c->conv2_b);
       g.act = 1;
       g.pos = c->enc_pos;
-      g.pos_period = c->Te;
       g.out = p.x0;
       g.out_pre = p.u2;
-      g.ldc = d;
       RC(launch_gemm(g, st));
     }
     const bf16_t* x = p.x0;
@@ -1006,8 +1032,7 @@ extern "C" int oasr_train_fwd_bwd_s(oasr_ctx* c, const float* mel, const int64_t
     // rows of 3d elements at stride 2d from h1 - d (per-sample stride 3000*d == 1500 rows * 2d, so the view is plain).
     // Only window (b, t = 0) is wrong in its first d elements (it sees the last row of sample b-1, or the zeroed guard row,
     // instead of the left zero padding); that rank-B term is subtracted by a second, tiny GEMM over the B first rows.
-    OASR_CHECK_HIP(hipMemsetAsync(p.h1 - d, 0, (size_t)d * 2, st));
-    RC(r.wgrad(p.gln, d, Me, d, plain_view(p.h1 - d, 2L * d), 3 * d, p.tmp_w2p, 3 * d));
+    RC(r.wgrad(p.gln, d, Me, d, plain_view(p.h1 - d, 2L * d), 3 * d, p.tmp_w2p, 3 * d));  // (guard row zeroed by the forward)
     {
       GemmArgs g = gemm_defaults();
       g.A = plain_view(p.gln, (long)c->Te * d);          // dY rows (b, t = 0)
@@ -1033,9 +1058,7 @@ extern "C" int oasr_train_fwd_bwd_s(oasr_ctx* c, const float* mel, const int64_t
     // see the neighbouring sample (or a zeroed guard row) instead of the zero padding -> two rank-B corrections.
     {
       const int nm = c->dims.n_mels;
-      OASR_CHECK_HIP(hipMemsetAsync(p.mel_tm - 256, 0, 256 * 2, st));
-      OASR_CHECK_HIP(hipMemsetAsync(p.mel_tm + M1 * nm, 0, 256 * 2, st));
-      RC(r.wgrad(p.gu, d, M1, d, plain_view(p.mel_tm - nm, nm), 256, p.tmp_w1p, 256));
+      RC(r.wgrad(p.gu, d, M1, d, plain_view(p.mel_tm - nm, nm), 256, p.tmp_w1p, 256));  // (guard rows zeroed by the forward)
       for (int side = 0; side < 2; ++side) {
         GemmArgs g = gemm_defaults();
         g.A = plain_view(p.gu + (side ? (long)(c->T1 - 1) * d : 0), (long)c->T1 * d);  // dU rows (b, 0) / (b, T1-1)

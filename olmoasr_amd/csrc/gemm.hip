@@ -406,8 +406,8 @@ __device__ __forceinline__ void glds16(const __amdgpu_buffer_rsrc_t rs, char* ds
 // Bit-identical to epilogue_math(): every later op starts from the bf16-rounded pre-activation.
 __host__ __device__ __forceinline__ bool fast_rows_ok(const GemmArgs& p) {
   const unsigned long al = (unsigned long)p.out | (unsigned long)p.out_pre | (unsigned long)p.resid | (unsigned long)p.dgelu_u;
-  return !p.out_f32 && !p.pos && (p.N % 8) == 0 && (p.ldc % 8) == 0 && (al & 15) == 0 && (!p.resid || (p.ldr % 8) == 0) &&
-         (!p.dgelu_u || (p.ldu % 8) == 0) && !(p.resid && p.dgelu_u);
+  return !p.out_f32 && (!p.pos || (!p.resid && !p.dgelu_u)) && (p.N % 8) == 0 && (p.ldc % 8) == 0 && (al & 15) == 0 &&
+         (!p.resid || (p.ldr % 8) == 0) && (!p.dgelu_u || (p.ldu % 8) == 0) && !(p.resid && p.dgelu_u);
 }
 
 // stg: this wave's staging tile, 8-row groups of 1 KiB placed GS bytes apart; bias_lds: 64 floats of wave-private LDS.
@@ -416,7 +416,7 @@ __device__ __forceinline__ void fast_epilogue_rows(const GemmArgs& p, f32x16_t (
                                                    int mrow0, int ncol0, int lane) {
   const int h = lane >> 5, row = lane & 31;
   const bool has_bias = p.bias != nullptr, has_side = p.dgelu_u != nullptr || p.resid != nullptr, has_u = p.dgelu_u != nullptr;
-  const bool has_pre = p.out_pre != nullptr, has_out = p.out != nullptr, gelu = p.act == 1;
+  const bool has_pre = p.out_pre != nullptr, has_out = p.out != nullptr, gelu = p.act == 1, has_pos = p.pos != nullptr;
   const bf16_t* side = has_u ? p.dgelu_u : p.resid;  // at most one of the two (fast_rows_ok)
   const long lds_ = has_u ? p.ldu : p.ldr;
   const int ch = lane & 7, nn = ncol0 + ch * 8;
@@ -480,7 +480,7 @@ __device__ __forceinline__ void fast_epilogue_rows(const GemmArgs& p, f32x16_t (
       const u32x4_t pre = *(lds_u32x4_ptr)(size_t)(rbase + i * GS);  // rows r2 = i*8 + (lane >> 3): (r2 & 7) == lane >> 3
       if (has_pre && ok) *(u32x4_t*)(p.out_pre + (long)mm * p.ldc + nn) = pre;
       u32x4_t fin = pre;
-      if (gelu || has_side) {
+      if (gelu || has_side || has_pos) {
         float x[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -490,6 +490,15 @@ __device__ __forceinline__ void fast_epilogue_rows(const GemmArgs& p, f32x16_t (
         if (gelu) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) x[e] = gelu_f(x[e]);
+        }
+        if (has_pos && ok) {  // positional embedding row (m mod period), fp32 (conv2 + sinusoids)
+          const float* pp = p.pos + (long)(mm % p.pos_period) * p.N + nn;
+          const f32x4_t p0 = *(const f32x4_t*)pp, p1 = *(const f32x4_t*)(pp + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            x[e] = bf_round(x[e]) + p0[e];
+            x[4 + e] = bf_round(x[4 + e]) + p1[e];
+          }
         }
         if (has_side) {
           const u32x4_t sv = PF ? sd[i] : sn[i];
