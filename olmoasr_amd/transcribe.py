@@ -21,7 +21,7 @@ from .decoding import DecodingOptions, decode
 
 
 @torch.no_grad()
-def transcribe(model, audio, *, verbose: Optional[bool] = None, temperature: float = 0.0, batch_windows: int = 8,
+def transcribe(model, audio, *, verbose: Optional[bool] = None, temperature=0.0, batch_windows: int = 16,
                no_speech_threshold: Optional[float] = None, logprob_threshold: Optional[float] = -1.0, **decode_options):
     temperatures = tuple(temperature) if isinstance(temperature, (tuple, list)) else (float(temperature),)
     if isinstance(audio, str):
