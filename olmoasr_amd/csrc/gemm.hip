@@ -733,7 +733,9 @@ __global__ __launch_bounds__(512, 2) void oasr_gemm_pp_kernel(GemmArgs p) {
       tn = t - tm * tiles_n;
     } else {
       const int bid = xcd_remap(blockIdx.x, gridDim.x);
-      int gm = p.raster_gm > 0 ? p.raster_gm : 32 / tiles_n;  // one group of tile rows resident per XCD (32 CUs)
+      // groups of 8 tile rows, walked rows-first: the 32 tiles an XCD runs at once are 8 row panels x 4 column panels
+      // (12 operand panels through its L2 instead of 2 x 16 = 18: -6 % on the N = 4096 layers, scripts/gemm_ab.py)
+      int gm = p.raster_gm > 0 ? p.raster_gm : 8;
       gm = gm < 1 ? 1 : (gm > 16 ? 16 : gm);
       const int per_group = gm * tiles_n;
       const int group = bid / per_group, in_group = bid - group * per_group;
