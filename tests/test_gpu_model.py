@@ -116,7 +116,7 @@ def test_loss_and_grads_vs_oracle(native_tiny, oracle_tiny, tiny_case):
     # Tolerances for a bf16 backward against the fp32 reference gradients: every tensor must be as close as the CPU
     # bf16 mirror of the reference is (measured: both ~2.5 % worst case on attention projections of this random-init
     # model), i.e. <= max(2 x mirror, 3 %) per tensor, cosine > 0.999, and <= 2 % over the whole gradient.
-    # (Needs the fp32 copy of the attention output for the backward's delta term: with delta taken from the
+    # (Needs an fp32-grade attention output (O + its bf16 rounding residual) for the backward's delta term: with delta taken from the
     # bf16-rounded O the cross-attention gradients were 7-9 % off -- see tests/test_gpu_ops.py::
     # test_attention_bwd_delta_precision.)
     assert all(cos > 0.999 for _, _, cos, _ in worst), worst[:3]
