@@ -527,6 +527,99 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// One query row per (batch, head): the KV-cached decode step (Tq == 1).  The 128-row flash tile above spends a whole
+// workgroup's prologue/epilogue on one row (measured 16 us per call, 27 % of a decode step); here a workgroup streams
+// the K rows once (8 lanes x 16 bytes per key, 32 keys per pass), keeps the scores in LDS, and streams V once.
+// Numerics as the tiled kernel: fp32 scores and normaliser, P rounded to bf16 before it multiplies V.
+__global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
+  __shared__ float sc[1536];
+  __shared__ float red[32][64];
+  __shared__ float lsum[32];
+  __shared__ float wmax[4];
+  const int tid = threadIdx.x, l8 = tid & 7, grp = tid >> 3, wave = tid >> 6, lane = tid & 63;
+  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  int Tk = a.kv_len ? a.kv_len[b] : a.Tk;
+  Tk = Tk < a.Tk ? Tk : a.Tk;
+  const u32x4_t q4 = *(const u32x4_t*)(a.q + (long)b * a.bsq + h * 64 + l8 * 8);
+  float qv[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    qv[2 * i] = bf_lo(q4[i]);
+    qv[2 * i + 1] = bf_hi(q4[i]);
+  }
+  const bf16_t* kp = a.k + (long)b * a.bsk + h * 64 + l8 * 8;
+  const bf16_t* vp = a.v + (long)b * a.bsv + h * 64 + l8 * 8;
+  float mx = NEG;
+  for (int t0 = grp; t0 < Tk; t0 += 32 * 8) {  // 8 independent 16-byte loads in flight per lane
+    u32x4_t k4[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int t = t0 + 32 * u;
+      k4[u] = *(const u32x4_t*)(kp + (long)(t < Tk ? t : Tk - 1) * a.ldk);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int t = t0 + 32 * u;
+      float d = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) d += qv[2 * i] * bf_lo(k4[u][i]) + qv[2 * i + 1] * bf_hi(k4[u][i]);
+      d += __shfl_xor(d, 1, 64);
+      d += __shfl_xor(d, 2, 64);
+      d += __shfl_xor(d, 4, 64);
+      const float s2 = d * (SCALE * LOG2E);
+      if (t < Tk) {
+        if (l8 == 0) sc[t] = s2;
+        mx = fmaxf(mx, s2);
+      }
+    }
+  }
+  mx = wave_max(mx);
+  if (lane == 0) wmax[wave] = mx;
+  __syncthreads();
+  const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+  float l = 0.f, o[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = 0.f;
+  for (int t0 = grp; t0 < Tk; t0 += 32 * 8) {
+    u32x4_t v4[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int t = t0 + 32 * u;
+      v4[u] = *(const u32x4_t*)(vp + (long)(t < Tk ? t : Tk - 1) * a.ldv);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int t = t0 + 32 * u;
+      const float p = t < Tk ? __builtin_amdgcn_exp2f(sc[t] - m) : 0.f;
+      l += p;
+      const float pb = bf_round(p);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        o[2 * i] += pb * bf_lo(v4[u][i]);
+        o[2 * i + 1] += pb * bf_hi(v4[u][i]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[grp][l8 * 8 + j] = o[j];
+  if (l8 == 0) lsum[grp] = l;
+  __syncthreads();
+  if (tid < 64) {
+    float acc = 0.f, lt = 0.f;
+#pragma unroll 8
+    for (int g = 0; g < 32; ++g) {
+      acc += red[g][tid];
+      lt += lsum[g];
+    }
+    const float val = lt > 0.f ? acc / lt : 0.f;
+    const float nb = __shfl_xor(val, 1, 64);
+    if ((tid & 1) == 0) *(uint32_t*)(a.o + (long)b * a.bso + h * 64 + tid) = pack_bf2(val, nb);
+    if (tid == 0 && a.lse) a.lse[(long)b * a.H + h] = lt > 0.f ? (m + __builtin_amdgcn_logf(lt)) * LN2 : NEG;
+  }
+}
+
 int check_args(const AttnArgs& a, bool bwd) {
   OASR_REQUIRE(a.q && a.k && a.v && a.o, "attention: null pointer");
   OASR_REQUIRE(a.B > 0 && a.H > 0 && a.Tq > 0 && a.Tk > 0, "attention: bad shape");
@@ -541,6 +634,11 @@ int check_args(const AttnArgs& a, bool bwd) {
 int launch_attention_fwd(const AttnArgs& a, hipStream_t s) {
   int rc = check_args(a, false);
   if (rc) return rc;
+  if (a.Tq == 1 && a.Tk <= 1536 && !a.o_lo) {  // decode step (causality is implied: every cached key is visible)
+    hipLaunchKernelGGL(attn_decode_kernel, dim3(a.B * a.H), dim3(256), 0, s, a);
+    OASR_LAUNCH_CHECK();
+    return OASR_OK;
+  }
   dim3 grid(cdiv(a.Tq, 128) * a.B * a.H);
   if (a.causal)
     hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, s, a);

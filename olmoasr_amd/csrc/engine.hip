@@ -806,23 +806,24 @@ extern "C" int oasr_decode_logits(oasr_ctx* c, const int64_t* tokens, const void
 // ---- cached greedy decoding (OLMoASR.install_kv_cache_hooks, olmoasr/model.py:925-964 / inf_model.py:422-453) -----------
 // The reference caches every key/value Linear output in a dict via forward hooks (self-attention K/V grow by torch.cat per
 // token, cross-attention K/V are computed once per window).  Here the cache is one caller-owned buffer:
-//   per decoder layer: self K [B, n_text_ctx, d] | self V [B, n_text_ctx, d] | cross KV [B, n_audio_ctx, 2d]   (bf16)
+//   per decoder layer: self Q|K|V [B, n_text_ctx, 3d] | cross KV [B, n_audio_ctx, 2d]   (bf16)
 // oasr_decode_begin fills the cross K/V of all layers from xa; oasr_decode_step runs the decoder on ONE new token per
-// sequence at position `pos`, the K/V projections write straight into the cache rows (GEMM output row stride = one
-// sequence's cache), attention reads the first pos+1 cached keys.
+// sequence at position `pos`: ONE fused q|k|v projection writes straight into the cache row of that position (GEMM output
+// row stride = one sequence's cache; the q slot is scratch that keeps the three projections in a single launch),
+// attention reads q from that row and the first pos+1 cached keys/values through strides.
 extern "C" size_t oasr_kv_cache_bytes(const oasr_ctx* c, int B) {
   if (!c || B <= 0) return 0;
-  const size_t per_layer = ((size_t)2 * B * c->S_max * c->d + (size_t)B * c->Te * 2 * c->d) * 2;
+  const size_t per_layer = ((size_t)3 * B * c->S_max * c->d + (size_t)B * c->Te * 2 * c->d) * 2;
   return per_layer * c->L_dec + 256;
 }
 namespace {
 struct KvLayer {
-  bf16_t *k, *v, *ckv;
+  bf16_t *qkv, *ckv;  // self [B, S_max, 3d] (q | k | v per position), cross [B, Te, 2d]
 };
 KvLayer kv_layer(const oasr_ctx* c, void* cache, int B, int layer) {
-  const size_t per_layer = (size_t)2 * B * c->S_max * c->d + (size_t)B * c->Te * 2 * c->d;
+  const size_t per_layer = (size_t)3 * B * c->S_max * c->d + (size_t)B * c->Te * 2 * c->d;
   bf16_t* base = (bf16_t*)cache + per_layer * layer;
-  return KvLayer{base, base + (size_t)B * c->S_max * c->d, base + (size_t)2 * B * c->S_max * c->d};
+  return KvLayer{base, base + (size_t)3 * B * c->S_max * c->d};
 }
 }  // namespace
 
@@ -874,31 +875,27 @@ extern "C" int oasr_decode_step(oasr_ctx* c, const int64_t* tokens_last, int B, 
     const BlockP& bp = c->dec[i];
     KvLayer kl = kv_layer(c, kv_cache, B, i);
     RC(launch_layernorm_fwd(cur, c->P(bp.attn_ln_w), c->P(bp.attn_ln_b), ln, mean, rstd, B, d, st));
-    RC(r.linear(ln, B, d, c->W(bp.attn.qw), d, c->P(bp.attn.qb), 0, nullptr, q, nullptr));
-    {  // K and V rows of this position go straight into the cache: output row b lands at [b, pos, :]
+    {  // q | k | v of this position in one launch, straight into the cache: output row b lands at [b, pos, 0:3d]
       GemmArgs g = gemm_defaults();
       g.A = plain_view(ln, d);
+      g.B = plain_view(c->W(bp.attn.qw), d);  // query | key | value weights are adjacent in the arena
       g.M = B;
-      g.N = d;
+      g.N = 3 * d;
       g.K = d;
-      g.ldc = (long)S_max * d;
-      g.B = plain_view(c->W(bp.attn.kw), d);
-      g.out = kl.k + (size_t)pos * d;
-      RC(launch_gemm(g, st));
-      g.B = plain_view(c->W(bp.attn.vw), d);
-      g.bias = c->P(bp.attn.vb);
-      g.out = kl.v + (size_t)pos * d;
+      g.bias = c->aux(bp.attn.fused_bias);    // [q_bias | 0 | v_bias]
+      g.ldc = (long)S_max * 3 * d;
+      g.out = kl.qkv + (size_t)pos * 3 * d;
       RC(launch_gemm(g, st));
     }
     AttnArgs a;
     memset(&a, 0, sizeof(a));
-    a.q = q;
-    a.ldq = d;
-    a.bsq = d;
-    a.k = kl.k;
-    a.v = kl.v;
-    a.ldk = a.ldv = d;
-    a.bsk = a.bsv = (long)S_max * d;
+    a.q = kl.qkv + (size_t)pos * 3 * d;
+    a.ldq = 3 * d;
+    a.bsq = (long)S_max * 3 * d;
+    a.k = kl.qkv + d;
+    a.v = kl.qkv + 2 * d;
+    a.ldk = a.ldv = 3 * d;
+    a.bsk = a.bsv = (long)S_max * 3 * d;
     a.o = o;
     a.ldo = d;
     a.bso = d;
@@ -911,6 +908,9 @@ extern "C" int oasr_decode_step(oasr_ctx* c, const int64_t* tokens_last, int B, 
     RC(r.linear(o, B, d, c->W(bp.attn.ow), d, c->P(bp.attn.ob), 0, cur, x2, nullptr));
     RC(launch_layernorm_fwd(x2, c->P(bp.cln_w), c->P(bp.cln_b), ln, mean, rstd, B, d, st));
     RC(r.linear(ln, B, d, c->W(bp.cattn.qw), d, c->P(bp.cattn.qb), 0, nullptr, q, nullptr));
+    a.q = q;
+    a.ldq = d;
+    a.bsq = d;
     a.k = kl.ckv;
     a.v = kl.ckv + d;
     a.ldk = a.ldv = 2 * d;

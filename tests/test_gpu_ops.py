@@ -378,3 +378,20 @@ def test_gemm_skinny_decode_shapes(M, N, K):
     o32 = torch.full((M, N), float("nan"), device=DEV)
     ops().gemm(A, B, M, N, K, out_f32=o32)
     close(o32, ref, rtol=2e-3, atol=2e-3, name="skinny fp32 out")
+
+
+@pytest.mark.parametrize("Tk,kv", [(1, False), (37, False), (448, True), (1500, False)])
+def test_attention_decode_step_kernel(Tk, kv):
+    """Tq == 1 takes the decode-step kernel (one query row per (batch, head), K/V streamed once): strided cache layouts
+    (q | k | v interleaved rows, as the KV cache stores them), optional per-sequence lengths."""
+    B, H = 3, 4
+    d = H * 64
+    cache = rnd(B, Tk, 3 * d, seed=41)                      # [q | k | v] per position
+    q = cache[:, Tk - 1:Tk, :d].unflatten(2, (H, 64))       # the query lives in the last position's row
+    k = cache[:, :, d:2 * d].unflatten(2, (H, 64))
+    v = cache[:, :, 2 * d:].unflatten(2, (H, 64))
+    kv_len = torch.tensor([Tk, max(1, Tk // 2), max(1, Tk - 3)], dtype=torch.int32, device=DEV) if kv else None
+    o, lse = ops().attention_fwd(q, k, v, kv_len, False)
+    ro, rlse = ref_attention(q, k, v, kv_len, False)
+    close(o, ro, atol=2e-3 + 1e-2 * float(ro.abs().mean()), name=f"decode attn o Tk={Tk}")
+    close(lse, rlse, rtol=1e-3, atol=2e-3, name="decode attn lse")
