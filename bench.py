@@ -62,6 +62,14 @@ def synth_batch(n, device, seed):
     return pcm, text_input.contiguous(), text_y, (L - 1).to(torch.int32)
 
 
+def _flush_c_stdio():
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def host_cores():
     """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota when there is one."""
     n = len(os.sched_getaffinity(0))
@@ -134,16 +142,21 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # OASR_BENCH_FORCE_DDP=1: take the multi-GPU code path (RCCL group, broadcast, event-driven bucket all-reduce, barriers) with
+    # a world of one -- a single-GPU rehearsal of what the N > 1 launches execute
+    ddp_path = world > 1 or os.environ.get("OASR_BENCH_FORCE_DDP") == "1"
+    if ddp_path:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
 
     dims = VARIANT_TO_DIMS[args.variant]
     net = OLMoASR(dims, device=dev, seed=0)
     ddp.broadcast_parameters(net.flat_params)
     net.refresh_shadow()
     net.init_optimizer_state()
-    reducer = ddp.GradReducer(net.flat_grads, net.grad_segments, bucket_cap_mb=args.bucket_mb, algo=args.reducer) if world > 1 else None
+    reducer = ddp.GradReducer(net.flat_grads, net.grad_segments, bucket_cap_mb=args.bucket_mb, algo=args.reducer,
+                              force=world == 1) if ddp_path else None
 
     B = args.per_gpu_batch
     if args.micro_batch > 0:
@@ -155,7 +168,7 @@ def main():
             if cand <= B and B % cand == 0 and N.lib().oasr_workspace_bytes(net._ctx, cand, dims.n_text_ctx, 1) + (24 << 30) <= free:
                 mb = cand
                 break
-        if world > 1:  # same choice on every rank
+        if ddp_path:  # same choice on every rank
             t = torch.tensor([mb], device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             mb = int(t)
@@ -190,7 +203,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if ddp_path:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -202,7 +215,7 @@ def main():
         one_step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if ddp_path:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
@@ -244,6 +257,7 @@ def main():
                 "by_layout_tflops": {layouts[k]: round(fl[k] / ms[k] / 1e9, 1) for k in range(4) if cnt[k]},
                 "gemm_ms_per_step": round(sum(ms), 2)}
 
+    out = None
     if rank == 0:
         ms_per_step = 1000.0 * elapsed / args.steps
         value = world * B * 30.0 * args.steps / elapsed
@@ -267,10 +281,17 @@ def main():
             out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.variant)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+    # The JSON line must be the LAST line on stdout: RCCL prints its version banner (NCCL_DEBUG=VERSION is set on the GPU
+    # boxes) through C stdio, which is block-buffered when stdout is a pipe and would otherwise surface after our line, at
+    # process exit.  Every rank flushes C stdio, then the group is torn down, then rank 0 prints.
+    if ddp_path:
+        dist.barrier()
+        _flush_c_stdio()
         dist.barrier()
         dist.destroy_process_group()
+    _flush_c_stdio()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
