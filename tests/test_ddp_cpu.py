@@ -74,3 +74,18 @@ def test_grad_reducer_world2_gloo():
     for p in procs:
         p.join(30)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def test_synth_loader_order_and_determinism():
+    """The background loader (the reference's DataLoader role) yields the sampler's batches in order, bit-identical to
+    direct generation, whatever the worker count / prefetch depth."""
+    from olmoasr_amd.synth import SynthLoader, synth_samples
+    order = [[0, 1], [2, 3], [4, 5], [1, 0]]
+    dev = torch.device("cpu")
+    for workers, depth in ((1, 1), (4, 3)):
+        got = list(SynthLoader(order, dev, workers=workers, depth=depth))
+        assert len(got) == len(order)
+        for idx, batch in zip(order, got):
+            ref = synth_samples(idx, dev)
+            assert all(torch.equal(a, b) for a, b in zip(batch, ref))
+            assert batch[0].dtype == torch.int16 and batch[0].shape == (2, 480000) and batch[3].dtype == torch.int32
