@@ -82,31 +82,106 @@ def host_cores():
     return n
 
 
-def cpu_baseline(variant, seconds_budget=30.0):
-    """The CPU oracle (oracle/model_oracle.py == the reference's algorithm, pinned by tests/golden) timed on this host:
-    ONE clip through the full step (forward + CE + backward + clip + AdamW), fp32, all host cores."""
+def cpu_baseline(variant, sd, budget_s=75.0):
+    """The CPU oracle (oracle/model_oracle.py == the reference's algorithm, pinned by tests/golden) timed on this host's
+    cores: ONE 30 s clip through the full step (log-mel + forward + CE + backward + clip + AdamW) with the SAME weights the
+    GPU model holds, fp32 and under the reference's autocast(bfloat16) rounding points; per dtype 1 warm-up run, then the
+    median of up to 3 timed runs; repeats stop early once `budget_s` of CPU time is spent so the
+    default bench run stays within minutes.  Returns (json block, fp32 loss, fp32 logits of the clip) -- the last two feed
+    the `parity` block."""
+    import statistics
+
     import numpy as np
     from oracle import mel_oracle as me
     from oracle import model_oracle as mo
     cores = host_cores()
     torch.set_num_threads(cores)
     dims = mo.VARIANTS[variant]
-    sd = mo.init_state_dict(dims, seed=0)
     pcm, ti, ty, tl = mo.synthetic_batch([0])
-    t0 = time.time()
-    mel = torch.from_numpy(me.log_mel_batch(pcm.numpy(), dtype=np.float32))
-    loss, grads, _ = mo.loss_and_grads(sd, dims, mel, ti, ty, tl)
-    _, coef = mo.clip_coef(grads, 1.0)
-    names = list(grads)
-    for n in names:
-        grads[n].mul_(coef)
-    m = {n: torch.zeros_like(sd[n]) for n in names}
-    v = {n: torch.zeros_like(sd[n]) for n in names}
-    mo.adamw_step(sd, grads, m, v, step=1, lr=1.5e-3)
-    dt = time.time() - t0
-    return {"value": round(30.0 / dt, 3), "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
-            "sample": f"1 clip x 30 s, OLMoASR-{variant} fp32 full step (log-mel + fwd + CE + bwd + clip + AdamW) in {dt:.1f} s, "
-                      f"torch {torch.get_num_threads()} threads"}
+    spent = [0.0]
+    keep = {}
+
+    def one(bf16):
+        w = {k: v.clone() for k, v in sd.items()}
+        t0 = time.time()
+        mel = torch.from_numpy(me.log_mel_batch(pcm.numpy(), dtype=np.float32))
+        loss, grads, logits = mo.loss_and_grads(w, dims, mel, ti, ty, tl, autocast_bf16=bf16)
+        _, coef = mo.clip_coef(grads, 1.0)
+        names = list(grads)
+        for n in names:
+            grads[n].mul_(coef)
+        m = {n: torch.zeros_like(w[n]) for n in names}
+        v = {n: torch.zeros_like(w[n]) for n in names}
+        mo.adamw_step(w, grads, m, v, step=1, lr=1.5e-3)
+        dt = time.time() - t0
+        spent[0] += dt
+        if not bf16 and "loss" not in keep:
+            keep["loss"], keep["logits"] = float(loss), logits
+        return dt
+
+    res = {}
+    for tag, bf16 in (("fp32", False), ("autocast_bf16", True)):
+        one(bf16)  # warm-up (thread pool, oneDNN primitive caches, page faults of the 3 GB of weights + state)
+        times = [one(bf16)]
+        while len(times) < 3 and spent[0] < budget_s:
+            times.append(one(bf16))
+        res[tag] = {"audio_s_per_s": round(30.0 / statistics.median(times), 3), "median_s": round(statistics.median(times), 2),
+                    "runs": len(times)}
+    out = {"value": res["fp32"]["audio_s_per_s"], "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
+           "fp32": res["fp32"], "autocast_bf16": res["autocast_bf16"],
+           "sample": f"1 clip x 30 s, OLMoASR-{variant} full step (log-mel + fwd + CE + bwd + clip + AdamW), torch "
+                     f"{torch.get_num_threads()} threads; per dtype 1 warm-up + median of the timed runs; value = fp32 (the "
+                     f"reference's CPU default); /root/reference is not on the GPU box, so the restatement (pinned to it by "
+                     f"tests/) is what is timed"}
+    return out, keep["loss"], keep["logits"]
+
+
+def hbm_kernel_rooflines(net, dims, mb, dev):
+    """Achieved HBM GB/s of the bandwidth-bound kernels at the benchmarked shapes (torch events on the launch stream,
+    5 launches each after a warm-up) against the algorithmic bytes DESIGN.md section 3 states for them."""
+    from olmoasr_amd import ops
+    d = dims.n_audio_state
+    rows = mb * dims.n_audio_ctx
+    BF = torch.bfloat16
+    out = {}
+
+    def timed(fn, reps=5):
+        fn()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    def line(name, t, nbytes, note):
+        out[name] = {"achieved_GBps": round(nbytes / t / 1e9, 1), "frac_of_8TBps": round(nbytes / t / 8e12, 3), "us": round(t * 1e6, 1),
+                     "alg_bytes": int(nbytes), "shape": note}
+
+    x = torch.randn(rows, d, device=dev).to(BF)
+    gamma, beta = torch.ones(d, device=dev), torch.zeros(d, device=dev)
+    y, mean, rstd = ops.layernorm_fwd(x, gamma, beta)
+    line("ln_fwd_kernel", timed(lambda: ops.layernorm_fwd(x, gamma, beta)), rows * (4 * d + 8), f"[{rows}, {d}] bf16 in/out + fp32 stats")
+    dy = torch.randn(rows, d, device=dev).to(BF)
+    line("ln_bwd_kernel", timed(lambda: ops.layernorm_bwd(dy, x, gamma, mean, rstd, dy)), rows * (8 * d + 8),
+         f"[{rows}, {d}]: dy, x, dres in, dx out (+ stats)")
+    del x, y, dy
+    pcm = torch.zeros(mb, 480000, dtype=torch.int16, device=dev).random_(-3000, 3000)
+    line("logmel_main+finalize", timed(lambda: ops.log_mel(pcm)), mb * 1.92e6, f"{mb} clips: int16 PCM in + fp32 [80,3000] out")
+    del pcm
+    Vp, V = (dims.n_vocab + 1 + 127) // 128 * 128, dims.n_vocab + 1
+    rows_d = mb * dims.n_text_ctx
+    lg = torch.randn(rows_d, Vp, device=dev, dtype=BF)
+    tgt = torch.randint(0, 50000, (rows_d,), device=dev)
+    line("ce_kernel", timed(lambda: ops.cross_entropy_(lg, V, tgt, PAD_ID)), rows_d * 4 * Vp, f"[{rows_d}, {Vp}] bf16 logits -> dlogits in place")
+    del lg
+    n = net.flat_params.numel()
+    # (step count irrelevant for the timing; gradients are whatever the last step left, state is restored by nobody: run last)
+    line("grad_stats+adamw_kernel", timed(lambda: net.optim_step(step=1, lr=0.0), reps=3), n * (28 + 2 + 4),
+         f"{n} params: 16 B read + 12 B written + 2 B bf16 shadow + 4 B norm pass")
+    return out
 
 
 def main():
@@ -244,12 +319,16 @@ def main():
         dom = max(sym, key=lambda k: sym[k]["ms"])
         dsym = sym[dom]
         achieved = dsym["flops"] / dsym["ms"] / 1e9
-        traffic = None
+        traffic = traffic_src = None
         if args.traffic_json and os.path.exists(args.traffic_json):  # HBM bytes per launch from the PMC passes (profiles/)
-            traffic = json.load(open(args.traffic_json)).get(dom, {}).get("hbm_bytes_per_launch")
+            tj = json.load(open(args.traffic_json))
+            traffic = tj.get(dom, {}).get("hbm_bytes_per_launch")
+            if traffic is not None:
+                traffic_src = (f"REPLAYED from {os.path.relpath(args.traffic_json, ROOT)} (separate rocprofv3 --pmc passes of this "
+                               f"command, scripts/pmc_traffic.py; {tj.get('_meta', {}).get('collected', 'date not recorded')}) -- NOT measured in this run")
         layouts = {0: "NT (forward)", 1: "NN (dgrad)", 2: "TN", 3: "TN (wgrad)"}
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_us": round(1000.0 * dsym["ms"] / dsym["launches"], 2), "launches_per_step": dsym["launches"],
                 "alg_flops_per_launch": round(dsym["flops"] / dsym["launches"], 1),
                 "by_symbol": {k: {"launches": v["launches"], "avg_us": round(1000.0 * v["ms"] / v["launches"], 2),
@@ -280,7 +359,33 @@ def main():
         if roof:
             out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.variant)
+            # parity of the benchmarked model itself (outside the timed region): clip 0 of the oracle's generator through the
+            # HIP step and through the fp32 CPU oracle with the SAME weights (taken before the hbm-kernel timings touch them)
+            from oracle import model_oracle as mo
+            net._workspace = None  # the 240 GiB of saved-activation slots are no longer needed: one clip from here on
+            torch.cuda.empty_cache()
+            sd_cpu = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+            p_pcm, p_ti, p_ty, p_tl = mo.synthetic_batch([0])
+            net.zero_grad()
+            p_loss, p_logits = net.loss_and_backward(ops.log_mel(p_pcm.to(dev)), p_ti.to(dev), p_ty.to(dev), p_tl.to(dev), return_logits=True)
+            torch.cuda.synchronize(dev)
+            p_loss, p_logits = float(p_loss), p_logits.cpu()
+            out["cpu_baseline"], o_loss, o_logits = cpu_baseline(args.variant, sd_cpu)
+            nvalid = int(p_tl[0])
+            dl = (p_logits[0, :nvalid] - o_logits[0, :nvalid]).abs()
+            out["parity"] = {"what": "clip 0 of the seeded generator, this model's weights after the timed steps: HIP bf16 step vs CPU fp32 oracle",
+                             "loss": round(p_loss, 5), "oracle_loss": round(o_loss, 5), "max_dlogit": round(float(dl.max()), 4),
+                             "mean_dlogit": round(float(dl.mean()), 5), "logit_scale": round(float(o_logits[0, :nvalid].abs().max()), 2),
+                             "argmax_agree": round(float((p_logits[0, :nvalid].argmax(-1) == o_logits[0, :nvalid].argmax(-1)).float().mean()), 4)}
+            del p_logits, o_logits
+        if world == 1 and not args.no_profile:
+            net._workspace = None
+            torch.cuda.empty_cache()
+            roof_h = hbm_kernel_rooflines(net, dims, mb, dev)
+            if roof:
+                out["roofline"]["hbm_kernels"] = roof_h
+            else:
+                out["hbm_kernels"] = roof_h
     # The JSON line must be the LAST line on stdout: RCCL prints its version banner (NCCL_DEBUG=VERSION is set on the GPU
     # boxes) through C stdio, which is block-buffered when stdout is a pipe and would otherwise surface after our line, at
     # process exit.  Every rank flushes C stdio, then the group is torn down, then rank 0 prints.

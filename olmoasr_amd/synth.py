@@ -16,7 +16,25 @@ N_SAMPLES = 480000
 N_TEXT_CTX = 448
 
 
-def synth_sample(index: int):
+SOT, EOT, NO_TIMESTAMPS, TIMESTAMP_BEGIN = 50257, 50256, 50362, 50363
+
+
+def _layout(tokens: torch.Tensor):
+    """tokens i64 [L] -> (text_input [448], text_y [448], text_len): the teacher-forcing shift and 51864 padding of
+    AudioTextDataset.preprocess_text (train_timestamps.py:301-329)."""
+    L = tokens.numel()
+    assert L - 1 <= N_TEXT_CTX
+    text_input = torch.full((N_TEXT_CTX,), PAD_ID, dtype=torch.long)
+    text_y = torch.full((N_TEXT_CTX,), PAD_ID, dtype=torch.long)
+    text_input[:L - 1] = tokens[:-1]
+    text_y[:L - 1] = tokens[1:]
+    return text_input, text_y, L - 1
+
+
+def synth_sample(index: int, timestamps: bool = False):
+    """``timestamps=True`` lays the same text out in the reference's timestamp mode (``ts`` branch of
+    _process_non_empty_transcript / _build_timestamp_sequence, train_timestamps.py:401-506):
+    <sot> <|s0|> text0 <|e0|> <|s1|> text1 <|e1|> ... <|norm_end|> <eot>, timestamp token = 50363 + ms // 20."""
     g = torch.Generator().manual_seed(1234 + index)
     pcm = torch.clamp(torch.randn(N_SAMPLES, generator=g) * 0.1, -1, 1)
     pcm = torch.round(pcm * 32767).to(torch.int16)
@@ -25,16 +43,24 @@ def synth_sample(index: int):
         pcm[N_SAMPLES - n_sil:] = 0
     L = int(torch.randint(8, 221, (1,), generator=g))
     body = torch.randint(0, 50256, (L - 3,), generator=g)
-    tokens = torch.cat([torch.tensor([50257, 50362]), body, torch.tensor([50256])])
-    text_input = torch.full((N_TEXT_CTX,), PAD_ID, dtype=torch.long)
-    text_y = torch.full((N_TEXT_CTX,), PAD_ID, dtype=torch.long)
-    text_input[:L - 1] = tokens[:-1]
-    text_y[:L - 1] = tokens[1:]
-    return pcm, text_input, text_y, L - 1
+    if not timestamps:
+        tokens = torch.cat([torch.tensor([SOT, NO_TIMESTAMPS]), body, torch.tensor([EOT])])
+        return (pcm,) + _layout(tokens)
+    nb = L - 3
+    norm_end_ms = (N_SAMPLES - n_sil) // 16 // 20 * 20
+    n_seg = min(int(torch.randint(1, 5, (1,), generator=g)), nb)
+    stamps = torch.randint(0, norm_end_ms // 20 + 1, (2 * n_seg,), generator=g).sort().values + TIMESTAMP_BEGIN
+    split = torch.randint(0, nb + 1, (n_seg - 1,), generator=g).sort().values
+    edges = torch.cat([torch.zeros(1, dtype=torch.long), split, torch.tensor([nb])])
+    parts = [torch.tensor([SOT])]
+    for i in range(n_seg):
+        parts += [stamps[2 * i:2 * i + 1], body[int(edges[i]):int(edges[i + 1])], stamps[2 * i + 1:2 * i + 2]]
+    parts.append(torch.tensor([TIMESTAMP_BEGIN + norm_end_ms // 20, EOT]))
+    return (pcm,) + _layout(torch.cat(parts))
 
 
-def synth_samples(indices, device):
-    items = [synth_sample(int(i)) for i in indices]
+def synth_samples(indices, device, timestamps: bool = False):
+    items = [synth_sample(int(i), timestamps) for i in indices]
     pcm = torch.stack([it[0] for it in items]).to(device, non_blocking=True)
     ti = torch.stack([it[1] for it in items]).to(device, non_blocking=True)
     ty = torch.stack([it[2] for it in items]).to(device, non_blocking=True)
@@ -48,8 +74,9 @@ class SynthLoader:
     threads materialise samples (torch's CPU RNG / rounding kernels release the GIL), ``depth`` batches are kept in flight
     as pinned host tensors, the H2D copies are asynchronous.  ``order`` yields the sample indices of successive batches."""
 
-    def __init__(self, order, device, workers: int = 8, depth: int = 3):
+    def __init__(self, order, device, workers: int = 8, depth: int = 3, timestamps: bool = False):
         from concurrent.futures import ThreadPoolExecutor
+        self.timestamps = timestamps
         self.order = iter(order)
         self.device = device
         self.pool = ThreadPoolExecutor(max_workers=max(1, workers))
@@ -58,7 +85,7 @@ class SynthLoader:
         self._fill()
 
     def _submit(self, indices):
-        return [self.pool.submit(synth_sample, int(i)) for i in indices]
+        return [self.pool.submit(synth_sample, int(i), self.timestamps) for i in indices]
 
     def _fill(self):
         while len(self.pending) < self.depth:

@@ -337,8 +337,56 @@ def greedy_decode(sd, dims, mel, initial_tokens, max_new=224, eot=50256, suppres
 
 
 # ---- synthetic batch generator, SURVEY.md §8(d) ------------------------------------------------------
-def synthetic_sample(index: int, n_text_ctx=448):
-    """Deterministic (audio int16 [480000], text_input i64 [448], text_y i64 [448], text_len)."""
+SOT, EOT, NO_TIMESTAMPS, TIMESTAMP_BEGIN = 50257, 50256, 50362, 50363  # English-only GPT-2 specials
+
+
+def timestamp_token(ms: int):
+    """AudioTextDataset._convert_to_token_idx, train_timestamps.py:218-236: None past 30 s, else begin + ms // 20."""
+    if ms > 30000:
+        return None
+    return TIMESTAMP_BEGIN + (ms // 20)
+
+
+def build_token_sequence(segments, norm_end_ms: int, timestamp_mode: bool):
+    """Token layout of one training sample from its transcript segments [(start_ms, end_ms, [text token ids])]:
+    no-timestamp mode  <sot> <notimestamps> text... <eot>                      (train_timestamps.py:421-426)
+    timestamp mode     <sot> <ts s0> text0 <ts e0> <ts s1> text1 <ts e1> ... <ts norm_end> <eot>
+                       (_build_timestamp_sequence, train_timestamps.py:462-506; None -> fall back to no-timestamp
+                       mode when a boundary lies past 30 s, :437-452)."""
+    if timestamp_mode:
+        rng = []
+        for s, e, _ in segments:
+            a, b = timestamp_token(s), timestamp_token(e)
+            if a is None or b is None:
+                rng = None
+                break
+            rng.append((a, b))
+        if rng is not None:
+            out = []
+            for i, ((a, b), (_, _, text)) in enumerate(zip(rng, segments)):
+                out.extend(([SOT] if i == 0 else []) + [a] + list(text) + [b])
+            nxt = TIMESTAMP_BEGIN + (30000 // 20 if norm_end_ms > 30000 else norm_end_ms // 20)
+            out.extend([nxt, EOT])
+            return out, True
+    flat = [t for _, _, text in segments for t in text]
+    return [SOT, NO_TIMESTAMPS] + flat + [EOT], False
+
+
+def pad_sample(tokens, n_text_ctx=448):
+    """text_input = tokens[:-1], text_y = tokens[1:], both padded with 51864; text_len = len(text_input) = the first
+    -inf column of the padding mask (train_timestamps.py:301-329)."""
+    L = len(tokens)
+    text_input = torch.full((n_text_ctx,), PAD_ID, dtype=torch.long)
+    text_y = torch.full((n_text_ctx,), PAD_ID, dtype=torch.long)
+    text_input[:L - 1] = torch.tensor(tokens[:-1], dtype=torch.long)
+    text_y[:L - 1] = torch.tensor(tokens[1:], dtype=torch.long)
+    return text_input, text_y, L - 1
+
+
+def synthetic_sample(index: int, n_text_ctx=448, timestamps: bool = False):
+    """Deterministic (audio int16 [480000], text_input i64 [448], text_y i64 [448], text_len).
+    timestamps=True: the same audio and text body cut into 1-4 transcript segments whose boundaries are multiples of
+    20 ms inside the non-silent part of the clip, laid out in the reference's timestamp mode."""
     g = torch.Generator().manual_seed(1234 + index)
     pcm = torch.clamp(torch.randn(480000, generator=g) * 0.1, -1, 1)
     pcm = torch.round(pcm * 32767).to(torch.int16)
@@ -347,16 +395,23 @@ def synthetic_sample(index: int, n_text_ctx=448):
         pcm[480000 - n_sil:] = 0
     L = int(torch.randint(8, 221, (1,), generator=g))
     body = torch.randint(0, 50256, (L - 3,), generator=g)
-    tokens = torch.cat([torch.tensor([50257, 50362]), body, torch.tensor([50256])])
-    text_input = torch.full((n_text_ctx,), PAD_ID, dtype=torch.long)
-    text_y = torch.full((n_text_ctx,), PAD_ID, dtype=torch.long)
-    text_input[:L - 1] = tokens[:-1]
-    text_y[:L - 1] = tokens[1:]
-    return pcm, text_input, text_y, L - 1
+    if not timestamps:
+        tokens, _ = build_token_sequence([(0, 0, body.tolist())], 0, False)
+    else:
+        norm_end = (480000 - n_sil) // 16 // 20 * 20  # ms of audio before the silence, on the 20 ms grid
+        n_seg = int(torch.randint(1, 5, (1,), generator=g))
+        n_seg = min(n_seg, L - 3)
+        cuts = sorted(int(x) for x in torch.randint(0, norm_end // 20 + 1, (2 * n_seg,), generator=g))
+        split = sorted(int(x) for x in torch.randint(0, L - 3 + 1, (n_seg - 1,), generator=g))
+        edges = [0] + split + [L - 3]
+        segs = [(cuts[2 * i] * 20, cuts[2 * i + 1] * 20, body[edges[i]:edges[i + 1]].tolist()) for i in range(n_seg)]
+        tokens, _ = build_token_sequence(segs, norm_end, True)
+    text_input, text_y, text_len = pad_sample(tokens, n_text_ctx)
+    return pcm, text_input, text_y, text_len
 
 
-def synthetic_batch(indices):
-    items = [synthetic_sample(i) for i in indices]
+def synthetic_batch(indices, timestamps: bool = False):
+    items = [synthetic_sample(i, timestamps=timestamps) for i in indices]
     pcm = torch.stack([it[0] for it in items])
     ti = torch.stack([it[1] for it in items])
     ty = torch.stack([it[2] for it in items])
