@@ -47,6 +47,16 @@ int oasr_mel_filterbank(float* out_host);
 oasr_ctx* oasr_create(const oasr_dims* dims); /* training model: n_vocab + 1 embedding rows (pad row, model.py:665-667) */
 /* embed_rows = n_vocab selects olmoasr.inf_model.OLMoASR's layout (inf_model.py:302; scripts/eval/gen_inf_ckpt.py) */
 oasr_ctx* oasr_create_ex(const oasr_dims* dims, int embed_rows);
+/* compute_dtype selects the arithmetic of the whole context -- the reference's --precision flag
+ * (scripts/training/train_timestamps.py:2128: "bfloat16" | "float32"; autocast + dtype policy :1414, :2220-2224):
+ *   OASR_DTYPE_BF16  production: bf16 MFMA operands / activations, fp32 accumulation and master weights (= autocast(bfloat16))
+ *   OASR_DTYPE_F32   validation: the same engine schedule on plain fp32 kernels (fp32 activations, operands, softmax,
+ *                    residual stream; exact-erf GELU).  Every `void*` activation the ABI exchanges (xa, kv_cache) then holds
+ *                    fp32 instead of bf16.  This is the mode the "logits within 1e-3" criterion is tested in. */
+#define OASR_DTYPE_BF16 0
+#define OASR_DTYPE_F32 1
+oasr_ctx* oasr_create_ex2(const oasr_dims* dims, int embed_rows, int compute_dtype);
+int oasr_compute_dtype(const oasr_ctx*);
 void oasr_destroy(oasr_ctx*);
 
 /* Parameter table: one flat fp32 arena in gradient-ready (reverse-backward) order; the Python modules expose

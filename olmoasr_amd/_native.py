@@ -52,6 +52,8 @@ def _declare(lib):
         "oasr_mel_filterbank": (i32, [vp]),
         "oasr_create": (vp, [C.POINTER(Dims)]),
         "oasr_create_ex": (vp, [C.POINTER(Dims), i32]),
+        "oasr_create_ex2": (vp, [C.POINTER(Dims), i32, i32]),
+        "oasr_compute_dtype": (i32, [vp]),
         "oasr_encode": (i32, [vp, vp, i32, vp, vp, sz, vp]),
         "oasr_kv_cache_bytes": (sz, [vp, i32]),
         "oasr_decode_step_workspace_bytes": (sz, [vp, i32]),
@@ -122,7 +124,6 @@ def ptr(t):
     """Device (or host) address of a tensor; None -> NULL."""
     if t is None:
         return None
-    assert t.is_contiguous() or t.numel() == 0 or True
     return C.c_void_p(t.data_ptr())
 
 

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void embedding_fwd_kernel(const int64_t* __res
 // dE[tok[b,s]] += dx[b,s,:] with fp32 atomics (tokens repeat across the batch)
 __global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* __restrict__ tok, const bf16_t* __restrict__ dx,
                                                             float* __restrict__ dE, float* __restrict__ dpos, int B, int S, int d,
-                                                            long pad_id) {
+                                                            long pad_id, long n_embed) {
   const int s = blockIdx.x;
   for (int c = threadIdx.x; c < d; c += 256) {
     float acc = 0.f;
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* __res
       const float g = bf2f(dx[r * d + c]);
       acc += g;
       const long t = tok[r];
-      if (t != pad_id) unsafeAtomicAdd(dE + t * d + c, g);
+      if (t != pad_id && t >= 0 && t < n_embed) unsafeAtomicAdd(dE + t * d + c, g);  // ids outside the table: no scatter (fwd read zeros)
     }
     dpos[(long)s * d + c] += acc;
   }
@@ -205,6 +205,25 @@ __global__ __launch_bounds__(256) void col2im_dgelu_kernel(const bf16_t* __restr
   }
 }
 
+__global__ __launch_bounds__(256) void logits_to_f32_kernel(const bf16_t* __restrict__ lg, long ld, int V, float* __restrict__ out,
+                                                           long total) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / V;
+    const int col = (int)(i - r * V);
+    out[i] = bf2f(lg[r * ld + col]);
+  }
+}
+__global__ __launch_bounds__(256) void dgelu_mul_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ u, bf16_t* __restrict__ out,
+                                                       long n8) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const u32x4_t a = ((const u32x4_t*)dy)[i], b = ((const u32x4_t*)u)[i];
+    u32x4_t o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = pack_bf2(bf_lo(a[j]) * dgelu_f(bf_lo(b[j])), bf_hi(a[j]) * dgelu_f(bf_hi(b[j])));
+    ((u32x4_t*)out)[i] = o;
+  }
+}
+
 __global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ src, float* __restrict__ dst, long n, float a) {
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] += a * src[i];
 }
@@ -251,10 +270,10 @@ int launch_embedding_fwd(const int64_t* tok, const float* E, const float* pos, b
   OASR_LAUNCH_CHECK();
   return OASR_OK;
 }
-int launch_embedding_bwd(const int64_t* tok, const bf16_t* dx, float* dE, float* dpos, int B, int S, int d, long pad_id,
+int launch_embedding_bwd(const int64_t* tok, const bf16_t* dx, float* dE, float* dpos, int B, int S, int d, long pad_id, long n_embed,
                          hipStream_t s) {
   OASR_REQUIRE(tok && dx && dE && dpos, "embedding_bwd: bad args");
-  hipLaunchKernelGGL(embedding_bwd_kernel, dim3(S), dim3(256), 0, s, tok, dx, dE, dpos, B, S, d, pad_id);
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3(S), dim3(256), 0, s, tok, dx, dE, dpos, B, S, d, pad_id, n_embed);
   OASR_LAUNCH_CHECK();
   return OASR_OK;
 }
@@ -279,6 +298,18 @@ int launch_conv2_col2im_dgelu(const bf16_t* dA, const bf16_t* u1, bf16_t* dpre1,
 int launch_axpy_f32(const float* src, float* dst, long n, float a, hipStream_t s) {
   if (n <= 0) return OASR_OK;
   hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, s, src, dst, n, a);
+  OASR_LAUNCH_CHECK();
+  return OASR_OK;
+}
+int launch_dgelu_mul(const bf16_t* dy, const bf16_t* u, bf16_t* out, long n, hipStream_t s) {
+  OASR_REQUIRE(dy && u && out && n % 8 == 0, "dgelu_mul: bad args");
+  hipLaunchKernelGGL(dgelu_mul_kernel, dim3(grid_for(n / 8)), dim3(256), 0, s, dy, u, out, n / 8);
+  OASR_LAUNCH_CHECK();
+  return OASR_OK;
+}
+int launch_logits_to_f32(const bf16_t* logits, long ld, long rows, int V, float* out, hipStream_t s) {
+  const long total = rows * V;
+  hipLaunchKernelGGL(logits_to_f32_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, s, logits, ld, V, out, total);
   OASR_LAUNCH_CHECK();
   return OASR_OK;
 }

@@ -55,11 +55,23 @@ struct oasr_ctx {
   // shadow layout (bytes)
   size_t sh_flat, sh_w1p, sh_w2p, sh_aux, sh_total;
   int64_t aux_floats;
-  const bf16_t* W(int64_t off) const { return (const bf16_t*)(shadow + sh_flat) + off; }
+  int f32 = 0;  // compute_dtype: 0 = bf16 production kernels, 1 = fp32 validation kernels (fp32ref.hip)
+  // compute copy of the weight at arena offset `off`: the bf16 shadow, or -- fp32 validation -- the master weights themselves
+  template <typename T>
+  const T* Wt(int64_t off) const;
+  template <typename T>
+  const T* w1p() const { return (const T*)(shadow + sh_w1p); }  // packed conv1 kernel [d][256]
+  template <typename T>
+  const T* w2p() const { return (const T*)(shadow + sh_w2p); }  // packed conv2 kernel [d][3d]
   const float* P(int64_t off) const { return params + off; }
   float* G(int64_t off) const { return grads + off; }
   const float* aux(int64_t off) const { return (const float*)(shadow + sh_aux) + off; }
 };
+
+template <>
+inline const bf16_t* oasr_ctx::Wt<bf16_t>(int64_t off) const { return (const bf16_t*)(shadow + sh_flat) + off; }
+template <>
+inline const float* oasr_ctx::Wt<float>(int64_t off) const { return params + off; }
 
 namespace {
 
@@ -125,73 +137,87 @@ struct Arena {
     cur += bytes;
     return p;
   }
-  bf16_t* bf(size_t n) { return (bf16_t*)raw(n * 2 + 64); }  // +64: conv windows / 16-byte tails may over-read
+  template <typename T>
+  T* act(size_t n) { return (T*)raw((n + 32) * sizeof(T)); }  // +32 elements: conv windows / 16-byte tails may over-read
   float* f32(size_t n) { return (float*)raw(n * 4); }
 };
 
+#define RC(x)            \
+  do {                   \
+    int _rc = (x);       \
+    if (_rc) return _rc; \
+  } while (0)
+
+// Everything below is written once for both compute dtypes: T = bf16_t (production) or float (validation).
+template <typename T>
+struct Engine {
+  typedef OperandViewT<T> View;
+  typedef GemmArgsT<T> Gemm;
+  typedef AttnArgsT<T> Attn;
+
 struct AttnSave {
-  bf16_t *ln, *qkv, *o;  // self: qkv [M,3d];  cross: qkv = q [M,d]
-  bf16_t* kv;            // cross only: [B*Te, 2d]
+  T *ln, *qkv, *o;  // self: qkv [M,3d];  cross: qkv = q [M,d]
+  T* kv;            // cross only: [B*Te, 2d]
   float *mean, *rstd, *lse;
-  bf16_t* o_lo;  // training only: bf16 rounding residual of the attention output (o + o_lo = fp32-grade O for the backward's delta)
+  T* o_lo;  // training only: bf16 rounding residual of the attention output (o + o_lo = fp32-grade O for the backward's delta)
 };
 struct BlockSave {
-  bf16_t* x_in;  // residual stream entering the block (owned by the previous stage)
+  T* x_in;  // residual stream entering the block (owned by the previous stage)
   AttnSave sa, ca;
-  bf16_t *x_mid, *x_mid2, *ln2, *u, *hg, *x_out;
+  T *x_mid, *x_mid2, *ln2, *u, *hg, *x_out;
   float *mean2, *rstd2;
 };
 
 struct Plan {
   // encoder
-  bf16_t *mel_tm, *u1, *h1, *u2, *x0, *xa;
+  T *mel_tm, *u1, *h1, *u2, *x0, *xa;
   float *mean_p, *rstd_p;
   std::vector<BlockSave> enc, dec;
   // decoder
-  bf16_t *dx0, *lnf, *logits;
+  T *dx0, *lnf, *logits;
   float *mean_f, *rstd_f, *row_loss;
   int32_t* n_valid;
   // backward temporaries
-  bf16_t *ga, *gb, *gc, *gln, *gqkv, *go, *gu, *gxa, *gkv, *gq, *gA2;
+  T *ga, *gb, *gc, *gln, *gqkv, *go, *gu, *gxa, *gkv, *gq, *gA2;
   float *delta, *tmp_w1p, *tmp_w2p;
 };
 
-void plan_attn(Arena& A, AttnSave& s, long M, long Mkv, int d, int B, int H, long Tq, bool cross, bool train) {
-  s.ln = A.bf(M * d);
-  s.qkv = A.bf(M * (cross ? d : 3 * d));
-  s.kv = cross ? A.bf(Mkv * 2 * d) : nullptr;
-  s.o = A.bf(M * d);
+static void plan_attn(Arena& A, AttnSave& s, long M, long Mkv, int d, int B, int H, long Tq, bool cross, bool train) {
+  s.ln = A.template act<T>(M * d);
+  s.qkv = A.template act<T>(M * (cross ? d : 3 * d));
+  s.kv = cross ? A.template act<T>(Mkv * 2 * d) : nullptr;
+  s.o = A.template act<T>(M * d);
   s.mean = A.f32(M);
   s.rstd = A.f32(M);
   s.lse = A.f32((long)B * H * Tq);
-  s.o_lo = train ? A.bf(M * d) : nullptr;
+  s.o_lo = train ? A.template act<T>(M * d) : nullptr;
 }
 
 // In inference mode the per-layer buffers are shared between layers (allocated once); in training each layer
 // gets its own slots because the backward needs them.
-void make_plan(const oasr_ctx* c, Arena& A, Plan& p, int B, int S, bool train) {
+static void make_plan(const oasr_ctx* c, Arena& A, Plan& p, int B, int S, bool train) {
   const int d = c->d;
   const long Me = (long)B * c->Te, M1 = (long)B * c->T1, Md = (long)B * S;
-  p.mel_tm = A.bf(M1 * c->dims.n_mels + 2 * 256) + 256;  // zeroed guard rows on both sides (conv1 weight gradient windows)
-  p.u1 = A.bf(M1 * d);
-  p.h1 = A.bf(M1 * d + d) + d;  // one zeroed time row in front: the conv2 weight gradient reads h1 as overlapping windows from h1 - d
-  p.u2 = A.bf(Me * d);
-  p.x0 = A.bf(Me * d);
+  p.mel_tm = A.template act<T>(M1 * c->dims.n_mels + 2 * 256) + 256;  // zeroed guard rows on both sides (conv1 weight gradient windows)
+  p.u1 = A.template act<T>(M1 * d);
+  p.h1 = A.template act<T>(M1 * d + d) + d;  // one zeroed time row in front: the conv2 weight gradient reads h1 as overlapping windows from h1 - d
+  p.u2 = A.template act<T>(Me * d);
+  p.x0 = A.template act<T>(Me * d);
   auto plan_block = [&](BlockSave& s, long M, long Tq, bool cross) {
     plan_attn(A, s.sa, M, 0, d, B, c->H, Tq, false, train);
-    s.x_mid = A.bf(M * d);
+    s.x_mid = A.template act<T>(M * d);
     if (cross) {
       plan_attn(A, s.ca, M, Me, d, B, c->H, Tq, true, train);
-      s.x_mid2 = A.bf(M * d);
+      s.x_mid2 = A.template act<T>(M * d);
     } else {
       s.x_mid2 = nullptr;
     }
-    s.ln2 = A.bf(M * d);
-    s.u = A.bf(M * 4 * d);
-    s.hg = A.bf(M * 4 * d);
+    s.ln2 = A.template act<T>(M * d);
+    s.u = A.template act<T>(M * 4 * d);
+    s.hg = A.template act<T>(M * 4 * d);
     s.mean2 = A.f32(M);
     s.rstd2 = A.f32(M);
-    s.x_out = A.bf(M * d);
+    s.x_out = A.template act<T>(M * d);
   };
   p.enc.resize(c->L_enc);
   p.dec.resize(c->L_dec);
@@ -201,52 +227,46 @@ void make_plan(const oasr_ctx* c, Arena& A, Plan& p, int B, int S, bool train) {
     BlockSave s0, s1;
     plan_block(s0, Me, c->Te, false);
     s1 = s0;
-    s1.x_out = A.bf(Me * d);  // ping-pong the residual stream
+    s1.x_out = A.template act<T>(Me * d);  // ping-pong the residual stream
     for (int i = 0; i < c->L_enc; ++i) p.enc[i] = (i & 1) ? s1 : s0;
   }
-  p.xa = A.bf(Me * d);
+  p.xa = A.template act<T>(Me * d);
   p.mean_p = A.f32(Me);
   p.rstd_p = A.f32(Me);
-  p.dx0 = A.bf(Md * d);
+  p.dx0 = A.template act<T>(Md * d);
   if (train) {
     for (auto& s : p.dec) plan_block(s, Md, S, true);
   } else {
     BlockSave s0, s1;
     plan_block(s0, Md, S, true);
     s1 = s0;
-    s1.x_out = A.bf(Md * d);
+    s1.x_out = A.template act<T>(Md * d);
     for (int i = 0; i < c->L_dec; ++i) p.dec[i] = (i & 1) ? s1 : s0;
   }
-  p.lnf = A.bf(Md * d);
+  p.lnf = A.template act<T>(Md * d);
   p.mean_f = A.f32(Md);
   p.rstd_f = A.f32(Md);
-  p.logits = A.bf(Md * c->Vp);
+  p.logits = A.template act<T>(Md * c->Vp);
   p.row_loss = A.f32(Md);
   p.n_valid = (int32_t*)A.raw(256);
   if (train) {
     const long Mmax = Me > Md ? Me : Md;
-    p.ga = A.bf(Mmax * d);
-    p.gb = A.bf(Mmax * d);
-    p.gc = A.bf(Mmax * d);
-    p.gln = A.bf(Mmax * d);
-    p.gqkv = A.bf(Mmax * 3 * d);
-    p.go = A.bf(Mmax * d);
-    p.gu = A.bf(M1 * d > Mmax * 4 * d ? M1 * d : Mmax * 4 * d);  // also holds dpre1 [B*3000, d]
-    p.gxa = A.bf(Me * d);
-    p.gkv = A.bf(Me * 2 * d);
-    p.gq = A.bf(Md * d);
-    p.gA2 = A.bf(Me * 3 * d);
+    p.ga = A.template act<T>(Mmax * d);
+    p.gb = A.template act<T>(Mmax * d);
+    p.gc = A.template act<T>(Mmax * d);
+    p.gln = A.template act<T>(Mmax * d);
+    p.gqkv = A.template act<T>(Mmax * 3 * d);
+    p.go = A.template act<T>(Mmax * d);
+    p.gu = A.template act<T>(M1 * d > Mmax * 4 * d ? M1 * d : Mmax * 4 * d);  // also holds dpre1 [B*3000, d]
+    p.gxa = A.template act<T>(Me * d);
+    p.gkv = A.template act<T>(Me * 2 * d);
+    p.gq = A.template act<T>(Md * d);
+    p.gA2 = A.template act<T>(Me * 3 * d);
     p.delta = A.f32((long)B * c->H * c->Te);
     p.tmp_w1p = A.f32((long)d * 256);
     p.tmp_w2p = A.f32((long)d * 3 * d);
   }
 }
-
-#define RC(x)            \
-  do {                   \
-    int _rc = (x);       \
-    if (_rc) return _rc; \
-  } while (0)
 
 struct Runner {
   const oasr_ctx* c;
@@ -254,9 +274,9 @@ struct Runner {
   int B, S;
   const int32_t* text_len;
 
-  int linear(const bf16_t* x, long M, int K, const bf16_t* W, int N, const float* bias, int act, const bf16_t* resid, bf16_t* out,
-             bf16_t* out_pre) {
-    GemmArgs g = gemm_defaults();
+  int linear(const T* x, long M, int K, const T* W, int N, const float* bias, int act, const T* resid, T* out,
+             T* out_pre) {
+    Gemm g = gemm_defaults_t<T>();
     g.A = plain_view(x, K);
     g.B = plain_view(W, K);
     g.M = (int)M;
@@ -272,9 +292,9 @@ struct Runner {
     return launch_gemm(g, st);
   }
   // dx[M,K] = dy[M,N] . W[N,K]  (* gelu'(u))  (+ resid)
-  int dgrad(const bf16_t* dy, long M, int N, const bf16_t* W, int K, const bf16_t* dgelu_u, const bf16_t* resid, bf16_t* dx,
+  int dgrad(const T* dy, long M, int N, const T* W, int K, const T* dgelu_u, const T* resid, T* dx,
             float* colsum = nullptr) {
-    GemmArgs g = gemm_defaults();
+    Gemm g = gemm_defaults_t<T>();
     g.A = plain_view(dy, N);
     g.B = plain_view(W, K);
     g.tb = 1;
@@ -291,8 +311,8 @@ struct Runner {
     return launch_gemm(g, st);
   }
   // dW[N,K] += dy[M,N]^T . x[M,K]   (fp32 atomics, split over the token dimension)
-  int wgrad(const bf16_t* dy, long ldy, long M, int N, const OperandView& x, int K, float* dW, long ldw) {
-    GemmArgs g = gemm_defaults();
+  int wgrad(const T* dy, long ldy, long M, int N, const View& x, int K, float* dW, long ldw) {
+    Gemm g = gemm_defaults_t<T>();
     g.A = plain_view(dy, ldy);
     g.ta = 1;
     g.B = x;
@@ -324,7 +344,7 @@ struct Runner {
     g.split_k = (int)split;
     return launch_gemm(g, st);
   }
-  int attn_args(AttnArgs& a, const AttnSave& s, bool cross, long Tq, long Tk, bool causal) {
+  int attn_args(Attn& a, const AttnSave& s, bool cross, long Tq, long Tk, bool causal) {
     const int d = c->d;
     memset(&a, 0, sizeof(a));
     if (!cross) {
@@ -356,38 +376,38 @@ struct Runner {
     return OASR_OK;
   }
 
-  int block_fwd(const BlockP& bp, BlockSave& s, const bf16_t* x_in, long M, long Tq, const bf16_t* xa, bool causal) {
+  int block_fwd(const BlockP& bp, BlockSave& s, const T* x_in, long M, long Tq, const T* xa, bool causal) {
     const int d = c->d;
-    s.x_in = const_cast<bf16_t*>(x_in);
+    s.x_in = const_cast<T*>(x_in);
     RC(launch_layernorm_fwd(x_in, c->P(bp.attn_ln_w), c->P(bp.attn_ln_b), s.sa.ln, s.sa.mean, s.sa.rstd, M, d, st));
-    RC(linear(s.sa.ln, M, d, c->W(bp.attn.qw), 3 * d, c->aux(bp.attn.fused_bias), 0, nullptr, s.sa.qkv, nullptr));
-    AttnArgs a;
+    RC(linear(s.sa.ln, M, d, c->template Wt<T>(bp.attn.qw), 3 * d, c->aux(bp.attn.fused_bias), 0, nullptr, s.sa.qkv, nullptr));
+    Attn a;
     attn_args(a, s.sa, false, Tq, Tq, causal);
     RC(launch_attention_fwd(a, st));
-    RC(linear(s.sa.o, M, d, c->W(bp.attn.ow), d, c->P(bp.attn.ob), 0, x_in, s.x_mid, nullptr));
-    const bf16_t* xm = s.x_mid;
+    RC(linear(s.sa.o, M, d, c->template Wt<T>(bp.attn.ow), d, c->P(bp.attn.ob), 0, x_in, s.x_mid, nullptr));
+    const T* xm = s.x_mid;
     if (bp.cross) {
       RC(launch_layernorm_fwd(xm, c->P(bp.cln_w), c->P(bp.cln_b), s.ca.ln, s.ca.mean, s.ca.rstd, M, d, st));
-      RC(linear(s.ca.ln, M, d, c->W(bp.cattn.qw), d, c->P(bp.cattn.qb), 0, nullptr, s.ca.qkv, nullptr));
-      RC(linear(xa, (long)B * c->Te, d, c->W(bp.cattn.kw), 2 * d, c->aux(bp.cattn.fused_bias) + d, 0, nullptr, s.ca.kv, nullptr));
+      RC(linear(s.ca.ln, M, d, c->template Wt<T>(bp.cattn.qw), d, c->P(bp.cattn.qb), 0, nullptr, s.ca.qkv, nullptr));
+      RC(linear(xa, (long)B * c->Te, d, c->template Wt<T>(bp.cattn.kw), 2 * d, c->aux(bp.cattn.fused_bias) + d, 0, nullptr, s.ca.kv, nullptr));
       attn_args(a, s.ca, true, Tq, c->Te, false);
       RC(launch_attention_fwd(a, st));
-      RC(linear(s.ca.o, M, d, c->W(bp.cattn.ow), d, c->P(bp.cattn.ob), 0, xm, s.x_mid2, nullptr));
+      RC(linear(s.ca.o, M, d, c->template Wt<T>(bp.cattn.ow), d, c->P(bp.cattn.ob), 0, xm, s.x_mid2, nullptr));
       xm = s.x_mid2;
     }
     RC(launch_layernorm_fwd(xm, c->P(bp.mlp_ln_w), c->P(bp.mlp_ln_b), s.ln2, s.mean2, s.rstd2, M, d, st));
-    RC(linear(s.ln2, M, d, c->W(bp.w1), 4 * d, c->P(bp.b1), 1, nullptr, s.hg, s.u));
-    RC(linear(s.hg, M, 4 * d, c->W(bp.w2), d, c->P(bp.b2), 0, xm, s.x_out, nullptr));
+    RC(linear(s.ln2, M, d, c->template Wt<T>(bp.w1), 4 * d, c->P(bp.b1), 1, nullptr, s.hg, s.u));
+    RC(linear(s.hg, M, 4 * d, c->template Wt<T>(bp.w2), d, c->P(bp.b2), 0, xm, s.x_out, nullptr));
     return OASR_OK;
   }
 
-  OperandView conv1_view(const bf16_t* mel_tm) const {
+  View conv1_view(const T* mel_tm) const {
     const int nm = c->dims.n_mels;
-    return OperandView{mel_tm, nm, c->T1, (long)c->T1 * nm, nm, 3 * nm, 2 * nm};
+    return View{mel_tm, nm, c->T1, (long)c->T1 * nm, nm, 3 * nm, 2 * nm};
   }
-  OperandView conv2_view(const bf16_t* h1) const {
+  View conv2_view(const T* h1) const {
     const int d = c->d;
-    return OperandView{h1, 2L * d, c->Te, (long)c->T1 * d, d, 3 * d, 3 * d};
+    return View{h1, 2L * d, c->Te, (long)c->T1 * d, d, 3 * d, 3 * d};
   }
 
   int encoder_fwd(Plan& p, const float* mel) {
@@ -401,11 +421,11 @@ struct Runner {
     // B (conv2) output rows are recomputed afterwards by a small GEMM over one-row-per-sample window views whose
     // padding IS an out-of-range predicate (OperandView with rpb = 1).
     const int nm = c->dims.n_mels;
-    OASR_CHECK_HIP(hipMemsetAsync(p.mel_tm - 256, 0, 256 * 2, st));
-    OASR_CHECK_HIP(hipMemsetAsync(p.mel_tm + M1 * nm, 0, 256 * 2, st));
-    OASR_CHECK_HIP(hipMemsetAsync(p.h1 - d, 0, (size_t)d * 2, st));
+    OASR_CHECK_HIP(hipMemsetAsync(p.mel_tm - 256, 0, 256 * sizeof(T), st));
+    OASR_CHECK_HIP(hipMemsetAsync(p.mel_tm + M1 * nm, 0, 256 * sizeof(T), st));
+    OASR_CHECK_HIP(hipMemsetAsync(p.h1 - d, 0, (size_t)d * sizeof(T), st));
     for (int pass = 0; pass < 3; ++pass) {  // 0: all rows through the plain view; 1: rows (b, 0); 2: rows (b, T1-1)
-      GemmArgs g = gemm_defaults();
+      Gemm g = gemm_defaults_t<T>();
       long row_off = 0;
       if (pass == 0) {
         g.A = plain_view(p.mel_tm - nm, nm);
@@ -413,12 +433,12 @@ struct Runner {
         g.ldc = d;
       } else {
         row_off = pass == 1 ? 0 : c->T1 - 1;
-        g.A = pass == 1 ? OperandView{p.mel_tm, nm, 1, (long)c->T1 * nm, nm, 3 * nm, 3 * nm}
-                        : OperandView{p.mel_tm + (long)(c->T1 - 2) * nm, nm, 1, (long)c->T1 * nm, 0, 3 * nm, 2 * nm};
+        g.A = pass == 1 ? View{p.mel_tm, nm, 1, (long)c->T1 * nm, nm, 3 * nm, 3 * nm}
+                        : View{p.mel_tm + (long)(c->T1 - 2) * nm, nm, 1, (long)c->T1 * nm, 0, 3 * nm, 2 * nm};
         g.M = B;
         g.ldc = (long)c->T1 * d;
       }
-      g.B = plain_view((const bf16_t*)(c->shadow + c->sh_w1p), 256);
+      g.B = plain_view(c->template w1p<T>(), 256);
       g.N = d;
       g.K = 256;
       g.bias = c->P(c->conv1_b);
@@ -428,19 +448,19 @@ struct Runner {
       RC(launch_gemm(g, st));
     }
     for (int pass = 0; pass < 2; ++pass) {  // 0: all rows; 1: rows (b, 0)
-      GemmArgs g = gemm_defaults();
+      Gemm g = gemm_defaults_t<T>();
       if (pass == 0) {
         g.A = plain_view(p.h1 - d, 2L * d);
         g.M = (int)Me;
         g.ldc = d;
         g.pos_period = c->Te;
       } else {
-        g.A = OperandView{p.h1, 2L * d, 1, (long)c->T1 * d, d, 3 * d, 3 * d};
+        g.A = View{p.h1, 2L * d, 1, (long)c->T1 * d, d, 3 * d, 3 * d};
         g.M = B;
         g.ldc = (long)c->Te * d;
         g.pos_period = 1;  // every recomputed row is position 0
       }
-      g.B = plain_view((const bf16_t*)(c->shadow + c->sh_w2p), 3 * d);
+      g.B = plain_view(c->template w2p<T>(), 3 * d);
       g.N = d;
       g.K = 3 * d;
       g.bias = c->P(c->conv2_b);
@@ -450,7 +470,7 @@ struct Runner {
       g.out_pre = p.u2;
       RC(launch_gemm(g, st));
     }
-    const bf16_t* x = p.x0;
+    const T* x = p.x0;
     for (int i = 0; i < c->L_enc; ++i) {
       RC(block_fwd(c->enc[i], p.enc[i], x, Me, c->Te, nullptr, false));
       x = p.enc[i].x_out;
@@ -463,16 +483,16 @@ struct Runner {
     const int d = c->d;
     const long Md = (long)B * S;
     RC(launch_embedding_fwd(tokens, c->P(c->tok_emb), c->P(c->dec_pos), p.dx0, B, S, d, c->V, st));
-    const bf16_t* x = p.dx0;
+    const T* x = p.dx0;
     for (int i = 0; i < c->L_dec; ++i) {
       RC(block_fwd(c->dec[i], p.dec[i], x, Md, S, p.xa, true));
       x = p.dec[i].x_out;
     }
     RC(launch_layernorm_fwd(x, c->P(c->dec_ln_w), c->P(c->dec_ln_b), p.lnf, p.mean_f, p.rstd_f, Md, d, st));
     if (last_only) {  // greedy decoding only needs position S-1 of every sequence: M = B rows, row stride S*d
-      GemmArgs g = gemm_defaults();
+      Gemm g = gemm_defaults_t<T>();
       g.A = plain_view(p.lnf + (long)(S - 1) * d, (long)S * d);
-      g.B = plain_view(c->W(c->tok_emb), d);
+      g.B = plain_view(c->template Wt<T>(c->tok_emb), d);
       g.M = B;
       g.N = c->Vp;
       g.K = d;
@@ -480,7 +500,7 @@ struct Runner {
       g.ldc = c->Vp;
       return launch_gemm(g, st);
     }
-    RC(linear(p.lnf, Md, d, c->W(c->tok_emb), c->Vp, nullptr, 0, nullptr, p.logits, nullptr));
+    RC(linear(p.lnf, Md, d, c->template Wt<T>(c->tok_emb), c->Vp, nullptr, 0, nullptr, p.logits, nullptr));
     return OASR_OK;
   }
 
@@ -494,25 +514,25 @@ struct Runner {
   // residual-stream gradient, and every such gradient is produced by a LayerNorm backward -> that kernel accumulates
   // them (its `dsum` output).  The caller's LN backward already filled this block's mlp.2.bias gradient from dx_out;
   // `dsum_next` is the bias gradient the produced dx_in belongs to (previous block's mlp.2.bias, or null).
-  int block_bwd(const BlockP& bp, const BlockSave& s, Plan& p, const bf16_t* dx_out, bf16_t* scratch_a, bf16_t* scratch_b, long M,
-                long Tq, bool causal, bool first_cross, float* dsum_next, const bf16_t** dx_in) {
+  int block_bwd(const BlockP& bp, const BlockSave& s, Plan& p, const T* dx_out, T* scratch_a, T* scratch_b, long M,
+                long Tq, bool causal, bool first_cross, float* dsum_next, const T** dx_in) {
     const int d = c->d;
-    const bf16_t* xm = bp.cross ? s.x_mid2 : s.x_mid;
+    const T* xm = bp.cross ? s.x_mid2 : s.x_mid;
     // ---- MLP -----------------------------------------------------------------------------------------------
     RC(wgrad(dx_out, d, M, d, plain_view(s.hg, 4 * d), 4 * d, c->G(bp.w2), 4 * d));
-    RC(dgrad(dx_out, M, d, c->W(bp.w2), 4 * d, s.u, nullptr, p.gu, c->G(bp.b1)));  // + fused mlp.0.bias gradient
+    RC(dgrad(dx_out, M, d, c->template Wt<T>(bp.w2), 4 * d, s.u, nullptr, p.gu, c->G(bp.b1)));  // + fused mlp.0.bias gradient
     RC(wgrad(p.gu, 4 * d, M, 4 * d, plain_view(s.ln2, d), d, c->G(bp.w1), d));
-    RC(dgrad(p.gu, M, 4 * d, c->W(bp.w1), d, nullptr, nullptr, p.gln));
+    RC(dgrad(p.gu, M, 4 * d, c->template Wt<T>(bp.w1), d, nullptr, nullptr, p.gln));
     RC(launch_layernorm_bwd(p.gln, xm, c->P(bp.mlp_ln_w), s.mean2, s.rstd2, dx_out, scratch_a, c->G(bp.mlp_ln_w), c->G(bp.mlp_ln_b),
                             c->G(bp.cross ? bp.cattn.ob : bp.attn.ob), M, d, st));
-    const bf16_t* dx = scratch_a;
-    bf16_t* nxt = scratch_b;
+    const T* dx = scratch_a;
+    T* nxt = scratch_b;
     // ---- cross attention ---------------------------------------------------------------------------------------
     if (bp.cross) {
       const long Mkv = (long)B * c->Te;
       RC(wgrad(dx, d, M, d, plain_view(s.ca.o, d), d, c->G(bp.cattn.ow), d));
-      RC(dgrad(dx, M, d, c->W(bp.cattn.ow), d, nullptr, nullptr, p.go));
-      AttnArgs a;
+      RC(dgrad(dx, M, d, c->template Wt<T>(bp.cattn.ow), d, nullptr, nullptr, p.go));
+      Attn a;
       attn_args(a, s.ca, true, Tq, c->Te, false);
       a.d_o = p.go;
       a.delta = p.delta;
@@ -525,18 +545,18 @@ struct Runner {
       RC(wgrad(p.gkv, 2 * d, Mkv, 2 * d, plain_view(p.xa, d), d, c->G(bp.cattn.kw), d));
       RC(launch_colsum_accum(p.gkv + d, 2 * d, Mkv, d, c->G(bp.cattn.vb), st));
       // d(xa) accumulates over the decoder layers (bf16, like autograd's accumulation into xa.grad)
-      RC(dgrad(p.gkv, Mkv, 2 * d, c->W(bp.cattn.kw), d, nullptr, first_cross ? nullptr : p.gxa, p.gxa));
-      RC(dgrad(p.gq, M, d, c->W(bp.cattn.qw), d, nullptr, nullptr, p.gln));
+      RC(dgrad(p.gkv, Mkv, 2 * d, c->template Wt<T>(bp.cattn.kw), d, nullptr, first_cross ? nullptr : p.gxa, p.gxa));
+      RC(dgrad(p.gq, M, d, c->template Wt<T>(bp.cattn.qw), d, nullptr, nullptr, p.gln));
       RC(launch_layernorm_bwd(p.gln, s.x_mid, c->P(bp.cln_w), s.ca.mean, s.ca.rstd, dx, nxt, c->G(bp.cln_w), c->G(bp.cln_b),
                               c->G(bp.attn.ob), M, d, st));
-      const bf16_t* t = dx;
+      const T* t = dx;
       dx = nxt;
-      nxt = const_cast<bf16_t*>(t);
+      nxt = const_cast<T*>(t);
     }
     // ---- self attention ----------------------------------------------------------------------------------------
     RC(wgrad(dx, d, M, d, plain_view(s.sa.o, d), d, c->G(bp.attn.ow), d));
-    RC(dgrad(dx, M, d, c->W(bp.attn.ow), d, nullptr, nullptr, p.go));
-    AttnArgs a;
+    RC(dgrad(dx, M, d, c->template Wt<T>(bp.attn.ow), d, nullptr, nullptr, p.go));
+    Attn a;
     attn_args(a, s.sa, false, Tq, Tq, causal);
     a.d_o = p.go;
     a.delta = p.delta;
@@ -547,7 +567,7 @@ struct Runner {
     RC(wgrad(p.gqkv, 3 * d, M, 3 * d, plain_view(s.sa.ln, d), d, c->G(bp.attn.qw), d));
     RC(launch_colsum_accum(p.gqkv, 3 * d, M, d, c->G(bp.attn.qb), st));
     RC(launch_colsum_accum(p.gqkv + 2 * d, 3 * d, M, d, c->G(bp.attn.vb), st));
-    RC(dgrad(p.gqkv, M, 3 * d, c->W(bp.attn.qw), d, nullptr, nullptr, p.gln));
+    RC(dgrad(p.gqkv, M, 3 * d, c->template Wt<T>(bp.attn.qw), d, nullptr, nullptr, p.gln));
     RC(launch_layernorm_bwd(p.gln, s.x_in, c->P(bp.attn_ln_w), s.sa.mean, s.sa.rstd, dx, nxt, c->G(bp.attn_ln_w), c->G(bp.attn_ln_b),
                             dsum_next, M, d, st));
     *dx_in = nxt;
@@ -555,44 +575,17 @@ struct Runner {
   }
 };
 
-int write_logits_f32(const bf16_t* logits, long ld, long rows, int V, float* out, hipStream_t st);
+};  // struct Engine
 
 }  // namespace
 
 // ---- small kernels local to the engine -------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void logits_to_f32_kernel(const bf16_t* __restrict__ lg, long ld, int V, float* __restrict__ out,
-                                                           long total) {
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long r = i / V;
-    const int col = (int)(i - r * V);
-    out[i] = bf2f(lg[r * ld + col]);
-  }
-}
 __global__ __launch_bounds__(256) void fused_bias_kernel(const float* __restrict__ qb, const float* __restrict__ vb, float* __restrict__ out,
                                                         int d) {
   for (int i = blockIdx.x * 256 + threadIdx.x; i < 3 * d; i += gridDim.x * 256)
     out[i] = i < d ? qb[i] : (i < 2 * d ? 0.f : vb[i - 2 * d]);
 }
-__global__ __launch_bounds__(256) void dgelu_mul_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ u, bf16_t* __restrict__ out,
-                                                       long n8) {
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
-    const u32x4_t a = ((const u32x4_t*)dy)[i], b = ((const u32x4_t*)u)[i];
-    u32x4_t o;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = pack_bf2(bf_lo(a[j]) * dgelu_f(bf_lo(b[j])), bf_hi(a[j]) * dgelu_f(bf_hi(b[j])));
-    ((u32x4_t*)out)[i] = o;
-  }
-}
-
 namespace {
-int write_logits_f32(const bf16_t* logits, long ld, long rows, int V, float* out, hipStream_t st) {
-  const long total = rows * V;
-  long nb = (total + 255) / 256;
-  if (nb > 4096) nb = 4096;
-  hipLaunchKernelGGL(logits_to_f32_kernel, dim3((unsigned)nb), dim3(256), 0, st, logits, ld, V, out, total);
-  OASR_LAUNCH_CHECK();
-  return OASR_OK;
-}
 int check_bound(const oasr_ctx* c, bool need_grads) {
   OASR_REQUIRE(c, "null context");
   if (!c->params || !c->shadow || !c->enc_pos || (need_grads && !c->grads)) {
@@ -604,12 +597,19 @@ int check_bound(const oasr_ctx* c, bool need_grads) {
 }  // namespace
 
 // ================================================ C ABI ============================================================
-extern "C" oasr_ctx* oasr_create_ex(const oasr_dims* dm, int embed_rows);
-extern "C" oasr_ctx* oasr_create(const oasr_dims* dm) { return oasr_create_ex(dm, dm ? dm->n_vocab + 1 : 0); }
+extern "C" oasr_ctx* oasr_create_ex2(const oasr_dims* dm, int embed_rows, int compute_dtype);
+extern "C" oasr_ctx* oasr_create_ex(const oasr_dims* dm, int embed_rows) { return oasr_create_ex2(dm, embed_rows, OASR_DTYPE_BF16); }
+extern "C" oasr_ctx* oasr_create(const oasr_dims* dm) { return oasr_create_ex2(dm, dm ? dm->n_vocab + 1 : 0, OASR_DTYPE_BF16); }
 
 // embed_rows: rows of decoder.token_embedding -- n_vocab + 1 for the training model (pad row, olmoasr/model.py:665-667),
 // n_vocab for the inference model (olmoasr/inf_model.py:302; checkpoints written by scripts/eval/gen_inf_ckpt.py)
-extern "C" oasr_ctx* oasr_create_ex(const oasr_dims* dm, int embed_rows) {
+// compute_dtype: OASR_DTYPE_BF16 = the production kernels; OASR_DTYPE_F32 = the fp32 validation kernels on the same
+// schedule (reference: precision="float32", scripts/training/train_timestamps.py:2128,2220-2224)
+extern "C" oasr_ctx* oasr_create_ex2(const oasr_dims* dm, int embed_rows, int compute_dtype) {
+  if (compute_dtype != OASR_DTYPE_BF16 && compute_dtype != OASR_DTYPE_F32) {
+    oasr_set_error("oasr_create_ex2: compute_dtype must be OASR_DTYPE_BF16 or OASR_DTYPE_F32");
+    return nullptr;
+  }
   if (!dm) {
     oasr_set_error("oasr_create: null dims");
     return nullptr;
@@ -625,6 +625,7 @@ extern "C" oasr_ctx* oasr_create_ex(const oasr_dims* dm, int embed_rows) {
     return nullptr;
   }
   oasr_ctx* c = new oasr_ctx();
+  c->f32 = compute_dtype == OASR_DTYPE_F32;
   c->dims = *dm;
   c->d = d;
   c->H = dm->n_audio_head;
@@ -634,7 +635,7 @@ extern "C" oasr_ctx* oasr_create_ex(const oasr_dims* dm, int embed_rows) {
   c->T1 = 2 * dm->n_audio_ctx;
   c->S_max = dm->n_text_ctx;
   c->V = embed_rows;
-  c->Vp = (c->V + 127) / 128 * 128;
+  c->Vp = c->f32 ? c->V : (c->V + 127) / 128 * 128;  // (the fp32 kernels need no padded vocabulary)
   c->aux_floats = 0;
   Builder b{c};
   {  // decoder.ln
@@ -674,17 +675,19 @@ extern "C" oasr_ctx* oasr_create_ex(const oasr_dims* dm, int embed_rows) {
   // shadow: [bf16 flat arena + zero pad rows for the padded vocab] [W1p d x 256] [W2p d x 3d] [aux fp32]
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   c->sh_flat = 0;
-  size_t off = al(((size_t)c->numel + (size_t)(c->Vp - c->V) * d + 64) * 2);
+  const size_t esz = c->f32 ? 4 : 2;  // fp32 validation: no shadow of the flat arena (the master weights are the operands)
+  size_t off = c->f32 ? 256 : al(((size_t)c->numel + (size_t)(c->Vp - c->V) * d + 64) * 2);
   c->sh_w1p = off;
-  off = al(off + (size_t)d * 256 * 2);
+  off = al(off + (size_t)d * 256 * esz);
   c->sh_w2p = off;
-  off = al(off + (size_t)d * 3 * d * 2);
+  off = al(off + (size_t)d * 3 * d * esz);
   c->sh_aux = off;
   off = al(off + (size_t)c->aux_floats * 4);
   c->sh_total = off;
   return c;
 }
 extern "C" void oasr_destroy(oasr_ctx* c) { delete c; }
+extern "C" int oasr_compute_dtype(const oasr_ctx* c) { return c && c->f32 ? OASR_DTYPE_F32 : OASR_DTYPE_BF16; }
 extern "C" int oasr_param_count(const oasr_ctx* c) { return c ? (int)c->tensors.size() : 0; }
 extern "C" int64_t oasr_param_numel(const oasr_ctx* c) { return c ? c->numel : 0; }
 extern "C" int oasr_param_info(const oasr_ctx* c, int idx, char* name, int name_cap, int64_t* offset, int64_t* numel, int* ndim,
@@ -724,8 +727,13 @@ extern "C" int oasr_bind_shadow(oasr_ctx* c, void* shadow) {
 
 static int refresh_packed(oasr_ctx* c, hipStream_t st) {
   const int d = c->d;
-  RC(launch_pack_conv_weight(c->P(c->conv1_w), (bf16_t*)(c->shadow + c->sh_w1p), d, c->dims.n_mels, 256, st));
-  RC(launch_pack_conv_weight(c->P(c->conv2_w), (bf16_t*)(c->shadow + c->sh_w2p), d, d, 3 * d, st));
+  if (c->f32) {
+    RC(launch_pack_conv_weight(c->P(c->conv1_w), (float*)(c->shadow + c->sh_w1p), d, c->dims.n_mels, 256, st));
+    RC(launch_pack_conv_weight(c->P(c->conv2_w), (float*)(c->shadow + c->sh_w2p), d, d, 3 * d, st));
+  } else {
+    RC(launch_pack_conv_weight(c->P(c->conv1_w), (bf16_t*)(c->shadow + c->sh_w1p), d, c->dims.n_mels, 256, st));
+    RC(launch_pack_conv_weight(c->P(c->conv2_w), (bf16_t*)(c->shadow + c->sh_w2p), d, d, 3 * d, st));
+  }
   float* aux = (float*)(c->shadow + c->sh_aux);
   auto fb = [&](const AttnP& a) {
     hipLaunchKernelGGL(fused_bias_kernel, dim3(cdiv(3 * d, 256)), dim3(256), 0, st, c->P(a.qb), c->P(a.vb), aux + a.fused_bias, d);
@@ -742,65 +750,89 @@ static int refresh_packed(oasr_ctx* c, hipStream_t st) {
 extern "C" int oasr_refresh_shadow(oasr_ctx* c, void* stream) {
   RC(check_bound(c, false));
   hipStream_t st = (hipStream_t)stream;
-  bf16_t* flat = (bf16_t*)(c->shadow + c->sh_flat);
-  RC(launch_cast_f32_bf16(c->params, flat, c->numel, st));
-  OASR_CHECK_HIP(hipMemsetAsync(flat + c->numel, 0, ((size_t)(c->Vp - c->V) * c->d + 64) * 2, st));
+  if (!c->f32) {
+    bf16_t* flat = (bf16_t*)(c->shadow + c->sh_flat);
+    RC(launch_cast_f32_bf16(c->params, flat, c->numel, st));
+    OASR_CHECK_HIP(hipMemsetAsync(flat + c->numel, 0, ((size_t)(c->Vp - c->V) * c->d + 64) * 2, st));
+  }
   return refresh_packed(c, st);
 }
 
 extern "C" size_t oasr_workspace_bytes(const oasr_ctx* c, int B, int S, int mode) {
   if (!c || B <= 0 || S <= 0) return 0;
   Arena A(nullptr, 0);
-  Plan p;
-  make_plan(c, A, p, B, S, mode == OASR_MODE_TRAIN);
+  if (c->f32) {
+    Engine<float>::Plan p;
+    Engine<float>::make_plan(c, A, p, B, S, mode == OASR_MODE_TRAIN);
+  } else {
+    Engine<bf16_t>::Plan p;
+    Engine<bf16_t>::make_plan(c, A, p, B, S, mode == OASR_MODE_TRAIN);
+  }
   return A.cur + 4096;
 }
 
-extern "C" int oasr_forward(oasr_ctx* c, const float* mel, const int64_t* tokens, const int32_t* text_len, int B, int S,
+template <typename T>
+static int oasr_forward_impl(oasr_ctx* c, const float* mel, const int64_t* tokens, const int32_t* text_len, int B, int S,
                             float* logits_out, void* xa_out, void* workspace, size_t workspace_bytes, void* stream) {
   RC(check_bound(c, false));
   OASR_REQUIRE(mel && tokens && workspace && B > 0 && S > 0 && S <= c->S_max, "oasr_forward: bad args (B=%d S=%d)", B, S);
   OASR_REQUIRE(workspace_bytes >= oasr_workspace_bytes(c, B, S, OASR_MODE_INFER), "oasr_forward: workspace too small");
   Arena A(workspace, workspace_bytes);
-  Plan p;
-  make_plan(c, A, p, B, S, false);
-  Runner r{c, (hipStream_t)stream, B, S, text_len};
+  typename Engine<T>::Plan p;
+  Engine<T>::make_plan(c, A, p, B, S, false);
+  typename Engine<T>::Runner r{c, (hipStream_t)stream, B, S, text_len};
   RC(r.encoder_fwd(p, mel));
   RC(r.decoder_fwd(p, tokens));
   if (xa_out)
-    OASR_CHECK_HIP(hipMemcpyAsync(xa_out, p.xa, (size_t)B * c->Te * c->d * 2, hipMemcpyDeviceToDevice, r.st));
-  if (logits_out) RC(write_logits_f32(p.logits, c->Vp, (long)B * S, c->V, logits_out, r.st));
+    OASR_CHECK_HIP(hipMemcpyAsync(xa_out, p.xa, (size_t)B * c->Te * c->d * sizeof(T), hipMemcpyDeviceToDevice, r.st));
+  if (logits_out) RC(launch_logits_to_f32(p.logits, c->Vp, (long)B * S, c->V, logits_out, r.st));
   return OASR_OK;
+}
+extern "C" int oasr_forward(oasr_ctx* c, const float* mel, const int64_t* tokens, const int32_t* text_len, int B, int S,
+                            float* logits_out, void* xa_out, void* workspace, size_t workspace_bytes, void* stream) {
+  OASR_REQUIRE(c, "oasr_forward: null context");
+  return c->f32 ? oasr_forward_impl<float>(c, mel, tokens, text_len, B, S, logits_out, xa_out, workspace, workspace_bytes, stream) : oasr_forward_impl<bf16_t>(c, mel, tokens, text_len, B, S, logits_out, xa_out, workspace, workspace_bytes, stream);
 }
 
 // AudioEncoder.forward (olmoasr/model.py:571-623): mel -> xa bf16 [B, n_audio_ctx, d]
-extern "C" int oasr_encode(oasr_ctx* c, const float* mel, int B, void* xa_out, void* workspace, size_t workspace_bytes, void* stream) {
+template <typename T>
+static int oasr_encode_impl(oasr_ctx* c, const float* mel, int B, void* xa_out, void* workspace, size_t workspace_bytes, void* stream) {
   RC(check_bound(c, false));
   OASR_REQUIRE(mel && xa_out && workspace && B > 0, "oasr_encode: bad args");
   OASR_REQUIRE(workspace_bytes >= oasr_workspace_bytes(c, B, 1, OASR_MODE_INFER), "oasr_encode: workspace too small");
   Arena A(workspace, workspace_bytes);
-  Plan p;
-  make_plan(c, A, p, B, 1, false);
-  Runner r{c, (hipStream_t)stream, B, 1, nullptr};
+  typename Engine<T>::Plan p;
+  Engine<T>::make_plan(c, A, p, B, 1, false);
+  typename Engine<T>::Runner r{c, (hipStream_t)stream, B, 1, nullptr};
   RC(r.encoder_fwd(p, mel));
-  OASR_CHECK_HIP(hipMemcpyAsync(xa_out, p.xa, (size_t)B * c->Te * c->d * 2, hipMemcpyDeviceToDevice, r.st));
+  OASR_CHECK_HIP(hipMemcpyAsync(xa_out, p.xa, (size_t)B * c->Te * c->d * sizeof(T), hipMemcpyDeviceToDevice, r.st));
   return OASR_OK;
+}
+extern "C" int oasr_encode(oasr_ctx* c, const float* mel, int B, void* xa_out, void* workspace, size_t workspace_bytes, void* stream) {
+  OASR_REQUIRE(c, "oasr_encode: null context");
+  return c->f32 ? oasr_encode_impl<float>(c, mel, B, xa_out, workspace, workspace_bytes, stream) : oasr_encode_impl<bf16_t>(c, mel, B, xa_out, workspace, workspace_bytes, stream);
 }
 
 // TextDecoder.forward without kv_cache (olmoasr/model.py:688-775) on given audio features: OLMoASR.logits(tokens, xa).
 // last_only != 0: logits_out is f32 [B, rows] for position S-1 only (greedy decode step); else f32 [B, S, rows].
-extern "C" int oasr_decode_logits(oasr_ctx* c, const int64_t* tokens, const void* xa, const int32_t* text_len, int B, int S,
+template <typename T>
+static int oasr_decode_logits_impl(oasr_ctx* c, const int64_t* tokens, const void* xa, const int32_t* text_len, int B, int S,
                                   int last_only, float* logits_out, void* workspace, size_t workspace_bytes, void* stream) {
   RC(check_bound(c, false));
   OASR_REQUIRE(tokens && xa && logits_out && workspace && B > 0 && S > 0 && S <= c->S_max, "oasr_decode_logits: bad args");
   OASR_REQUIRE(workspace_bytes >= oasr_workspace_bytes(c, B, S, OASR_MODE_INFER), "oasr_decode_logits: workspace too small");
   Arena A(workspace, workspace_bytes);
-  Plan p;
-  make_plan(c, A, p, B, S, false);
-  Runner r{c, (hipStream_t)stream, B, S, text_len};
-  OASR_CHECK_HIP(hipMemcpyAsync(p.xa, xa, (size_t)B * c->Te * c->d * 2, hipMemcpyDeviceToDevice, r.st));
+  typename Engine<T>::Plan p;
+  Engine<T>::make_plan(c, A, p, B, S, false);
+  typename Engine<T>::Runner r{c, (hipStream_t)stream, B, S, text_len};
+  OASR_CHECK_HIP(hipMemcpyAsync(p.xa, xa, (size_t)B * c->Te * c->d * sizeof(T), hipMemcpyDeviceToDevice, r.st));
   RC(r.decoder_fwd(p, tokens, last_only != 0));
-  return write_logits_f32(p.logits, c->Vp, last_only ? (long)B : (long)B * S, c->V, logits_out, r.st);
+  return launch_logits_to_f32(p.logits, c->Vp, last_only ? (long)B : (long)B * S, c->V, logits_out, r.st);
+}
+extern "C" int oasr_decode_logits(oasr_ctx* c, const int64_t* tokens, const void* xa, const int32_t* text_len, int B, int S,
+                                  int last_only, float* logits_out, void* workspace, size_t workspace_bytes, void* stream) {
+  OASR_REQUIRE(c, "oasr_decode_logits: null context");
+  return c->f32 ? oasr_decode_logits_impl<float>(c, tokens, xa, text_len, B, S, last_only, logits_out, workspace, workspace_bytes, stream) : oasr_decode_logits_impl<bf16_t>(c, tokens, xa, text_len, B, S, last_only, logits_out, workspace, workspace_bytes, stream);
 }
 
 // ---- cached greedy decoding (OLMoASR.install_kv_cache_hooks, olmoasr/model.py:925-964 / inf_model.py:422-453) -----------
@@ -813,72 +845,80 @@ extern "C" int oasr_decode_logits(oasr_ctx* c, const int64_t* tokens, const void
 // attention reads q from that row and the first pos+1 cached keys/values through strides.
 extern "C" size_t oasr_kv_cache_bytes(const oasr_ctx* c, int B) {
   if (!c || B <= 0) return 0;
-  const size_t per_layer = ((size_t)3 * B * c->S_max * c->d + (size_t)B * c->Te * 2 * c->d) * 2;
+  const size_t per_layer = ((size_t)3 * B * c->S_max * c->d + (size_t)B * c->Te * 2 * c->d) * (c->f32 ? 4 : 2);
   return per_layer * c->L_dec + 256;
 }
 namespace {
+template <typename T>
 struct KvLayer {
-  bf16_t *qkv, *ckv;  // self [B, S_max, 3d] (q | k | v per position), cross [B, Te, 2d]
+  T *qkv, *ckv;  // self [B, S_max, 3d] (q | k | v per position), cross [B, Te, 2d]
 };
-KvLayer kv_layer(const oasr_ctx* c, void* cache, int B, int layer) {
+template <typename T>
+KvLayer<T> kv_layer(const oasr_ctx* c, void* cache, int B, int layer) {
   const size_t per_layer = (size_t)3 * B * c->S_max * c->d + (size_t)B * c->Te * 2 * c->d;
-  bf16_t* base = (bf16_t*)cache + per_layer * layer;
-  return KvLayer{base, base + (size_t)3 * B * c->S_max * c->d};
+  T* base = (T*)cache + per_layer * layer;
+  return KvLayer<T>{base, base + (size_t)3 * B * c->S_max * c->d};
 }
 }  // namespace
 
 extern "C" size_t oasr_decode_step_workspace_bytes(const oasr_ctx* c, int B) {
   if (!c || B <= 0) return 0;
   // x, ln, q, o, x2 (5 * B*d) + u, hg (2 * B*4d) + logits (B*Vp) bf16 + stats
-  return ((size_t)B * c->d * 6 + (size_t)B * 8 * c->d + (size_t)B * c->Vp) * 2 + (size_t)B * c->H * 8 + (size_t)B * 16 + 8192;
+  return ((size_t)B * c->d * 6 + (size_t)B * 8 * c->d + (size_t)B * c->Vp + 9 * 32) * (c->f32 ? 4 : 2) + (size_t)B * c->H * 8 + (size_t)B * 16 + 8192;
 }
 
-extern "C" int oasr_decode_begin(oasr_ctx* c, const void* xa, int B, void* kv_cache, void* stream) {
+template <typename T>
+static int oasr_decode_begin_impl(oasr_ctx* c, const void* xa, int B, void* kv_cache, void* stream) {
   RC(check_bound(c, false));
   OASR_REQUIRE(xa && kv_cache && B > 0, "oasr_decode_begin: bad args");
-  Runner r{c, (hipStream_t)stream, B, 1, nullptr};
+  typename Engine<T>::Runner r{c, (hipStream_t)stream, B, 1, nullptr};
   const int d = c->d;
   for (int i = 0; i < c->L_dec; ++i) {
     const BlockP& bp = c->dec[i];
-    KvLayer kl = kv_layer(c, kv_cache, B, i);
-    RC(r.linear((const bf16_t*)xa, (long)B * c->Te, d, c->W(bp.cattn.kw), 2 * d, c->aux(bp.cattn.fused_bias) + d, 0, nullptr, kl.ckv, nullptr));
+    KvLayer<T> kl = kv_layer<T>(c, kv_cache, B, i);
+    RC(r.linear((const T*)xa, (long)B * c->Te, d, c->template Wt<T>(bp.cattn.kw), 2 * d, c->aux(bp.cattn.fused_bias) + d, 0, nullptr, kl.ckv, nullptr));
   }
   return OASR_OK;
 }
+extern "C" int oasr_decode_begin(oasr_ctx* c, const void* xa, int B, void* kv_cache, void* stream) {
+  OASR_REQUIRE(c, "oasr_decode_begin: null context");
+  return c->f32 ? oasr_decode_begin_impl<float>(c, xa, B, kv_cache, stream) : oasr_decode_begin_impl<bf16_t>(c, xa, B, kv_cache, stream);
+}
 
 // tokens_last i64 [B]: the token at position pos of every sequence.  logits_out f32 [B, rows] for the NEXT position.
-extern "C" int oasr_decode_step(oasr_ctx* c, const int64_t* tokens_last, int B, int pos, void* kv_cache, float* logits_out,
+template <typename T>
+static int oasr_decode_step_impl(oasr_ctx* c, const int64_t* tokens_last, int B, int pos, void* kv_cache, float* logits_out,
                                 void* workspace, size_t workspace_bytes, void* stream) {
   RC(check_bound(c, false));
   OASR_REQUIRE(tokens_last && kv_cache && logits_out && workspace && B > 0 && pos >= 0 && pos < c->S_max, "oasr_decode_step: bad args");
   OASR_REQUIRE(workspace_bytes >= oasr_decode_step_workspace_bytes(c, B), "oasr_decode_step: workspace too small");
   const int d = c->d, S_max = c->S_max;
   hipStream_t st = (hipStream_t)stream;
-  Runner r{c, st, B, 1, nullptr};
+  typename Engine<T>::Runner r{c, st, B, 1, nullptr};
   Arena A(workspace, workspace_bytes);
-  bf16_t* x = A.bf((size_t)B * d);
-  bf16_t* ln = A.bf((size_t)B * d);
-  bf16_t* q = A.bf((size_t)B * d);
-  bf16_t* o = A.bf((size_t)B * d);
-  bf16_t* x2 = A.bf((size_t)B * d);
-  bf16_t* x3 = A.bf((size_t)B * d);
-  bf16_t* u = A.bf((size_t)B * 4 * d);
-  bf16_t* hg = A.bf((size_t)B * 4 * d);
-  bf16_t* logits = A.bf((size_t)B * c->Vp);
+  T* x = A.template act<T>((size_t)B * d);
+  T* ln = A.template act<T>((size_t)B * d);
+  T* q = A.template act<T>((size_t)B * d);
+  T* o = A.template act<T>((size_t)B * d);
+  T* x2 = A.template act<T>((size_t)B * d);
+  T* x3 = A.template act<T>((size_t)B * d);
+  T* u = A.template act<T>((size_t)B * 4 * d);
+  T* hg = A.template act<T>((size_t)B * 4 * d);
+  T* logits = A.template act<T>((size_t)B * c->Vp);
   float* lse = A.f32((size_t)B * c->H);
   float* mean = A.f32(B);
   float* rstd = A.f32(B);
   // token + positional embedding of position pos: S = 1 per sequence, positional row offset by pos
   RC(launch_embedding_fwd(tokens_last, c->P(c->tok_emb), c->P(c->dec_pos) + (size_t)pos * d, x, B, 1, d, c->V, st));
-  bf16_t* cur = x;
+  T* cur = x;
   for (int i = 0; i < c->L_dec; ++i) {
     const BlockP& bp = c->dec[i];
-    KvLayer kl = kv_layer(c, kv_cache, B, i);
+    KvLayer<T> kl = kv_layer<T>(c, kv_cache, B, i);
     RC(launch_layernorm_fwd(cur, c->P(bp.attn_ln_w), c->P(bp.attn_ln_b), ln, mean, rstd, B, d, st));
     {  // q | k | v of this position in one launch, straight into the cache: output row b lands at [b, pos, 0:3d]
-      GemmArgs g = gemm_defaults();
+      GemmArgsT<T> g = gemm_defaults_t<T>();
       g.A = plain_view(ln, d);
-      g.B = plain_view(c->W(bp.attn.qw), d);  // query | key | value weights are adjacent in the arena
+      g.B = plain_view(c->template Wt<T>(bp.attn.qw), d);  // query | key | value weights are adjacent in the arena
       g.M = B;
       g.N = 3 * d;
       g.K = d;
@@ -887,7 +927,7 @@ extern "C" int oasr_decode_step(oasr_ctx* c, const int64_t* tokens_last, int B, 
       g.out = kl.qkv + (size_t)pos * 3 * d;
       RC(launch_gemm(g, st));
     }
-    AttnArgs a;
+    AttnArgsT<T> a;
     memset(&a, 0, sizeof(a));
     a.q = kl.qkv + (size_t)pos * 3 * d;
     a.ldq = 3 * d;
@@ -905,9 +945,9 @@ extern "C" int oasr_decode_step(oasr_ctx* c, const int64_t* tokens_last, int B, 
     a.Tq = 1;
     a.Tk = pos + 1;
     RC(launch_attention_fwd(a, st));
-    RC(r.linear(o, B, d, c->W(bp.attn.ow), d, c->P(bp.attn.ob), 0, cur, x2, nullptr));
+    RC(r.linear(o, B, d, c->template Wt<T>(bp.attn.ow), d, c->P(bp.attn.ob), 0, cur, x2, nullptr));
     RC(launch_layernorm_fwd(x2, c->P(bp.cln_w), c->P(bp.cln_b), ln, mean, rstd, B, d, st));
-    RC(r.linear(ln, B, d, c->W(bp.cattn.qw), d, c->P(bp.cattn.qb), 0, nullptr, q, nullptr));
+    RC(r.linear(ln, B, d, c->template Wt<T>(bp.cattn.qw), d, c->P(bp.cattn.qb), 0, nullptr, q, nullptr));
     a.q = q;
     a.ldq = d;
     a.bsq = d;
@@ -917,15 +957,20 @@ extern "C" int oasr_decode_step(oasr_ctx* c, const int64_t* tokens_last, int B, 
     a.bsk = a.bsv = (long)c->Te * 2 * d;
     a.Tk = c->Te;
     RC(launch_attention_fwd(a, st));
-    RC(r.linear(o, B, d, c->W(bp.cattn.ow), d, c->P(bp.cattn.ob), 0, x2, x3, nullptr));
+    RC(r.linear(o, B, d, c->template Wt<T>(bp.cattn.ow), d, c->P(bp.cattn.ob), 0, x2, x3, nullptr));
     RC(launch_layernorm_fwd(x3, c->P(bp.mlp_ln_w), c->P(bp.mlp_ln_b), ln, mean, rstd, B, d, st));
-    RC(r.linear(ln, B, d, c->W(bp.w1), 4 * d, c->P(bp.b1), 1, nullptr, hg, u));
-    RC(r.linear(hg, B, 4 * d, c->W(bp.w2), d, c->P(bp.b2), 0, x3, cur == x ? x2 : x, nullptr));
+    RC(r.linear(ln, B, d, c->template Wt<T>(bp.w1), 4 * d, c->P(bp.b1), 1, nullptr, hg, u));
+    RC(r.linear(hg, B, 4 * d, c->template Wt<T>(bp.w2), d, c->P(bp.b2), 0, x3, cur == x ? x2 : x, nullptr));
     cur = (cur == x) ? x2 : x;
   }
   RC(launch_layernorm_fwd(cur, c->P(c->dec_ln_w), c->P(c->dec_ln_b), ln, mean, rstd, B, d, st));
-  RC(r.linear(ln, B, d, c->W(c->tok_emb), c->Vp, nullptr, 0, nullptr, logits, nullptr));
-  return write_logits_f32(logits, c->Vp, B, c->V, logits_out, st);
+  RC(r.linear(ln, B, d, c->template Wt<T>(c->tok_emb), c->Vp, nullptr, 0, nullptr, logits, nullptr));
+  return launch_logits_to_f32(logits, c->Vp, B, c->V, logits_out, st);
+}
+extern "C" int oasr_decode_step(oasr_ctx* c, const int64_t* tokens_last, int B, int pos, void* kv_cache, float* logits_out,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  OASR_REQUIRE(c, "oasr_decode_step: null context");
+  return c->f32 ? oasr_decode_step_impl<float>(c, tokens_last, B, pos, kv_cache, logits_out, workspace, workspace_bytes, stream) : oasr_decode_step_impl<bf16_t>(c, tokens_last, B, pos, kv_cache, logits_out, workspace, workspace_bytes, stream);
 }
 
 extern "C" int oasr_zero_grad(oasr_ctx* c, void* stream) {
@@ -945,7 +990,8 @@ extern "C" int oasr_train_fwd_bwd(oasr_ctx* c, const float* mel, const int64_t* 
 // rounded up, the loss, every gradient and therefore the optimizer step are those of the full padded context: positions
 // past the last real token only ever see ignore_index targets, and no real query attends to them (causal mask), so
 // the reference spends their share of the decoder on exact zeros (train_timestamps.py:318-329 pads every sample to 448).
-extern "C" int oasr_train_fwd_bwd_s(oasr_ctx* c, const float* mel, const int64_t* tokens, const int64_t* targets,
+template <typename T>
+static int oasr_train_fwd_bwd_s_impl(oasr_ctx* c, const float* mel, const int64_t* tokens, const int64_t* targets,
                                     const int32_t* text_len, int B, int S, float loss_scale, float inv_accum, float* loss_out,
                                     int accumulate_loss, float* logits_out, void** ev, void* workspace, size_t workspace_bytes,
                                     void* stream) {
@@ -956,15 +1002,15 @@ extern "C" int oasr_train_fwd_bwd_s(oasr_ctx* c, const float* mel, const int64_t
   const int d = c->d;
   const long Md = (long)B * S, Me = (long)B * c->Te, M1 = (long)B * c->T1;
   Arena A(workspace, workspace_bytes);
-  Plan p;
-  make_plan(c, A, p, B, S, true);
-  Runner r{c, (hipStream_t)stream, B, S, text_len};
+  typename Engine<T>::Plan p;
+  Engine<T>::make_plan(c, A, p, B, S, true);
+  typename Engine<T>::Runner r{c, (hipStream_t)stream, B, S, text_len};
   hipStream_t st = r.st;
 
   // ---------------- forward ----------------
   RC(r.encoder_fwd(p, mel));
   RC(r.decoder_fwd(p, tokens));
-  if (logits_out) RC(write_logits_f32(p.logits, c->Vp, Md, c->V, logits_out, st));
+  if (logits_out) RC(launch_logits_to_f32(p.logits, c->Vp, Md, c->V, logits_out, st));
   RC(launch_count_valid(targets, Md, PAD_ID, p.n_valid, st));
   RC(launch_cross_entropy(p.logits, c->Vp, c->V, targets, Md, PAD_ID, loss_scale * inv_accum, p.n_valid, p.row_loss, 1, st));
   RC(launch_loss_reduce(p.row_loss, Md, p.n_valid, inv_accum, loss_out, accumulate_loss, st));
@@ -978,55 +1024,51 @@ extern "C" int oasr_train_fwd_bwd_s(oasr_ctx* c, const float* mel, const int64_t
     RC(r.wgrad(p.logits, c->Vp, Md, v8, plain_view(p.lnf, d), d, c->G(c->tok_emb), d));
     if (v8 < c->V) RC(r.wgrad(p.logits + v8, c->Vp, Md, c->V - v8, plain_view(p.lnf, d), d, c->G(c->tok_emb) + (long)v8 * d, d));
   }
-  RC(r.dgrad(p.logits, Md, c->Vp, c->W(c->tok_emb), d, nullptr, nullptr, p.gln));
-  const bf16_t* x_last = c->L_dec ? p.dec[c->L_dec - 1].x_out : p.dx0;
+  RC(r.dgrad(p.logits, Md, c->Vp, c->template Wt<T>(c->tok_emb), d, nullptr, nullptr, p.gln));
+  const T* x_last = c->L_dec ? p.dec[c->L_dec - 1].x_out : p.dx0;
   RC(launch_layernorm_bwd(p.gln, x_last, c->P(c->dec_ln_w), p.mean_f, p.rstd_f, nullptr, p.ga, c->G(c->dec_ln_w), c->G(c->dec_ln_b),
                           c->L_dec ? c->G(c->dec[c->L_dec - 1].b2) : nullptr, Md, d, st));
   RC(r.record(ev, seg++));
-  const bf16_t* dx = p.ga;
-  auto others = [&](const bf16_t* cur, bf16_t** a, bf16_t** b) {  // the two stream-gradient buffers that are not `cur`
-    bf16_t* all[3] = {p.ga, p.gb, p.gc};
+  const T* dx = p.ga;
+  auto others = [&](const T* cur, T** a, T** b) {  // the two stream-gradient buffers that are not `cur`
+    T* all[3] = {p.ga, p.gb, p.gc};
     int n = 0;
-    bf16_t* o[2] = {nullptr, nullptr};
+    T* o[2] = {nullptr, nullptr};
     for (int j = 0; j < 3; ++j)
       if (all[j] != cur && n < 2) o[n++] = all[j];
     *a = o[0];
     *b = o[1];
   };
   for (int i = c->L_dec - 1; i >= 0; --i) {
-    bf16_t *sa, *sb;
+    T *sa, *sb;
     others(dx, &sa, &sb);
-    const bf16_t* dx_in = nullptr;
+    const T* dx_in = nullptr;
     RC(r.block_bwd(c->dec[i], p.dec[i], p, dx, sa, sb, Md, S, true, i == c->L_dec - 1, i > 0 ? c->G(c->dec[i - 1].b2) : nullptr, &dx_in));
     dx = dx_in;
     RC(r.record(ev, seg++));
   }
-  RC(launch_embedding_bwd(tokens, dx, c->G(c->tok_emb), c->G(c->dec_pos), B, S, d, PAD_ID, st));
+  RC(launch_embedding_bwd(tokens, dx, c->G(c->tok_emb), c->G(c->dec_pos), B, S, d, PAD_ID, c->V, st));
   RC(r.record(ev, seg++));  // decoder.positional_embedding
   RC(r.record(ev, seg++));  // token embedding (arena tail)
 
   // ---------------- backward: encoder ----------------
-  const bf16_t* xe_last = c->L_enc ? p.enc[c->L_enc - 1].x_out : p.x0;
-  if (c->L_dec == 0) OASR_CHECK_HIP(hipMemsetAsync(p.gxa, 0, (size_t)Me * d * 2, st));
+  const T* xe_last = c->L_enc ? p.enc[c->L_enc - 1].x_out : p.x0;
+  if (c->L_dec == 0) OASR_CHECK_HIP(hipMemsetAsync(p.gxa, 0, (size_t)Me * d * sizeof(T), st));
   RC(launch_layernorm_bwd(p.gxa, xe_last, c->P(c->enc_lnp_w), p.mean_p, p.rstd_p, nullptr, p.ga, c->G(c->enc_lnp_w), c->G(c->enc_lnp_b),
                           c->L_enc ? c->G(c->enc[c->L_enc - 1].b2) : nullptr, Me, d, st));
   RC(r.record(ev, seg++));
   dx = p.ga;
   for (int i = c->L_enc - 1; i >= 0; --i) {
-    bf16_t *sa, *sb;
+    T *sa, *sb;
     others(dx, &sa, &sb);
-    const bf16_t* dx_in = nullptr;
+    const T* dx_in = nullptr;
     RC(r.block_bwd(c->enc[i], p.enc[i], p, dx, sa, sb, Me, c->Te, false, false, i > 0 ? c->G(c->enc[i - 1].b2) : nullptr, &dx_in));
     dx = dx_in;
     RC(r.record(ev, seg++));
   }
   // conv stem: x0 = gelu(u2) + pos ; u2 = conv2(h1) ; h1 = gelu(u1) ; u1 = conv1(mel)
   {
-    long n8 = Me * d / 8;
-    long nb = (n8 + 255) / 256;
-    if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(dgelu_mul_kernel, dim3((unsigned)nb), dim3(256), 0, st, dx, p.u2, p.gln, n8);  // gln = d(u2)
-    OASR_LAUNCH_CHECK();
+    RC(launch_dgelu_mul(dx, p.u2, p.gln, Me * d, st));  // gln = d(u2)
     OASR_CHECK_HIP(hipMemsetAsync(p.tmp_w2p, 0, (size_t)d * 3 * d * 4, st));
     // conv2 weight gradient on the direct-to-LDS kernel: the im2col matrix [B*1500][3d] is h1 itself read as overlapping
     // rows of 3d elements at stride 2d from h1 - d (per-sample stride 3000*d == 1500 rows * 2d, so the view is plain).
@@ -1034,7 +1076,7 @@ extern "C" int oasr_train_fwd_bwd_s(oasr_ctx* c, const float* mel, const int64_t
     // instead of the left zero padding); that rank-B term is subtracted by a second, tiny GEMM over the B first rows.
     RC(r.wgrad(p.gln, d, Me, d, plain_view(p.h1 - d, 2L * d), 3 * d, p.tmp_w2p, 3 * d));  // (guard row zeroed by the forward)
     {
-      GemmArgs g = gemm_defaults();
+      GemmArgsT<T> g = gemm_defaults_t<T>();
       g.A = plain_view(p.gln, (long)c->Te * d);          // dY rows (b, t = 0)
       g.ta = 1;
       g.B = plain_view(p.h1 - d, (long)c->T1 * d);       // what those windows wrongly saw as their first tap
@@ -1050,7 +1092,7 @@ extern "C" int oasr_train_fwd_bwd_s(oasr_ctx* c, const float* mel, const int64_t
     }
     RC(launch_unpack_conv_grad(p.tmp_w2p, c->G(c->conv2_w), d, d, 3 * d, st));
     RC(launch_colsum_accum(p.gln, d, Me, d, c->G(c->conv2_b), st));
-    RC(r.dgrad(p.gln, Me, d, (const bf16_t*)(c->shadow + c->sh_w2p), 3 * d, nullptr, nullptr, p.gA2));
+    RC(r.dgrad(p.gln, Me, d, c->template w2p<T>(), 3 * d, nullptr, nullptr, p.gA2));
     RC(launch_conv2_col2im_dgelu(p.gA2, p.u1, p.gu, B, c->T1, d, st));  // gu = d(u1) [B*3000, d]
     OASR_CHECK_HIP(hipMemsetAsync(p.tmp_w1p, 0, (size_t)d * 256 * 4, st));
     // conv1 weight gradient, same trick: windows of 3*n_mels (+ junk up to 256, whose gradient columns are never
@@ -1060,7 +1102,7 @@ extern "C" int oasr_train_fwd_bwd_s(oasr_ctx* c, const float* mel, const int64_t
       const int nm = c->dims.n_mels;
       RC(r.wgrad(p.gu, d, M1, d, plain_view(p.mel_tm - nm, nm), 256, p.tmp_w1p, 256));  // (guard rows zeroed by the forward)
       for (int side = 0; side < 2; ++side) {
-        GemmArgs g = gemm_defaults();
+        GemmArgsT<T> g = gemm_defaults_t<T>();
         g.A = plain_view(p.gu + (side ? (long)(c->T1 - 1) * d : 0), (long)c->T1 * d);  // dU rows (b, 0) / (b, T1-1)
         g.ta = 1;
         g.B = plain_view(side ? p.mel_tm + (long)c->T1 * nm : p.mel_tm - nm, (long)c->T1 * nm);
@@ -1085,6 +1127,13 @@ extern "C" int oasr_train_fwd_bwd_s(oasr_ctx* c, const float* mel, const int64_t
   }
   return OASR_OK;
 }
+extern "C" int oasr_train_fwd_bwd_s(oasr_ctx* c, const float* mel, const int64_t* tokens, const int64_t* targets,
+                                    const int32_t* text_len, int B, int S, float loss_scale, float inv_accum, float* loss_out,
+                                    int accumulate_loss, float* logits_out, void** ev, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+  OASR_REQUIRE(c, "oasr_train_fwd_bwd_s: null context");
+  return c->f32 ? oasr_train_fwd_bwd_s_impl<float>(c, mel, tokens, targets, text_len, B, S, loss_scale, inv_accum, loss_out, accumulate_loss, logits_out, ev, workspace, workspace_bytes, stream) : oasr_train_fwd_bwd_s_impl<bf16_t>(c, mel, tokens, targets, text_len, B, S, loss_scale, inv_accum, loss_out, accumulate_loss, logits_out, ev, workspace, workspace_bytes, stream);
+}
 
 extern "C" int oasr_optim_step(oasr_ctx* c, float inv_loss_scale, float max_grad_norm, float lr, float beta1, float beta2, float eps,
                                float weight_decay, int64_t step, float* stats_out, void* scratch, void* stream) {
@@ -1094,7 +1143,7 @@ extern "C" int oasr_optim_step(oasr_ctx* c, float inv_loss_scale, float max_grad
   RC(launch_grad_stats(c->grads, c->numel, (double*)scratch, stats_out, st));
   const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
   const float bc2 = (float)(1.0 - pow((double)beta2, (double)step));
-  RC(launch_adamw(c->params, c->grads, c->m, c->v, (bf16_t*)(c->shadow + c->sh_flat), c->numel, stats_out, inv_loss_scale, max_grad_norm,
+  RC(launch_adamw(c->params, c->grads, c->m, c->v, c->f32 ? nullptr : (bf16_t*)(c->shadow + c->sh_flat), c->numel, stats_out, inv_loss_scale, max_grad_norm,
                   lr, beta1, beta2, eps, weight_decay, bc1, bc2, st));
   return refresh_packed(c, st);
 }

@@ -8,8 +8,12 @@
 //             zero when k >= kvalid, or (t == 0 && k < lead), or (t == rpb-1 && k >= trail_from).
 //             conv1 (k3,s1,p1) over time-major mel [B][3000][80]  : ld=80,  rpb=3000, lead=80, kvalid=240, trail_from=160
 //             conv2 (k3,s2,p1) over time-major h1 [B][3000][d]    : ld=2d,  rpb=1500, lead=d,  kvalid=3d,  trail_from=3d
-struct OperandView {
-  const bf16_t* ptr;
+// T = bf16_t: the production kernels.  T = float: the fp32 VALIDATION kernels (fp32ref.hip) that run the same engine
+// schedule with fp32 activations, fp32 operands and fp32 accumulation -- the reference's precision="float32" path
+// (scripts/training/train_timestamps.py:2128,2220-2224), used to hold the engine to 1e-3 against the fp32 CPU oracle.
+template <typename T>
+struct OperandViewT {
+  const T* ptr;
   long ld;
   int rpb;
   long bstride;
@@ -17,7 +21,12 @@ struct OperandView {
   int kvalid;
   int trail_from;
 };
-static inline OperandView plain_view(const bf16_t* p, long ld) { return OperandView{p, ld, 0, 0, 0, 0, 0}; }
+typedef OperandViewT<bf16_t> OperandView;
+typedef OperandViewT<float> OperandViewF;
+template <typename T>
+static inline OperandViewT<T> plain_view(const T* p, long ld) {
+  return OperandViewT<T>{p, ld, 0, 0, 0, 0, 0};
+}
 
 // C[M,N] = epilogue( alpha * sum_k A(m,k) * B(n,k) )
 //   ta == 0 : A stored [M][K] (k contiguous);  ta == 1 : A stored [K][M] (m contiguous)
@@ -26,8 +35,9 @@ static inline OperandView plain_view(const bf16_t* p, long ld) { return OperandV
 //   v = alpha*acc (+ bias[n]) ; out_pre <- bf16(v) ; if act: v = gelu(bf16(v)) ;
 //   if pos: v = bf16(v) + pos[(m % pos_period)*N + n] ; if dgelu_u: v = bf16(v) * gelu'(u[m,n]) ;
 //   if resid: v = bf16(v) + resid[m,n] ; out <- bf16(v) ; out_f32 <- (atomic ? += v : beta*out_f32 + v)
-struct GemmArgs {
-  OperandView A, B;
+template <typename T>
+struct GemmArgsT {
+  OperandViewT<T> A, B;
   int M, N, K;
   int ta, tb;
   float alpha;
@@ -35,12 +45,12 @@ struct GemmArgs {
   int act;  // 0 none, 1 exact-erf GELU
   const float* pos;
   int pos_period;
-  const bf16_t* dgelu_u;
+  const T* dgelu_u;
   long ldu;
-  const bf16_t* resid;
+  const T* resid;
   long ldr;
-  bf16_t* out;
-  bf16_t* out_pre;
+  T* out;
+  T* out_pre;
   long ldc;
   float* out_f32;
   long ldc32;
@@ -50,18 +60,23 @@ struct GemmArgs {
   int split_k;  // >= 1; > 1 requires atomic out_f32 and no other output
   int raster_gm;  // fast path: tile rows per L2 group (0 = choose from residency)
 };
+typedef GemmArgsT<bf16_t> GemmArgs;
+typedef GemmArgsT<float> GemmArgsF;
 int launch_gemm(const GemmArgs& a, hipStream_t stream);
+int launch_gemm(const GemmArgsF& a, hipStream_t stream);  // fp32 validation kernel: any shape / view, split_k ignored
 // bench-only: time every GEMM launch with HIP events on its stream; collect() sums per variant (2*ta+tb)
 void gemm_profile_enable(int on);
 void gemm_force_general(int on);  // tests: disable the direct-to-LDS fast path
 int gemm_profile_collect(double ms[4], double flops[4], long count[4], char* by_symbol, int cap);
-static inline GemmArgs gemm_defaults() {
-  GemmArgs g;
+template <typename T>
+static inline GemmArgsT<T> gemm_defaults_t() {
+  GemmArgsT<T> g;
   memset(&g, 0, sizeof(g));
   g.alpha = 1.0f;
   g.split_k = 1;
   return g;
 }
+static inline GemmArgs gemm_defaults() { return gemm_defaults_t<bf16_t>(); }
 
 // LayerNorm over the last dim (eps 1e-5, fp32 internals, bf16 in/out; reference model.py:39)
 int launch_layernorm_fwd(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y, float* mean, float* rstd,
@@ -70,26 +85,35 @@ int launch_layernorm_fwd(const bf16_t* x, const float* gamma, const float* beta,
 // sums of the produced dx (= the bias gradient of the Linear whose output this residual-stream gradient belongs to)
 int launch_layernorm_bwd(const bf16_t* dy, const bf16_t* x, const float* gamma, const float* mean, const float* rstd,
                          const bf16_t* dres, bf16_t* dx, float* dgamma, float* dbeta, float* dsum, long rows, int d, hipStream_t s);
+int launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, long rows, int d,
+                         hipStream_t s);
+int launch_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, const float* dres,
+                         float* dx, float* dgamma, float* dbeta, float* dsum, long rows, int d, hipStream_t s);
 
 // Flash attention over head_dim 64.  Q/K/V are strided views [B, T, H, 64] (row strides in elements);
 // key j visible to query i iff j < kv_len[b] (nullptr -> Tk) and (!causal || j <= i).  scale = 1/8.
-struct AttnArgs {
-  const bf16_t *q, *k, *v;
+template <typename T>
+struct AttnArgsT {
+  const T *q, *k, *v;
   long ldq, ldk, ldv;        // token strides
   long bsq, bsk, bsv;        // batch strides
-  bf16_t* o;                 // [B, Tq, H*64]
+  T* o;                      // [B, Tq, H*64]
   long ldo, bso;
   float* lse;                // [B, H, Tq] natural-log-sum-exp of scaled scores
-  bf16_t* o_lo;              // optional bf16 rounding residual of o (same strides): fwd writes it, bwd uses o + o_lo for delta = rowsum(dO*O)
+  T* o_lo;                   // optional bf16 rounding residual of o (same strides): fwd writes it, bwd uses o + o_lo for delta = rowsum(dO*O)
   const int32_t* kv_len;     // [B] or null
   int B, H, Tq, Tk, causal;
   // backward only
-  const bf16_t* d_o;         // [B, Tq, H*64], same strides as o
+  const T* d_o;              // [B, Tq, H*64], same strides as o
   float* delta;              // [B, H, Tq] workspace: rowsum(dO * O)
-  bf16_t *dq, *dk, *dv;      // same strides as q/k/v
+  T *dq, *dk, *dv;           // same strides as q/k/v
 };
+typedef AttnArgsT<bf16_t> AttnArgs;
+typedef AttnArgsT<float> AttnArgsF;
 int launch_attention_fwd(const AttnArgs& a, hipStream_t s);
 int launch_attention_bwd(const AttnArgs& a, hipStream_t s);
+int launch_attention_fwd(const AttnArgsF& a, hipStream_t s);  // fp32 validation kernels (o_lo unused: O is fp32)
+int launch_attention_bwd(const AttnArgsF& a, hipStream_t s);
 
 // ---- elementwise / reductions -------------------------------------------------------------------------
 int launch_cast_f32_bf16(const float* src, bf16_t* dst, long n, hipStream_t s);
@@ -105,7 +129,7 @@ int launch_mel_to_time_major(const float* mel, bf16_t* out, int B, int n_mels, i
 int launch_embedding_fwd(const int64_t* tok, const float* E, const float* pos, bf16_t* x, int B, int S, int d, long n_embed,
                          hipStream_t s);
 // dE[tok] += dx (skipping pad_id), dpos[s] += sum_b dx
-int launch_embedding_bwd(const int64_t* tok, const bf16_t* dx, float* dE, float* dpos, int B, int S, int d, long pad_id,
+int launch_embedding_bwd(const int64_t* tok, const bf16_t* dx, float* dE, float* dpos, int B, int S, int d, long pad_id, long n_embed,
                          hipStream_t s);
 // out[n] += sum_m x[m, n]   (x bf16 [M, ld], columns [0, ncols))
 int launch_colsum_accum(const bf16_t* x, long ld, long M, int ncols, float* out, hipStream_t s);
@@ -114,6 +138,18 @@ int launch_conv2_col2im_dgelu(const bf16_t* dA /*[B*T2][3d]*/, const bf16_t* u1 
                               int d, hipStream_t s);
 // dst(f32) += src(f32) over n  (grad of the fp32 sinusoid buffer is not needed; used for misc accumulations)
 int launch_axpy_f32(const float* src, float* dst, long n, float a, hipStream_t s);
+// fp32 validation overloads (fp32ref.hip): same contracts with fp32 activations
+int launch_pack_conv_weight(const float* w, float* dst, int co, int ci, int ldk, hipStream_t s);
+int launch_mel_to_time_major(const float* mel, float* out, int B, int n_mels, int T, hipStream_t s);
+int launch_embedding_fwd(const int64_t* tok, const float* E, const float* pos, float* x, int B, int S, int d, long n_embed, hipStream_t s);
+int launch_embedding_bwd(const int64_t* tok, const float* dx, float* dE, float* dpos, int B, int S, int d, long pad_id, long n_embed,
+                         hipStream_t s);
+int launch_colsum_accum(const float* x, long ld, long M, int ncols, float* out, hipStream_t s);
+int launch_conv2_col2im_dgelu(const float* dA, const float* u1, float* dpre1, int B, int T1, int d, hipStream_t s);
+int launch_dgelu_mul(const bf16_t* dy, const bf16_t* u, bf16_t* out, long n, hipStream_t s);
+int launch_dgelu_mul(const float* dy, const float* u, float* out, long n, hipStream_t s);
+int launch_logits_to_f32(const bf16_t* logits, long ld, long rows, int V, float* out, hipStream_t s);
+int launch_logits_to_f32(const float* logits, long ld, long rows, int V, float* out, hipStream_t s);
 
 // ---- loss -------------------------------------------------------------------------------------------------
 // logits bf16 [rows][ld] (first V entries valid).  Writes, in place, dlogits = (softmax - onehot) * gscale / n_valid
@@ -122,6 +158,8 @@ int launch_axpy_f32(const float* src, float* dst, long n, float a, hipStream_t s
 int launch_count_valid(const int64_t* targets, long rows, long ignore, int32_t* n_valid_dev, hipStream_t s);
 int launch_cross_entropy(bf16_t* logits, long ld, int V, const int64_t* targets, long rows, long ignore, float gscale,
                          const int32_t* n_valid_dev, float* row_loss, int write_grad, hipStream_t s);
+int launch_cross_entropy(float* logits, long ld, int V, const int64_t* targets, long rows, long ignore, float gscale,
+                         const int32_t* n_valid_dev, float* row_loss, int write_grad, hipStream_t s);  // fp32 validation
 int launch_loss_reduce(const float* row_loss, long rows, const int32_t* n_valid_dev, float mul, float* loss_out, int accumulate,
                        hipStream_t s);
 

@@ -28,7 +28,9 @@ __global__ __launch_bounds__(256) void ce_kernel(bf16_t* __restrict__ logits, lo
   bf16_t* lr = logits + row * ld;
   const long tgt = targets[row];
   const int nchunk = (int)(ld >> 3);
-  if (tgt == ignore) {  // ignored row: zero gradient, zero loss (uniform branch)
+  // ignored row: zero gradient, zero loss (uniform branch).  A target outside [0, V) (F.cross_entropy would raise) is
+  // treated the same way instead of reading / writing outside the row; hosts that want the raise validate ids up front.
+  if (tgt == ignore || tgt < 0 || tgt >= V) {
     if (write_grad) {
       const u32x4_t z = {0u, 0u, 0u, 0u};
       for (int ch = threadIdx.x; ch < nchunk; ch += 256) *(u32x4_t*)(lr + ch * 8) = z;
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(256) void ce_kernel(bf16_t* __restrict__ logits, lo
 __global__ __launch_bounds__(256) void count_valid_kernel(const int64_t* __restrict__ t, long rows, long ignore, int32_t* out) {
   __shared__ int red[4];
   int c = 0;
-  for (long i = threadIdx.x; i < rows; i += 256) c += (t[i] != ignore) ? 1 : 0;
+  for (long i = threadIdx.x; i < rows; i += 256) c += (t[i] != ignore) ? 1 : 0;  // (== F.cross_entropy's denominator)
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;

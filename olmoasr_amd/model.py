@@ -145,12 +145,23 @@ _FAN_IN_OF_BIAS = {}
 class OLMoASR(nn.Module):
     """MI355X-native ``olmoasr.model.OLMoASR`` (reference model.py:778-968)."""
 
-    def __init__(self, dims: ModelDimensions, device=None, seed: Optional[int] = None, inference: bool = False):
+    def __init__(self, dims: ModelDimensions, device=None, seed: Optional[int] = None, inference: bool = False,
+                 compute_dtype="bfloat16"):
         """``inference=True`` gives the layout of the reference's ``olmoasr.inf_model.OLMoASR`` (token embedding with
-        n_vocab rows, no pad row: inf_model.py:302), i.e. what ``load_model(..., inference=True)`` builds."""
+        n_vocab rows, no pad row: inf_model.py:302), i.e. what ``load_model(..., inference=True)`` builds.
+
+        ``compute_dtype`` is the reference's ``--precision`` (train_timestamps.py:2128): "bfloat16" = the production
+        kernels (autocast(bfloat16) numerics), "float32" = the fp32 validation kernels on the same engine schedule (every
+        activation, operand and accumulation in fp32) -- the mode in which logits match the fp32 reference to 1e-3."""
         super().__init__()
         lib = N.lib()
         self.inference = inference
+        cdt = {"bfloat16": 0, "bf16": 0, torch.bfloat16: 0, "float32": 1, "fp32": 1, torch.float32: 1}.get(compute_dtype)
+        if cdt is None:
+            raise N.NativeError(f"compute_dtype {compute_dtype!r}: the native engine computes in 'bfloat16' or 'float32' "
+                                "(the reference's float16 autocast has no MI355X-native counterpart here; see DESIGN.md section 4)")
+        self.compute_dtype = "float32" if cdt else "bfloat16"
+        self._act_dtype = torch.float32 if cdt else torch.bfloat16
         if device is None:
             device = "cuda"
         device = torch.device(device)
@@ -162,7 +173,7 @@ class OLMoASR(nn.Module):
                                    pad_row=not inference)
         cd = N.Dims(*[getattr(dims, f[0]) for f in N.Dims._fields_])
         self._n_rows = dims.n_vocab + (0 if inference else 1)
-        self._ctx = lib.oasr_create_ex(C.byref(cd), self._n_rows)
+        self._ctx = lib.oasr_create_ex2(C.byref(cd), self._n_rows, cdt)
         if not self._ctx:
             raise N.NativeError("oasr_create: " + lib.oasr_last_error().decode())
         self._numel = lib.oasr_param_numel(self._ctx)
@@ -309,7 +320,7 @@ class OLMoASR(nn.Module):
         tokens = tokens.to(torch.int64).contiguous()
         ws = self._ws(B, S, 0)
         logits = torch.empty(B, S, self._n_rows, device=mel.device, dtype=torch.float32) if want_logits else None
-        xa = torch.empty(B, self.dims.n_audio_ctx, self.dims.n_audio_state, device=mel.device, dtype=torch.bfloat16) if want_xa else None
+        xa = torch.empty(B, self.dims.n_audio_ctx, self.dims.n_audio_state, device=mel.device, dtype=self._act_dtype) if want_xa else None
         with torch.cuda.device(mel.device):
             N.check(N.lib().oasr_forward(self._ctx, N.ptr(mel), N.ptr(tokens), N.ptr(text_len), B, S, N.ptr(logits), N.ptr(xa),
                                          N.ptr(ws), ws.numel(), N.stream_ptr()), "oasr_forward")
@@ -327,13 +338,13 @@ class OLMoASR(nn.Module):
 
     @torch.no_grad()
     def embed_audio(self, mel: Tensor) -> Tensor:
-        """AudioEncoder forward (reference model.py:815): bf16 [B, n_audio_ctx, n_audio_state]."""
+        """AudioEncoder forward (reference model.py:815): [B, n_audio_ctx, n_audio_state] in the compute dtype."""
         N.require_gpu(mel, "mel")
         B = mel.shape[0]
         assert mel.shape[1:] == (self.dims.n_mels, 2 * self.dims.n_audio_ctx), "incorrect audio shape"
         mel = mel.float().contiguous()
         ws = self._ws(B, 1, 0)
-        xa = torch.empty(B, self.dims.n_audio_ctx, self.dims.n_audio_state, device=mel.device, dtype=torch.bfloat16)
+        xa = torch.empty(B, self.dims.n_audio_ctx, self.dims.n_audio_state, device=mel.device, dtype=self._act_dtype)
         with torch.cuda.device(mel.device):
             N.check(N.lib().oasr_encode(self._ctx, N.ptr(mel), B, N.ptr(xa), N.ptr(ws), ws.numel(), N.stream_ptr()), "oasr_encode")
         return xa
@@ -345,7 +356,7 @@ class OLMoASR(nn.Module):
         N.require_gpu(tokens, "tokens")
         N.require_gpu(audio_features, "audio_features")
         B, S = tokens.shape
-        xa = audio_features.to(torch.bfloat16).contiguous()
+        xa = audio_features.to(self._act_dtype).contiguous()
         assert xa.shape == (B, self.dims.n_audio_ctx, self.dims.n_audio_state)
         tokens = tokens.to(torch.int64).contiguous()
         text_len = None
@@ -365,7 +376,7 @@ class OLMoASR(nn.Module):
     def kv_cache_begin(self, audio_features: Tensor):
         """Allocates the KV cache for this batch of windows and fills the cross-attention K/V of every decoder layer."""
         N.require_gpu(audio_features, "audio_features")
-        xa = audio_features.to(torch.bfloat16).contiguous()
+        xa = audio_features.to(self._act_dtype).contiguous()
         B = xa.shape[0]
         lib = N.lib()
         cache = torch.empty(lib.oasr_kv_cache_bytes(self._ctx, B), dtype=torch.uint8, device=xa.device)
