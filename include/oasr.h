@@ -135,6 +135,7 @@ typedef struct oasr_gemm_args {
   const float* bias; int act; const float* pos; int pos_period;
   const void* dgelu_u; int64_t ldu; const void* resid; int64_t ldr;
   void* out; void* out_pre; int64_t ldc; float* out_f32; int64_t ldc32; float beta; float* colsum; int atomic; int split_k;
+  int dgelu_deriv; /* dgelu_u holds GELU'(u) itself (written by an act == 2 forward: out_pre = GELU'(pre)) */
 } oasr_gemm_args;
 int oasr_gemm(const oasr_gemm_args*, void* stream);
 int oasr_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int64_t rows, int d, void* stream);

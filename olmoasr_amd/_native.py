@@ -31,7 +31,7 @@ class GemmArgs(C.Structure):
                 ("pos_period", C.c_int), ("dgelu_u", C.c_void_p), ("ldu", C.c_int64), ("resid", C.c_void_p),
                 ("ldr", C.c_int64), ("out", C.c_void_p), ("out_pre", C.c_void_p), ("ldc", C.c_int64),
                 ("out_f32", C.c_void_p), ("ldc32", C.c_int64), ("beta", C.c_float), ("colsum", C.c_void_p), ("atomic", C.c_int),
-                ("split_k", C.c_int)]
+                ("split_k", C.c_int), ("dgelu_deriv", C.c_int)]
 
 
 class AttnArgs(C.Structure):

@@ -50,6 +50,8 @@ extern "C" int oasr_gemm(const oasr_gemm_args* a, void* stream) {
   g.colsum = a->colsum;
   g.atomic = a->atomic;
   g.split_k = a->split_k < 1 ? 1 : a->split_k;
+  g.dgelu_deriv = a->dgelu_deriv;
+  OASR_REQUIRE(a->act >= 0 && a->act <= 2, "oasr_gemm: act must be 0 (none), 1 (GELU) or 2 (GELU, out_pre = GELU')");
   return launch_gemm(g, (hipStream_t)stream);
 }
 

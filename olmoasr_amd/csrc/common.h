@@ -99,6 +99,12 @@ __device__ __forceinline__ float gelu_f(float x) {
   const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f);
   return fmaf(-fabsf(x), half_poly * e, fmaxf(x, 0.f));
 }
+// both at once (the act == 2 epilogue): gelu = x * Phi(x), gelu' = Phi(x) + x * pdf(x)
+__device__ __forceinline__ void gelu_and_deriv(float x, float& g, float& d) {
+  const GeluParts p = gelu_parts(x);
+  g = x * p.cdf;
+  d = fmaf(x * p.e, 0.3989422804014327f, p.cdf);
+}
 __device__ __forceinline__ float dgelu_f(float x) {
   const GeluParts g = gelu_parts(x);
   return g.cdf + x * g.e * 0.3989422804014327f;

@@ -273,6 +273,7 @@ struct Runner {
   hipStream_t st;
   int B, S;
   const int32_t* text_len;
+  bool train = false;  // the training forward saves GELU'(u) in place of u (GemmArgs.act == 2)
 
   int linear(const T* x, long M, int K, const T* W, int N, const float* bias, int act, const T* resid, T* out,
              T* out_pre) {
@@ -293,7 +294,7 @@ struct Runner {
   }
   // dx[M,K] = dy[M,N] . W[N,K]  (* gelu'(u))  (+ resid)
   int dgrad(const T* dy, long M, int N, const T* W, int K, const T* dgelu_u, const T* resid, T* dx,
-            float* colsum = nullptr) {
+            float* colsum = nullptr, bool u_is_deriv = false) {
     Gemm g = gemm_defaults_t<T>();
     g.A = plain_view(dy, N);
     g.B = plain_view(W, K);
@@ -302,6 +303,7 @@ struct Runner {
     g.N = K;
     g.K = N;
     g.dgelu_u = dgelu_u;
+    g.dgelu_deriv = u_is_deriv ? 1 : 0;
     g.ldu = K;
     g.resid = resid;
     g.ldr = K;
@@ -396,7 +398,7 @@ struct Runner {
       xm = s.x_mid2;
     }
     RC(launch_layernorm_fwd(xm, c->P(bp.mlp_ln_w), c->P(bp.mlp_ln_b), s.ln2, s.mean2, s.rstd2, M, d, st));
-    RC(linear(s.ln2, M, d, c->template Wt<T>(bp.w1), 4 * d, c->P(bp.b1), 1, nullptr, s.hg, s.u));
+    RC(linear(s.ln2, M, d, c->template Wt<T>(bp.w1), 4 * d, c->P(bp.b1), train ? 2 : 1, nullptr, s.hg, train ? s.u : nullptr));
     RC(linear(s.hg, M, 4 * d, c->template Wt<T>(bp.w2), d, c->P(bp.b2), 0, xm, s.x_out, nullptr));
     return OASR_OK;
   }
@@ -520,7 +522,7 @@ struct Runner {
     const T* xm = bp.cross ? s.x_mid2 : s.x_mid;
     // ---- MLP -----------------------------------------------------------------------------------------------
     RC(wgrad(dx_out, d, M, d, plain_view(s.hg, 4 * d), 4 * d, c->G(bp.w2), 4 * d));
-    RC(dgrad(dx_out, M, d, c->template Wt<T>(bp.w2), 4 * d, s.u, nullptr, p.gu, c->G(bp.b1)));  // + fused mlp.0.bias gradient
+    RC(dgrad(dx_out, M, d, c->template Wt<T>(bp.w2), 4 * d, s.u, nullptr, p.gu, c->G(bp.b1), true));  // s.u = GELU'(u); + fused mlp.0.bias gradient
     RC(wgrad(p.gu, 4 * d, M, 4 * d, plain_view(s.ln2, d), d, c->G(bp.w1), d));
     RC(dgrad(p.gu, M, 4 * d, c->template Wt<T>(bp.w1), d, nullptr, nullptr, p.gln));
     RC(launch_layernorm_bwd(p.gln, xm, c->P(bp.mlp_ln_w), s.mean2, s.rstd2, dx_out, scratch_a, c->G(bp.mlp_ln_w), c->G(bp.mlp_ln_b),
@@ -1005,6 +1007,7 @@ static int oasr_train_fwd_bwd_s_impl(oasr_ctx* c, const float* mel, const int64_
   typename Engine<T>::Plan p;
   Engine<T>::make_plan(c, A, p, B, S, true);
   typename Engine<T>::Runner r{c, (hipStream_t)stream, B, S, text_len};
+  r.train = true;
   hipStream_t st = r.st;
 
   // ---------------- forward ----------------

@@ -91,10 +91,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgsF p) {
       if (n >= p.N) continue;
       float v = p.alpha * acc[i][j];
       if (p.bias) v += p.bias[n];
-      if (p.out_pre) p.out_pre[m * p.ldc + n] = v;
-      if (p.act == 1) v = gelu_exact(v);
+      if (p.out_pre) p.out_pre[m * p.ldc + n] = p.act == 2 ? dgelu_exact(v) : v;
+      if (p.act) v = gelu_exact(v);
       if (p.pos) v += p.pos[(m % p.pos_period) * p.N + n];
-      if (p.dgelu_u) v *= dgelu_exact(p.dgelu_u[m * p.ldu + n]);
+      if (p.dgelu_u) v *= p.dgelu_deriv ? p.dgelu_u[m * p.ldu + n] : dgelu_exact(p.dgelu_u[m * p.ldu + n]);
       if (p.resid) v += p.resid[m * p.ldr + n];
       if (p.out) p.out[m * p.ldc + n] = v;
       if (p.out_f32) {

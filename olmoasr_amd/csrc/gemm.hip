@@ -175,6 +175,14 @@ __device__ __forceinline__ void epilogue_math(const GemmArgs& p, int m, int n, i
     v[1] = gelu_f(bf_hi(pre[0]));
     v[2] = gelu_f(bf_lo(pre[1]));
     v[3] = gelu_f(bf_hi(pre[1]));
+  } else if (p.act == 2) {
+    float d[4];
+    gelu_and_deriv(bf_lo(pre[0]), v[0], d[0]);
+    gelu_and_deriv(bf_hi(pre[0]), v[1], d[1]);
+    gelu_and_deriv(bf_lo(pre[1]), v[2], d[2]);
+    gelu_and_deriv(bf_hi(pre[1]), v[3], d[3]);
+    pre[0] = pack_bf2(d[0], d[1]);
+    pre[1] = pack_bf2(d[2], d[3]);
   }
   if (p.pos) {
     const f32x4_t p4 = *(const f32x4_t*)(p.pos + (long)pos_row * p.N + n);
@@ -183,10 +191,10 @@ __device__ __forceinline__ void epilogue_math(const GemmArgs& p, int m, int n, i
   }
   if (p.dgelu_u) {
     const u32x2_t u = *(const u32x2_t*)(p.dgelu_u + (long)m * p.ldu + n);
-    v[0] = bf_round(v[0]) * dgelu_f(bf_lo(u[0]));
-    v[1] = bf_round(v[1]) * dgelu_f(bf_hi(u[0]));
-    v[2] = bf_round(v[2]) * dgelu_f(bf_lo(u[1]));
-    v[3] = bf_round(v[3]) * dgelu_f(bf_hi(u[1]));
+    v[0] = bf_round(v[0]) * (p.dgelu_deriv ? bf_lo(u[0]) : dgelu_f(bf_lo(u[0])));
+    v[1] = bf_round(v[1]) * (p.dgelu_deriv ? bf_hi(u[0]) : dgelu_f(bf_hi(u[0])));
+    v[2] = bf_round(v[2]) * (p.dgelu_deriv ? bf_lo(u[1]) : dgelu_f(bf_lo(u[1])));
+    v[3] = bf_round(v[3]) * (p.dgelu_deriv ? bf_hi(u[1]) : dgelu_f(bf_hi(u[1])));
   }
   if (p.resid) {
     const u32x2_t r = *(const u32x2_t*)(p.resid + (long)m * p.ldr + n);
@@ -416,7 +424,8 @@ __device__ __forceinline__ void fast_epilogue_rows(const GemmArgs& p, f32x16_t (
                                                    int mrow0, int ncol0, int lane) {
   const int h = lane >> 5, row = lane & 31;
   const bool has_bias = p.bias != nullptr, has_side = p.dgelu_u != nullptr || p.resid != nullptr, has_u = p.dgelu_u != nullptr;
-  const bool has_pre = p.out_pre != nullptr, has_out = p.out != nullptr, gelu = p.act == 1, has_pos = p.pos != nullptr;
+  const bool has_pre = p.out_pre != nullptr, has_out = p.out != nullptr, gelu = p.act != 0, has_pos = p.pos != nullptr;
+  const bool save_deriv = p.act == 2, u_is_deriv = p.dgelu_deriv != 0;
   const bf16_t* side = has_u ? p.dgelu_u : p.resid;  // at most one of the two (fast_rows_ok)
   const long lds_ = has_u ? p.ldu : p.ldr;
   const int ch = lane & 7, nn = ncol0 + ch * 8;
@@ -478,7 +487,7 @@ __device__ __forceinline__ void fast_epilogue_rows(const GemmArgs& p, f32x16_t (
       const int mm = mrow0 + mt * 32 + r2;
       const bool ok = n_ok && mm < p.M;
       const u32x4_t pre = *(lds_u32x4_ptr)(size_t)(rbase + i * GS);  // rows r2 = i*8 + (lane >> 3): (r2 & 7) == lane >> 3
-      if (has_pre && ok) *(u32x4_t*)(p.out_pre + (long)mm * p.ldc + nn) = pre;
+      if (has_pre && !save_deriv && ok) *(u32x4_t*)(p.out_pre + (long)mm * p.ldc + nn) = pre;
       u32x4_t fin = pre;
       if (gelu || has_side || has_pos) {
         float x[8];
@@ -487,7 +496,17 @@ __device__ __forceinline__ void fast_epilogue_rows(const GemmArgs& p, f32x16_t (
           x[2 * e] = bf_lo(pre[e]);
           x[2 * e + 1] = bf_hi(pre[e]);
         }
-        if (gelu) {
+        if (save_deriv) {  // GELU and GELU' share the erf polynomial and the exponential
+          float dv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) gelu_and_deriv(x[e], x[e], dv[e]);
+          if (has_pre && ok) {
+            u32x4_t dpk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dpk[e] = pack_bf2(dv[2 * e], dv[2 * e + 1]);
+            *(u32x4_t*)(p.out_pre + (long)mm * p.ldc + nn) = dpk;
+          }
+        } else if (gelu) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) x[e] = gelu_f(x[e]);
         }
@@ -502,7 +521,13 @@ __device__ __forceinline__ void fast_epilogue_rows(const GemmArgs& p, f32x16_t (
         }
         if (has_side) {
           const u32x4_t sv = PF ? sd[i] : sn[i];
-          if (has_u) {
+          if (has_u && u_is_deriv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              x[2 * e] = bf_round(x[2 * e]) * bf_lo(sv[e]);
+              x[2 * e + 1] = bf_round(x[2 * e + 1]) * bf_hi(sv[e]);
+            }
+          } else if (has_u) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               x[2 * e] = bf_round(x[2 * e]) * dgelu_f(bf_lo(sv[e]));

@@ -33,7 +33,9 @@ static inline OperandViewT<T> plain_view(const T* p, long ld) {
 //   tb == 0 : B stored [N][K];                 tb == 1 : B stored [K][N]
 // Epilogue, in this order, every pointer optional (fp32 math on the accumulator):
 //   v = alpha*acc (+ bias[n]) ; out_pre <- bf16(v) ; if act: v = gelu(bf16(v)) ;
-//   if pos: v = bf16(v) + pos[(m % pos_period)*N + n] ; if dgelu_u: v = bf16(v) * gelu'(u[m,n]) ;
+//   (act == 2: as act == 1, but out_pre <- bf16(gelu'(bf16(v))) -- the training forward of mlp.0 saves the derivative the
+//    backward needs in the slot of the pre-activation, same bytes, so the dgrad epilogue is one multiply instead of ~25 VALU)
+//   if pos: v = bf16(v) + pos[(m % pos_period)*N + n] ; if dgelu_u: v = bf16(v) * (dgelu_deriv ? u[m,n] : gelu'(u[m,n])) ;
 //   if resid: v = bf16(v) + resid[m,n] ; out <- bf16(v) ; out_f32 <- (atomic ? += v : beta*out_f32 + v)
 template <typename T>
 struct GemmArgsT {
@@ -42,7 +44,7 @@ struct GemmArgsT {
   int ta, tb;
   float alpha;
   const float* bias;
-  int act;  // 0 none, 1 exact-erf GELU
+  int act;  // 0 none, 1 exact-erf GELU, 2 exact-erf GELU with out_pre = GELU'(pre-activation)
   const float* pos;
   int pos_period;
   const T* dgelu_u;
@@ -59,6 +61,7 @@ struct GemmArgsT {
   int atomic;   // out_f32 += v with hardware fp32 atomics (split-K safe)
   int split_k;  // >= 1; > 1 requires atomic out_f32 and no other output
   int raster_gm;  // fast path: tile rows per L2 group (0 = choose from residency)
+  int dgelu_deriv;  // dgelu_u already holds GELU'(u) (written by an act == 2 forward)
 };
 typedef GemmArgsT<bf16_t> GemmArgs;
 typedef GemmArgsT<float> GemmArgsF;

@@ -15,7 +15,7 @@ def _op(t, ld=None, rpb=0, bstride=0, lead=0, kvalid=0, trail_from=0):
 
 def gemm(A, B, M, N_, K, *, ta=False, tb=False, a_view=None, b_view=None, bias=None, act=0, pos=None, pos_period=0,
          dgelu_u=None, resid=None, out=None, out_pre=None, ldc=None, out_f32=None, beta=0.0, atomic=False, split_k=1,
-         alpha=1.0, colsum=None):
+         alpha=1.0, colsum=None, dgelu_deriv=False):
     """C[M,N] = epilogue(alpha * sum_k A(m,k) B(n,k)); see olmoasr_amd/csrc/kernels.h GemmArgs."""
     g = N.GemmArgs()
     g.A = a_view if a_view is not None else _op(A)
@@ -36,6 +36,7 @@ def gemm(A, B, M, N_, K, *, ta=False, tb=False, a_view=None, b_view=None, bias=N
     g.ldc32 = out_f32.stride(0) if out_f32 is not None else 0
     g.beta, g.atomic, g.split_k = beta, int(atomic), split_k
     g.colsum = colsum.data_ptr() if colsum is not None else None
+    g.dgelu_deriv = int(dgelu_deriv)
     N.check(N.lib().oasr_gemm(C.byref(g), N.stream_ptr()), "oasr_gemm")
 
 

@@ -164,6 +164,16 @@ def test_gemm_epilogues(gemm_path):
     uf = u.float().cpu().requires_grad_(True)
     F.gelu(uf).sum().backward()
     close(out, (A.float() @ B.float().t()).to(BF).float() * uf.grad.to(DEV), name="dgelu")
+    # act == 2 (training forward of mlp.0): out = gelu(pre), out_pre = gelu'(pre); the dgrad consumes it with dgelu_deriv
+    dsave = torch.empty(M, N, device=DEV, dtype=BF)
+    ops().gemm(A, B, M, N, K, bias=bias, act=2, out=out, out_pre=dsave)
+    pf = pre.float().cpu().requires_grad_(True)
+    F.gelu(pf).sum().backward()
+    close(out, F.gelu(pre.float()), name="act=2 gelu")
+    close(dsave, pf.grad.to(DEV), name="act=2 saved gelu'")
+    out2 = torch.empty(M, N, device=DEV, dtype=BF)
+    ops().gemm(A, B, M, N, K, dgelu_u=dsave, dgelu_deriv=True, out=out2)
+    close(out2, (A.float() @ B.float().t()).to(BF).float() * dsave.float(), name="dgelu from the saved derivative")
     c32 = torch.ones(M, N, device=DEV)
     ops().gemm(A, B, M, N, K, out_f32=c32, beta=1.0)
     close(c32, A.float() @ B.float().t() + 1.0, rtol=1e-4, atol=1e-3, name="f32 beta=1")

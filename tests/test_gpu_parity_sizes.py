@@ -188,16 +188,11 @@ def test_gemm_dgrad_at_bench_shapes(M, N, K, dgelu):
     dy, W = _rnd((M, K), 0.05, 5), _rnd((K, N), K ** -0.5, 6)
     Wf = W.float()
     out = torch.empty(M, N, device=DEV, dtype=BF)
-    if dgelu:
-        u = _rnd((M, N), 1.0, 7)
+    if dgelu:  # the engine's form: u holds GELU'(pre) saved by the act == 2 forward (values in [-0.13, 1.13])
+        u = (_rnd((M, N), 1.0, 7).float().sigmoid() * 1.26 - 0.13).to(BF)
         cs = torch.zeros(N, device=DEV)
-        ops.gemm(dy, W, M, N, K, tb=True, dgelu_u=u, out=out, colsum=cs)
-
-        def ref(a, b):
-            uf = u[a:b].float().requires_grad_(True)
-            torch.nn.functional.gelu(uf).sum().backward()
-            return (dy[a:b].float() @ Wf).to(BF).float() * uf.grad
-        _check_rows(out, ref, M, 1e-2, 1e-2, "dgrad*gelu'")
+        ops.gemm(dy, W, M, N, K, tb=True, dgelu_u=u, dgelu_deriv=True, out=out, colsum=cs)
+        _check_rows(out, lambda a, b: (dy[a:b].float() @ Wf).to(BF).float() * u[a:b].float(), M, 1e-2, 1e-2, "dgrad*gelu'")
         want = out.float().sum(0)
         assert float((cs - want).abs().max()) <= 1e-3 * float(want.abs().max()) + 1e-3
     else:
