@@ -144,6 +144,7 @@ int oasr_layernorm_bwd(const void* dy, const void* x, const float* gamma, const 
 typedef struct oasr_attn_args {
   const void *q, *k, *v; int64_t ldq, ldk, ldv, bsq, bsk, bsv; void* o; int64_t ldo, bso; float* lse; void* o_lo; const int32_t* kv_len;
   int B, H, Tq, Tk, causal; const void* d_o; float* delta; void *dq, *dk, *dv;
+  float *dq_colsum, *dv_colsum; /* optional [H*64], accumulated: column sums of dq / dv = query / value bias gradients */
 } oasr_attn_args;
 int oasr_attention_fwd(const oasr_attn_args*, void* stream);
 int oasr_attention_bwd(const oasr_attn_args*, void* stream);
@@ -155,6 +156,7 @@ int oasr_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
  * summed milliseconds, summed algorithmic flops (2*M*N*K, conv windows at their real width) and launch count; by_symbol
  * receives the same sums keyed by the kernel symbol rocprofv3 prints, so the two can be compared line by line. */
 int oasr_profile_gemm(int enable);
+int oasr_gemm_set_stagger(int sleeps, int phases); /* experiments: first-wave phase stagger of the 256x256 kernel (0 = off) */
 int oasr_gemm_force_general(int on); /* tests: route every GEMM through the register-staged general kernel */
 int oasr_profile_gemm_collect(double* ms4, double* flops4, int64_t* count4, char* by_symbol /* "symbol\tlaunches\tms\tflops\n"... or NULL */, int cap);
 int oasr_probe_lds_oob(const void* src_u16 /*[512]*/, void* dst_u16 /*[512]*/, void* stream);

@@ -39,7 +39,8 @@ class AttnArgs(C.Structure):
                 ("ldv", C.c_int64), ("bsq", C.c_int64), ("bsk", C.c_int64), ("bsv", C.c_int64), ("o", C.c_void_p),
                 ("ldo", C.c_int64), ("bso", C.c_int64), ("lse", C.c_void_p), ("o_lo", C.c_void_p), ("kv_len", C.c_void_p), ("B", C.c_int),
                 ("H", C.c_int), ("Tq", C.c_int), ("Tk", C.c_int), ("causal", C.c_int), ("d_o", C.c_void_p),
-                ("delta", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p)]
+                ("delta", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p), ("dq_colsum", C.c_void_p),
+                ("dv_colsum", C.c_void_p)]
 
 
 def _declare(lib):
@@ -87,6 +88,7 @@ def _declare(lib):
         "oasr_probe_lds_oob": (i32, [vp, vp, vp]),
         "oasr_profile_gemm": (i32, [i32]),
         "oasr_gemm_force_general": (i32, [i32]),
+        "oasr_gemm_set_stagger": (i32, [i32, i32]),
         "oasr_profile_gemm_collect": (i32, [vp, vp, vp, C.c_char_p, i32]),
     }
     for name, (res, args) in sig.items():

@@ -59,6 +59,10 @@ extern "C" int oasr_profile_gemm(int enable) {
   gemm_profile_enable(enable);
   return OASR_OK;
 }
+extern "C" int oasr_gemm_set_stagger(int sleeps, int phases) {
+  gemm_set_stagger(sleeps, phases);
+  return OASR_OK;
+}
 extern "C" int oasr_gemm_force_general(int on) {
   gemm_force_general(on);
   return OASR_OK;
@@ -109,6 +113,8 @@ static AttnArgs to_attn(const oasr_attn_args* a) {
   r.dq = (bf16_t*)a->dq;
   r.dk = (bf16_t*)a->dk;
   r.dv = (bf16_t*)a->dv;
+  r.dq_colsum = a->dq_colsum;
+  r.dv_colsum = a->dv_colsum;
   return r;
 }
 extern "C" int oasr_attention_fwd(const oasr_attn_args* a, void* stream) {

@@ -97,8 +97,9 @@ __device__ __forceinline__ int acc_row(int r, int hh) { return (r & 3) + 8 * (r 
 // 32 rows per instruction (measured: the forward kernel spends 14 % of its time issuing them).  Instead each wave
 // transposes through a private LDS tile and every lane stores 16 contiguous bytes, 8 lanes covering one 128-byte row
 // segment.  `stg`: wave-private, 4 KiB; all waves must be done with the operand tiles.
+// `colsum` (optional, 64 floats for this head): += the column sums of the bf16 values stored for the valid rows.
 __device__ __forceinline__ void store_rows_bf16(char* stg, const f32x16_t (&T)[2], float scale, bf16_t* gbase, long ld, int rows_valid,
-                                                int lane) {
+                                                int lane, float* colsum = nullptr) {
   const int row = lane & 31, hh = lane >> 5;
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
@@ -110,16 +111,55 @@ __device__ __forceinline__ void store_rows_bf16(char* stg, const f32x16_t (&T)[2
       *(u32x2_t*)(stg + row * 128 + (((dt * 4 + g4) ^ (row & 7)) << 4) + hh * 8) = o;
     }
   __builtin_amdgcn_wave_barrier();
+  float cs[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) cs[e] = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r2 = i * 8 + (lane >> 3), ch = lane & 7;
     const u32x4_t v = *(const u32x4_t*)(stg + r2 * 128 + ((ch ^ (r2 & 7)) << 4));
-    if (r2 < rows_valid) *(u32x4_t*)(gbase + (long)r2 * ld + ch * 8) = v;
+    if (r2 < rows_valid) {
+      *(u32x4_t*)(gbase + (long)r2 * ld + ch * 8) = v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        cs[2 * e] += bf_lo(v[e]);
+        cs[2 * e + 1] += bf_hi(v[e]);
+      }
+    }
+  }
+  if (colsum) {  // (wave-uniform) lanes sharing (lane & 7) hold partial sums of the same 8 columns
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = cs[e];
+      t += __shfl_xor(t, 8, 64);
+      t += __shfl_xor(t, 16, 64);
+      t += __shfl_xor(t, 32, 64);
+      cs[e] = t;
+    }
+    if (lane < 8 && rows_valid > 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) unsafeAtomicAdd(colsum + lane * 8 + e, cs[e]);
+    }
   }
   __builtin_amdgcn_wave_barrier();
 }
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+// Softmax arithmetic on pairs: gfx950's v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 process two fp32 values per lane per
+// issue slot.  With head_dim 64 these kernels are VALU-issue bound (16 MFMAs against ~145 scalar VALU per 64-key tile and
+// wave in the forward), so halving the fma / add / mul counts is what moves them; the exponential stays one v_exp_f32 each.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t pk_fma(f32x2_t a, f32x2_t b, f32x2_t c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2_t pk_exp2(f32x2_t a) {
+  f32x2_t r;
+  r[0] = __builtin_amdgcn_exp2f(a[0]);
+  r[1] = __builtin_amdgcn_exp2f(a[1]);
+  return r;
+}
+// Lazy rescale (log2 domain): the running reference maximum is only raised -- and O / l only rescaled -- when some row of
+// the wave grows past it by more than this; until then P = exp2(s - m_ref) <= 2^8, harmless in fp32 / bf16.
+constexpr float RESCALE_THR = 8.0f;
 
 // ------------------------------------------------------------------------------------------------------------
 template <bool CAUSAL>
@@ -155,7 +195,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oT[i][r] = 0.f;
-  float m_run = NEG, l_run = 0.f;
+  float m_run = NEG;
+  f32x2_t l_run2 = {0.f, 0.f};
 
   // Unconditional prologue (ntiles >= 1 by construction): a guarded one leaves "Q/dO fragment loads may be pending" in
   // the compiler's wait-count state at the loop header, and hipcc then re-waits vmcnt(3..0) in front of the first MFMAs
@@ -207,23 +248,38 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
         }
     }
     m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
-    const float m_new = fmaxf(m_run, m_tile * C);  // NEG * C stays hugely negative
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    float psum = 0.f;
+    const float m_cand = m_tile * C;  // NEG * C stays hugely negative
+    if (__any(m_cand > m_run + RESCALE_THR)) {  // wave-uniform; rare after the first tiles
+      const float m_new = fmaxf(m_run, m_cand);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      const f32x2_t a2 = {alpha, alpha};
+      l_run2 *= a2;
+      m_run = m_new;
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+      for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(fmaf(sT[kt][r], C, -m_new));
-        sT[kt][r] = p;
-        psum += p;
-      }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
+        for (int r = 0; r < 16; r += 2) {
+          f32x2_t o2 = {oT[dt][r], oT[dt][r + 1]};
+          o2 *= a2;
+          oT[dt][r] = o2[0];
+          oT[dt][r + 1] = o2[1];
+        }
+    }
+    {
+      const f32x2_t c2 = {C, C}, nm2 = {-m_run, -m_run};
+      f32x2_t psum2 = {0.f, 0.f};
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+      for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) oT[dt][r] *= alpha;
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2_t s2 = {sT[kt][r], sT[kt][r + 1]};
+          const f32x2_t p2 = pk_exp2(pk_fma(s2, c2, nm2));
+          sT[kt][r] = p2[0];
+          sT[kt][r + 1] = p2[1];
+          psum2 += p2;
+        }
+      l_run2 += psum2;
+    }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -240,6 +296,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
     __syncthreads();
   }
 
+  const float l_run = l_run2[0] + l_run2[1];
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
   {
@@ -353,10 +410,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
       }
       const bool full = (t * 64 + kt * 32 + 32 <= kv_len) && (!CAUSAL || (t * 64 + kt * 32 + 31 <= q0 + wave * 32));
       if (full) {
+        const f32x2_t c2 = {SCALE * LOG2E, SCALE * LOG2E}, nl2 = {-lse2, -lse2}, nd2 = {-delta, -delta};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(sT[r], SCALE * LOG2E, -lse2));
-          sT[r] = p * (dpT[r] - delta);
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2_t s2 = {sT[r], sT[r + 1]}, dp2 = {dpT[r], dpT[r + 1]};
+          const f32x2_t ds2 = pk_exp2(pk_fma(s2, c2, nl2)) * (dp2 + nd2);
+          sT[r] = ds2[0];
+          sT[r + 1] = ds2[1];
         }
       } else {
 #pragma unroll
@@ -383,7 +443,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   }
   // (the loop ended on a barrier: the K/V stages are free for the per-wave staging tiles)
   store_rows_bf16(smem + wave * 4096, dqT, SCALE, a.dq + (long)b * a.bsq + (long)(q0 + wave * 32) * a.ldq + h * 64, a.ldq,
-                  a.Tq - (q0 + wave * 32), lane);
+                  a.Tq - (q0 + wave * 32), lane, a.dq_colsum ? a.dq_colsum + h * 64 : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -487,22 +547,40 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
       }
       const int key_hi = k0 + wave * 32 + 31;  // largest key of this wave
       const bool full = (t * 64 + qt * 32 + 32 <= a.Tq) && (key_hi < kv_len) && (!CAUSAL || key_hi <= t * 64 + qt * 32);
+      if (full) {  // wave-uniform: no masks, pairs of queries per packed instruction
+        const f32x2_t c2 = {SCALE * LOG2E, SCALE * LOG2E};
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int ql = qt * 32 + 8 * g4 + 4 * hh;
-        const f32x4_t l4 = *(const f32x4_t*)(stat + ql);
-        const f32x4_t d4 = *(const f32x4_t*)(stat + 64 + ql);
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int ql = qt * 32 + 8 * g4 + 4 * hh;
+          const f32x4_t l4 = *(const f32x4_t*)(stat + ql);
+          const f32x4_t d4 = *(const f32x4_t*)(stat + 64 + ql);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int r = 4 * g4 + i;
-          float p = __builtin_amdgcn_exp2f(fmaf(s[r], SCALE * LOG2E, -l4[i]));
-          if (!full) {
+          for (int i = 0; i < 4; i += 2) {
+            const int r = 4 * g4 + i;
+            const f32x2_t s2 = {s[r], s[r + 1]}, dp2 = {dp[r], dp[r + 1]}, nl2 = {-l4[i], -l4[i + 1]}, nd2 = {-d4[i], -d4[i + 1]};
+            const f32x2_t p2 = pk_exp2(pk_fma(s2, c2, nl2));
+            const f32x2_t ds2 = p2 * (dp2 + nd2);
+            s[r] = p2[0];
+            s[r + 1] = p2[1];
+            dp[r] = ds2[0];
+            dp[r + 1] = ds2[1];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int ql = qt * 32 + 8 * g4 + 4 * hh;
+          const f32x4_t l4 = *(const f32x4_t*)(stat + ql);
+          const f32x4_t d4 = *(const f32x4_t*)(stat + 64 + ql);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int r = 4 * g4 + i;
             const int qg = t * 64 + ql + i;
             const bool ok = (qg < a.Tq) && (mykey < kv_len) && (!CAUSAL || mykey <= qg);
-            p = ok ? p : 0.f;
+            const float p = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], SCALE * LOG2E, -l4[i])) : 0.f;
+            s[r] = p;
+            dp[r] = p * (dp[r] - d4[i]);
           }
-          s[r] = p;
-          dp[r] = p * (dp[r] - d4[i]);
         }
       }
 #pragma unroll
@@ -523,7 +601,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
     char* stg = smem + wave * 4096;  // the loop ended on a barrier: both stages are free
     const int rows_valid = a.Tk - (k0 + wave * 32);
     store_rows_bf16(stg, dkT, SCALE, a.dk + (long)b * a.bsk + (long)(k0 + wave * 32) * a.ldk + h * 64, a.ldk, rows_valid, lane);
-    store_rows_bf16(stg, dvT, 1.0f, a.dv + (long)b * a.bsv + (long)(k0 + wave * 32) * a.ldv + h * 64, a.ldv, rows_valid, lane);
+    store_rows_bf16(stg, dvT, 1.0f, a.dv + (long)b * a.bsv + (long)(k0 + wave * 32) * a.ldv + h * 64, a.ldv, rows_valid, lane,
+                    a.dv_colsum ? a.dv_colsum + h * 64 : nullptr);
   }
 }
 

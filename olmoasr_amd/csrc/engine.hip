@@ -541,11 +541,11 @@ struct Runner {
       a.dq = p.gq;
       a.dk = p.gkv;
       a.dv = p.gkv + d;
+      a.dq_colsum = c->G(bp.cattn.qb);  // query / value bias gradients = column sums of dq / dv, fused into the store epilogues
+      a.dv_colsum = c->G(bp.cattn.vb);
       RC(launch_attention_bwd(a, st));
       RC(wgrad(p.gq, d, M, d, plain_view(s.ca.ln, d), d, c->G(bp.cattn.qw), d));
-      RC(launch_colsum_accum(p.gq, d, M, d, c->G(bp.cattn.qb), st));
       RC(wgrad(p.gkv, 2 * d, Mkv, 2 * d, plain_view(p.xa, d), d, c->G(bp.cattn.kw), d));
-      RC(launch_colsum_accum(p.gkv + d, 2 * d, Mkv, d, c->G(bp.cattn.vb), st));
       // d(xa) accumulates over the decoder layers (bf16, like autograd's accumulation into xa.grad)
       RC(dgrad(p.gkv, Mkv, 2 * d, c->template Wt<T>(bp.cattn.kw), d, nullptr, first_cross ? nullptr : p.gxa, p.gxa));
       RC(dgrad(p.gq, M, d, c->template Wt<T>(bp.cattn.qw), d, nullptr, nullptr, p.gln));
@@ -565,10 +565,10 @@ struct Runner {
     a.dq = p.gqkv;
     a.dk = p.gqkv + d;
     a.dv = p.gqkv + 2 * d;
+    a.dq_colsum = c->G(bp.attn.qb);
+    a.dv_colsum = c->G(bp.attn.vb);
     RC(launch_attention_bwd(a, st));
     RC(wgrad(p.gqkv, 3 * d, M, 3 * d, plain_view(s.sa.ln, d), d, c->G(bp.attn.qw), d));
-    RC(launch_colsum_accum(p.gqkv, 3 * d, M, d, c->G(bp.attn.qb), st));
-    RC(launch_colsum_accum(p.gqkv + 2 * d, 3 * d, M, d, c->G(bp.attn.vb), st));
     RC(dgrad(p.gqkv, M, 3 * d, c->template Wt<T>(bp.attn.qw), d, nullptr, nullptr, p.gln));
     RC(launch_layernorm_bwd(p.gln, s.x_in, c->P(bp.attn_ln_w), s.sa.mean, s.sa.rstd, dx, nxt, c->G(bp.attn_ln_w), c->G(bp.attn_ln_b),
                             dsum_next, M, d, st));

@@ -188,6 +188,7 @@ __global__ __launch_bounds__(64) void attn_bwd_q_f32_kernel(AttnArgsF a) {
 #pragma unroll 8
   for (int j = 0; j < nk; ++j) dq = fmaf(ds[j], K[(long)j * a.ldk + lane], dq);
   a.dq[(long)b * a.bsq + (long)i * a.ldq + h * 64 + lane] = ATT_SCALE * dq;
+  if (a.dq_colsum) atomicAdd(a.dq_colsum + h * 64 + lane, ATT_SCALE * dq);
 }
 
 // per key row: dK_j, dV_j (delta must have been written by attn_bwd_q_f32_kernel)
@@ -223,6 +224,7 @@ __global__ __launch_bounds__(64) void attn_bwd_kv_f32_kernel(AttnArgsF a) {
   }
   a.dk[(long)b * a.bsk + (long)j * a.ldk + h * 64 + lane] = ATT_SCALE * dk;
   a.dv[(long)b * a.bsv + (long)j * a.ldv + h * 64 + lane] = dv;
+  if (a.dv_colsum) atomicAdd(a.dv_colsum + h * 64 + lane, dv);
 }
 
 // ---- LayerNorm (one wave per row, d <= 2048) --------------------------------------------------------------------

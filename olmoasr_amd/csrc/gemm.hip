@@ -46,6 +46,7 @@ struct GemmProfile {
 };
 GemmProfile g_prof;
 bool g_force_general = false;
+int g_stagger = 0, g_stagger_phases = 2;  // experiment hook (oasr_gemm_set_stagger)
 int g_fast_geometry = 0;  // 0 = heuristic, 1 = force 256x128 (4 waves), 2 = force 256x256 (8 waves, 2 stages)  // tests: run the register-staged general kernel even where the fast path applies
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -777,6 +778,13 @@ __global__ __launch_bounds__(512, 2) void oasr_gemm_pp_kernel(GemmArgs p) {
   const int kt0 = ksplit * per;
   const int nt = min(kt_total, kt0 + per) - kt0;  // K-tiles of this workgroup
   if (nt <= 0) return;
+  // Phase stagger of the first wave of workgroups (one per CU): with equal-length tiles every CU reaches its epilogue at
+  // the same moment and the 256 x 128 KiB of output must drain to HBM in one burst while the matrix cores idle; delaying
+  // the CUs of each XCD by k/phases of a tile period spreads the stores under the other CUs' main loops.
+  if (p.stagger > 0 && blockIdx.x < 256 && blockIdx.y == 0) {
+    const int ph = (blockIdx.x >> 3) % p.stagger_phases;
+    for (int i = 0; i < ph * p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
 
   // staging offsets: image i (0,1 = A halves; 2,3 = B halves), 2 pieces per wave
   unsigned off[4][2];
@@ -1132,8 +1140,19 @@ int launch_t(const GemmArgs& a, hipStream_t stream) {
 
 }  // namespace
 
+void gemm_set_stagger(int sleeps, int phases) {
+  g_stagger = sleeps < 0 ? 0 : sleeps;
+  g_stagger_phases = phases < 2 ? 2 : phases;
+}
+
 int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   OASR_REQUIRE(a.A.ptr && a.B.ptr, "gemm: null operand");
+  if (g_stagger > 0 && a.stagger == 0) {
+    GemmArgs b = a;
+    b.stagger = g_stagger;
+    b.stagger_phases = g_stagger_phases;
+    return launch_gemm(b, stream);
+  }
   OASR_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: bad shape %d %d %d", a.M, a.N, a.K);
   OASR_REQUIRE((a.N % 4) == 0, "gemm: N (%d) must be a multiple of 4", a.N);
   OASR_REQUIRE((a.A.ld % 8) == 0 && (a.B.ld % 8) == 0, "gemm: operand leading dims must be multiples of 8 (16-byte loads)");

@@ -62,6 +62,7 @@ struct GemmArgsT {
   int split_k;  // >= 1; > 1 requires atomic out_f32 and no other output
   int raster_gm;  // fast path: tile rows per L2 group (0 = choose from residency)
   int dgelu_deriv;  // dgelu_u already holds GELU'(u) (written by an act == 2 forward)
+  int stagger, stagger_phases;  // ping-pong kernel: first-wave phase stagger in units of s_sleep(127) (0 = off)
 };
 typedef GemmArgsT<bf16_t> GemmArgs;
 typedef GemmArgsT<float> GemmArgsF;
@@ -70,6 +71,7 @@ int launch_gemm(const GemmArgsF& a, hipStream_t stream);  // fp32 validation ker
 // bench-only: time every GEMM launch with HIP events on its stream; collect() sums per variant (2*ta+tb)
 void gemm_profile_enable(int on);
 void gemm_force_general(int on);  // tests: disable the direct-to-LDS fast path
+void gemm_set_stagger(int sleeps, int phases);  // experiments: first-wave phase stagger of the ping-pong kernel
 int gemm_profile_collect(double ms[4], double flops[4], long count[4], char* by_symbol, int cap);
 template <typename T>
 static inline GemmArgsT<T> gemm_defaults_t() {
@@ -110,6 +112,9 @@ struct AttnArgsT {
   const T* d_o;              // [B, Tq, H*64], same strides as o
   float* delta;              // [B, H, Tq] workspace: rowsum(dO * O)
   T *dq, *dk, *dv;           // same strides as q/k/v
+  // optional [H*64] fp32, ACCUMULATED: column sums over all (b, t) rows of the stored dq / dv = the gradients of the
+  // query / value projection biases (key has none, olmoasr/model.py:259), fused into the backward kernels' store epilogues
+  float *dq_colsum, *dv_colsum;
 };
 typedef AttnArgsT<bf16_t> AttnArgs;
 typedef AttnArgsT<float> AttnArgsF;

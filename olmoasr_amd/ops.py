@@ -87,7 +87,7 @@ def attention_fwd(q, k, v, kv_len=None, causal=False, want_o_lo=False):
     return (o, lse, o_lo) if want_o_lo else (o, lse)
 
 
-def attention_bwd(q, k, v, o, lse, d_o, kv_len=None, causal=False, o_lo=None):
+def attention_bwd(q, k, v, o, lse, d_o, kv_len=None, causal=False, o_lo=None, dq_colsum=None, dv_colsum=None):
     B, Tq, H, _ = q.shape
     # gradients use the operands' own (possibly fused-qkv) strides
     dq, dk, dv = (torch.empty_strided(t.shape, t.stride(), device=t.device, dtype=t.dtype) for t in (q, k, v))
@@ -96,6 +96,8 @@ def attention_bwd(q, k, v, o, lse, d_o, kv_len=None, causal=False, o_lo=None):
     a.d_o, a.delta = d_o.data_ptr(), delta.data_ptr()
     a.o_lo = o_lo.data_ptr() if o_lo is not None else None
     a.dq, a.dk, a.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    a.dq_colsum = dq_colsum.data_ptr() if dq_colsum is not None else None
+    a.dv_colsum = dv_colsum.data_ptr() if dv_colsum is not None else None
     N.check(N.lib().oasr_attention_bwd(C.byref(a), N.stream_ptr()), "attention_bwd")
     return dq, dk, dv
 

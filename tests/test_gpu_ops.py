@@ -300,6 +300,13 @@ def test_attention_fwd_bwd(case):
     d_o = rnd(B, Tq, d, seed=18, scale=0.5)
     dq, dk, dv = ops().attention_bwd(q, k, v, o, lse, d_o, kv_len, case["causal"], o_lo=o_lo)
     dq2, dk2, dv2 = ops().attention_bwd(q, k, v, o, lse, d_o, kv_len, case["causal"])  # delta from the bf16 O
+    # fused query / value bias gradients: column sums of the STORED bf16 dq / dv, accumulated into fp32
+    csq, csv = torch.full((d,), 0.25, device=DEV), torch.full((d,), -0.5, device=DEV)
+    dq3, _, dv3 = ops().attention_bwd(q, k, v, o, lse, d_o, kv_len, case["causal"], o_lo=o_lo, dq_colsum=csq, dv_colsum=csv)
+    assert torch.equal(dq3, dq) and torch.equal(dv3, dv)
+    wq, wv = dq.float().sum((0, 1)).reshape(d) + 0.25, dv.float().sum((0, 1)).reshape(d) - 0.5
+    close(csq, wq, rtol=1e-4, atol=1e-3 * float(wq.abs().max()) + 1e-4, name="fused dq column sums")
+    close(csv, wv, rtol=1e-4, atol=1e-3 * float(wv.abs().max()) + 1e-4, name="fused dv column sums")
     ro.backward(d_o.float())
     for nm, got, ref in (("dq", dq, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
         # dS/P are rounded to bf16 before the second MFMA: error is relative to the largest entries of a row
