@@ -145,12 +145,19 @@ typedef struct oasr_attn_args {
   const void *q, *k, *v; int64_t ldq, ldk, ldv, bsq, bsk, bsv; void* o; int64_t ldo, bso; float* lse; void* o_lo; const int32_t* kv_len;
   int B, H, Tq, Tk, causal; const void* d_o; float* delta; void *dq, *dk, *dv;
   float *dq_colsum, *dv_colsum; /* optional [H*64], accumulated: column sums of dq / dv = query / value bias gradients */
+  float* colsum_scratch;        /* with either of them: B * (ceil(Tq/128) + ceil(Tk/128)) * H*64 floats of scratch */
 } oasr_attn_args;
 int oasr_attention_fwd(const oasr_attn_args*, void* stream);
 int oasr_attention_bwd(const oasr_attn_args*, void* stream);
 int oasr_cross_entropy(void* logits_bf16, int64_t ld, int V, const int64_t* targets, int64_t rows, int64_t ignore, float gscale,
                        int32_t* n_valid_dev, float* row_loss, float* loss_out, int write_grad, void* stream);
 int oasr_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* Per-row token pick over fp32 logits [rows, ld] (first V columns): tok = argmax(logits + mask + mask2) with the lowest index
+ * among equal maxima, logprob = log_softmax(logits + masks)[tok] (NULL to skip).  masks: additive f32 [V] (0 / -inf) or NULL.
+ * = the tail of whisper.decoding GreedyDecoder.update (argmax + log_softmax gather) after SuppressBlank / SuppressTokens,
+ * and gen_pred's argmax over teacher-forced logits (scripts/training/train_timestamps.py:1096-1098). */
+int oasr_pick_tokens(const float* logits, int64_t ld, int V, int64_t rows, const float* mask, const float* mask2, int64_t* tok,
+                     float* logprob, void* stream);
 /* bench.py's live roofline measurement: when enabled every GEMM launch is bracketed by HIP events on ITS stream;
  * collect() synchronises and returns, per kernel variant (index 2*ta+tb: 0 = NT forward, 1 = NN dgrad, 3 = TN wgrad),
  * summed milliseconds, summed algorithmic flops (2*M*N*K, conv windows at their real width) and launch count; by_symbol

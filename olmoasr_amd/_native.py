@@ -40,7 +40,7 @@ class AttnArgs(C.Structure):
                 ("ldo", C.c_int64), ("bso", C.c_int64), ("lse", C.c_void_p), ("o_lo", C.c_void_p), ("kv_len", C.c_void_p), ("B", C.c_int),
                 ("H", C.c_int), ("Tq", C.c_int), ("Tk", C.c_int), ("causal", C.c_int), ("d_o", C.c_void_p),
                 ("delta", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p), ("dq_colsum", C.c_void_p),
-                ("dv_colsum", C.c_void_p)]
+                ("dv_colsum", C.c_void_p), ("colsum_scratch", C.c_void_p)]
 
 
 def _declare(lib):
@@ -84,6 +84,7 @@ def _declare(lib):
         "oasr_attention_bwd": (i32, [C.POINTER(AttnArgs), vp]),
         "oasr_cross_entropy": (i32, [vp, i64, i32, vp, i64, i64, f32, vp, vp, vp, i32, vp]),
         "oasr_cast_f32_bf16": (i32, [vp, vp, i64, vp]),
+        "oasr_pick_tokens": (i32, [vp, i64, i32, i64, vp, vp, vp, vp, vp]),
         "oasr_probe_tr16": (i32, [vp, vp, vp]),
         "oasr_probe_lds_oob": (i32, [vp, vp, vp]),
         "oasr_profile_gemm": (i32, [i32]),

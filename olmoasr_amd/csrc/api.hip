@@ -115,6 +115,7 @@ static AttnArgs to_attn(const oasr_attn_args* a) {
   r.dv = (bf16_t*)a->dv;
   r.dq_colsum = a->dq_colsum;
   r.dv_colsum = a->dv_colsum;
+  r.colsum_scratch = a->colsum_scratch;
   return r;
 }
 extern "C" int oasr_attention_fwd(const oasr_attn_args* a, void* stream) {
@@ -135,6 +136,11 @@ extern "C" int oasr_cross_entropy(void* logits, int64_t ld, int V, const int64_t
   if (rc) return rc;
   if (loss_out) rc = launch_loss_reduce(row_loss, rows, n_valid_dev, 1.0f, loss_out, 0, st);
   return rc;
+}
+
+extern "C" int oasr_pick_tokens(const float* logits, int64_t ld, int V, int64_t rows, const float* mask, const float* mask2, int64_t* tok,
+                                float* logprob, void* stream) {
+  return launch_pick_tokens(logits, ld, V, rows, mask, mask2, tok, logprob, (hipStream_t)stream);
 }
 
 extern "C" int oasr_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream) {

@@ -97,9 +97,11 @@ __device__ __forceinline__ int acc_row(int r, int hh) { return (r & 3) + 8 * (r 
 // 32 rows per instruction (measured: the forward kernel spends 14 % of its time issuing them).  Instead each wave
 // transposes through a private LDS tile and every lane stores 16 contiguous bytes, 8 lanes covering one 128-byte row
 // segment.  `stg`: wave-private, 4 KiB; all waves must be done with the operand tiles.
-// `colsum` (optional, 64 floats for this head): += the column sums of the bf16 values stored for the valid rows.
+// `wave_sums` (optional, 64 floats of LDS owned by this wave): receives the column sums of the bf16 values stored for
+// the valid rows (the caller combines the waves and writes ONE partial row per workgroup -- fp32 atomics from every wave
+// onto the same d addresses were measured to cost more than the kernel itself).
 __device__ __forceinline__ void store_rows_bf16(char* stg, const f32x16_t (&T)[2], float scale, bf16_t* gbase, long ld, int rows_valid,
-                                                int lane, float* colsum = nullptr) {
+                                                int lane, float* wave_sums = nullptr) {
   const int row = lane & 31, hh = lane >> 5;
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
@@ -127,7 +129,7 @@ __device__ __forceinline__ void store_rows_bf16(char* stg, const f32x16_t (&T)[2
       }
     }
   }
-  if (colsum) {  // (wave-uniform) lanes sharing (lane & 7) hold partial sums of the same 8 columns
+  if (wave_sums) {  // (wave-uniform) lanes sharing (lane & 7) hold partial sums of the same 8 columns
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float t = cs[e];
@@ -136,9 +138,9 @@ __device__ __forceinline__ void store_rows_bf16(char* stg, const f32x16_t (&T)[2
       t += __shfl_xor(t, 32, 64);
       cs[e] = t;
     }
-    if (lane < 8 && rows_valid > 0) {
+    if (lane < 8) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) unsafeAtomicAdd(colsum + lane * 8 + e, cs[e]);
+      for (int e = 0; e < 8; ++e) wave_sums[lane * 8 + e] = cs[e];  // zeros when this wave has no valid row
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -442,8 +444,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     __syncthreads();
   }
   // (the loop ended on a barrier: the K/V stages are free for the per-wave staging tiles)
+  float* wsum = (float*)(smem + 16384);  // [4 waves][64], behind the staging tiles
   store_rows_bf16(smem + wave * 4096, dqT, SCALE, a.dq + (long)b * a.bsq + (long)(q0 + wave * 32) * a.ldq + h * 64, a.ldq,
-                  a.Tq - (q0 + wave * 32), lane, a.dq_colsum ? a.dq_colsum + h * 64 : nullptr);
+                  a.Tq - (q0 + wave * 32), lane, a.dq_colsum ? wsum + wave * 64 : nullptr);
+  if (a.dq_colsum) {  // one partial row per workgroup: colsum_scratch[(b, query block)][h*64 + c], reduced by the launcher
+    __syncthreads();
+    if (tid < 64)
+      a.colsum_scratch[((long)(b * nqb + (bid - bh * nqb)) * a.H + h) * 64 + tid] =
+          (wsum[tid] + wsum[64 + tid]) + (wsum[128 + tid] + wsum[192 + tid]);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -507,7 +516,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
     tile_commit(st + TILE, tid, rd);
     if (tid < 128) ((float*)(st + 2 * TILE))[tid] = rstat;
   };
+  // dv partial rows live behind the dq ones: [B * ceil(Tq/128)][H*64] then [B * ceil(Tk/128)][H*64]
+  const long dv_scratch_off = (long)a.B * ((a.Tq + 127) >> 7) * a.H * 64;
   if (!any) {  // every key of this block is padding: dK = dV = 0 (uniform early exit, before any load is issued)
+    if (a.dv_colsum && tid < 64) a.colsum_scratch[dv_scratch_off + ((long)(b * nkb + (bid - bh * nkb)) * a.H + h) * 64 + tid] = 0.f;
     if (mykey < a.Tk) {
       bf16_t* dkp0 = a.dk + (long)b * a.bsk + (long)mykey * a.ldk + h * 64;
       bf16_t* dvp0 = a.dv + (long)b * a.bsv + (long)mykey * a.ldv + h * 64;
@@ -601,8 +613,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
     char* stg = smem + wave * 4096;  // the loop ended on a barrier: both stages are free
     const int rows_valid = a.Tk - (k0 + wave * 32);
     store_rows_bf16(stg, dkT, SCALE, a.dk + (long)b * a.bsk + (long)(k0 + wave * 32) * a.ldk + h * 64, a.ldk, rows_valid, lane);
+    float* wsum = (float*)(smem + 16384);
     store_rows_bf16(stg, dvT, 1.0f, a.dv + (long)b * a.bsv + (long)(k0 + wave * 32) * a.ldv + h * 64, a.ldv, rows_valid, lane,
-                    a.dv_colsum ? a.dv_colsum + h * 64 : nullptr);
+                    a.dv_colsum ? wsum + wave * 64 : nullptr);
+    if (a.dv_colsum) {
+      __syncthreads();
+      if (tid < 64)
+        a.colsum_scratch[dv_scratch_off + ((long)(b * nkb + (bid - bh * nkb)) * a.H + h) * 64 + tid] =
+            (wsum[tid] + wsum[64 + tid]) + (wsum[128 + tid] + wsum[192 + tid]);
+    }
   }
 }
 
@@ -705,6 +724,7 @@ int check_args(const AttnArgs& a, bool bwd) {
   OASR_REQUIRE((a.ldq % 8) == 0 && (a.ldk % 8) == 0 && (a.ldv % 8) == 0 && (a.ldo % 8) == 0, "attention: strides must be multiples of 8");
   OASR_REQUIRE(!a.causal || a.Tq == a.Tk, "attention: causal needs Tq == Tk");
   if (bwd) OASR_REQUIRE(a.d_o && a.lse && a.delta && a.dq && a.dk && a.dv, "attention_bwd: null pointer");
+  if (bwd) OASR_REQUIRE((!a.dq_colsum && !a.dv_colsum) || a.colsum_scratch, "attention_bwd: fused bias gradients need colsum_scratch");
   return OASR_OK;
 }
 
@@ -739,5 +759,16 @@ int launch_attention_bwd(const AttnArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, gk, dim3(256), 0, s, a);
   }
   OASR_LAUNCH_CHECK();
+  // fused query / value bias gradients: reduce the per-workgroup partial rows (a few MB) into the fp32 gradients
+  const int d = a.H * 64;
+  const long rq = (long)a.B * cdiv(a.Tq, 128), rk = (long)a.B * cdiv(a.Tk, 128);
+  if (a.dq_colsum) {
+    int rc2 = launch_colsum_accum(a.colsum_scratch, d, rq, d, a.dq_colsum, s);
+    if (rc2) return rc2;
+  }
+  if (a.dv_colsum) {
+    int rc2 = launch_colsum_accum(a.colsum_scratch + rq * d, d, rk, d, a.dv_colsum, s);
+    if (rc2) return rc2;
+  }
   return OASR_OK;
 }

@@ -179,7 +179,7 @@ struct Plan {
   int32_t* n_valid;
   // backward temporaries
   T *ga, *gb, *gc, *gln, *gqkv, *go, *gu, *gxa, *gkv, *gq, *gA2;
-  float *delta, *tmp_w1p, *tmp_w2p;
+  float *delta, *tmp_w1p, *tmp_w2p, *cs_scratch;
 };
 
 static void plan_attn(Arena& A, AttnSave& s, long M, long Mkv, int d, int B, int H, long Tq, bool cross, bool train) {
@@ -263,6 +263,7 @@ static void make_plan(const oasr_ctx* c, Arena& A, Plan& p, int B, int S, bool t
     p.gq = A.template act<T>(Md * d);
     p.gA2 = A.template act<T>(Me * 3 * d);
     p.delta = A.f32((long)B * c->H * c->Te);
+    p.cs_scratch = A.f32(attn_colsum_scratch_floats(B, c->H, c->Te, c->Te));  // (the largest of the three attention shapes)
     p.tmp_w1p = A.f32((long)d * 256);
     p.tmp_w2p = A.f32((long)d * 3 * d);
   }
@@ -543,6 +544,7 @@ struct Runner {
       a.dv = p.gkv + d;
       a.dq_colsum = c->G(bp.cattn.qb);  // query / value bias gradients = column sums of dq / dv, fused into the store epilogues
       a.dv_colsum = c->G(bp.cattn.vb);
+      a.colsum_scratch = p.cs_scratch;
       RC(launch_attention_bwd(a, st));
       RC(wgrad(p.gq, d, M, d, plain_view(s.ca.ln, d), d, c->G(bp.cattn.qw), d));
       RC(wgrad(p.gkv, 2 * d, Mkv, 2 * d, plain_view(p.xa, d), d, c->G(bp.cattn.kw), d));
@@ -567,6 +569,7 @@ struct Runner {
     a.dv = p.gqkv + 2 * d;
     a.dq_colsum = c->G(bp.attn.qb);
     a.dv_colsum = c->G(bp.attn.vb);
+    a.colsum_scratch = p.cs_scratch;
     RC(launch_attention_bwd(a, st));
     RC(wgrad(p.gqkv, 3 * d, M, 3 * d, plain_view(s.sa.ln, d), d, c->G(bp.attn.qw), d));
     RC(dgrad(p.gqkv, M, 3 * d, c->template Wt<T>(bp.attn.qw), d, nullptr, nullptr, p.gln));

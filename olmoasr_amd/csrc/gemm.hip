@@ -781,7 +781,7 @@ __global__ __launch_bounds__(512, 2) void oasr_gemm_pp_kernel(GemmArgs p) {
   // Phase stagger of the first wave of workgroups (one per CU): with equal-length tiles every CU reaches its epilogue at
   // the same moment and the 256 x 128 KiB of output must drain to HBM in one burst while the matrix cores idle; delaying
   // the CUs of each XCD by k/phases of a tile period spreads the stores under the other CUs' main loops.
-  if (p.stagger > 0 && blockIdx.x < 256 && blockIdx.y == 0) {
+  if (p.stagger > 0 && p.stagger_phases > 1 && blockIdx.x < 256 && blockIdx.y == 0) {
     const int ph = (blockIdx.x >> 3) % p.stagger_phases;
     for (int i = 0; i < ph * p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
   }
@@ -1140,8 +1140,8 @@ int launch_t(const GemmArgs& a, hipStream_t stream) {
 
 }  // namespace
 
-void gemm_set_stagger(int sleeps, int phases) {
-  g_stagger = sleeps < 0 ? 0 : sleeps;
+void gemm_set_stagger(int sleeps, int phases) {  // sleeps < 0: stagger off everywhere (A/B baseline)
+  g_stagger = sleeps;
   g_stagger_phases = phases < 2 ? 2 : phases;
 }
 
@@ -1151,6 +1151,14 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     GemmArgs b = a;
     b.stagger = g_stagger;
     b.stagger_phases = g_stagger_phases;
+    return launch_gemm(b, stream);
+  }
+  // measured (scripts/gemm_stagger_ab.py, M = 192000): +14 % on N = 1024, K = 1024 (tiles of ~8 us whose epilogues collide),
+  // 0..-3 % on every longer tile -> only the short ones are staggered: 8 phases x one s_sleep(127)
+  if (g_stagger == 0 && a.stagger == 0 && a.N <= 1024 && a.K <= 1024 && a.M >= 16384 && a.out && !a.out_f32) {
+    GemmArgs b = a;
+    b.stagger = 1;
+    b.stagger_phases = 8;
     return launch_gemm(b, stream);
   }
   OASR_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: bad shape %d %d %d", a.M, a.N, a.K);

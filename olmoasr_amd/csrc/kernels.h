@@ -115,7 +115,11 @@ struct AttnArgsT {
   // optional [H*64] fp32, ACCUMULATED: column sums over all (b, t) rows of the stored dq / dv = the gradients of the
   // query / value projection biases (key has none, olmoasr/model.py:259), fused into the backward kernels' store epilogues
   float *dq_colsum, *dv_colsum;
+  float* colsum_scratch;     // required with either: fp32 [(B*ceil(Tq/128) + B*ceil(Tk/128)) * H*64] per-workgroup partial rows
 };
+static inline size_t attn_colsum_scratch_floats(int B, int H, int Tq, int Tk) {
+  return (size_t)B * ((size_t)(Tq + 127) / 128 + (size_t)(Tk + 127) / 128) * H * 64;
+}
 typedef AttnArgsT<bf16_t> AttnArgs;
 typedef AttnArgsT<float> AttnArgsF;
 int launch_attention_fwd(const AttnArgs& a, hipStream_t s);
@@ -169,6 +173,10 @@ int launch_cross_entropy(bf16_t* logits, long ld, int V, const int64_t* targets,
 int launch_cross_entropy(float* logits, long ld, int V, const int64_t* targets, long rows, long ignore, float gscale,
                          const int32_t* n_valid_dev, float* row_loss, int write_grad, hipStream_t s);  // fp32 validation
 int launch_loss_reduce(const float* row_loss, long rows, const int32_t* n_valid_dev, float mul, float* loss_out, int accumulate,
+                       hipStream_t s);
+
+// tok[r] = argmax_c (logits[r][c] + mask[c] + mask2[c]) (lowest index on ties), logprob[r] = log_softmax of that entry (optional)
+int launch_pick_tokens(const float* logits, long ld, int V, long rows, const float* mask, const float* mask2, int64_t* tok, float* logprob,
                        hipStream_t s);
 
 // ---- optimizer (flat fp32 arenas) ---------------------------------------------------------------------------

@@ -121,7 +121,76 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restric
   }
 }
 
+// Token pick over the vocabulary (the per-step tail of whisper.decoding's GreedyDecoder.update, and gen_pred's argmax,
+// train_timestamps.py:1096-1098): one workgroup per row of fp32 logits;
+//   x[c] = logits[c] + mask[c] (+ mask2[c])          (additive 0 / -inf suppress masks, optional)
+//   tok = argmax_c x[c] (lowest index among equal maxima), logprob = x[tok] - logsumexp(x)
+__global__ __launch_bounds__(256) void pick_kernel(const float* __restrict__ logits, long ld, int V, const float* __restrict__ mask,
+                                                  const float* __restrict__ mask2, int64_t* __restrict__ tok, float* __restrict__ logprob) {
+  __shared__ float red[4];
+  __shared__ float bv[4];
+  __shared__ int bi[4];
+  const float* lr = logits + (long)blockIdx.x * ld;
+  float best = -INFINITY;
+  int besti = 0x7fffffff;
+  for (int c = threadIdx.x; c < V; c += 256) {
+    float x = lr[c];
+    if (mask) x += mask[c];
+    if (mask2) x += mask2[c];
+    if (x > best) {  // strict: keeps the lowest index of this thread's stride
+      best = x;
+      besti = c;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(besti, o, 64);
+    if (ov > best || (ov == best && oi < besti)) {
+      best = ov;
+      besti = oi;
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    bv[wave] = best;
+    bi[wave] = besti;
+  }
+  __syncthreads();
+  best = bv[0];
+  besti = bi[0];
+#pragma unroll
+  for (int w = 1; w < 4; ++w)
+    if (bv[w] > best || (bv[w] == best && bi[w] < besti)) {
+      best = bv[w];
+      besti = bi[w];
+    }
+  float sum = 0.f;
+  if (logprob) {
+    for (int c = threadIdx.x; c < V; c += 256) {
+      float x = lr[c];
+      if (mask) x += mask[c];
+      if (mask2) x += mask2[c];
+      sum += __expf(x - best);
+    }
+    sum = block_reduce(sum, red, false);
+  }
+  if (threadIdx.x == 0) {
+    tok[blockIdx.x] = besti == 0x7fffffff ? 0 : besti;
+    if (logprob) logprob[blockIdx.x] = -__logf(sum);
+  }
+}
+
 }  // namespace
+
+int launch_pick_tokens(const float* logits, long ld, int V, long rows, const float* mask, const float* mask2, int64_t* tok, float* logprob,
+                       hipStream_t s) {
+  OASR_REQUIRE(logits && tok && V > 0 && ld >= V, "pick_tokens: bad args");
+  if (rows <= 0) return OASR_OK;
+  hipLaunchKernelGGL(pick_kernel, dim3((unsigned)rows), dim3(256), 0, s, logits, ld, V, mask, mask2, tok, logprob);
+  OASR_LAUNCH_CHECK();
+  return OASR_OK;
+}
 
 int launch_count_valid(const int64_t* targets, long rows, long ignore, int32_t* n_valid_dev, hipStream_t s) {
   OASR_REQUIRE(targets && n_valid_dev && rows > 0, "count_valid: bad args");

@@ -98,6 +98,11 @@ def attention_bwd(q, k, v, o, lse, d_o, kv_len=None, causal=False, o_lo=None, dq
     a.dq, a.dk, a.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
     a.dq_colsum = dq_colsum.data_ptr() if dq_colsum is not None else None
     a.dv_colsum = dv_colsum.data_ptr() if dv_colsum is not None else None
+    scratch = None
+    if dq_colsum is not None or dv_colsum is not None:
+        Tk = k.shape[1]
+        scratch = torch.empty(B * ((Tq + 127) // 128 + (Tk + 127) // 128) * H * 64, device=q.device, dtype=torch.float32)
+        a.colsum_scratch = scratch.data_ptr()
     N.check(N.lib().oasr_attention_bwd(C.byref(a), N.stream_ptr()), "attention_bwd")
     return dq, dk, dv
 
@@ -134,3 +139,18 @@ def log_mel(pcm):
     ws = torch.empty(N.lib().oasr_log_mel_workspace_bytes(B), device=pcm.device, dtype=torch.uint8)
     N.check(N.lib().oasr_log_mel(N.ptr(pcm), dt, B, n, N.ptr(mel), N.ptr(ws), N.stream_ptr()), "oasr_log_mel")
     return mel
+
+
+def pick_tokens(logits, mask=None, mask2=None, want_logprob=True):
+    """logits fp32 [rows, V] (row stride free) -> (argmax ids int64 [rows], log_softmax at the argmax fp32 [rows] | None);
+    ``mask`` / ``mask2``: additive fp32 [V] (0 / -inf)."""
+    N.require_gpu(logits, "logits")
+    assert logits.dtype == torch.float32 and logits.dim() == 2 and logits.stride(1) == 1
+    rows, V = logits.shape
+    tok = torch.empty(rows, device=logits.device, dtype=torch.int64)
+    lp = torch.empty(rows, device=logits.device, dtype=torch.float32) if want_logprob else None
+    for m in (mask, mask2):
+        assert m is None or (m.dtype == torch.float32 and m.numel() == V and m.is_contiguous())
+    N.check(N.lib().oasr_pick_tokens(N.ptr(logits), logits.stride(0), V, rows, N.ptr(mask), N.ptr(mask2), N.ptr(tok), N.ptr(lp),
+                                     N.stream_ptr()), "oasr_pick_tokens")
+    return tok, lp

@@ -1,0 +1,295 @@
+"""CPU oracle for decoding and the long-form window driver.  TEST INFRASTRUCTURE ONLY (tests/, smoke, bench cpu leg).
+
+What is restated and from where.  The reference binds ``whisper.decoding.decode`` as ``OLMoASR.decode``
+(olmoasr/model.py:966-968, inf_model.py:455-457) and drives it from ``olmoasr/transcribe.py:193-233`` (temperature
+fallback) inside the seek loop ``olmoasr/transcribe.py:281-517``; evaluation uses beam 5 + the fallback tuple
+(scripts/eval/eval.py:2077-2084), training-time evaluation greedy (scripts/training/train_timestamps.py:1916-1919).
+``openai-whisper`` itself is an un-vendored, unpinned dependency (requirements.txt:21; the model code cites upstream commit
+ba3f3cd54b0e5b8ce1ab3de13e32122d0d5f98ab): its ``DecodingTask`` -- GreedyDecoder, BeamSearchDecoder,
+MaximumLikelihoodRanker, SuppressBlank, SuppressTokens, ApplyTimestampRules -- is restated here from the published
+algorithm at TOKEN level (no tokenizer offline: text, the compression-ratio test and word timestamps are outside).
+**Parity unpinned by the reference**: it ships neither tests nor golden vectors for decoding; this file is anchored on
+the reference's call sites and on ``transcribe.py``, which IS in the reference tree and is followed line by line.
+
+Everything runs on ``oracle.model_oracle`` (pinned to the unmodified reference model), plain Python + torch CPU, written
+for clarity, independent of olmoasr_amd/*.
+"""
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from . import model_oracle as mo
+
+# English-only GPT-2 specials (consistent with train_timestamps.py:236,354,543)
+EOT, SOT, TRANSLATE, TRANSCRIBE, SOT_LM, SOT_PREV, NO_SPEECH, NO_TIMESTAMPS, TIMESTAMP_BEGIN = (
+    50256, 50257, 50357, 50358, 50359, 50360, 50361, 50362, 50363)
+BLANK = 220  # GPT-2 BPE id of " " (tokenizer.encode(" ")), what SuppressBlank masks at the first sampled position
+N_FRAMES, HOP_LENGTH, SAMPLE_RATE, FRAMES_PER_SECOND = 3000, 160, 16000, 100
+
+
+@dataclass
+class Options:  # whisper.decoding.DecodingOptions (token-level fields)
+    temperature: float = 0.0
+    sample_len: Optional[int] = None
+    best_of: Optional[int] = None
+    beam_size: Optional[int] = None
+    patience: Optional[float] = None
+    length_penalty: Optional[float] = None
+    suppress_tokens: Optional[Sequence[int]] = (-1,)   # "-1": the non-speech symbol list + the specials
+    non_speech_tokens: Sequence[int] = ()              # tokenizer.non_speech_tokens (needs the tokenizer: caller-supplied)
+    suppress_blank: bool = True
+    without_timestamps: bool = False
+    max_initial_timestamp: Optional[float] = 1.0
+    seed: int = 0
+
+
+@dataclass
+class Result:
+    tokens: List[int] = field(default_factory=list)
+    avg_logprob: float = float("nan")
+    no_speech_prob: float = float("nan")
+    temperature: float = 0.0
+    sum_logprob: float = float("nan")
+
+
+def suppress_list(opt: Options) -> List[int]:
+    """DecodingTask._get_suppress_tokens."""
+    sup = list(opt.suppress_tokens) if opt.suppress_tokens is not None else []
+    if -1 in sup:
+        sup = [t for t in sup if t >= 0] + list(opt.non_speech_tokens)
+    sup += [TRANSCRIBE, TRANSLATE, SOT, SOT_PREV, SOT_LM, NO_SPEECH]
+    return sorted(set(sup))
+
+
+def apply_timestamp_rules(logits: torch.Tensor, tokens: torch.Tensor, sample_begin: int, max_initial_index: Optional[int]):
+    """whisper.decoding.ApplyTimestampRules.apply, in place on logits [n, V]."""
+    logits[:, NO_TIMESTAMPS] = -math.inf
+    for k in range(tokens.shape[0]):
+        seq = tokens[k, sample_begin:].tolist()
+        last_was_ts = len(seq) >= 1 and seq[-1] >= TIMESTAMP_BEGIN
+        penultimate_was_ts = len(seq) < 2 or seq[-2] >= TIMESTAMP_BEGIN
+        if last_was_ts:
+            if penultimate_was_ts:
+                logits[k, TIMESTAMP_BEGIN:] = -math.inf
+            else:
+                logits[k, :EOT] = -math.inf
+        stamps = [t for t in seq if t >= TIMESTAMP_BEGIN]
+        if stamps:
+            last = stamps[-1] if (last_was_ts and not penultimate_was_ts) else stamps[-1] + 1
+            logits[k, TIMESTAMP_BEGIN:last] = -math.inf
+    if tokens.shape[1] == sample_begin:
+        logits[:, :TIMESTAMP_BEGIN] = -math.inf
+        if max_initial_index is not None:
+            logits[:, TIMESTAMP_BEGIN + max_initial_index + 1:] = -math.inf
+    logprobs = F.log_softmax(logits.float(), dim=-1)
+    for k in range(tokens.shape[0]):
+        if logprobs[k, TIMESTAMP_BEGIN:].logsumexp(-1) > logprobs[k, :TIMESTAMP_BEGIN].max():
+            logits[k, :TIMESTAMP_BEGIN] = -math.inf
+
+
+def decode(sd, dims, mel: torch.Tensor, opt: Options) -> List[Result]:
+    """DecodingTask.run for a batch of 30 s windows mel [n_audio, 80, 3000] (no prompt / prefix: the reference has
+    prompt conditioning commented out, transcribe.py:297-302)."""
+    xa = mo.encoder_forward(sd, dims, mel)
+    n_audio = mel.shape[0]
+    init = [SOT, NO_TIMESTAMPS] if opt.without_timestamps else [SOT]
+    sample_begin, sot_index = len(init), 0
+    sample_len = opt.sample_len or dims.n_text_ctx // 2
+    n_group = opt.beam_size or opt.best_of or 1
+    sup = suppress_list(opt) if opt.suppress_tokens is not None else []
+    max_initial_index = None
+    if not opt.without_timestamps and opt.max_initial_timestamp is not None:
+        max_initial_index = round(opt.max_initial_timestamp / 0.02)
+    gen = torch.Generator().manual_seed(opt.seed)
+
+    xa_g = xa.repeat_interleave(n_group, dim=0)
+    tokens = torch.tensor([init] * (n_audio * n_group), dtype=torch.long)
+    sum_logprobs = torch.zeros(n_audio * n_group)
+    no_speech = [float("nan")] * n_audio
+    finished: List[dict] = [dict() for _ in range(n_audio)]
+    max_candidates = round(opt.beam_size * (opt.patience or 1.0)) if opt.beam_size else None
+
+    for i in range(sample_len):
+        full = mo.decoder_forward(sd, dims, tokens, xa_g)  # cache-less re-forward (notebooks/ow_decoding.py:42-72 style)
+        if i == 0:
+            probs = full[:, sot_index].float().softmax(-1)
+            no_speech = probs[::n_group, NO_SPEECH].tolist()
+        logits = full[:, -1].clone()
+        if opt.suppress_blank and tokens.shape[1] == sample_begin:
+            logits[:, [BLANK, EOT]] = -math.inf
+        if sup:
+            logits[:, sup] = -math.inf
+        if not opt.without_timestamps:
+            apply_timestamp_rules(logits, tokens, sample_begin, max_initial_index)
+        if opt.beam_size:  # BeamSearchDecoder.update
+            logprobs = F.log_softmax(logits.float(), dim=-1)
+            nxt, src, fin = [], [], []
+            for a in range(n_audio):
+                scores, sources, done = {}, {}, {}
+                for j in range(opt.beam_size):
+                    idx = a * opt.beam_size + j
+                    prefix = tokens[idx].tolist()
+                    top = logprobs[idx].topk(opt.beam_size + 1)
+                    for lp, t in zip(top.values.tolist(), top.indices.tolist()):
+                        seq = tuple(prefix + [t])
+                        scores[seq] = float(sum_logprobs[idx]) + lp
+                        sources[seq] = idx
+                saved = 0
+                for seq in sorted(scores, key=scores.get, reverse=True):
+                    if seq[-1] == EOT:
+                        done[seq] = scores[seq]
+                    else:
+                        sum_logprobs_new = scores[seq]
+                        nxt.append(list(seq))
+                        src.append((sources[seq], sum_logprobs_new))
+                        saved += 1
+                        if saved == opt.beam_size:
+                            break
+                fin.append(done)
+            tokens = torch.tensor(nxt, dtype=torch.long)
+            sum_logprobs = torch.tensor([s for _, s in src])
+            for prev, new in zip(finished, fin):
+                for seq in sorted(new, key=new.get, reverse=True):
+                    if len(prev) >= max_candidates:
+                        break
+                    prev[seq] = new[seq]
+            completed = all(len(f) >= max_candidates for f in finished)
+        else:  # GreedyDecoder.update
+            if opt.temperature == 0:
+                nxt = logits.argmax(-1)
+            else:
+                nxt = torch.multinomial(F.softmax(logits.float() / opt.temperature, -1), 1, generator=gen)[:, 0]
+            logprobs = F.log_softmax(logits.float(), dim=-1)
+            cur = logprobs[torch.arange(len(nxt)), nxt]
+            alive = tokens[:, -1] != EOT
+            sum_logprobs = sum_logprobs + cur * alive
+            nxt = torch.where(alive, nxt, torch.full_like(nxt, EOT))
+            tokens = torch.cat([tokens, nxt[:, None]], dim=-1)
+            completed = bool((tokens[:, -1] == EOT).all())
+        if completed or tokens.shape[-1] > dims.n_text_ctx:
+            break
+
+    # finalize + MaximumLikelihoodRanker
+    out = []
+    for a in range(n_audio):
+        if opt.beam_size:
+            f = dict(finished[a])
+            if len(f) < opt.beam_size:  # BeamSearchDecoder.finalize: add the best unfinished beams, closed with eot
+                order = sorted(range(opt.beam_size), key=lambda j: float(sum_logprobs[a * opt.beam_size + j]), reverse=True)
+                for j in order:
+                    f[tuple(tokens[a * opt.beam_size + j].tolist() + [EOT])] = float(sum_logprobs[a * opt.beam_size + j])
+                    if len(f) >= opt.beam_size:
+                        break
+            cands = [(list(seq), lp) for seq, lp in f.items()]
+        else:
+            cands = [(tokens[a * n_group + j].tolist() + [EOT], float(sum_logprobs[a * n_group + j])) for j in range(n_group)]
+        cut = []
+        for seq, lp in cands:
+            body = seq[sample_begin:]
+            cut.append((body[:body.index(EOT)], lp))
+
+        def score(c):
+            length = len(c[0])
+            pen = length if opt.length_penalty is None else ((5 + length) / 6) ** opt.length_penalty
+            return c[1] / pen if pen else -math.inf
+        best = max(cut, key=score)
+        out.append(Result(tokens=best[0], sum_logprob=best[1], avg_logprob=best[1] / (len(best[0]) + 1), no_speech_prob=no_speech[a],
+                          temperature=opt.temperature))
+    return out
+
+
+def transcribe(sd, dims, mel_padded: torch.Tensor, *, temperature=(0.0, 0.2, 0.4, 0.6, 0.8, 1.0), logprob_threshold: Optional[float] = -1.0,
+               no_speech_threshold: Optional[float] = 0.6, clip_timestamps: Sequence[float] = (0.0,), **decode_kw) -> dict:
+    """olmoasr/transcribe.py:147-517 at token level.  ``mel_padded`` = log_mel_spectrogram(audio, padding=N_SAMPLES)
+    [80, content_frames + 3000] (:148).  compression_ratio_threshold / word_timestamps / hallucination_silence_threshold need
+    text and are outside; prompt conditioning is commented out in the reference (:297-302)."""
+    content_frames = mel_padded.shape[-1] - N_FRAMES
+    seek_points = [round(ts * FRAMES_PER_SECOND) for ts in clip_timestamps] or [0]
+    if len(seek_points) % 2 == 1:
+        seek_points.append(content_frames)
+    seek_clips = list(zip(seek_points[::2], seek_points[1::2]))
+    temps = [temperature] if isinstance(temperature, (int, float)) else list(temperature)
+    input_stride, time_precision = 2, 0.02
+
+    def decode_with_fallback(segment):  # :193-233
+        res = None
+        for t in temps:
+            kw = dict(decode_kw)
+            if t > 0:
+                kw.pop("beam_size", None)
+                kw.pop("patience", None)
+            else:
+                kw.pop("best_of", None)
+            res = decode(sd, dims, segment[None], Options(temperature=t, **kw))[0]
+            needs_fallback = logprob_threshold is not None and res.avg_logprob < logprob_threshold
+            if (no_speech_threshold is not None and res.no_speech_prob > no_speech_threshold and logprob_threshold is not None
+                    and res.avg_logprob < logprob_threshold):
+                needs_fallback = False
+            if not needs_fallback:
+                break
+        return res
+
+    all_tokens, all_segments, seeks = [], [], []
+    clip_idx, seek = 0, seek_clips[0][0]
+    while clip_idx < len(seek_clips):
+        clip_start, clip_end = seek_clips[clip_idx]
+        if seek < clip_start:
+            seek = clip_start
+        if seek >= clip_end:
+            clip_idx += 1
+            if clip_idx < len(seek_clips):
+                seek = seek_clips[clip_idx][0]
+            continue
+        seeks.append(seek)
+        time_offset = seek * HOP_LENGTH / SAMPLE_RATE
+        segment_size = min(N_FRAMES, content_frames - seek, clip_end - seek)
+        seg = mel_padded[:, seek:seek + segment_size]
+        segment_duration = segment_size * HOP_LENGTH / SAMPLE_RATE
+        seg = F.pad(seg, (0, N_FRAMES - seg.shape[-1]))  # pad_or_trim: literal zeros (:295)
+        result = decode_with_fallback(seg)
+        tokens = result.tokens
+        if no_speech_threshold is not None:
+            should_skip = result.no_speech_prob > no_speech_threshold
+            if logprob_threshold is not None and result.avg_logprob > logprob_threshold:
+                should_skip = False
+            if should_skip:
+                seek += segment_size
+                continue
+        current = []
+
+        def new_segment(start, end, toks):
+            return {"seek": seek, "start": start, "end": end, "tokens": list(toks), "temperature": result.temperature,
+                    "avg_logprob": result.avg_logprob, "no_speech_prob": result.no_speech_prob}
+        is_ts = [t >= TIMESTAMP_BEGIN for t in tokens]
+        single_timestamp_ending = is_ts[-2:] == [False, True]
+        consecutive = [i + 1 for i in range(len(tokens) - 1) if is_ts[i] and is_ts[i + 1]]
+        if consecutive:
+            slices = list(consecutive)
+            if single_timestamp_ending:
+                slices.append(len(tokens))
+            last_slice = 0
+            for cur in slices:
+                sl = tokens[last_slice:cur]
+                current.append(new_segment(time_offset + (sl[0] - TIMESTAMP_BEGIN) * time_precision,
+                                           time_offset + (sl[-1] - TIMESTAMP_BEGIN) * time_precision, sl))
+                last_slice = cur
+            if single_timestamp_ending:
+                seek += segment_size
+            else:
+                seek += (tokens[last_slice - 1] - TIMESTAMP_BEGIN) * input_stride
+        else:
+            duration = segment_duration
+            stamps = [t for t in tokens if t >= TIMESTAMP_BEGIN]
+            if stamps and stamps[-1] != TIMESTAMP_BEGIN:
+                duration = (stamps[-1] - TIMESTAMP_BEGIN) * time_precision
+            current.append(new_segment(time_offset, time_offset + duration, tokens))
+            seek += segment_size
+        for s in current:  # "instantaneous or does not contain text" (:494-499); text == tokens below eot here
+            if s["start"] == s["end"] or not any(t < EOT for t in s["tokens"]):
+                s["tokens"] = []
+        all_segments.extend({"id": len(all_segments) + i, **s} for i, s in enumerate(current))
+        all_tokens.extend(t for s in current for t in s["tokens"])
+    return {"tokens": all_tokens, "segments": all_segments, "seeks": seeks}
