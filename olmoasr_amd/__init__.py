@@ -18,7 +18,7 @@ def __getattr__(name):
     if name in ("load_model", "gen_inf_ckpt", "MODEL2LINK"):
         from . import hub
         return getattr(hub, name)
-    if name in ("model", "audio", "ddp", "ops", "synth", "decoding", "transcribe", "hub"):
+    if name in ("model", "inf_model", "audio", "ddp", "ops", "synth", "decoding", "transcribe", "hub"):
         import importlib
         return importlib.import_module(f"{__name__}.{name}")
     raise AttributeError(name)

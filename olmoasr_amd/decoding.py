@@ -1,48 +1,42 @@
-"""Greedy decoding on the native engine.
+"""Decoding on the native engine: ``OLMoASR.decode`` (reference binding olmoasr/model.py:966-968, inf_model.py:455-457).
 
-Replaces the greedy subset of ``whisper.decoding.decode`` that the reference binds as ``OLMoASR.decode``
-(olmoasr/model.py:966-968, olmoasr/inf_model.py:455-457) and calls at scripts/training/train_timestamps.py:1916-1919
-(``DecodingOptions(language="en", without_timestamps=True)``, temperature 0) and scripts/eval/eval.py:1846-1847.
+The reference calls ``whisper.decoding.decode`` -- at scripts/training/train_timestamps.py:1916-1919 (greedy,
+``DecodingOptions(language="en", without_timestamps=True)``), scripts/eval/eval.py:1846-1847 and, through
+``decode_with_fallback``, olmoasr/transcribe.py:193-233 (eval.py:2077-2084: beam 5 + temperature fallback).
 ``openai-whisper`` is not vendored by the reference (requirements.txt:21) and its tokenizer (tiktoken) is unavailable
-offline, so the *token-level* behaviour of ``DecodingTask``/``GreedyDecoder`` is restated here and text decoding is left to
-the caller:
+offline, so the TOKEN-level behaviour of its ``DecodingTask`` is restated here (``oracle/decode_oracle.py`` holds an
+independent CPU restatement; tests compare token ids and scores exactly in fp32 validation mode); text decoding, the
+text-based compression ratio and word timestamps are left to the caller.  Parity for this file is "unpinned by the
+reference": it ships no tests or vectors for decoding.
 
-  tokens = initial_tokens (default [sot 50257, notimestamps 50362], the English-only specials the reference's Dataset
-  writes at train_timestamps.py:345-506); repeat up to ``sample_len`` (= n_text_ctx // 2 = 224) times:
-      logits = decoder(tokens, audio_features)[:, -1, :n_vocab]   (the pad class of the training head is never sampled)
-      logits += suppress_mask (SuppressBlank / SuppressTokens as an explicit additive mask; -inf entries)
-      next = argmax(logits); rows that already emitted eot keep emitting eot; stop when every row has.
-  sum_logprobs accumulates log_softmax(logits)[next] of the sampled (non-eot-padding) tokens -> avg_logprob, as whisper.
+  DecodingTask.run:  initial tokens [sot] (+ [notimestamps] when without_timestamps) -- the English-only specials the
+  reference's Dataset writes (train_timestamps.py:345-506); up to sample_len (= n_text_ctx // 2) steps of
+      logits = decoder(tokens, audio_features)[:, -1]          (every row the head has: the training model's pad class too)
+      SuppressBlank (blank " " and eot at the first sampled position), SuppressTokens ("-1" = caller-supplied non-speech
+      symbol ids + transcribe/translate/sot/sot_prev/sot_lm/no_speech), ApplyTimestampRules (unless without_timestamps)
+      GreedyDecoder (argmax, or Categorical(logits / T) with best_of samples) or BeamSearchDecoder (beam_size, patience)
+  then MaximumLikelihoodRanker (sum_logprob / length, or the length_penalty form) and avg_logprob = sum / (len + 1);
+  no_speech_prob = softmax(logits at the sot position)[no_speech].
 
-Beyond greedy, restated from the published algorithm of ``whisper.decoding`` at token level
-(no tokenizer is needed for any of it; text decoding and the text-based compression-ratio test are the caller's):
-  * ``beam_size`` (+ ``patience``): BeamSearchDecoder -- per audio, expand every beam by its top ``beam_size + 1`` tokens,
-    keep the best ``beam_size`` unfinished continuations, collect finished ones until ``round(beam_size * patience)``;
-    unfinished beams are closed with eot at the end; the winner maximises sum_logprob / length (MaximumLikelihoodRanker with
-    length_penalty None).
-  * ``temperature > 0`` (+ ``best_of``): multinomial sampling from softmax(logits / T), ``best_of`` independent samples per
-    audio ranked the same way.
-  * ``without_timestamps=False``: ApplyTimestampRules with the English-only ids the reference's Dataset writes
-    (timestamp_begin 50363 = ``<|0.00|>``, 20 ms per id, train_timestamps.py:236): timestamps come in pairs, are
-    non-decreasing, ``<|notimestamps|>`` is never sampled, the first sampled token is a timestamp no later than
-    ``max_initial_timestamp``, and a timestamp is forced when the timestamp mass beats every text token.
-  * ``no_speech_prob``: softmax probability of ``<|nospeech|>`` (50361) at the sot position.
-
-Two step engines: (default) the KV-cached one -- ``OLMoASR.kv_cache_begin/kv_cache_step`` = the reference's
-``install_kv_cache_hooks`` (model.py:925-964) + a one-token decoder step, cross-attention K/V computed once per window;
-and, for cross-checking, the cache-less one that re-runs the decoder on the whole prefix (the reference-internal pattern
-of notebooks/ow_decoding.py:42-72), computing only the last position's logits.
+Step engines: greedy / sampling run on the engine-owned KV cache (``kv_cache_begin/kv_cache_step`` = the reference's
+``install_kv_cache_hooks`` (model.py:925-964) + a one-token decoder step; the per-step argmax + log-softmax gather with the
+suppress masks is one HIP kernel, ``oasr_pick_tokens``); beam search re-runs the decoder on the whole prefix each step
+(rows are re-gathered between steps), as does ``use_kv_cache=False`` (the pattern of notebooks/ow_decoding.py:42-72).
 """
 from dataclasses import dataclass, field
-from typing import List, Optional, Sequence
+from typing import List, Optional, Sequence, Union
 
 import torch
 
-SOT = 50257
+from . import ops
+
 EOT = 50256
+SOT = 50257
+TRANSLATE, TRANSCRIBE, SOT_LM, SOT_PREV = 50357, 50358, 50359, 50360
 NO_SPEECH = 50361
 NO_TIMESTAMPS = 50362
 TIMESTAMP_BEGIN = 50363  # <|0.00|>; id = TIMESTAMP_BEGIN + ms // 20 (train_timestamps.py:236)
+BLANK = 220              # GPT-2 BPE id of " ": what whisper's SuppressBlank masks (tokenizer.encode(" "))
 
 
 @dataclass(frozen=True)
@@ -51,32 +45,79 @@ class DecodingOptions:
     language: Optional[str] = "en"
     temperature: float = 0.0
     sample_len: Optional[int] = None
-    without_timestamps: bool = True
-    initial_tokens: Optional[Sequence[int]] = None  # default [sot, notimestamps]
-    suppress_mask: Optional[torch.Tensor] = None    # additive [n_vocab] (0 / -inf)
+    best_of: Optional[int] = None
     beam_size: Optional[int] = None
     patience: Optional[float] = None
-    best_of: Optional[int] = None
     length_penalty: Optional[float] = None
+    prompt: Optional[Sequence[int]] = None   # accepted for signature parity; the reference has prompt conditioning commented out
+    prefix: Optional[Sequence[int]] = None
+    suppress_tokens: Optional[Union[str, Sequence[int]]] = "-1"
+    suppress_blank: bool = True
+    without_timestamps: bool = False
     max_initial_timestamp: Optional[float] = 1.0
-    seed: Optional[int] = None  # sampling generator seed (temperature > 0)
     fp16: bool = True
-    use_kv_cache: bool = True  # False: re-run the decoder on the whole prefix every step (ow_decoding.py style)
+    # --- not in whisper: what its tokenizer would have supplied, and engine switches -----------------------------------
+    non_speech_tokens: Sequence[int] = ()            # tokenizer.non_speech_tokens (ids of the symbols "-1" expands to)
+    initial_tokens: Optional[Sequence[int]] = None   # override of the sot sequence
+    suppress_mask: Optional[torch.Tensor] = None     # extra additive mask [rows] (0 / -inf)
+    seed: Optional[int] = None                       # sampling generator seed (temperature > 0)
+    use_kv_cache: bool = True
 
 
 @dataclass
 class DecodingResult:
     audio_features: torch.Tensor
+    language: str = "en"
     tokens: List[int] = field(default_factory=list)
     text: str = ""
     avg_logprob: float = float("nan")
     no_speech_prob: float = float("nan")
-    temperature: float = 0.0
-    language: str = "en"
+    temperature: float = float("nan")
+    compression_ratio: float = float("nan")  # needs text (gzip of the decoded string): not available without the tokenizer
+
+
+def suppress_list(options: DecodingOptions) -> List[int]:
+    """DecodingTask._get_suppress_tokens."""
+    sup = options.suppress_tokens
+    if sup is None:
+        return []
+    if isinstance(sup, str):
+        sup = [int(t) for t in sup.split(",") if t.strip()]
+    sup = list(sup)
+    if -1 in sup:
+        sup = [t for t in sup if t >= 0] + list(options.non_speech_tokens)
+    sup += [TRANSCRIBE, TRANSLATE, SOT, SOT_PREV, SOT_LM, NO_SPEECH]
+    return sorted(set(sup))
+
+
+def _timestamp_rules(logits: torch.Tensor, tokens: torch.Tensor, sample_begin: int, max_initial_index: Optional[int]):
+    """whisper.decoding.ApplyTimestampRules on logits [n, rows], in place."""
+    ninf = -float("inf")
+    logits[:, NO_TIMESTAMPS] = ninf
+    for k, seq in enumerate(tokens[:, sample_begin:].tolist()):
+        last_was_ts = len(seq) >= 1 and seq[-1] >= TIMESTAMP_BEGIN
+        penultimate_was_ts = len(seq) < 2 or seq[-2] >= TIMESTAMP_BEGIN
+        if last_was_ts:
+            if penultimate_was_ts:
+                logits[k, TIMESTAMP_BEGIN:] = ninf   # has to be non-timestamp
+            else:
+                logits[k, :EOT] = ninf               # cannot be normal text tokens
+        ts = [t for t in seq if t >= TIMESTAMP_BEGIN]
+        if ts:  # timestamps shouldn't decrease; also force each segment to have a nonzero length
+            last = ts[-1] if (last_was_ts and not penultimate_was_ts) else ts[-1] + 1
+            logits[k, TIMESTAMP_BEGIN:last] = ninf
+    if tokens.shape[1] == sample_begin:
+        logits[:, :TIMESTAMP_BEGIN] = ninf           # suppress generating non-timestamp tokens at the beginning
+        if max_initial_index is not None:
+            logits[:, TIMESTAMP_BEGIN + max_initial_index + 1:] = ninf
+    logprobs = torch.log_softmax(logits.float(), dim=-1)
+    force = logprobs[:, TIMESTAMP_BEGIN:].logsumexp(dim=-1) > logprobs[:, :TIMESTAMP_BEGIN].max(dim=-1).values
+    logits[force, :TIMESTAMP_BEGIN] = ninf            # timestamp mass beats every text token: sample a timestamp
 
 
 @torch.no_grad()
 def decode(model, mel: torch.Tensor, options: Optional[DecodingOptions] = None, **kwargs):
+    """``mel``: [80, 3000] or [n, 80, 3000] windows (or already-encoded audio features).  Returns DecodingResult / list."""
     if options is None:
         options = DecodingOptions(**kwargs)
     elif kwargs:
@@ -87,99 +128,20 @@ def decode(model, mel: torch.Tensor, options: Optional[DecodingOptions] = None, 
         raise ValueError("best_of with greedy sampling (T=0) is not compatible")
     if options.patience is not None and options.beam_size is None:
         raise ValueError("patience requires beam_size to be given")
-    if options.temperature != 0.0 or options.beam_size or options.best_of or not options.without_timestamps:
-        return _decode_general(model, mel, options)
+    if options.length_penalty is not None and not (0 <= options.length_penalty <= 1):
+        raise ValueError("length_penalty (alpha) should be a value between 0 and 1")
     single = mel.dim() == 2
     if single:
         mel = mel[None]
     dims = model.dims
-    B = mel.shape[0]
-    xa = model.embed_audio(mel) if mel.shape[-2:] == (dims.n_mels, 2 * dims.n_audio_ctx) else mel
-    init = list(options.initial_tokens) if options.initial_tokens is not None else [SOT, NO_TIMESTAMPS]
-    sample_len = options.sample_len or dims.n_text_ctx // 2
-    sample_len = min(sample_len, dims.n_text_ctx - len(init))
-    toks = torch.tensor([init] * B, dtype=torch.int64, device=xa.device)
-    done = torch.zeros(B, dtype=torch.bool, device=xa.device)
-    sum_logprobs = torch.zeros(B, device=xa.device)
-    sup = options.suppress_mask.to(xa.device) if options.suppress_mask is not None else None
-    # no_speech_prob: P(<|nospeech|>) at the sot position (one extra 1-token decoder pass)
-    no_speech = [float("nan")] * B
-    if SOT in init:
-        k = init.index(SOT) + 1
-        p0 = torch.softmax(model.logits(toks[:, :k], xa, last_only=True)[:, :dims.n_vocab].float(), dim=-1)[:, NO_SPEECH]
-        no_speech = p0.tolist()
-    state = None
-    if options.use_kv_cache:
-        state = model.kv_cache_begin(xa)
-        for p in range(len(init) - 1):  # prefill the prompt; the last prompt token is fed by the first loop iteration
-            model.kv_cache_step(state, toks[:, p])
-    for _ in range(sample_len):
-        if state is not None:
-            lg = model.kv_cache_step(state, toks[:, -1])[:, :dims.n_vocab]
-        else:
-            lg = model.logits(toks, xa, last_only=True)[:, :dims.n_vocab]
-        if sup is not None:
-            lg = lg + sup
-        logp = torch.log_softmax(lg.float(), dim=-1)
-        nxt = lg.argmax(-1)
-        cur = logp.gather(1, nxt[:, None])[:, 0]
-        sum_logprobs += torch.where(done, torch.zeros_like(cur), cur)
-        nxt = torch.where(done, torch.full_like(nxt, EOT), nxt)
-        toks = torch.cat([toks, nxt[:, None]], dim=1)
-        done |= nxt == EOT
-        if bool(done.all()):
-            break
-    results = []
-    for b in range(B):
-        row = toks[b, len(init):].tolist()
-        if EOT in row:
-            row = row[:row.index(EOT)]
-        results.append(DecodingResult(audio_features=xa[b], tokens=row, avg_logprob=float(sum_logprobs[b]) / (len(row) + 1),  # whisper: sum / (len(tokens) + 1)
-                                      no_speech_prob=no_speech[b], temperature=0.0))
-    return results[0] if single else results
-
-
-def _timestamp_rules(logits: torch.Tensor, tokens: torch.Tensor, sample_begin: int, n_vocab: int, max_initial_index: Optional[int]):
-    """whisper.decoding.ApplyTimestampRules on additive logits [n, n_vocab], in place."""
-    logits[:, NO_TIMESTAMPS] = -float("inf")
-    for k in range(tokens.shape[0]):
-        seq = tokens[k, sample_begin:].tolist()
-        last_was_ts = len(seq) >= 1 and seq[-1] >= TIMESTAMP_BEGIN
-        penultimate_was_ts = len(seq) < 2 or seq[-2] >= TIMESTAMP_BEGIN
-        if last_was_ts:
-            if penultimate_was_ts:
-                logits[k, TIMESTAMP_BEGIN:] = -float("inf")   # has to be non-timestamp
-            else:
-                logits[k, :EOT] = -float("inf")               # cannot be normal text tokens
-        ts = [t for t in seq if t >= TIMESTAMP_BEGIN]
-        if ts:  # timestamps shouldn't decrease; also force each segment to have a nonzero length
-            last = ts[-1] if (last_was_ts and not penultimate_was_ts) else ts[-1] + 1
-            logits[k, TIMESTAMP_BEGIN:last] = -float("inf")
-    if tokens.shape[1] == sample_begin:
-        logits[:, :TIMESTAMP_BEGIN] = -float("inf")           # suppress generating non-timestamp tokens at the beginning
-        if max_initial_index is not None:
-            logits[:, TIMESTAMP_BEGIN + max_initial_index + 1:] = -float("inf")
-    logprobs = torch.log_softmax(logits.float(), dim=-1)
-    ts_lp = logprobs[:, TIMESTAMP_BEGIN:].logsumexp(dim=-1)
-    max_text = logprobs[:, :TIMESTAMP_BEGIN].max(dim=-1).values
-    force = ts_lp > max_text                                    # timestamp mass beats every text token: sample a timestamp
-    logits[force, :TIMESTAMP_BEGIN] = -float("inf")
-
-
-def _decode_general(model, mel: torch.Tensor, options: DecodingOptions):
-    """Beam search / temperature sampling / timestamp rules (DecodingTask of whisper.decoding at token level).  Runs the
-    cache-less step engine: every beam is a batch row and rows are re-gathered each step."""
-    single = mel.dim() == 2
-    if single:
-        mel = mel[None]
-    dims = model.dims
-    V = dims.n_vocab
+    rows = model._n_rows
     n_audio = mel.shape[0]
     xa = model.embed_audio(mel) if mel.shape[-2:] == (dims.n_mels, 2 * dims.n_audio_ctx) else mel
     dev = xa.device
     init = list(options.initial_tokens) if options.initial_tokens is not None else (
         [SOT, NO_TIMESTAMPS] if options.without_timestamps else [SOT])
     sample_begin = len(init)
+    sot_index = init.index(SOT) if SOT in init else 0
     sample_len = min(options.sample_len or dims.n_text_ctx // 2, dims.n_text_ctx - sample_begin)
     n_group = options.beam_size or options.best_of or 1
     beam = options.beam_size
@@ -188,46 +150,68 @@ def _decode_general(model, mel: torch.Tensor, options: DecodingOptions):
     if options.temperature > 0:
         gen = torch.Generator(device=dev)
         gen.manual_seed(options.seed if options.seed is not None else 0)
-    sup = options.suppress_mask.to(dev) if options.suppress_mask is not None else None
     max_init_idx = None
     if not options.without_timestamps and options.max_initial_timestamp is not None:
         max_init_idx = round(options.max_initial_timestamp / 0.02)
+    # additive masks: every step / first sampled position only
+    base_mask = torch.zeros(rows, device=dev)
+    sup = [t for t in suppress_list(options) if t < rows]
+    if sup:
+        base_mask[sup] = -float("inf")
+    if options.suppress_mask is not None:
+        base_mask[: options.suppress_mask.numel()] += options.suppress_mask.to(dev).float()
+    first_mask = None
+    if options.suppress_blank:
+        first_mask = torch.zeros(rows, device=dev)
+        first_mask[[BLANK, EOT]] = -float("inf")
 
-    xa_g = xa.repeat_interleave(n_group, dim=0)
-    tokens = torch.tensor([init] * (n_audio * n_group), dtype=torch.int64, device=dev)
-    sum_logprobs = torch.zeros(n_audio * n_group, device=dev)
-    no_speech = [float("nan")] * n_audio
+    xa_g = xa.repeat_interleave(n_group, dim=0) if n_group > 1 else xa
+    n = n_audio * n_group
+    tokens = torch.tensor([init] * n, dtype=torch.int64, device=dev)
+    sum_logprobs = torch.zeros(n, device=dev)
     finished = [dict() for _ in range(n_audio)] if beam else None
-
+    cached = options.use_kv_cache and not beam
+    state = None
+    # position sot_index gives no_speech_prob; with the cache it is the logits returned while the prompt is being fed
+    if cached:
+        state = model.kv_cache_begin(xa_g)
+        step_logits = None
+        for p in range(sample_begin):
+            step_logits = model.kv_cache_step(state, tokens[:, p])
+            if p == sot_index:
+                no_speech = torch.softmax(step_logits.float(), dim=-1)[::n_group, NO_SPEECH].tolist()
     for i in range(sample_len):
-        if i == 0:  # no_speech_prob from the sot position of the first forward
-            full = model.logits(tokens, xa_g)  # [n, len(init), V(+1)]
-            sot_index = init.index(SOT) if SOT in init else 0
-            p0 = torch.softmax(full[:, sot_index, :V].float(), dim=-1)[:, NO_SPEECH]
-            no_speech = p0[::n_group].tolist()
-            lg = full[:, -1, :V].float().clone()
+        if cached:
+            lg = step_logits if i == 0 else model.kv_cache_step(state, tokens[:, -1])
+        elif i == 0:
+            full = model.logits(tokens, xa_g)
+            no_speech = torch.softmax(full[:, sot_index].float(), dim=-1)[::n_group, NO_SPEECH].tolist()
+            lg = full[:, -1].contiguous()
         else:
-            lg = model.logits(tokens, xa_g, last_only=True)[:, :V].float().clone()
-        if sup is not None:
-            lg = lg + sup
-        if not options.without_timestamps:
-            _timestamp_rules(lg, tokens, sample_begin, V, max_init_idx)
-        if beam:
+            lg = model.logits(tokens, xa_g, last_only=True)
+        fm = first_mask if i == 0 else None
+        simple = options.without_timestamps and not beam and options.temperature == 0
+        if simple:  # argmax + log-softmax gather + masks in ONE kernel
+            nxt, cur = ops.pick_tokens(lg, base_mask, fm)
+        else:
+            lg = lg.float() + base_mask
+            if fm is not None:
+                lg = lg + fm
+            if not options.without_timestamps:
+                _timestamp_rules(lg, tokens, sample_begin, max_init_idx)
+        if beam:  # BeamSearchDecoder.update
             logprobs = torch.log_softmax(lg, dim=-1)
             top_lp, top_tok = logprobs.topk(beam + 1, dim=-1)
             top_lp, top_tok = top_lp.cpu(), top_tok.cpu()
-            prev_sum = sum_logprobs.cpu()
-            tok_cpu = tokens.cpu()
-            next_tokens, source, new_sum = [], [], []
+            prev_sum, tok_cpu = sum_logprobs.cpu(), tokens.cpu()
+            next_tokens, new_sum = [], []
             for a in range(n_audio):
-                scores, sources, newly = {}, {}, {}
+                scores, newly = {}, {}
                 for j in range(beam):
                     idx = a * beam + j
                     prefix = tok_cpu[idx].tolist()
                     for lp, t in zip(top_lp[idx].tolist(), top_tok[idx].tolist()):
-                        seq = tuple(prefix + [t])
-                        scores[seq] = float(prev_sum[idx]) + lp
-                        sources[seq] = idx
+                        scores[tuple(prefix + [t])] = float(prev_sum[idx]) + lp
                 saved = 0
                 for seq in sorted(scores, key=scores.get, reverse=True):
                     if seq[-1] == EOT:
@@ -235,7 +219,6 @@ def _decode_general(model, mel: torch.Tensor, options: DecodingOptions):
                     else:
                         new_sum.append(scores[seq])
                         next_tokens.append(list(seq))
-                        source.append(sources[seq])
                         saved += 1
                         if saved == beam:
                             break
@@ -246,14 +229,13 @@ def _decode_general(model, mel: torch.Tensor, options: DecodingOptions):
             tokens = torch.tensor(next_tokens, dtype=torch.int64, device=dev)
             sum_logprobs = torch.tensor(new_sum, device=dev)
             completed = all(len(f) >= max_candidates for f in finished)
-        else:
-            if options.temperature == 0:
-                nxt = lg.argmax(-1)
-            else:
-                probs = torch.softmax(lg / options.temperature, dim=-1)
-                nxt = torch.multinomial(probs, 1, generator=gen)[:, 0]
-            logprobs = torch.log_softmax(lg, dim=-1)
-            cur = logprobs.gather(1, nxt[:, None])[:, 0]
+        else:  # GreedyDecoder.update
+            if not simple:
+                if options.temperature == 0:
+                    nxt = lg.argmax(-1)
+                else:
+                    nxt = torch.multinomial(torch.softmax(lg / options.temperature, dim=-1), 1, generator=gen)[:, 0]
+                cur = torch.log_softmax(lg, dim=-1).gather(1, nxt[:, None])[:, 0]
             alive = tokens[:, -1] != EOT
             sum_logprobs = sum_logprobs + cur * alive
             nxt = torch.where(alive, nxt, torch.full_like(nxt, EOT))
@@ -262,42 +244,46 @@ def _decode_general(model, mel: torch.Tensor, options: DecodingOptions):
         if completed or tokens.shape[-1] > dims.n_text_ctx:
             break
 
-    # ---- finalize + rank (MaximumLikelihoodRanker): sum_logprob / length, or Google-NMT penalty when given
-    def rank(cands):  # [(tokens after the prompt incl. eot, sum_logprob)]
+    # ---- finalize + rank (MaximumLikelihoodRanker): sum_logprob / length, or the Google-NMT penalty when given
+    def rank(cands):  # [(tokens between the prompt and eot, sum_logprob)]
         def score(c):
-            length = len(c[0]) - (1 if c[0] and c[0][-1] == EOT else 0)  # whisper ranks on the tokens before eot
+            length = len(c[0])
             pen = length if options.length_penalty is None else ((5 + length) / 6) ** options.length_penalty
-            return c[1] / max(pen, 1e-6) if length else -float("inf")
+            return c[1] / pen if pen else -float("inf")
         return max(cands, key=score)
 
     results = []
     tok_cpu, sums = tokens.cpu(), sum_logprobs.cpu()
     for a in range(n_audio):
-        cands = []
         if beam:
             f = dict(finished[a])
-            if len(f) < beam:  # close the best unfinished beams with eot
-                order = sorted(range(beam), key=lambda j: float(sums[a * beam + j]), reverse=True)
-                for j in order:
+            if len(f) < beam:  # BeamSearchDecoder.finalize: close the best unfinished beams with eot
+                for j in sorted(range(beam), key=lambda j: float(sums[a * beam + j]), reverse=True):
                     f[tuple(tok_cpu[a * beam + j].tolist() + [EOT])] = float(sums[a * beam + j])
                     if len(f) >= beam:
                         break
-            cands = [(list(seq[sample_begin:]), lp) for seq, lp in f.items()]
+            seqs = [(list(seq), lp) for seq, lp in f.items()]
         else:
-            for j in range(n_group):
-                row = tok_cpu[a * n_group + j, sample_begin:].tolist()
-                if EOT in row:
-                    row = row[:row.index(EOT) + 1]
-                cands.append((row, float(sums[a * n_group + j])))
+            seqs = [(tok_cpu[a * n_group + j].tolist() + [EOT], float(sums[a * n_group + j])) for j in range(n_group)]
+        cands = []
+        for seq, lp in seqs:
+            body = seq[sample_begin:]
+            cands.append((body[:body.index(EOT)], lp))
         best, lp = rank(cands)
-        toks = best[:best.index(EOT)] if EOT in best else best
-        results.append(DecodingResult(audio_features=xa[a], tokens=toks, avg_logprob=lp / (len(toks) + 1), no_speech_prob=no_speech[a],
+        results.append(DecodingResult(audio_features=xa[a], tokens=best, avg_logprob=lp / (len(best) + 1), no_speech_prob=no_speech[a],
                                       temperature=options.temperature))
     return results[0] if single else results
 
 
+def detect_language(model, mel: torch.Tensor, tokenizer=None):
+    """whisper.decoding.detect_language as bound at olmoasr/model.py:966: the OLMoASR checkpoints are English-only
+    (n_vocab 51864: no language tokens), for which whisper raises exactly this error."""
+    raise ValueError("This model doesn't have language tokens so it can't perform lang id")
+
+
 def greedy_token_matrix(model, mel: torch.Tensor, max_new: int, initial_tokens=(SOT, NO_TIMESTAMPS)) -> torch.Tensor:
-    """[B, len(initial)+n] token matrix exactly as oracle.model_oracle.greedy_decode produces it (parity tests)."""
+    """[B, len(initial)+n] token matrix exactly as oracle.model_oracle.greedy_decode produces it (plain argmax over the
+    n_vocab classes, no suppression -- the notebooks/ow_decoding.py:42-72 loop; parity tests)."""
     xa = model.embed_audio(mel)
     B = mel.shape[0]
     toks = torch.tensor([list(initial_tokens)] * B, dtype=torch.int64, device=xa.device)

@@ -43,8 +43,55 @@ class _ParamModule(nn.Module):
     """Leaf holder: parameters are attached later as views of the flat arena."""
 
     def forward(self, *a, **k):  # pragma: no cover
-        raise N.NativeError(f"{type(self).__name__}.forward: sub-module calls are not part of the native hot path; "
-                            "call OLMoASR.forward / embed_audio / logits / loss_and_backward")
+        raise N.NativeError(f"{type(self).__name__}.forward: the native engine runs whole stacks -- call model.encoder(mel), "
+                            "model.decoder(tokens, xa[, kv_cache]), OLMoASR.forward / embed_audio / logits / loss_and_backward")
+
+    def _engine(self):
+        owner = self.__dict__.get("_owner")
+        owner = owner() if owner is not None else None
+        if owner is None:
+            raise N.NativeError(f"{type(self).__name__} is not attached to an OLMoASR model")
+        return owner
+
+
+class _EngineKV:
+    """What the engine-owned KV cache looks like from the reference's side of ``install_kv_cache_hooks``: the ONE value of
+    the cache dict.  It quacks like the cached key tensor for the two things callers do with it -- ``.shape[1]`` = positions
+    consumed so far (TextDecoder.forward's ``offset``, olmoasr/model.py:716) and ``tensor[source_indices].detach()`` (whisper's
+    PyTorchInference.rearrange_kv_cache for beam search) -- while the data stay in the engine's layout."""
+
+    def __init__(self, owner, state):
+        self.owner, self.state = owner, state
+
+    @property
+    def shape(self):
+        return (self.state["B"], self.state["pos"], self.owner.dims.n_text_state)
+
+    def detach(self):
+        return self
+
+    def __getitem__(self, idx):
+        m = self.owner
+        idx = torch.as_tensor(idx, device=self.state["cache"].device, dtype=torch.long).reshape(-1)
+        B, L, d = self.state["B"], m.dims.n_text_layer, m.dims.n_text_state
+        n_self, n_cross = 3 * B * m.dims.n_text_ctx * d, B * m.dims.n_audio_ctx * 2 * d
+        esz = 4 if m._act_dtype == torch.float32 else 2
+        flat = self.state["cache"][: (n_self + n_cross) * L * esz].view(m._act_dtype).view(L, n_self + n_cross)
+        parts = [flat[:, :n_self].view(L, B, -1).index_select(1, idx).reshape(L, -1),
+                 flat[:, n_self:].view(L, B, -1).index_select(1, idx).reshape(L, -1)]
+        Bn = idx.numel()
+        lib = N.lib()
+        cache = torch.empty(lib.oasr_kv_cache_bytes(m._ctx, Bn), dtype=torch.uint8, device=flat.device)
+        cache[: (n_self + n_cross) // B * Bn * L * esz].view(m._act_dtype).copy_(torch.cat(parts, 1).reshape(-1))
+        ws = torch.empty(lib.oasr_decode_step_workspace_bytes(m._ctx, Bn), dtype=torch.uint8, device=flat.device)
+        return _EngineKV(m, {"cache": cache, "ws": ws, "B": Bn, "pos": self.state["pos"]})
+
+
+class _HookHandle:
+    """RemovableHandle stand-in returned by install_kv_cache_hooks (there are no module hooks to remove)."""
+
+    def remove(self):
+        pass
 
 
 class LayerNorm(_ParamModule):
@@ -112,6 +159,10 @@ class AudioEncoder(_ParamModule):
         self.blocks = nn.ModuleList([ResidualAttentionBlock(n_state, n_head) for _ in range(n_layer)])
         self.ln_post = LayerNorm(n_state)
 
+    def forward(self, x: Tensor, verbose: bool = False):
+        """AudioEncoder.forward (olmoasr/model.py:571-623): mel [B, n_mels, 3000] -> [B, n_audio_ctx, n_state]."""
+        return self._engine().embed_audio(x)
+
 
 class TextDecoder(_ParamModule):
     def __init__(self, n_vocab: int, n_ctx: int, n_state: int, n_head: int, n_layer: int, pad_row: bool = True):
@@ -119,6 +170,24 @@ class TextDecoder(_ParamModule):
         self.token_embedding = Embedding(n_vocab + (1 if pad_row else 0), n_state, padding_idx=51864 if n_vocab == 51864 else 51865)
         self.blocks = nn.ModuleList([ResidualAttentionBlock(n_state, n_head, cross_attention=True) for _ in range(n_layer)])
         self.ln = LayerNorm(n_state)
+
+    def forward(self, x: Tensor, xa: Tensor, kv_cache: Optional[dict] = None, padding_mask: Optional[Tensor] = None,
+                verbose: bool = False):
+        """TextDecoder.forward (olmoasr/model.py:688-775): fp32 logits [B, n_tokens, rows].  ``kv_cache`` is the dict of
+        ``install_kv_cache_hooks``: empty on the first call (all prompt tokens are consumed), afterwards only the new
+        tokens are passed (whisper's PyTorchInference.logits feeds ``tokens[:, -1:]``)."""
+        m = self._engine()
+        if kv_cache is None:
+            return m.logits(x, xa, padding_mask)
+        entry = next(iter(kv_cache.values()), None)
+        if entry is None:
+            entry = _EngineKV(m, m.kv_cache_begin(xa))
+            kv_cache[self] = entry
+        elif not isinstance(entry, _EngineKV):
+            raise N.NativeError("kv_cache must be the dict returned by install_kv_cache_hooks() of this model")
+        if entry.state["B"] != x.shape[0]:
+            raise N.NativeError(f"kv_cache holds {entry.state['B']} sequences, got {x.shape[0]}")
+        return torch.stack([m.kv_cache_step(entry.state, x[:, p]) for p in range(x.shape[1])], dim=1)
 
 
 def _reference_init_(name: str, t: Tensor, gen: Optional[torch.Generator]):
@@ -208,6 +277,9 @@ class OLMoASR(nn.Module):
         self._gflat = None
         self._shadow = torch.zeros(lib.oasr_shadow_bytes(self._ctx), dtype=torch.uint8, device=device)
         self._workspace = None
+        import weakref
+        for sub in (self.encoder, self.decoder):  # stack-level forward()s call back into the engine (no module cycle)
+            sub.__dict__["_owner"] = weakref.ref(self)
         self._attach_views()
         self.to(device)  # moves the sinusoid buffer; parameters are already there (see _apply)
         self._bind()
@@ -245,6 +317,10 @@ class OLMoASR(nn.Module):
             self._gflat = fn(self._gflat).contiguous()
         self._shadow = self._shadow.to(self._flat.device)
         self._workspace = None
+        if getattr(self, "_opt_state", None) is not None:  # optimizer arenas follow the parameters
+            self._opt_state = tuple(fn(t).contiguous() for t in self._opt_state)
+            self._opt_stats = self._opt_stats.to(self._flat.device)
+            self._opt_scratch = self._opt_scratch.to(self._flat.device)
         for m in self.modules():  # buffers only
             for k, b in m._buffers.items():
                 if b is not None:
@@ -398,8 +474,24 @@ class OLMoASR(nn.Module):
         state["pos"] += 1
         return out
 
-    def install_kv_cache_hooks(self, cache=None):
-        raise N.NativeError("the native engine owns the KV cache: use kv_cache_begin()/kv_cache_step() (or decode(), which does)")
+    def install_kv_cache_hooks(self, cache: Optional[dict] = None):
+        """olmoasr/model.py:925-964.  The reference hooks every key/value Linear and keeps their outputs in a dict; here the
+        engine owns ONE cache buffer (self-attention K/V rows per position, cross-attention K/V once per window), so the
+        returned dict starts empty and receives a single entry (an ``_EngineKV``) on the first
+        ``model.decoder(tokens, xa, kv_cache=cache)`` call.  Usage is the reference's / whisper's:
+
+            cache, hooks = model.install_kv_cache_hooks()
+            logits = model.decoder(prompt_tokens, xa, kv_cache=cache)      # first pass: the whole prompt
+            logits = model.decoder(tokens[:, -1:], xa, kv_cache=cache)     # then one token at a time
+            for h in hooks: h.remove()
+        """
+        cache = {**cache} if cache is not None else {}
+        return cache, [_HookHandle()]
+
+    def detect_language(self, mel: Tensor, tokenizer=None):
+        """whisper.decoding.detect_language as bound at olmoasr/model.py:966."""
+        from .decoding import detect_language as _detect
+        return _detect(self, mel, tokenizer)
 
     @torch.no_grad()
     def decode(self, mel: Tensor, options=None, **kwargs):

@@ -1,68 +1,171 @@
-"""Long-form transcription driver on the native engine (greedy subset).
+"""Long-form transcription driver on the native engine: ``OLMoASR.transcribe`` (reference olmoasr/transcribe.py:47-523).
 
-Mirrors the control flow of the reference's ``olmoasr/transcribe.py::transcribe`` (:47-523) for the configuration
-BASELINE.json names (config 5: greedy, temperature 0): the whole waveform is converted to log-mel once with
-``padding=N_SAMPLES`` (:148), then 30 s windows ``mel[:, seek:seek+3000]`` are padded/trimmed to 3000 frames (:293-295)
-and decoded WITHOUT conditioning on previous text (the reference has prompt conditioning commented out, :297-302).
-Without timestamp tokens the seek advances by a full window (:404-408, the no-timestamp branch).  ``temperature`` may be a
-tuple: ``decode_with_fallback`` (:193-233) retries a window at the next temperature while its ``avg_logprob`` is below
-``logprob_threshold`` (beam options apply at temperature 0 only, ``best_of`` above it), and keeps a silent window
-(``no_speech_prob > no_speech_threshold`` with a low ``avg_logprob``) out of the token stream (:305-320).  The
-compression-ratio test and word timestamps need text, i.e. the tokenizer of the un-vendored openai-whisper, and are out of
-scope; results carry token ids, not text.
+Same signature, defaults and control flow as the reference at TOKEN level (no tokenizer offline, so ``text`` is None and
+the text-based tests -- ``compression_ratio_threshold``, ``word_timestamps``, ``hallucination_silence_threshold``,
+``initial_prompt`` -- are accepted and ignored with a warning):
+
+  * whole-file log-mel once with ``padding=N_SAMPLES`` (:148), ``content_frames = n_frames - 3000`` (:149)
+  * ``clip_timestamps`` -> seek clips (:177-186); window = ``mel[:, seek : seek + segment_size]`` with
+    ``segment_size = min(3000, content_frames - seek, clip_end - seek)``, zero-padded to 3000 frames (:292-295) -- the
+    padding is literal 0.0, not the log-mel silence floor
+  * ``decode_with_fallback`` (:193-233): temperatures in turn while ``avg_logprob < logprob_threshold`` (beam options at
+    temperature 0 only, ``best_of`` above it); a window whose ``no_speech_prob > no_speech_threshold`` and low logprob is
+    silence, not a failure
+  * no-speech skip (:305-320), then the TIMESTAMP-DRIVEN SEEK (:348-408): consecutive timestamp-token pairs cut the window
+    into segments and ``seek`` moves to the last closed timestamp (or by the whole window when the output ends on a single
+    timestamp / has no pairs); segments that are instantaneous or hold no text tokens are cleared (:494-499)
+  * prompt conditioning is commented out in the reference (:297-302) and absent here.
+
+With ``without_timestamps=True`` the seek always advances by a full window, so windows are independent and are decoded
+``batch_windows`` at a time (an MI355X-side batching the reference's one-window loop cannot do); with timestamps the loop is
+sequential, as in the reference.
 """
-from typing import Optional
+import warnings
+from typing import List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 import torch
 
-from .audio import HOP_LENGTH, N_FRAMES, N_SAMPLES, SAMPLE_RATE, log_mel_spectrogram, pad_or_trim
-from .decoding import DecodingOptions, decode
+from .audio import FRAMES_PER_SECOND, HOP_LENGTH, N_FRAMES, N_SAMPLES, SAMPLE_RATE, log_mel_spectrogram, pad_or_trim
+from .decoding import EOT, TIMESTAMP_BEGIN, DecodingOptions, DecodingResult, decode
 
 
 @torch.no_grad()
-def transcribe(model, audio, *, verbose: Optional[bool] = None, temperature=0.0, batch_windows: int = 16,
-               no_speech_threshold: Optional[float] = None, logprob_threshold: Optional[float] = -1.0, **decode_options):
-    temperatures = tuple(temperature) if isinstance(temperature, (tuple, list)) else (float(temperature),)
+def transcribe(model, audio, *, verbose: Optional[bool] = None,
+               temperature: Union[float, Tuple[float, ...]] = (0.0, 0.2, 0.4, 0.6, 0.8, 1.0),
+               compression_ratio_threshold: Optional[float] = 2.4, logprob_threshold: Optional[float] = -1.0,
+               no_speech_threshold: Optional[float] = 0.6, condition_on_previous_text: bool = True,
+               initial_prompt: Optional[str] = None, carry_initial_prompt: bool = False, word_timestamps: bool = False,
+               prepend_punctuations: str = "", append_punctuations: str = "", clip_timestamps: Union[str, Sequence[float]] = "0",
+               hallucination_silence_threshold: Optional[float] = None, batch_windows: int = 16, **decode_options):
     if isinstance(audio, str):
         raise NotImplementedError("audio file decoding (ffmpeg) is out of scope: pass a waveform array/tensor")
+    if word_timestamps or initial_prompt is not None or hallucination_silence_threshold is not None:
+        warnings.warn("word_timestamps / initial_prompt / hallucination_silence_threshold need the tokenizer's text and are ignored")
     if not torch.is_tensor(audio):
         audio = torch.from_numpy(np.ascontiguousarray(audio))
-    mel = log_mel_spectrogram(audio, model.dims.n_mels, padding=N_SAMPLES, device=model.device)  # [80, n_frames + 3000]
+    mel = log_mel_spectrogram(audio, model.dims.n_mels, padding=N_SAMPLES, device=model.device)  # [80, content + 3000]
     content_frames = mel.shape[-1] - N_FRAMES
-    options = DecodingOptions(**{"without_timestamps": True, **decode_options})
-    seeks = list(range(0, content_frames, N_FRAMES))
-    all_tokens, segments = [], []
-    for i in range(0, len(seeks), batch_windows):
-        chunk = seeks[i:i + batch_windows]
-        windows = torch.stack([pad_or_trim(mel[:, s:s + N_FRAMES], N_FRAMES) for s in chunk])  # windows are independent here
-        results = [None] * len(chunk)
-        todo = list(range(len(chunk)))
-        for t in temperatures:  # decode_with_fallback, per window, batched over the windows still failing
-            kw = dict(options.__dict__, temperature=t)
+    if decode_options.get("language", None) is None:
+        decode_options["language"] = "en"  # not model.is_multilingual (:152-154)
+    if isinstance(clip_timestamps, str):
+        clip_timestamps = [float(ts) for ts in (clip_timestamps.split(",") if clip_timestamps else [])]
+    seek_points: List[int] = [round(ts * FRAMES_PER_SECOND) for ts in clip_timestamps]
+    if len(seek_points) == 0:
+        seek_points.append(0)
+    if len(seek_points) % 2 == 1:
+        seek_points.append(content_frames)
+    seek_clips = list(zip(seek_points[::2], seek_points[1::2]))
+    temperatures = [temperature] if isinstance(temperature, (int, float)) else list(temperature)
+    input_stride = N_FRAMES // model.dims.n_audio_ctx          # mel frames per output token: 2
+    time_precision = input_stride * HOP_LENGTH / SAMPLE_RATE   # 0.02 s
+
+    def decode_with_fallback(segments: torch.Tensor) -> List[DecodingResult]:
+        """:193-233 for a batch of windows: each temperature is tried on the windows still failing."""
+        results: List[Optional[DecodingResult]] = [None] * segments.shape[0]
+        todo = list(range(segments.shape[0]))
+        for t in temperatures:
+            kwargs = {**decode_options}
             if t > 0:
-                kw.update(beam_size=None, patience=None)   # disable beam_size and patience when t > 0
+                kwargs.pop("beam_size", None)   # disable beam_size and patience when t > 0
+                kwargs.pop("patience", None)
             else:
-                kw.update(best_of=None)                    # disable best_of when t == 0
-            out = decode(model, windows[todo], DecodingOptions(**kw))
+                kwargs.pop("best_of", None)     # disable best_of when t == 0
+            out = decode(model, segments[todo], DecodingOptions(**kwargs, temperature=t))
             still = []
             for j, r in zip(todo, out):
                 results[j] = r
                 needs_fallback = logprob_threshold is not None and r.avg_logprob < logprob_threshold
-                if no_speech_threshold is not None and r.no_speech_prob == r.no_speech_prob and r.no_speech_prob > no_speech_threshold:
-                    needs_fallback = False                 # silence
+                if (no_speech_threshold is not None and r.no_speech_prob > no_speech_threshold and logprob_threshold is not None
+                        and r.avg_logprob < logprob_threshold):
+                    needs_fallback = False      # silence
                 if needs_fallback:
                     still.append(j)
             todo = still
             if not todo:
                 break
-        for s, r in zip(chunk, results):
-            t0 = s * HOP_LENGTH / SAMPLE_RATE
-            t1 = min(s + N_FRAMES, content_frames) * HOP_LENGTH / SAMPLE_RATE
-            silent = (no_speech_threshold is not None and r.no_speech_prob == r.no_speech_prob and r.no_speech_prob > no_speech_threshold
-                      and not (logprob_threshold is not None and r.avg_logprob > logprob_threshold))
-            toks = [] if silent else r.tokens
-            segments.append({"id": len(segments), "seek": s, "start": t0, "end": t1, "tokens": toks, "temperature": r.temperature,
-                             "avg_logprob": r.avg_logprob, "no_speech_prob": r.no_speech_prob})
-            all_tokens.extend(toks)
-    return {"tokens": all_tokens, "segments": segments, "language": "en", "text": None}
+        return results
+
+    def window(seek: int, clip_end: int):
+        segment_size = min(N_FRAMES, content_frames - seek, clip_end - seek)
+        return pad_or_trim(mel[:, seek:seek + segment_size], N_FRAMES), segment_size
+
+    all_tokens: List[int] = []
+    all_segments: List[dict] = []
+    independent = bool(decode_options.get("without_timestamps", False))
+    clip_idx = 0
+    seek = seek_clips[clip_idx][0]
+    pending: List[Tuple[int, int, DecodingResult]] = []  # (seek, segment_size, result) decoded ahead (independent windows only)
+    while clip_idx < len(seek_clips):
+        seek_clip_start, seek_clip_end = seek_clips[clip_idx]
+        if seek < seek_clip_start:
+            seek = seek_clip_start
+        if seek >= seek_clip_end:
+            clip_idx += 1
+            if clip_idx < len(seek_clips):
+                seek = seek_clips[clip_idx][0]
+            continue
+        if pending and pending[0][0] == seek:
+            _, segment_size, result = pending.pop(0)
+        else:
+            pending = []
+            ahead = [seek]
+            if independent:  # without timestamps every window advances by segment_size: decode a batch of them at once
+                while len(ahead) < batch_windows and ahead[-1] + N_FRAMES < seek_clip_end and ahead[-1] + N_FRAMES < content_frames:
+                    ahead.append(ahead[-1] + N_FRAMES)
+            wins = [window(s, seek_clip_end) for s in ahead]
+            res = decode_with_fallback(torch.stack([w for w, _ in wins]))
+            pending = [(s, sz, r) for s, (_, sz), r in zip(ahead, wins, res)]
+            _, segment_size, result = pending.pop(0)
+        time_offset = float(seek * HOP_LENGTH / SAMPLE_RATE)
+        segment_duration = segment_size * HOP_LENGTH / SAMPLE_RATE
+        tokens = list(result.tokens)
+
+        if no_speech_threshold is not None:  # no voice activity check (:305-320)
+            should_skip = result.no_speech_prob > no_speech_threshold
+            if logprob_threshold is not None and result.avg_logprob > logprob_threshold:
+                should_skip = False          # don't skip if the logprob is high enough, despite the no_speech_prob
+            if should_skip:
+                seek += segment_size         # fast-forward to the next segment boundary
+                continue
+
+        current_segments: List[dict] = []
+
+        def new_segment(*, start: float, end: float, toks: List[int]):
+            return {"seek": seek, "start": start, "end": end, "text": None, "tokens": list(toks), "temperature": result.temperature,
+                    "avg_logprob": result.avg_logprob, "compression_ratio": result.compression_ratio,
+                    "no_speech_prob": result.no_speech_prob}
+
+        is_ts = [t >= TIMESTAMP_BEGIN for t in tokens]
+        single_timestamp_ending = is_ts[-2:] == [False, True]
+        consecutive = [i + 1 for i in range(len(tokens) - 1) if is_ts[i] and is_ts[i + 1]]
+        if len(consecutive) > 0:  # the output contains two consecutive timestamp tokens
+            slices = list(consecutive)
+            if single_timestamp_ending:
+                slices.append(len(tokens))
+            last_slice = 0
+            for current_slice in slices:
+                sliced = tokens[last_slice:current_slice]
+                current_segments.append(new_segment(start=time_offset + (sliced[0] - TIMESTAMP_BEGIN) * time_precision,
+                                                    end=time_offset + (sliced[-1] - TIMESTAMP_BEGIN) * time_precision, toks=sliced))
+                last_slice = current_slice
+            if single_timestamp_ending:
+                seek += segment_size  # single timestamp at the end means no speech after the last timestamp
+            else:                     # otherwise, ignore the unfinished segment and seek to the last timestamp
+                seek += (tokens[last_slice - 1] - TIMESTAMP_BEGIN) * input_stride
+        else:
+            duration = segment_duration
+            stamps = [t for t in tokens if t >= TIMESTAMP_BEGIN]
+            if len(stamps) > 0 and stamps[-1] != TIMESTAMP_BEGIN:
+                duration = (stamps[-1] - TIMESTAMP_BEGIN) * time_precision  # no consecutive timestamps but it has one: use the last
+            current_segments.append(new_segment(start=time_offset, end=time_offset + duration, toks=tokens))
+            seek += segment_size
+
+        # if a segment is instantaneous or does not contain text, clear it (text == token ids below eot here)
+        for seg in current_segments:
+            if seg["start"] == seg["end"] or not any(t < EOT for t in seg["tokens"]):
+                seg["tokens"] = []
+        all_segments.extend({"id": i, **seg} for i, seg in enumerate(current_segments, start=len(all_segments)))
+        all_tokens.extend(t for seg in current_segments for t in seg["tokens"])
+
+    return {"text": None, "tokens": all_tokens, "segments": all_segments, "language": decode_options["language"]}

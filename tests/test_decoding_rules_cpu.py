@@ -11,7 +11,7 @@ NEG = -float("inf")
 def _rules(prefix, logits=None, sample_begin=1, max_initial_index=50):
     toks = torch.tensor([prefix], dtype=torch.int64)
     lg = torch.zeros(1, V) if logits is None else logits.clone()
-    _timestamp_rules(lg, toks, sample_begin, V, max_initial_index)
+    _timestamp_rules(lg, toks, sample_begin, max_initial_index)
     return lg[0]
 
 
@@ -51,3 +51,31 @@ def test_timestamp_mass_forces_a_timestamp():
     lg[0, t + 30:t + 40] = -8.0  # now their mass does not beat the text token
     out = _rules([SOT, t + 10, 100], lg)
     assert torch.isfinite(out[100])
+
+
+def test_product_rules_equal_the_oracle_restatement_on_random_states():
+    """olmoasr_amd.decoding._timestamp_rules (vectorised) against oracle.decode_oracle.apply_timestamp_rules (row by row)
+    on random logits and random well-formed / ill-formed prefixes: identical masks, bit-identical surviving logits."""
+    from oracle import decode_oracle as do
+    g = torch.Generator().manual_seed(0)
+    t = TIMESTAMP_BEGIN
+    prefixes = [[SOT], [SOT, t + 3], [SOT, t + 3, 11, 12], [SOT, t + 3, 11, t + 40], [SOT, t + 3, 11, t + 40, t + 40],
+                [SOT, t + 3, 11, t + 40, t + 40, 99], [SOT, 5, 6, 7], [SOT, t, t], [SOT, t + 1499]]
+    for pre in prefixes:
+        for scale in (0.5, 4.0):
+            lg = torch.randn(3, V, generator=g) * scale
+            lg[1, t:] += 6.0  # one row where the timestamp mass wins
+            toks = torch.tensor([pre] * 3, dtype=torch.int64)
+            a, b = lg.clone(), lg.clone()
+            _timestamp_rules(a, toks, 1, 50)
+            do.apply_timestamp_rules(b, toks, 1, 50)
+            assert torch.equal(a, b), pre
+
+
+def test_suppress_lists_agree():
+    from olmoasr_amd.decoding import DecodingOptions, suppress_list
+    from oracle import decode_oracle as do
+    assert suppress_list(DecodingOptions()) == do.suppress_list(do.Options()) == [50257, 50357, 50358, 50359, 50360, 50361]
+    assert suppress_list(DecodingOptions(suppress_tokens="-1,7", non_speech_tokens=(1, 2))) == \
+        do.suppress_list(do.Options(suppress_tokens=(-1, 7), non_speech_tokens=(1, 2))) == [1, 2, 7, 50257, 50357, 50358, 50359, 50360, 50361]
+    assert suppress_list(DecodingOptions(suppress_tokens=None)) == []

@@ -132,7 +132,7 @@ def test_fp32_kv_cached_decode_vs_oracle(tiny_case):
         assert err <= 1e-3, (p, err)
     # greedy loop: cached native vs cache-less oracle, every position (fp32 both sides: no margin gating needed unless a tie)
     want = mo.greedy_decode(sd, dims, mel_cpu, [50257, 50362], max_new=8)
-    res = decode(net, mel, DecodingOptions(sample_len=8, use_kv_cache=True))
+    res = decode(net, mel, DecodingOptions(sample_len=8, use_kv_cache=True, without_timestamps=True, suppress_tokens=None, suppress_blank=False))
     for b, r in enumerate(res):
         got = r.tokens
         exp = [t for t in want[b, 2:].tolist()]

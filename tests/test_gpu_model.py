@@ -346,16 +346,16 @@ def test_inference_model_decode_and_transcribe(tmp_path, tiny_case):
             if float(top2[0] - top2[1]) > 0.15:
                 assert int(toks[b, t]) == int(ref[b, t])
                 agree += 1
-    res = net.decode(mel)
+    res = net.decode(mel, sample_len=8)
     assert len(res) == 2 and all(isinstance(r.tokens, list) for r in res) and all(r.avg_logprob <= 0 for r in res)
     # long-form driver: 70 s of audio -> 3 windows of 30 s, every window decoded, seek advances by 3000 frames
     pcm = torch.cat([mo.synthetic_sample(200 + i)[0] for i in range(3)])[: 70 * 16000]
-    out = net.transcribe(pcm, sample_len=3)
+    out = net.transcribe(pcm, sample_len=3, without_timestamps=True, temperature=0.0, logprob_threshold=None)
     assert [s["seek"] for s in out["segments"]] == [0, 3000, 6000] and out["segments"][-1]["end"] == 70.0
     assert len(out["tokens"]) == sum(len(s["tokens"]) for s in out["segments"])
     # window 0 of the long file == decoding the first 30 s alone
     mel0 = olmoasr_amd.log_mel_spectrogram(pcm[:480000])
-    r0 = net.decode(mel0, sample_len=3)
+    r0 = net.decode(mel0, sample_len=3, without_timestamps=True)
     print("greedy positions checked:", agree, "window0", out["segments"][0]["tokens"], r0.tokens)
 
 
@@ -376,8 +376,8 @@ def test_kv_cached_decode_matches_cacheless(tiny_case):
         step = net.kv_cache_step(st, toks[:, p])
         err = float((step - full[:, p]).abs().max())
         assert err < 0.08, (p, err)  # same bf16 math, different tile shapes / accumulation order
-    r_c = decode(net, mel, DecodingOptions(sample_len=5, use_kv_cache=True))
-    r_n = decode(net, mel, DecodingOptions(sample_len=5, use_kv_cache=False))
+    r_c = decode(net, mel, DecodingOptions(sample_len=5, use_kv_cache=True, without_timestamps=True))
+    r_n = decode(net, mel, DecodingOptions(sample_len=5, use_kv_cache=False, without_timestamps=True))
     for a, b in zip(r_c, r_n):
         assert abs(a.avg_logprob - b.avg_logprob) < 0.05
 
@@ -451,15 +451,15 @@ def test_beam_search_sampling_and_timestamp_rules(tiny_case):
     dims = mo.Dims(80, 1500, 384, 6, 2, 51864, 448, 384, 6, 2)
     net = OLMoASR(_dims(dims), device=DEV, seed=5, inference=True)
     mel = tiny_case["mel"].to(DEV)
-    greedy = decode(net, mel, DecodingOptions(sample_len=6, use_kv_cache=False))
-    beam1 = decode(net, mel, DecodingOptions(sample_len=6, beam_size=1))
-    beam4 = decode(net, mel, DecodingOptions(sample_len=6, beam_size=4, patience=1.0))
+    greedy = decode(net, mel, DecodingOptions(sample_len=6, use_kv_cache=False, without_timestamps=True))
+    beam1 = decode(net, mel, DecodingOptions(sample_len=6, beam_size=1, without_timestamps=True))
+    beam4 = decode(net, mel, DecodingOptions(sample_len=6, beam_size=4, patience=1.0, without_timestamps=True))
     for g, b1, b4 in zip(greedy, beam1, beam4):
         assert b1.tokens == g.tokens and abs(b1.avg_logprob - g.avg_logprob) < 2e-2
         assert b4.avg_logprob >= b1.avg_logprob - 2e-2  # the greedy path is one of the beam's candidates
         assert 0.0 <= g.no_speech_prob <= 1.0 and abs(g.no_speech_prob - b1.no_speech_prob) < 1e-3
-    s1 = decode(net, mel, DecodingOptions(sample_len=6, temperature=0.7, best_of=3, seed=11))
-    s2 = decode(net, mel, DecodingOptions(sample_len=6, temperature=0.7, best_of=3, seed=11))
+    s1 = decode(net, mel, DecodingOptions(sample_len=6, temperature=0.7, best_of=3, seed=11, without_timestamps=True))
+    s2 = decode(net, mel, DecodingOptions(sample_len=6, temperature=0.7, best_of=3, seed=11, without_timestamps=True))
     assert [r.tokens for r in s1] == [r.tokens for r in s2] and all(r.temperature == 0.7 for r in s1)
     ts = decode(net, mel, DecodingOptions(sample_len=8, without_timestamps=False))
     for r in ts:
@@ -471,7 +471,7 @@ def test_beam_search_sampling_and_timestamp_rules(tiny_case):
             assert not (toks[i] >= TIMESTAMP_BEGIN and toks[i + 1] >= TIMESTAMP_BEGIN and toks[i + 2] >= TIMESTAMP_BEGIN)
     # transcribe(): a random-init model is far below logprob_threshold -1.0, so every window walks all temperatures
     audio = tiny_case["pcm"][0].float() / 32768.0
-    out = net.transcribe(audio, temperature=(0.0, 0.4), sample_len=4, logprob_threshold=-1.0, best_of=2)
+    out = net.transcribe(audio, temperature=(0.0, 0.4), sample_len=4, logprob_threshold=-1.0, best_of=2, without_timestamps=True)
     assert len(out["segments"]) == 1 and out["segments"][0]["temperature"] == 0.4 and len(out["segments"][0]["tokens"]) <= 4
-    out0 = net.transcribe(audio, temperature=(0.0, 0.4), sample_len=4, logprob_threshold=None)
+    out0 = net.transcribe(audio, temperature=(0.0, 0.4), sample_len=4, logprob_threshold=None, without_timestamps=True)
     assert out0["segments"][0]["temperature"] == 0.0
