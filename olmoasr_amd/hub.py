@@ -21,12 +21,46 @@ MODEL2LINK = {  # olmoasr/__init__.py:23-30
 }
 
 
+def dims_of(obj) -> ModelDimensions:
+    """``ckpt["dims"]`` in any of its forms: a dict (inference checkpoints, gen_inf_ckpt.py), the reference's dataclass
+    instance, or the SimpleNamespace this implementation writes (scripts/training/train_timestamps.py::build_checkpoint)."""
+    fields = obj if isinstance(obj, dict) else obj.__dict__
+    return ModelDimensions(**{k: int(fields[k]) for k in ModelDimensions.__dataclass_fields__})
+
+
+def load_checkpoint(path, map_location="cpu") -> dict:
+    """``torch.load`` of a checkpoint written by either side.  The reference pickles ``dims`` as an instance of
+    ``olmoasr.config.model_dims.ModelDimensions`` (train_timestamps.py:944): when the reference package is not importable,
+    that module path is aliased to this package's identical dataclass for the duration of the load."""
+    import importlib
+    import sys
+    import types
+    names = ("olmoasr", "olmoasr.config", "olmoasr.config.model_dims")
+    added = []
+    try:
+        try:
+            importlib.import_module("olmoasr.config.model_dims")
+        except Exception:
+            from .config import model_dims as md
+            for nm in names:
+                if nm not in sys.modules:
+                    m = types.ModuleType(nm)
+                    m.__path__ = []
+                    sys.modules[nm] = m
+                    added.append(nm)
+            sys.modules["olmoasr.config.model_dims"].ModelDimensions = md.ModelDimensions
+        return torch.load(path, map_location=map_location, weights_only=False)
+    finally:
+        for nm in added:
+            sys.modules.pop(nm, None)
+
+
 def gen_inf_ckpt(checkpoint: dict) -> dict:
-    """Training checkpoint -> inference checkpoint: strip the pad row of the token embedding, dict-ify dims."""
+    """Training checkpoint -> inference checkpoint (scripts/eval/gen_inf_ckpt.py:4-11): strip the pad row of the token
+    embedding, dict-ify dims."""
     sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in checkpoint["model_state_dict"].items()}
     sd["decoder.token_embedding.weight"] = sd["decoder.token_embedding.weight"][:-1, :]
-    dims = checkpoint["dims"]
-    return {"model_state_dict": sd, "dims": dims if isinstance(dims, dict) else dims.__dict__}
+    return {"model_state_dict": sd, "dims": dict(dims_of(checkpoint["dims"]).__dict__)}
 
 
 def load_model(name: str, device: Optional[Union[str, torch.device]] = None, download_root: Optional[str] = None,
@@ -43,9 +77,8 @@ def load_model(name: str, device: Optional[Union[str, torch.device]] = None, dow
         path = Path(name)
     else:
         raise RuntimeError(f"Model {name} not found; available models = {list(MODEL2LINK)}")
-    checkpoint = torch.load(path, map_location="cpu", weights_only=False)
-    dims = checkpoint["dims"]
-    dims = ModelDimensions(**dims) if isinstance(dims, dict) else ModelDimensions(**dims.__dict__)
+    checkpoint = load_checkpoint(path)
+    dims = dims_of(checkpoint["dims"])
     sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in checkpoint["model_state_dict"].items()}
     rows = sd["decoder.token_embedding.weight"].shape[0]
     if inference and rows == dims.n_vocab + 1:  # a training checkpoint handed to the inference loader

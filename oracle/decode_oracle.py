@@ -44,6 +44,7 @@ class Options:  # whisper.decoding.DecodingOptions (token-level fields)
     without_timestamps: bool = False
     max_initial_timestamp: Optional[float] = 1.0
     seed: int = 0
+    logit_bias: Optional[torch.Tensor] = None          # additive [rows] (tests: steer a random-init model); product: suppress_mask
 
 
 @dataclass
@@ -118,6 +119,8 @@ def decode(sd, dims, mel: torch.Tensor, opt: Options) -> List[Result]:
             probs = full[:, sot_index].float().softmax(-1)
             no_speech = probs[::n_group, NO_SPEECH].tolist()
         logits = full[:, -1].clone()
+        if opt.logit_bias is not None:
+            logits = logits + opt.logit_bias
         if opt.suppress_blank and tokens.shape[1] == sample_begin:
             logits[:, [BLANK, EOT]] = -math.inf
         if sup:

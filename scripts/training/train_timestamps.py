@@ -15,7 +15,6 @@ What is replaced: DataLoader/tokenizer/W&B/eval plumbing (out of scope, SURVEY.m
 with the reference's token layout, sharded like DistributedSampler (:633-638); model/loss/backward/optimizer/DDP -> the
 HIP engine (olmoasr_amd).  Data is int16 PCM on the device; log-mel runs on the GPU.
 """
-import argparse
 import ast
 import glob
 import json
@@ -34,39 +33,76 @@ if ROOT not in sys.path:
 HARDWARE_TO_FLOPS = {"H100": 900 * 10 ** 12, "L40": 366 * 10 ** 12, "A100": 312 * 10 ** 12, "MI355X": 2500 * 10 ** 12}
 
 
-def str2bool(v):
-    return str(v).lower() in ("1", "true", "yes")
+# The reference's entry is ``Fire(main)`` (train_timestamps.py:2098-2134): flags are ``--name=value`` / ``--name value`` with
+# Python-literal values (``--betas='(0.9, 0.98)'``, ``--pin_memory=True``, ``--ckpt_file_name=None``).  Same flag names and
+# defaults here; the flags of subsystems that are out of scope (data curation, eval sets, W&B) are
+# ACCEPTED -- the reference launcher (configs/job_configs/training/filtered/*_sn.sh:65-100) passes all of them -- and
+# reported as ignored.
+REFERENCE_FLAGS = dict(
+    model_variant="tiny", exp_name="olmoasr_amd_run", job_type="train", samples_dicts_dir=None, train_steps=10, epoch_steps=0,
+    ckpt_file_name=None, ckpt_dir="checkpoints", log_dir="logs", eval_dir="data/eval", run_id_dir="run_ids", lr=1.5e-3,
+    betas=(0.9, 0.98), eps=1e-6, weight_decay=0.1, max_grad_norm=1.0, eff_batch_size=256, train_batch_size=8, eval_batch_size=32,
+    num_workers=10, prefetch_factor=2, pin_memory=True, shuffle=True, persistent_workers=True, run_eval=False, train_log_freq=20000,
+    eval_freq=20000, ckpt_freq=2500, verbose=False, precision="bfloat16", hardware="MI355X", async_eval=False, eval_script_path=None,
+    eval_wandb_log=False, eval_on_gpu=True)
+IGNORED_FLAGS = ("samples_dicts_dir", "eval_dir", "eval_batch_size", "pin_memory", "shuffle", "persistent_workers", "eval_freq", "verbose",
+                 "async_eval", "eval_script_path", "eval_wandb_log", "eval_on_gpu", "job_type", "log_dir")
+NATIVE_FLAGS = dict(  # additions of this implementation
+    synthetic=True, n_synthetic=4096, timestamps=False, seed=0, bucket_cap_mb=128.0, reducer="allreduce", resume=False,
+    device_synth=False)
+
+
+class Args(dict):
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+def _literal(v):
+    if not isinstance(v, str):
+        return v
+    try:
+        return ast.literal_eval(v)
+    except (ValueError, SyntaxError):
+        return v
 
 
 def parse_args(argv=None):
-    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
-    ap.add_argument("--model_variant", default="tiny")
-    ap.add_argument("--exp_name", default="olmoasr_amd_run")
-    ap.add_argument("--job_type", default="train")
-    ap.add_argument("--ckpt_dir", default="checkpoints")
-    ap.add_argument("--log_dir", default="logs")
-    ap.add_argument("--eff_batch_size", type=int, default=512)
-    ap.add_argument("--train_batch_size", type=int, default=8)
-    ap.add_argument("--train_steps", type=int, default=10)
-    ap.add_argument("--epoch_steps", type=int, default=0)
-    ap.add_argument("--lr", type=float, default=1.5e-3)
-    ap.add_argument("--betas", default="(0.9, 0.98)")
-    ap.add_argument("--eps", type=float, default=1e-6)
-    ap.add_argument("--weight_decay", type=float, default=0.1)
-    ap.add_argument("--max_grad_norm", type=float, default=1.0)
-    ap.add_argument("--precision", default="bfloat16", choices=["bfloat16"])
-    ap.add_argument("--hardware", default="MI355X")
-    ap.add_argument("--train_log_freq", type=int, default=5)
-    ap.add_argument("--ckpt_freq", type=int, default=0)
-    ap.add_argument("--synthetic", type=str2bool, default=True)
-    ap.add_argument("--n_synthetic", type=int, default=4096, help="size of the synthetic dataset (samples)")
-    ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--num_workers", type=int, default=8, help="sample-generation threads (the reference's DataLoader workers)")
-    ap.add_argument("--bucket_cap_mb", type=float, default=128.0)
-    ap.add_argument("--reducer", default="allreduce", choices=["allreduce", "direct"])
-    ap.add_argument("--resume", type=str2bool, default=False, help="continue from the latest checkpoint of --exp_name")
-    ap.add_argument("--ckpt_file_name", default="", help="checkpoint to resume from: a path, or a file-name prefix in the run dir")
-    return ap.parse_args(argv)
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = Args({**REFERENCE_FLAGS, **NATIVE_FLAGS})
+    given = set()
+    i = 0
+    while i < len(argv):
+        tok = argv[i]
+        if not tok.startswith("--"):
+            raise SystemExit(f"unexpected positional argument {tok!r} (flags are --name=value, as with the reference's Fire entry)")
+        if "=" in tok:
+            name, val = tok[2:].split("=", 1)
+        elif i + 1 < len(argv) and not argv[i + 1].startswith("--"):
+            name, val = tok[2:], argv[i + 1]
+            i += 1
+        else:
+            name, val = tok[2:], "True"  # bare flag
+        name = name.replace("-", "_")
+        if name not in args:
+            raise SystemExit(f"unknown flag --{name}; known: {sorted(args)}")
+        args[name] = _literal(val)
+        given.add(name)
+        i += 1
+    ignored = sorted(f for f in given if f in IGNORED_FLAGS)
+    if ignored and int(os.environ.get("RANK", "0")) == 0:
+        print(json.dumps({"event": "ignored_flags", "flags": ignored,
+                          "why": "data curation / eval sets / W&B are outside the hot path (SURVEY.md section 2)"}), flush=True)
+    if args.ckpt_file_name in (None, "None"):
+        args.ckpt_file_name = ""            # train_timestamps.py:2198-2199
+    if isinstance(args.betas, str):
+        args.betas = ast.literal_eval(args.betas)
+    if args.precision == "float16":
+        raise SystemExit("--precision float16: the MI355X-native engine computes in bfloat16 (production, = the reference's "
+                         "autocast(bfloat16) path) or float32 (validation kernels); the fp16 autocast path of the reference "
+                         "(train_timestamps.py:2128 default) has no native counterpart -- pass --precision bfloat16")
+    if args.precision not in ("bfloat16", "float32"):
+        raise SystemExit(f"--precision must be bfloat16 | float32 | float16, got {args.precision!r}")
+    return args
 
 
 class GradScalerState:
@@ -109,36 +145,71 @@ def lr_lambda(global_step, train_steps):
     return max(0.0, float(train_steps - global_step) / float(max(1, train_steps - warmup)))
 
 
-def save_ckpt(net, opt_state, scaler, global_step, local_step, epoch, args, dims, rank, cursor=0, lr=0.0, betas=(0.9, 0.98)):
-    """Checkpoint dict with the reference's keys (train_timestamps.py:930-972); ``_ddp`` file has ``module.`` keys.  The
-    optimizer entry is torch.optim.AdamW's own state_dict layout, so either side can load the other's file."""
+TAGS = ["ddp-train", "grad-acc", "fp16"]  # train_timestamps.py:2201-2206 (part of the checkpoint file names)
+
+
+def scheduler_state(lr, train_steps, global_step):
+    """``LambdaLR.state_dict()`` of the reference's scheduler after ``global_step`` steps (what its load_ckpt feeds to
+    ``scheduler.load_state_dict``, :1056): produced by a real LambdaLR on a dummy parameter, so every key this torch
+    version expects is present (function lambdas are saved as None, as torch does)."""
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=lr)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda step: lr_lambda(step, train_steps))
+    sd = sched.state_dict()
+    sd["last_epoch"] = global_step
+    sd["_step_count"] = global_step + 1
+    sd["_last_lr"] = [lr * lr_lambda(global_step, train_steps)]
+    return sd
+
+
+def build_checkpoint(model_sd, optimizer_sd, scaler_sd, *, global_step, local_step, epoch, dims, lr, train_steps, cursor=0,
+                     optimizer_steps=None, best_eval_wer=None):
+    """The reference's checkpoint dict (train_timestamps.py:930-958), un-prefixed model keys.  ``dims`` is stored as a
+    ``types.SimpleNamespace`` of the ModelDimensions fields: the reference's load_ckpt does ``OLMoASR(dims=ckpt['dims'])``
+    (attribute access, :1036) and gen_inf_ckpt reads ``dims.__dict__`` -- both work on it, and it unpickles without this
+    package (or the reference's) being importable."""
+    import types
+    fields = dims if isinstance(dims, dict) else dims.__dict__
+    return {"global_step": global_step, "local_step": local_step, "epoch": epoch, "best_eval_wer": best_eval_wer,
+            "model_state_dict": model_sd, "optimizer_state_dict": optimizer_sd, "scaler_state_dict": scaler_sd,
+            "scheduler_state_dict": scheduler_state(lr, train_steps, global_step), "dims": types.SimpleNamespace(**fields),
+            "data_cursor": cursor, "optimizer_steps": global_step if optimizer_steps is None else optimizer_steps}
+
+
+def run_dir(args, run_id):
+    return os.path.join(args.ckpt_dir, f"{args.exp_name}_{run_id}")  # {ckpt_dir}/{exp_name}_{run_id} (:956)
+
+
+def save_ckpt(net, scaler, global_step, local_step, epoch, args, dims, rank, run_id, cursor=0, optimizer_steps=None,
+              file_name="latesttrain"):
+    """save_ckpt (train_timestamps.py:894-972): the ``_ddp`` file carries ``module.`` keys, the ``_non_ddp`` file plain ones."""
     if rank != 0:
         return None
-    os.makedirs(os.path.join(args.ckpt_dir, args.exp_name), exist_ok=True)
+    os.makedirs(run_dir(args, run_id), exist_ok=True)
     sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
-    base = {"global_step": global_step, "local_step": local_step, "epoch": epoch, "best_eval_wer": None,
-            "optimizer_state_dict": net.optimizer_state_dict(step=global_step, lr=lr, betas=betas, eps=args.eps,
-                                                             weight_decay=args.weight_decay),
-            "scaler_state_dict": scaler.state_dict(),
-            "scheduler_state_dict": {"last_epoch": global_step, "_step_count": global_step + 1, "base_lrs": [args.lr]},
-            "dims": dims.__dict__, "data_cursor": cursor}
-    tag = f"latesttrain_{global_step:08d}_{args.model_variant}_" + "_".join(["ddp", "fp16"])
+    steps = global_step if optimizer_steps is None else optimizer_steps
+    base = build_checkpoint(sd, net.optimizer_state_dict(step=steps, lr=args.lr * lr_lambda(global_step, args.train_steps), betas=args.betas,
+                                                         eps=args.eps, weight_decay=args.weight_decay),
+                            scaler.state_dict(), global_step=global_step, local_step=local_step, epoch=epoch, dims=dims, lr=args.lr,
+                            train_steps=args.train_steps, cursor=cursor, optimizer_steps=steps)
+    tag = f"{file_name}_{global_step:08}_{args.model_variant}_{'_'.join(TAGS)}"
     paths = []
     for suffix, prefix in (("ddp", "module."), ("non_ddp", "")):
         ck = dict(base)
         ck["model_state_dict"] = {prefix + k: v for k, v in sd.items()}
-        p = os.path.join(args.ckpt_dir, args.exp_name, f"{tag}_{suffix}.pt")
+        p = os.path.join(run_dir(args, run_id), f"{tag}_{suffix}.pt")
         torch.save(ck, p)
         paths.append(p)
     return paths
 
 
-def find_ckpt(args):
-    """File selection of the reference's load_ckpt (train_timestamps.py:1012-1030): explicit path, or the latest
-    ``*_ddp.pt`` of this experiment."""
-    if args.ckpt_file_name and "/" in args.ckpt_file_name:
-        return args.ckpt_file_name
-    pat = os.path.join(args.ckpt_dir, args.exp_name, f"{args.ckpt_file_name or '*'}_*_{args.model_variant}_*_ddp.pt")
+def find_ckpt(args, run_id):
+    """File selection of the reference's load_ckpt (train_timestamps.py:1012-1030): an explicit path, a file-name prefix in
+    the run directory, or the latest ``*_fp16_ddp.pt`` of this run."""
+    name = args.ckpt_file_name
+    if name and "/" in name:
+        return name
+    pat = os.path.join(run_dir(args, run_id), f"{name or '*'}_*_{args.model_variant}_*_fp16_ddp.pt")
     files = [f for f in glob.glob(pat) if not f.endswith("_non_ddp.pt")]
     if not files:
         raise FileNotFoundError(f"no checkpoint matches {pat}")
@@ -146,14 +217,99 @@ def find_ckpt(args):
 
 
 def load_ckpt(net, scaler, path):
-    """Resume (train_timestamps.py:975-1074): model (``module.`` keys), AdamW moments, GradScaler, counters."""
-    ck = torch.load(path, map_location="cpu", weights_only=False)
+    """Resume (train_timestamps.py:975-1074): model (``module.`` keys), AdamW moments, GradScaler, counters.  Accepts files
+    written by the reference (``dims`` pickled as ``olmoasr.config.model_dims.ModelDimensions``: see hub.load_checkpoint)."""
+    from olmoasr_amd import hub
+    ck = hub.load_checkpoint(path)
     net.load_state_dict({k[len("module."):] if k.startswith("module.") else k: v for k, v in ck["model_state_dict"].items()})
     net.refresh_shadow()
     opt_steps = net.load_optimizer_state_dict(ck["optimizer_state_dict"])
     scaler.load_state_dict(ck["scaler_state_dict"])
-    assert opt_steps in (0, ck["global_step"]), (opt_steps, ck["global_step"])
-    return ck["global_step"], ck["local_step"], ck["epoch"], int(ck.get("data_cursor", 0))
+    # torch's AdamW does not advance its step on a GradScaler-skipped iteration: opt_steps <= global_step
+    assert 0 <= opt_steps <= ck["global_step"], (opt_steps, ck["global_step"])
+    return ck["global_step"], ck["local_step"], ck["epoch"], int(ck.get("data_cursor", 0)), int(ck.get("optimizer_steps", opt_steps))
+
+
+def get_run_id(args, rank, world_size):
+    """Run id bookkeeping of main() (train_timestamps.py:2182-2196): {run_id_dir}/{exp_name}.txt names the run whose
+    checkpoint directory is {ckpt_dir}/{exp_name}_{run_id}; a new id is drawn when there is none (the reference takes
+    W&B's)."""
+    path = os.path.join(args.run_id_dir, f"{args.exp_name}.txt")
+    run_id = None
+    if os.path.exists(path):
+        run_id = open(path).read().strip()
+        if not os.path.exists(run_dir(args, run_id)):
+            run_id = None
+    if run_id is None:
+        import uuid
+        obj = [uuid.uuid4().hex[:8] if rank == 0 else None]
+        if world_size > 1:
+            dist.broadcast_object_list(obj, src=0)
+        run_id = obj[0]
+        if rank == 0:
+            os.makedirs(args.run_id_dir, exist_ok=True)
+            with open(path, "w") as f:
+                f.write(run_id)
+    return run_id
+
+
+def gen_pred(logits, text_y):
+    """gen_pred (train_timestamps.py:1077-1122) at token level: ``pred = argmax(softmax(logits))`` per position (a HIP
+    kernel over the fp32 logits: argmax is invariant under softmax), predictions cut after the first <|endoftext|>
+    (remove_after_endoftext), targets with the 51864 padding filtered out and closed by <|endoftext|>.  Decoding ids to text
+    (tokenizer.decode_with_timestamps) and the WER on text need the un-vendored tokenizer / jiwer: callers get ids."""
+    from olmoasr_amd import ops
+    B, S, V = logits.shape
+    pred, _ = ops.pick_tokens(logits.reshape(B * S, V), want_logprob=False)
+    preds, tgts = [], []
+    for row in pred.view(B, S).cpu().tolist():
+        preds.append(row[:row.index(50256) + 1] if 50256 in row else row)
+    for row in text_y.cpu().tolist():
+        row = [t for t in row if t != 51864]
+        tgts.append((row[:row.index(50256)] if 50256 in row else row) + [50256])
+    return preds, tgts
+
+
+def token_error_rate(preds, tgts):
+    """Token-level analogue of calc_pred_wer (:1125-1180): (substitutions + deletions + insertions) / reference tokens."""
+    errs = n = 0
+    for p, t in zip(preds, tgts):
+        prev = list(range(len(t) + 1))
+        for i, a in enumerate(p, 1):
+            cur = [i]
+            for j, b in enumerate(t, 1):
+                cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (a != b)))
+            prev = cur
+        errs += prev[-1]
+        n += len(t)
+    return errs / max(1, n)
+
+
+def evaluate(net, indices, dev, timestamps=False, sample_len=32, batch=8):
+    """evaluate() of the reference (train_timestamps.py:1835-1919) on held-out SYNTHETIC clips (the eval sets themselves are
+    out of scope): greedy ``model.decode(audio_input, DecodingOptions(language="en", without_timestamps=True))`` (:1916-1919),
+    scored as token error rate against the transcript ids."""
+    from olmoasr_amd import ops
+    from olmoasr_amd.decoding import DecodingOptions
+    from olmoasr_amd.synth import synth_samples
+    preds, tgts = [], []
+    for i in range(0, len(indices), batch):
+        pcm, ti, ty, tl = synth_samples(indices[i:i + batch], dev, timestamps)
+        res = net.decode(ops.log_mel(pcm), DecodingOptions(language="en", without_timestamps=True, sample_len=sample_len))
+        preds += [r.tokens for r in res]
+        tgts += [[t for t in row[1:n] if t < 50257][:sample_len] for row, n in zip(ti.cpu().tolist(), tl.cpu().tolist())]
+    return token_error_rate(preds, tgts)
+
+
+def host_cores():
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(p))))
+    except Exception:
+        pass
+    return n
 
 
 def main(argv=None):
@@ -163,7 +319,8 @@ def main(argv=None):
     from olmoasr_amd.model import OLMoASR
     from olmoasr_amd.synth import SynthLoader
 
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))          # env rank discovery, train_timestamps.py:2227-2230
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
     rank = int(os.environ.get("RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     torch.cuda.set_device(local_rank)
@@ -172,24 +329,30 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
 
-    betas = ast.literal_eval(args.betas) if isinstance(args.betas, str) else args.betas
+    betas = tuple(args.betas)
     dims = VARIANT_TO_DIMS[args.model_variant]
-    net = OLMoASR(dims, device=dev, seed=args.seed)
+    net = OLMoASR(dims, device=dev, seed=args.seed, compute_dtype=args.precision)
     ddp.broadcast_parameters(net.flat_params)  # DDP ctor _sync_module_states
     net.refresh_shadow()
-    opt_state = net.init_optimizer_state()
+    net.init_optimizer_state()
     reducer = ddp.GradReducer(net.flat_grads, net.grad_segments, bucket_cap_mb=args.bucket_cap_mb, algo=args.reducer) if world_size > 1 else None
     scaler = GradScalerState()
     accum = accumulation_steps(args.eff_batch_size, world_size, args.train_batch_size)
     mine = ddp.shard_indices(args.n_synthetic, rank, world_size)
     loss_buf = torch.zeros(1, device=dev)
-    global_step, local_step, cursor, epoch = 0, 0, 0, 0
+    global_step, local_step, cursor, epoch, optimizer_steps = 0, 0, 0, 0, 0
+    run_id = get_run_id(args, rank, world_size)
     if args.resume or args.ckpt_file_name:
-        global_step, local_step, epoch, cursor = load_ckpt(net, scaler, find_ckpt(args))
+        global_step, local_step, epoch, cursor, optimizer_steps = load_ckpt(net, scaler, find_ckpt(args, run_id))
+    # every rank of a node shares the host cores: the reference's --num_workers is per rank, but oversubscribing a 16-core
+    # cgroup with 8 x 10 generator threads would make the loader, not the GPU, set the pace
+    workers = max(1, min(int(args.num_workers), host_cores() // max(1, local_world)))
     log = []
     if rank == 0:
         print(json.dumps({"event": "start", "world_size": world_size, "accumulation_steps": accum, "model": args.model_variant,
-                          "params": net.flat_params.numel(), "hardware_peak_flops": HARDWARE_TO_FLOPS.get(args.hardware)}), flush=True)
+                          "precision": args.precision, "params": net.flat_params.numel(), "run_id": run_id, "loader_threads": workers,
+                          "hardware_peak_flops": HARDWARE_TO_FLOPS.get(args.hardware)}), flush=True)
+
     def batch_order(start):  # the sampler: this rank's shard, cyclic, train_batch_size indices per micro-batch
         c = start
         while True:
@@ -198,10 +361,13 @@ def main(argv=None):
             if c >= len(mine):
                 c = 0
 
-    loader = SynthLoader(batch_order(cursor), dev, workers=args.num_workers)
+    loader = SynthLoader(batch_order(cursor), dev, workers=workers, depth=max(1, int(args.prefetch_factor)), timestamps=bool(args.timestamps))
+    held_out = [args.n_synthetic + i for i in range(8)]  # evaluate(): clips outside every rank's training shard
     while global_step < args.train_steps:
         start_step = time.time()
         net.zero_grad()
+        log_now = ((global_step + 1) % args.train_log_freq) == 0  # gen_pred condition of the reference (:1480)
+        preds, tgts = [], []
         for i in range(accum):
             cursor += args.train_batch_size
             if cursor >= len(mine):
@@ -209,18 +375,27 @@ def main(argv=None):
             pcm, ti, ty, tl = next(loader)
             mel = ops.log_mel(pcm)
             last = i == accum - 1
-            net.loss_and_backward(mel, ti, ty, tl, loss_scale=scaler.scale, accumulation_steps=accum, loss_out=loss_buf,
-                                  accumulate_loss=i > 0, segment_events=reducer.segment_events() if (reducer and last) else None)
+            _, logits = net.loss_and_backward(mel, ti, ty, tl, loss_scale=scaler.scale, accumulation_steps=accum, loss_out=loss_buf,
+                                              accumulate_loss=i > 0, return_logits=log_now,
+                                              segment_events=reducer.segment_events() if (reducer and last) else None)
+            if log_now:
+                p_, t_ = gen_pred(logits, ty)
+                preds += p_
+                tgts += t_
             local_step += 1
         div = 1.0
         if reducer:
             reducer.reduce()
             div = reducer.grad_divisor
         lr = args.lr * lr_lambda(global_step, args.train_steps)
-        stats = net.optim_step(step=global_step + 1, lr=lr, inv_loss_scale=1.0 / (scaler.scale * div), max_grad_norm=args.max_grad_norm,
+        # torch's AdamW advances its per-parameter step only when GradScaler lets the step through: the bias correction
+        # follows the number of APPLIED steps, not global_step
+        stats = net.optim_step(step=optimizer_steps + 1, lr=lr, inv_loss_scale=1.0 / (scaler.scale * div), max_grad_norm=args.max_grad_norm,
                                betas=betas, eps=args.eps, weight_decay=args.weight_decay)
         found_inf = bool(stats[1].item() != 0)  # host sync once per optimizer step, like scaler.step()
         scaler.update(found_inf)
+        if not found_inf:
+            optimizer_steps += 1
         global_step += 1
         time_per_step = time.time() - start_step
         throughput = ((args.train_batch_size * accum * 30) / 60) / time_per_step  # audio_min_per_GPU_second (:1525-1527)
@@ -232,14 +407,18 @@ def main(argv=None):
                 rec = {"global_step": global_step, "train_loss": float(t) / world_size, "lr": lr, "loss_scale": scaler.scale,
                        "time_per_step": round(time_per_step, 4), "audio_min_per_GPU_second": round(throughput, 3),
                        "audio_sec_per_sec_node": round(throughput * 60 * world_size, 1), "found_inf": found_inf}
+                if preds:
+                    rec["train_token_error_rate"] = round(token_error_rate(preds, tgts), 4)
                 log.append(rec)
                 print(json.dumps(rec), flush=True)
+        if args.run_eval and args.eval_freq and global_step % int(args.eval_freq) == 0 and rank == 0:
+            print(json.dumps({"event": "eval", "global_step": global_step,
+                              "token_error_rate": round(evaluate(net, held_out, dev, bool(args.timestamps)), 4)}), flush=True)
         if args.ckpt_freq and global_step % args.ckpt_freq == 0:
-            save_ckpt(net, opt_state, scaler, global_step, local_step, epoch, args, dims, rank, cursor, lr, betas)
+            save_ckpt(net, scaler, global_step, local_step, epoch, args, dims, rank, run_id, cursor, optimizer_steps)
     loader.close()
-    if args.ckpt_freq:
-        save_ckpt(net, opt_state, scaler, global_step, local_step, epoch, args, dims, rank, cursor,
-                  args.lr * lr_lambda(max(global_step - 1, 0), args.train_steps), betas)
+    if args.ckpt_freq and (global_step % args.ckpt_freq) != 0:
+        save_ckpt(net, scaler, global_step, local_step, epoch, args, dims, rank, run_id, cursor, optimizer_steps)
     if world_size > 1:
         dist.barrier()
         dist.destroy_process_group()

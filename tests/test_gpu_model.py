@@ -391,20 +391,25 @@ def test_train_script_end_to_end(tmp_path):
     spec = importlib.util.spec_from_file_location("tt_gpu", os.path.join(root, "scripts", "training", "train_timestamps.py"))
     tt = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(tt)
-    log = tt.main(["--model_variant", "tiny", "--eff_batch_size", "8", "--train_batch_size", "4", "--train_steps", "12",
-                   "--lr", "1e-3", "--train_log_freq", "1", "--n_synthetic", "8", "--ckpt_freq", "12", "--ckpt_dir", str(tmp_path),
-                   "--exp_name", "t"])
+    log = tt.main(["--model_variant=tiny", "--eff_batch_size=8", "--train_batch_size=4", "--train_steps=12", "--lr=1e-3",
+                   "--train_log_freq=1", "--n_synthetic=8", "--ckpt_freq=12", f"--ckpt_dir={tmp_path}", f"--run_id_dir={tmp_path}/run_ids",
+                   "--exp_name=t", "--ckpt_file_name=None", "--betas=(0.9, 0.98)", "--pin_memory=True", "--samples_dicts_dir=/nowhere",
+                   "--timestamps=True"])
     assert len(log) == 12 and all(not r["found_inf"] for r in log)
+    assert all(0.0 <= r["train_token_error_rate"] for r in log[1:])  # gen_pred ran on the logged steps
     assert log[0]["lr"] == 0.0 and log[1]["lr"] == 1e-3  # warmup = ceil(0.002 * 12) = 1 step
     assert log[-1]["train_loss"] < log[0]["train_loss"] - 1.0
     assert log[-1]["audio_min_per_GPU_second"] > 0
-    files = sorted(os.listdir(tmp_path / "t"))
-    assert len(files) == 2 and files[0].endswith("_ddp.pt") and files[1].endswith("_non_ddp.pt")
-    ck = torch.load(tmp_path / "t" / files[0], weights_only=False)
+    run_id = open(tmp_path / "run_ids" / "t.txt").read().strip()
+    rdir = tmp_path / f"t_{run_id}"  # {ckpt_dir}/{exp_name}_{run_id} (train_timestamps.py:956)
+    files = sorted(os.listdir(rdir))
+    assert files == ["latesttrain_00000012_tiny_ddp-train_grad-acc_fp16_ddp.pt", "latesttrain_00000012_tiny_ddp-train_grad-acc_fp16_non_ddp.pt"]
+    ck = torch.load(rdir / files[0], weights_only=False)  # plain torch.load: dims is a SimpleNamespace
+    assert ck["dims"].n_audio_state == 384 and ck["scheduler_state_dict"]["last_epoch"] == 12
     assert {"global_step", "local_step", "epoch", "best_eval_wer", "model_state_dict", "optimizer_state_dict", "scaler_state_dict",
             "scheduler_state_dict", "dims"} <= set(ck)
     assert all(k.startswith("module.") for k in ck["model_state_dict"]) and ck["global_step"] == 12
-    net = olmoasr_amd.load_model(str(tmp_path / "t" / files[0]), device=DEV)
+    net = olmoasr_amd.load_model(str(rdir / files[0]), device=DEV)
     assert net.dims.n_audio_state == 384 and torch.isfinite(net.flat_params).all()
 
 
@@ -418,19 +423,23 @@ def test_resume_continues_the_run_and_adamw_state_is_torch_compatible(tmp_path):
     tt = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(tt)
     common = ["--model_variant", "tiny", "--eff_batch_size", "8", "--train_batch_size", "4", "--lr", "1e-3", "--train_log_freq", "1",
-              "--n_synthetic", "24", "--ckpt_dir", str(tmp_path), "--train_steps", "8"]
+              "--n_synthetic", "24", "--ckpt_dir", str(tmp_path), "--run_id_dir", str(tmp_path / "ids"), "--train_steps", "8"]
     straight = tt.main(common + ["--exp_name", "a", "--ckpt_freq", "8"])
     # same schedule (train_steps 8), stopped after 4 steps by checkpointing every 4 and resuming from step 4
     tt.main(common + ["--exp_name", "b", "--ckpt_freq", "4"])
-    first = sorted(f for f in os.listdir(tmp_path / "b") if f.endswith("_ddp.pt") and "non_ddp" not in f)[0]
+    bdir = tmp_path / ("b_" + open(tmp_path / "ids" / "b.txt").read().strip())
+    first = sorted(f for f in os.listdir(bdir) if f.endswith("_ddp.pt") and "non_ddp" not in f)[0]
     assert "_00000004_" in first
-    resumed = tt.main(common + ["--exp_name", "b2", "--ckpt_file_name", str(tmp_path / "b" / first)])
+    resumed = tt.main(common + ["--exp_name", "b2", "--ckpt_file_name", str(bdir / first)])
     assert [r["global_step"] for r in resumed] == [5, 6, 7, 8]
     for r, s in zip(resumed, straight[4:]):
         assert r["lr"] == s["lr"]
         assert abs(r["train_loss"] - s["train_loss"]) < 2e-2 * max(1.0, abs(s["train_loss"])), (r, s)  # atomics-order noise only
     # the AdamW entry loads into torch.optim.AdamW over parameters of the same shapes and order
-    ck = torch.load(tmp_path / "b" / first, weights_only=False)
+    # the run-directory form of resuming (load_ckpt with file_name "" = latest *_fp16_ddp.pt of {exp_name}_{run_id}, :1012-1021)
+    again = tt.main(common + ["--exp_name", "b", "--resume", "True"])
+    assert again == []  # the run already reached train_steps: its latest checkpoint is step 8
+    ck = torch.load(bdir / first, weights_only=False)
     shapes = [v.shape for k, v in ck["model_state_dict"].items() if not k.endswith("encoder.positional_embedding")]  # (a buffer)
     params = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
     opt = torch.optim.AdamW(params, lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.1)
@@ -475,3 +484,61 @@ def test_beam_search_sampling_and_timestamp_rules(tiny_case):
     assert len(out["segments"]) == 1 and out["segments"][0]["temperature"] == 0.4 and len(out["segments"][0]["tokens"]) <= 4
     out0 = net.transcribe(audio, temperature=(0.0, 0.4), sample_len=4, logprob_threshold=None, without_timestamps=True)
     assert out0["segments"][0]["temperature"] == 0.0
+
+
+def test_parameter_order_is_the_references(native_tiny, golden_dir):
+    """AdamW.state_dict() indexes parameters in ``model.parameters()`` order (train_timestamps.py:727-733,949): the native
+    module tree must enumerate them exactly like the unmodified reference (fixture: oracle/gen_param_order.py)."""
+    import json
+    want = json.load(open(os.path.join(golden_dir, "ref_param_order.json")))["tiny"]
+    assert [n for n, _ in native_tiny.named_parameters()] == want
+    assert [s[0] for s in native_tiny._param_slices()] == want
+
+
+def test_integration_stub_drives_the_reference_call_pattern(tmp_path, tiny_case):
+    """a package named ``olmoasr`` whose model.py subclasses the native OLMoASR, driven the way the
+    reference's train() does (scripts/training/train_timestamps.py:1440-1454,1509-1512)."""
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    stub = "from olmoasr_amd.model import OLMoASR as _NativeOLMoASR"
+    assert stub in open(os.path.join(root, "INTEGRATION.md")).read()
+    pkg = tmp_path / "olmoasr"
+    (pkg / "config").mkdir(parents=True)
+    (pkg / "__init__.py").write_text("from olmoasr_amd.audio import log_mel_spectrogram, pad_or_trim  # noqa: F401\n"
+                                     "from olmoasr_amd.hub import load_model  # noqa: F401\n")
+    (pkg / "config" / "__init__.py").write_text("")
+    (pkg / "config" / "model_dims.py").write_text("from olmoasr_amd.config.model_dims import ModelDimensions, VARIANT_TO_DIMS  # noqa: F401\n")
+    (pkg / "model.py").write_text(stub + "\nfrom olmoasr_amd.model import (AudioEncoder, TextDecoder, ResidualAttentionBlock, MultiHeadAttention,"
+                                  " LayerNorm, Linear, Conv1d, sinusoids)  # noqa: F401\n\n\nclass OLMoASR(_NativeOLMoASR):\n    pass\n")
+    (pkg / "inf_model.py").write_text("from olmoasr_amd.inf_model import *  # noqa: F401,F403\nfrom olmoasr_amd.inf_model import OLMoASR  # noqa: F401\n")
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == "olmoasr" or k.startswith("olmoasr.")}
+    sys.path.insert(0, str(tmp_path))
+    try:
+        olmoasr = importlib.import_module("olmoasr")
+        model_mod = importlib.import_module("olmoasr.model")
+        dims_mod = importlib.import_module("olmoasr.config.model_dims")
+        from oracle import model_oracle as mo
+        c = tiny_case
+        model = model_mod.OLMoASR(dims_mod.VARIANT_TO_DIMS["tiny"]).to("cuda")   # reference: OLMoASR(dims=model_dims).to(rank)
+        model.load_state_dict(c["sd"])
+        audio_input = olmoasr.log_mel_spectrogram(olmoasr.pad_or_trim(c["pcm"].float() / 32768.0).to(DEV))   # :207-214
+        text_input, text_y = c["tokens"].to(DEV), c["targets"].to(DEV)
+        padding_mask = mo.build_padding_mask(c["text_len"]).to(DEV)                    # :314-315
+        logits = model(audio_input, text_input, padding_mask, False)                   # :1440
+        assert logits.shape == (2, 448, 51865) and logits.dtype == torch.float32
+        train_loss = torch.nn.functional.cross_entropy(logits.view(-1, logits.shape[-1]), text_y.view(-1), ignore_index=51864)
+        # the fused step computes the same loss (and the backward the reference gets from autograd)
+        model.zero_grad()
+        loss, _ = model.loss_and_backward(audio_input, text_input, text_y, c["text_len"].to(DEV))
+        assert abs(float(loss) - float(train_loss)) < 2e-3
+        stats = model.optim_step(step=1, lr=1e-3)
+        assert float(stats[1]) == 0.0
+        inf = importlib.import_module("olmoasr.inf_model").OLMoASR(dims_mod.VARIANT_TO_DIMS["tiny"])
+        assert inf.decoder.token_embedding.weight.shape[0] == 51864 and inf.inference
+    finally:
+        sys.path.remove(str(tmp_path))
+        for k in list(sys.modules):
+            if k == "olmoasr" or k.startswith("olmoasr."):
+                sys.modules.pop(k)
+        sys.modules.update(saved)
