@@ -43,10 +43,13 @@ def plan_buckets(segments: Sequence[Tuple[int, int]], cap_elems: int) -> List[Tu
 
 
 class GradReducer:
-    """``algo``: "allreduce" (default: one RCCL all-reduce per bucket, RCCL picks rings/trees) or "direct": reduce-scatter
-    and all-gather written as one all-to-all each, so every rank talks to all its peers at once -- on a fully connected
-    xGMI node that uses all 7 links instead of the ring's one (~5 ms vs ~35 ms per 3 GB at medium).
-    Not the default because it could not be timed on a multi-GPU node yet; numerically it is a different summation order."""
+    """``algo``: "allreduce" (default: one RCCL all-reduce per bucket, RCCL picks rings/trees) or "direct": the all-reduce
+    spelled as its two halves, ``reduce_scatter_tensor`` + ``all_gather_into_tensor``, IN PLACE on the arena slice (rank r
+    owns chunk r of the bucket: the reduce-scatter's output and the all-gather's input alias that chunk, RCCL's in-place
+    form -- no staging buffers, no copies).  On a fully connected xGMI node each half talks to all 7 peers at once
+    (~5 ms vs ~35 ms per 3 GB at medium for a one-link ring); it is also the building block of a
+    ZeRO-1 step (run the optimizer on the owned chunk between the two halves).  Not the default: no multi-GPU node was
+    available to time it against RCCL's own all-reduce; numerically it is a different summation order."""
 
     def __init__(self, flat_grads: torch.Tensor, segments: Sequence[Tuple[int, int]], bucket_cap_mb: float = 128.0,
                  group: Optional[dist.ProcessGroup] = None, force: bool = False, algo: str = "allreduce"):
@@ -87,14 +90,15 @@ class GradReducer:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
             return
         W, n = self.world, t.numel()
-        per = (n + W - 1) // W
-        send = t if per * W == n else torch.cat([t, t.new_zeros(per * W - n)])
-        recv = torch.empty_like(send)
-        dist.all_to_all_single(recv, send, group=self.group)       # rank r receives everybody's chunk r ...
-        shard = recv.view(W, per).sum(0)                           # ... and owns its sum (reduce-scatter)
-        parts = [torch.empty_like(shard) for _ in range(W)]
-        dist.all_gather(parts, shard, group=self.group)            # every rank fetches every shard from its owner
-        t.copy_(torch.cat(parts)[:n])
+        per = n // W
+        rank = dist.get_rank(self.group)
+        if per:
+            body = t[: per * W]
+            mine = body[rank * per:(rank + 1) * per]
+            dist.reduce_scatter_tensor(mine, body, op=dist.ReduceOp.SUM, group=self.group)   # rank r ends up owning chunk r's sum
+            dist.all_gather_into_tensor(body, mine, group=self.group)                        # every rank fetches every chunk
+        if per * W < n:  # fewer than W trailing elements
+            dist.all_reduce(t[per * W:], op=dist.ReduceOp.SUM, group=self.group)
 
     def reduce(self, use_events: bool = True):
         """All-reduce (SUM) every bucket.  With events: bucket k starts as soon as its gradients are final."""

@@ -2,11 +2,19 @@
 reducer's SUM + folded 1/world mean, parameter broadcast and the DistributedSampler partition rule."""
 import os
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from olmoasr_amd import ddp
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
 
 
 def test_plan_buckets_tiles_arena_and_respects_completion_order():
@@ -66,7 +74,7 @@ def _worker(rank, world, port, q):
 def test_grad_reducer_world2_gloo():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -89,3 +97,100 @@ def test_synth_loader_order_and_determinism():
             ref = synth_samples(idx, dev)
             assert all(torch.equal(a, b) for a, b in zip(batch, ref))
             assert batch[0].dtype == torch.int16 and batch[0].shape == (2, 480000) and batch[3].dtype == torch.int32
+
+
+# ---- the whole data-parallel optimizer step, world 2 vs world 1, gradients from the CPU oracle --------------------------
+def _oracle_flat_grads(sd, dims, idx, loss_scale, accum, names):
+    """Gradients of (loss / accum) * loss_scale for the samples ``idx`` as one flat fp32 vector (arena stand-in)."""
+    import numpy as np
+    from oracle import mel_oracle as me
+    from oracle import model_oracle as mo
+    pcm, ti, ty, tl = mo.synthetic_batch(idx)
+    mel = torch.from_numpy(me.log_mel_batch(pcm.numpy(), dtype=np.float32))
+    loss, grads, _ = mo.loss_and_grads(sd, dims, mel, ti, ty, tl, loss_scale=loss_scale, accumulation_steps=accum)
+    return float(loss), torch.cat([grads[n].reshape(-1) for n in names])
+
+
+def _step_from_flat(sd, names, flat, inv_scale, lr=1e-3):
+    """unscale -> clip_grad_norm_(1.0) -> AdamW step 1 (train_timestamps.py:1509-1512) from a flat gradient vector."""
+    from oracle import model_oracle as mo
+    grads, off = {}, 0
+    for n in names:
+        k = sd[n].numel()
+        grads[n] = (flat[off:off + k] * inv_scale).view_as(sd[n]).clone()
+        off += k
+    total, coef = mo.clip_coef(grads, 1.0)
+    for n in names:
+        grads[n].mul_(coef)
+    params = {n: sd[n].clone() for n in names}
+    m = {n: torch.zeros_like(params[n]) for n in names}
+    v = {n: torch.zeros_like(params[n]) for n in names}
+    mo.adamw_step(params, grads, m, v, step=1, lr=lr)
+    return float(total), params
+
+
+def _dp_worker(rank, world, port, q, algo):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(4)
+        from oracle import model_oracle as mo
+        dims = mo.Dims(80, 1500, 64, 1, 1, 51864, 448, 64, 1, 1)
+        sd = mo.init_state_dict(dims, seed=0)
+        names = [k for k in sd if k != "encoder.positional_embedding"]
+        scale = 1024.0
+        # global batch of 4 samples: rank r holds indices[r::world] (DistributedSampler), one micro-batch of 2 per rank
+        mine = ddp.shard_indices(4, rank, world)
+        assert mine == [rank, rank + 2]
+        loss, flat = _oracle_flat_grads(sd, dims, [70 + i for i in mine], scale, 1, names)
+        n = flat.numel()
+        segs = [(0, n // 3), (n // 3, n // 2 - n // 3), (n // 2, n - n // 2)]
+        red = ddp.GradReducer(flat, segs, bucket_cap_mb=1.0, algo=algo)
+        assert len(red.buckets) == 3
+        red.reduce()                                              # SUM over ranks ...
+        inv = 1.0 / (scale * red.grad_divisor)                   # ... turned into DDP's mean inside the unscale factor
+        norm, params = _step_from_flat(sd, names, flat, inv)
+        lt = torch.tensor([loss])
+        dist.all_reduce(lt)
+        q.put((rank, "ok", norm, float(lt) / world, {k: v for k, v in list(params.items())[:3]}, float(sum(p.double().sum() for p in params.values()))))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "err: " + traceback.format_exc(), 0, 0, None, 0))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("algo", ["allreduce", "direct"])
+def test_data_parallel_step_world2_equals_world1(algo):
+    """one optimizer step on a global batch of 4 clips computed (a) by two ranks holding two clips
+    each -- sampler shard, per-rank backward of the loss-scaled loss, bucketed SUM of the flat gradient arena, 1/(scale *
+    world) folded into the unscale factor, clip, AdamW -- and (b) by one rank accumulating the same two micro-batches
+    (accumulation_steps = 2).  DDP's mean over ranks == the accumulation rule's 1/accum (train_timestamps.py:1450), so norms,
+    losses and updated weights must agree to summation-order noise."""
+    from oracle import model_oracle as mo
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, algo)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert all(r[1] == "ok" for r in res), res
+    # world 1, two accumulated micro-batches with the SAME per-rank sample split
+    torch.set_num_threads(8)
+    dims = mo.Dims(80, 1500, 64, 1, 1, 51864, 448, 64, 1, 1)
+    sd = mo.init_state_dict(dims, seed=0)
+    names = [k for k in sd if k != "encoder.positional_embedding"]
+    scale = 1024.0
+    l0, f0 = _oracle_flat_grads(sd, dims, [70, 72], scale, 2, names)
+    l1, f1 = _oracle_flat_grads(sd, dims, [71, 73], scale, 2, names)
+    norm1, params1 = _step_from_flat(sd, names, f0 + f1, 1.0 / scale)
+    for rank, _, norm, loss, head, checksum in res:
+        assert abs(norm - norm1) < 1e-5 * norm1, (norm, norm1)
+        assert abs(loss - (l0 + l1)) < 1e-5
+        for k, v in head.items():
+            assert torch.allclose(v, params1[k], atol=2e-6), k
+        assert abs(checksum - float(sum(p.double().sum() for p in params1.values()))) < 1e-2
+    assert res[0][2] == res[1][2]  # both ranks hold bit-identical results after the exchange
