@@ -158,16 +158,8 @@ int oasr_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
  * and gen_pred's argmax over teacher-forced logits (scripts/training/train_timestamps.py:1096-1098). */
 int oasr_pick_tokens(const float* logits, int64_t ld, int V, int64_t rows, const float* mask, const float* mask2, int64_t* tok,
                      float* logprob, void* stream);
-/* bench.py's live roofline measurement: when enabled every GEMM launch is bracketed by HIP events on ITS stream;
- * collect() synchronises and returns, per kernel variant (index 2*ta+tb: 0 = NT forward, 1 = NN dgrad, 3 = TN wgrad),
- * summed milliseconds, summed algorithmic flops (2*M*N*K, conv windows at their real width) and launch count; by_symbol
- * receives the same sums keyed by the kernel symbol rocprofv3 prints, so the two can be compared line by line. */
-int oasr_profile_gemm(int enable);
-int oasr_gemm_set_stagger(int sleeps, int phases); /* experiments: first-wave phase stagger of the 256x256 kernel (0 = off) */
-int oasr_gemm_force_general(int on); /* tests: route every GEMM through the register-staged general kernel */
-int oasr_profile_gemm_collect(double* ms4, double* flops4, int64_t* count4, char* by_symbol /* "symbol\tlaunches\tms\tflops\n"... or NULL */, int cap);
-int oasr_probe_lds_oob(const void* src_u16 /*[512]*/, void* dst_u16 /*[512]*/, void* stream);
-int oasr_probe_tr16(const void* src_bf16 /*[16][64]*/, void* dst_bf16 /*[64 lanes][4]*/, void* stream);
+/* Measurement / test hooks (GEMM launch timing for bench.py, kernel-path forcing, hardware probes) are declared in
+ * include/oasr_testing.h: they are exported by the same library but are not part of the product surface. */
 
 #ifdef __cplusplus
 }
