@@ -126,6 +126,16 @@ int oasr_zero_grad(oasr_ctx*, void* stream);
 int oasr_optim_step(oasr_ctx*, float inv_loss_scale, float max_grad_norm, float lr, float beta1, float beta2, float eps,
                     float weight_decay, int64_t step, float* stats_out, void* scratch, void* stream);
 
+/* ZeRO-1 (optimizer-state sharding; the reference's sharded variant is FSDP, scripts/training/train_fsdp_timestamps.py:2665-2719):
+ * the same fused step over a contiguous range [off, off+numel) of the arenas (multiples of 4).  sumsq_range: stats_out[0] = sum of
+ * squares of the scaled gradients in the range, [1] = non-finite flag.  step_range: `stats` = those two numbers summed over ALL
+ * ranges (all-reduce them), exp_avg / exp_avg_sq are shard-local buffers of numel floats.  After every rank has stepped its range
+ * and the parameters are all-gathered, call oasr_refresh_shadow.  Host side: olmoasr_amd/zero.py. */
+int oasr_grad_sumsq_range(oasr_ctx*, int64_t off, int64_t numel, float* stats_out, void* scratch, void* stream);
+int oasr_optim_step_range(oasr_ctx*, int64_t off, int64_t numel, float* exp_avg_shard, float* exp_avg_sq_shard, const float* stats,
+                          float inv_loss_scale, float max_grad_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
+                          int64_t step, void* stream);
+
 /* ---- unit operators (exposed for op-level parity tests; the engine calls the same launchers) ---------------------- */
 typedef struct oasr_operand { /* bf16 matrix, optionally a conv-window view: see olmoasr_amd/csrc/kernels.h */
   const void* ptr; int64_t ld; int rpb; int64_t bstride; int lead; int kvalid; int trail_from;

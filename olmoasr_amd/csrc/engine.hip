@@ -1153,3 +1153,31 @@ extern "C" int oasr_optim_step(oasr_ctx* c, float inv_loss_scale, float max_grad
                   lr, beta1, beta2, eps, weight_decay, bc1, bc2, st));
   return refresh_packed(c, st);
 }
+
+// ---- ZeRO-1 building blocks: the optimizer over a contiguous RANGE of the flat arenas --------------------------------------
+// The reference's sharded variant is FSDP (scripts/training/train_fsdp_timestamps.py:2665-2719).  Here optimizer-state
+// sharding follows from the flat arena: rank r owns one contiguous range, keeps exp_avg / exp_avg_sq for that range only,
+// and the step is  reduce-scatter(grads) -> partial sum of squares per rank -> all-reduce of 2 floats -> AdamW on the owned
+// range -> all-gather(params)  (olmoasr_amd/zero.py).  Two entry points: the gradient statistics of a range and the step of a
+// range given GLOBAL statistics.
+extern "C" int oasr_grad_sumsq_range(oasr_ctx* c, int64_t off, int64_t numel, float* stats_out, void* scratch, void* stream) {
+  RC(check_bound(c, true));
+  OASR_REQUIRE(stats_out && scratch && off >= 0 && numel > 0 && off + numel <= c->numel && (off % 4) == 0 && (numel % 4) == 0,
+               "oasr_grad_sumsq_range: bad range [%lld, +%lld) (multiples of 4 inside the arena)", (long long)off, (long long)numel);
+  return launch_grad_stats(c->grads + off, numel, (double*)scratch, stats_out, (hipStream_t)stream);
+}
+
+// stats: device f32[2] = [sum of squares of the scaled gradients over the WHOLE arena, non-finite flag] (already reduced
+// over ranks); m_shard / v_shard: this range's exp_avg / exp_avg_sq (numel floats each, shard-local buffers).
+extern "C" int oasr_optim_step_range(oasr_ctx* c, int64_t off, int64_t numel, float* m_shard, float* v_shard, const float* stats,
+                                     float inv_loss_scale, float max_grad_norm, float lr, float beta1, float beta2, float eps,
+                                     float weight_decay, int64_t step, void* stream) {
+  RC(check_bound(c, true));
+  OASR_REQUIRE(m_shard && v_shard && stats && step >= 1 && off >= 0 && numel > 0 && off + numel <= c->numel && (off % 4) == 0 &&
+                   (numel % 4) == 0,
+               "oasr_optim_step_range: bad args");
+  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  const float bc2 = (float)(1.0 - pow((double)beta2, (double)step));
+  return launch_adamw(c->params + off, c->grads + off, m_shard, v_shard, c->f32 ? nullptr : (bf16_t*)(c->shadow + c->sh_flat) + off, numel,
+                      stats, inv_loss_scale, max_grad_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2, (hipStream_t)stream);
+}

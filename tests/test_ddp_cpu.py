@@ -194,3 +194,87 @@ def test_data_parallel_step_world2_equals_world1(algo):
             assert torch.allclose(v, params1[k], atol=2e-6), k
         assert abs(checksum - float(sum(p.double().sum() for p in params1.values()))) < 1e-2
     assert res[0][2] == res[1][2]  # both ranks hold bit-identical results after the exchange
+
+
+# ---- ZeRO-1 schedule (olmoasr_amd/zero.py) under gloo, with a torch stand-in for the two range kernels -------------------
+class _TorchRangeBackend:
+    """CPU stand-in with the semantics of oasr_grad_sumsq_range / oasr_optim_step_range (fused unscale + clip + AdamW)."""
+
+    def __init__(self, p, g):
+        self.p, self.g = p, g
+
+    def alloc(self, n):
+        return torch.zeros(n)
+
+    def sumsq(self, off, n):
+        x = self.g[off:off + n]
+        return torch.tensor([float((x.double() ** 2).sum()), float((~torch.isfinite(x)).any())])
+
+    def step(self, off, n, m, v, stats, *, step, lr, inv_loss_scale, max_grad_norm, betas, eps, weight_decay):
+        if float(stats[1]) != 0:
+            return
+        total = float(stats[0]) ** 0.5 * inv_loss_scale
+        coef = min(1.0, max_grad_norm / (total + 1e-6))
+        g = self.g[off:off + n] * (coef * inv_loss_scale)
+        p = self.p[off:off + n]
+        p.mul_(1 - lr * weight_decay)
+        m.mul_(betas[0]).add_(g, alpha=1 - betas[0])
+        v.mul_(betas[1]).addcmul_(g, g, value=1 - betas[1])
+        denom = (v.sqrt() / (1 - betas[1] ** step) ** 0.5).add_(eps)
+        p.addcdiv_(m, denom, value=-lr / (1 - betas[0] ** step))
+
+    def after_gather(self):
+        pass
+
+
+def _zero_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from olmoasr_amd import zero
+        n = 1003 * 4 + 4  # not a multiple of world * 4: exercises the tail
+        p = torch.randn(n, generator=torch.Generator().manual_seed(0))
+        g = torch.randn(n, generator=torch.Generator().manual_seed(10 + rank)) * 1024.0  # this rank's loss-scaled gradients
+        opt = zero.ShardedOptimizer(p, g, _TorchRangeBackend(p, g))
+        assert opt.len == zero.shard_range(n, rank, world)[1] and opt.m.numel() == opt.len < n
+        outs = []
+        for step in (1, 2):
+            if step == 2:
+                g.copy_(torch.randn(n, generator=torch.Generator().manual_seed(20 + rank)) * 1024.0)
+            stats = opt.step(step=step, lr=1e-2, inv_loss_scale=1.0 / (1024.0 * opt.grad_divisor))
+            outs.append((p.clone(), float(stats[0])))
+        q.put((rank, "ok", outs, opt.off, opt.len))
+    except Exception:
+        import traceback
+        q.put((rank, traceback.format_exc(), None, 0, 0))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_zero1_sharded_step_equals_replicated_step():
+    """Two ranks, each keeping AdamW moments for half of the arena only: after reduce-scatter / partial norms / range step /
+    all-gather both hold the parameters a single replicated optimizer produces from the mean gradient -- for two consecutive
+    steps (the sharded moments carry over)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_zero_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for pr in procs:
+        pr.join(30)
+    assert all(r[1] == "ok" for r in res), res
+    n = 1003 * 4 + 4
+    p = torch.randn(n, generator=torch.Generator().manual_seed(0))
+    ref = _TorchRangeBackend(p, torch.zeros(n))
+    m, v = torch.zeros(n), torch.zeros(n)
+    for step, seeds in ((1, (10, 11)), (2, (20, 21))):
+        ref.g = sum(torch.randn(n, generator=torch.Generator().manual_seed(s)) * 1024.0 for s in seeds)
+        ref.step(0, n, m, v, ref.sumsq(0, n), step=step, lr=1e-2, inv_loss_scale=1.0 / 2048.0, max_grad_norm=1.0, betas=(0.9, 0.98), eps=1e-6,
+                 weight_decay=0.1)
+        for rank, _, outs, off, ln in res:
+            got, sumsq = outs[step - 1]
+            assert torch.allclose(got, p, atol=1e-6, rtol=0), (step, rank, float((got - p).abs().max()))
+            assert abs(sumsq - float(ref.sumsq(0, n)[0])) < 1e-3 * sumsq
+    assert res[0][3] == 0 and res[1][3] == res[0][4] and res[1][3] + res[1][4] == n  # the two ranges tile the arena

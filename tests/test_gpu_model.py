@@ -542,3 +542,55 @@ def test_integration_stub_drives_the_reference_call_pattern(tmp_path, tiny_case)
             if k == "olmoasr" or k.startswith("olmoasr."):
                 sys.modules.pop(k)
         sys.modules.update(saved)
+
+
+def test_zero1_range_kernels_equal_the_replicated_step(native_tiny, tiny_case):
+    """oasr_grad_sumsq_range + oasr_optim_step_range over 3 virtual shards (what 3 ranks would each do after the
+    reduce-scatter) reproduce oasr_optim_step bit for bit: parameters, bf16 shadow, and the moments laid side by side."""
+    from olmoasr_amd import _native as N
+    from olmoasr_amd import zero
+    c = tiny_case
+    net = native_tiny
+    net.load_state_dict(c["sd"])
+    net.init_optimizer_state()
+    for t in net._opt_state:
+        t.zero_()
+    net.zero_grad()
+    net.loss_and_backward(c["mel"].to(DEV), c["tokens"].to(DEV), c["targets"].to(DEV), c["text_len"].to(DEV), loss_scale=256.0)
+    grads = net.flat_grads.clone()
+    p0 = net.flat_params.clone()
+    hyper = dict(step=1, lr=1e-3, inv_loss_scale=1.0 / 256.0, max_grad_norm=1.0, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.1)
+    stats_full = net.optim_step(**hyper).clone()
+    torch.cuda.synchronize()
+    p_full, m_full, v_full = net.flat_params.clone(), net._opt_state[0].clone(), net._opt_state[1].clone()
+    n = p0.numel()
+    shadow_full = net._shadow[: 2 * n].clone()
+    # the same step, shard by shard
+    net.flat_params.copy_(p0)
+    net.flat_grads.copy_(grads)
+    net.refresh_shadow()
+    be = zero.NativeBackend(net)
+    W = 3
+    ranges = [zero.shard_range(n, r, W) for r in range(W)]
+    assert ranges[0][0] == 0 and sum(ln for _, ln in ranges) == n and all(off % 4 == 0 and ln % 4 == 0 for off, ln in ranges)
+    total = torch.zeros(2, device=DEV)
+    for off, ln in ranges:
+        total += be.sumsq(off, ln)          # all_reduce(SUM) of the per-rank partials
+    assert abs(float(total[0]) - float(stats_full[0])) < 1e-5 * float(stats_full[0]) and float(total[1]) == 0.0
+    moments = []
+    for off, ln in ranges:
+        m, v = be.alloc(ln), be.alloc(ln)
+        be.step(off, ln, m, v, stats_full, **hyper)   # (the exact global statistics, so the comparison is bitwise)
+        moments.append((m, v))
+    torch.cuda.synchronize()
+    assert torch.equal(net.flat_params, p_full)
+    assert torch.equal(torch.cat([m for m, _ in moments]), m_full) and torch.equal(torch.cat([v for _, v in moments]), v_full)
+    assert torch.equal(net._shadow[: 2 * n], shadow_full)
+    # world-1 ShardedOptimizer == the plain step as well
+    net.flat_params.copy_(p0)
+    net.flat_grads.copy_(grads)
+    opt = zero.ShardedOptimizer(net.flat_params, net.flat_grads, zero.NativeBackend(net))
+    opt.step(**hyper)
+    torch.cuda.synchronize()
+    assert torch.equal(net.flat_params, p_full) and opt.state_bytes_saved() == 0
+    net.load_state_dict(c["sd"])
