@@ -577,10 +577,12 @@ class OLMoASR(nn.Module):
         table = {name: (off, numel, shape) for name, off, numel, shape in self._table}
         return [(name,) + table[name] for name, _ in self.named_parameters()]
 
-    def optimizer_state_dict(self, *, step: int, lr: float, betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.1):
+    def optimizer_state_dict(self, *, step: int, lr: float, betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.1,
+                             moments=None):
         """What ``torch.optim.AdamW(model.parameters(), ...).state_dict()`` holds after ``step`` steps
-        (train_timestamps.py:727-733, saved at :949): the reference can ``optimizer.load_state_dict`` it."""
-        m, v = self.init_optimizer_state()
+        (train_timestamps.py:727-733, saved at :949): the reference can ``optimizer.load_state_dict`` it.  ``moments``:
+        full-length (exp_avg, exp_avg_sq) gathered from a sharded optimizer (olmoasr_amd/zero.py) instead of the model's own."""
+        m, v = moments if moments is not None else self.init_optimizer_state()
         state = {}
         for i, (_, off, numel, shape) in enumerate(self._param_slices()):
             state[i] = {"step": torch.tensor(float(step)), "exp_avg": m[off:off + numel].view(shape).detach().cpu().clone(),
@@ -589,9 +591,10 @@ class OLMoASR(nn.Module):
                  "foreach": None, "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(state)))}
         return {"state": state if step > 0 else {}, "param_groups": [group]}
 
-    def load_optimizer_state_dict(self, sd) -> int:
-        """Inverse of ``optimizer_state_dict`` (also accepts a checkpoint written by the reference).  Returns the step count."""
-        m, v = self.init_optimizer_state()
+    def load_optimizer_state_dict(self, sd, into=None) -> int:
+        """Inverse of ``optimizer_state_dict`` (also accepts a checkpoint written by the reference).  Returns the step count.
+        ``into``: full-length (exp_avg, exp_avg_sq) buffers to fill instead of the model's own (sharded optimizer)."""
+        m, v = into if into is not None else self.init_optimizer_state()
         m.zero_()
         v.zero_()
         step = 0

@@ -97,3 +97,22 @@ class ShardedOptimizer:
                 dist.broadcast(self.p[per * W:], src=dist.get_global_rank(self.group, W - 1) if self.group else W - 1, group=self.group)
         self.backend.after_gather()
         return stats
+
+    def gather_state(self):
+        """Full-length (exp_avg, exp_avg_sq) on every rank -- for checkpoints in torch.optim.AdamW's layout
+        (OLMoASR.optimizer_state_dict(moments=...)); transient, 8 B/param."""
+        n, W, per = self.p.numel(), self.world, self.per
+        out = []
+        for t in (self.m, self.v):
+            full = torch.zeros(n, device=t.device, dtype=t.dtype)
+            full[self.off:self.off + self.len] = t
+            if W > 1:
+                dist.all_gather_into_tensor(full[: per * W], full[self.rank * per:(self.rank + 1) * per].clone(), group=self.group)
+                if per * W < n:
+                    dist.broadcast(full[per * W:], src=dist.get_global_rank(self.group, W - 1) if self.group else W - 1, group=self.group)
+            out.append(full)
+        return tuple(out)
+
+    def load_state(self, m_full: torch.Tensor, v_full: torch.Tensor):
+        self.m.copy_(m_full[self.off:self.off + self.len])
+        self.v.copy_(v_full[self.off:self.off + self.len])

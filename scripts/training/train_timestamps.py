@@ -49,7 +49,7 @@ IGNORED_FLAGS = ("samples_dicts_dir", "eval_dir", "eval_batch_size", "pin_memory
                  "async_eval", "eval_script_path", "eval_wandb_log", "eval_on_gpu", "job_type", "log_dir")
 NATIVE_FLAGS = dict(  # additions of this implementation
     synthetic=True, n_synthetic=4096, timestamps=False, seed=0, bucket_cap_mb=128.0, reducer="allreduce", resume=False,
-    device_synth=False)
+    zero_stage=0)  # zero_stage 1: AdamW moments sharded over the ranks (olmoasr_amd/zero.py; the reference's FSDP script's role)
 
 
 class Args(dict):
@@ -181,15 +181,16 @@ def run_dir(args, run_id):
 
 
 def save_ckpt(net, scaler, global_step, local_step, epoch, args, dims, rank, run_id, cursor=0, optimizer_steps=None,
-              file_name="latesttrain"):
+              file_name="latesttrain", sharded=None):
     """save_ckpt (train_timestamps.py:894-972): the ``_ddp`` file carries ``module.`` keys, the ``_non_ddp`` file plain ones."""
+    moments = sharded.gather_state() if sharded is not None else None  # (collective: every rank takes part)
     if rank != 0:
         return None
     os.makedirs(run_dir(args, run_id), exist_ok=True)
     sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     steps = global_step if optimizer_steps is None else optimizer_steps
     base = build_checkpoint(sd, net.optimizer_state_dict(step=steps, lr=args.lr * lr_lambda(global_step, args.train_steps), betas=args.betas,
-                                                         eps=args.eps, weight_decay=args.weight_decay),
+                                                         eps=args.eps, weight_decay=args.weight_decay, moments=moments),
                             scaler.state_dict(), global_step=global_step, local_step=local_step, epoch=epoch, dims=dims, lr=args.lr,
                             train_steps=args.train_steps, cursor=cursor, optimizer_steps=steps)
     tag = f"{file_name}_{global_step:08}_{args.model_variant}_{'_'.join(TAGS)}"
@@ -216,14 +217,20 @@ def find_ckpt(args, run_id):
     return max(files, key=lambda f: int(os.path.basename(f).split("_")[1]))
 
 
-def load_ckpt(net, scaler, path):
+def load_ckpt(net, scaler, path, sharded=None):
     """Resume (train_timestamps.py:975-1074): model (``module.`` keys), AdamW moments, GradScaler, counters.  Accepts files
     written by the reference (``dims`` pickled as ``olmoasr.config.model_dims.ModelDimensions``: see hub.load_checkpoint)."""
     from olmoasr_amd import hub
     ck = hub.load_checkpoint(path)
     net.load_state_dict({k[len("module."):] if k.startswith("module.") else k: v for k, v in ck["model_state_dict"].items()})
     net.refresh_shadow()
-    opt_steps = net.load_optimizer_state_dict(ck["optimizer_state_dict"])
+    if sharded is not None:  # fill full-length scratch moments, keep this rank's range
+        full = (torch.zeros_like(net.flat_params), torch.zeros_like(net.flat_params))
+        opt_steps = net.load_optimizer_state_dict(ck["optimizer_state_dict"], into=full)
+        sharded.load_state(*full)
+        del full
+    else:
+        opt_steps = net.load_optimizer_state_dict(ck["optimizer_state_dict"])
     scaler.load_state_dict(ck["scaler_state_dict"])
     # torch's AdamW does not advance its step on a GradScaler-skipped iteration: opt_steps <= global_step
     assert 0 <= opt_steps <= ck["global_step"], (opt_steps, ck["global_step"])
@@ -334,8 +341,14 @@ def main(argv=None):
     net = OLMoASR(dims, device=dev, seed=args.seed, compute_dtype=args.precision)
     ddp.broadcast_parameters(net.flat_params)  # DDP ctor _sync_module_states
     net.refresh_shadow()
-    net.init_optimizer_state()
-    reducer = ddp.GradReducer(net.flat_grads, net.grad_segments, bucket_cap_mb=args.bucket_cap_mb, algo=args.reducer) if world_size > 1 else None
+    sharded = None
+    if int(args.zero_stage) == 1:
+        from olmoasr_amd import zero
+        sharded = zero.ShardedOptimizer(net.flat_params, net.flat_grads, zero.NativeBackend(net))  # moments for the owned range only
+    else:
+        net.init_optimizer_state()
+    reducer = (ddp.GradReducer(net.flat_grads, net.grad_segments, bucket_cap_mb=args.bucket_cap_mb, algo=args.reducer)
+               if world_size > 1 and sharded is None else None)
     scaler = GradScalerState()
     accum = accumulation_steps(args.eff_batch_size, world_size, args.train_batch_size)
     mine = ddp.shard_indices(args.n_synthetic, rank, world_size)
@@ -343,7 +356,7 @@ def main(argv=None):
     global_step, local_step, cursor, epoch, optimizer_steps = 0, 0, 0, 0, 0
     run_id = get_run_id(args, rank, world_size)
     if args.resume or args.ckpt_file_name:
-        global_step, local_step, epoch, cursor, optimizer_steps = load_ckpt(net, scaler, find_ckpt(args, run_id))
+        global_step, local_step, epoch, cursor, optimizer_steps = load_ckpt(net, scaler, find_ckpt(args, run_id), sharded)
     # every rank of a node shares the host cores: the reference's --num_workers is per rank, but oversubscribing a 16-core
     # cgroup with 8 x 10 generator threads would make the loader, not the GPU, set the pace
     workers = max(1, min(int(args.num_workers), host_cores() // max(1, local_world)))
@@ -390,8 +403,11 @@ def main(argv=None):
         lr = args.lr * lr_lambda(global_step, args.train_steps)
         # torch's AdamW advances its per-parameter step only when GradScaler lets the step through: the bias correction
         # follows the number of APPLIED steps, not global_step
-        stats = net.optim_step(step=optimizer_steps + 1, lr=lr, inv_loss_scale=1.0 / (scaler.scale * div), max_grad_norm=args.max_grad_norm,
-                               betas=betas, eps=args.eps, weight_decay=args.weight_decay)
+        hyper = dict(step=optimizer_steps + 1, lr=lr, max_grad_norm=args.max_grad_norm, betas=betas, eps=args.eps, weight_decay=args.weight_decay)
+        if sharded is not None:
+            stats = sharded.step(inv_loss_scale=1.0 / (scaler.scale * sharded.grad_divisor), **hyper)
+        else:
+            stats = net.optim_step(inv_loss_scale=1.0 / (scaler.scale * div), **hyper)
         found_inf = bool(stats[1].item() != 0)  # host sync once per optimizer step, like scaler.step()
         scaler.update(found_inf)
         if not found_inf:
@@ -415,10 +431,10 @@ def main(argv=None):
             print(json.dumps({"event": "eval", "global_step": global_step,
                               "token_error_rate": round(evaluate(net, held_out, dev, bool(args.timestamps)), 4)}), flush=True)
         if args.ckpt_freq and global_step % args.ckpt_freq == 0:
-            save_ckpt(net, scaler, global_step, local_step, epoch, args, dims, rank, run_id, cursor, optimizer_steps)
+            save_ckpt(net, scaler, global_step, local_step, epoch, args, dims, rank, run_id, cursor, optimizer_steps, sharded=sharded)
     loader.close()
     if args.ckpt_freq and (global_step % args.ckpt_freq) != 0:
-        save_ckpt(net, scaler, global_step, local_step, epoch, args, dims, rank, run_id, cursor, optimizer_steps)
+        save_ckpt(net, scaler, global_step, local_step, epoch, args, dims, rank, run_id, cursor, optimizer_steps, sharded=sharded)
     if world_size > 1:
         dist.barrier()
         dist.destroy_process_group()

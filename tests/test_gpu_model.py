@@ -439,6 +439,10 @@ def test_resume_continues_the_run_and_adamw_state_is_torch_compatible(tmp_path):
     # the run-directory form of resuming (load_ckpt with file_name "" = latest *_fp16_ddp.pt of {exp_name}_{run_id}, :1012-1021)
     again = tt.main(common + ["--exp_name", "b", "--resume", "True"])
     assert again == []  # the run already reached train_steps: its latest checkpoint is step 8
+    # --zero_stage 1 (world 1): the sharded-optimizer code path of the script gives the same trajectory and checkpoint layout
+    z = tt.main(common + ["--exp_name", "z", "--ckpt_freq", "8", "--zero_stage", "1"])
+    for r, s_ in zip(z, straight):
+        assert r["lr"] == s_["lr"] and abs(r["train_loss"] - s_["train_loss"]) < 2e-2 * max(1.0, abs(s_["train_loss"]))
     ck = torch.load(bdir / first, weights_only=False)
     shapes = [v.shape for k, v in ck["model_state_dict"].items() if not k.endswith("encoder.positional_embedding")]  # (a buffer)
     params = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
