@@ -59,6 +59,10 @@ extern "C" int oasr_profile_gemm(int enable) {
   gemm_profile_enable(enable);
   return OASR_OK;
 }
+extern "C" int oasr_gemm_set_variant(int dma_in_mma) {
+  gemm_set_variant(dma_in_mma);
+  return OASR_OK;
+}
 extern "C" int oasr_gemm_set_stagger(int sleeps, int phases) {
   gemm_set_stagger(sleeps, phases);
   return OASR_OK;

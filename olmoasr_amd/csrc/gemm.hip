@@ -47,6 +47,7 @@ struct GemmProfile {
 GemmProfile g_prof;
 bool g_force_general = false;
 int g_stagger = 0, g_stagger_phases = 2;  // experiment hook (oasr_gemm_set_stagger)
+int g_pp_dma_in_mma = -1;                 // ping-pong kernel variant (oasr_gemm_set_variant): -1 = per-layout default
 int g_fast_geometry = 0;  // 0 = heuristic, 1 = force 256x128 (4 waves), 2 = force 256x256 (8 waves, 2 stages)  // tests: run the register-staged general kernel even where the fast path applies
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -739,7 +740,7 @@ __global__ __launch_bounds__(128 * NWN, (NWN == 2 && !SWAP) ? 3 : 2) void oasr_g
 //        retired its reads (lgkmcnt(0)) before its first barrier (B1 in phase 1 -> B restaged in phase 2).
 #define OASR_PP_BARRIER() asm volatile("s_barrier" ::: "memory")
 
-template <bool TA, bool TB, bool SWAP, bool CSUM>
+template <bool TA, bool TB, bool SWAP, bool CSUM, bool DMA_IN_MMA>
 __global__ __launch_bounds__(512, 2) void oasr_gemm_pp_kernel(GemmArgs p) {
   constexpr int HALF = 128 * 64 * 2, BUF = 4 * HALF;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -829,16 +830,41 @@ __global__ __launch_bounds__(512, 2) void oasr_gemm_pp_kernel(GemmArgs p) {
 
   const int aoff = wm * HALF, boff = (2 + (wn >> 1)) * HALF, bsub = (wn & 1) * 64;
   bf16x8_t fa[2][4], fb0[4], fb1[4];
-#define OASR_PP_MMA(MT0, NT, FB)                                                                             \
+#define OASR_PP_MFMA1(MT0, NT, FB, KS, T)                                                                     \
+  do {                                                                                                       \
+    if (SWAP)                                                                                                \
+      acc[MT0 + T][NT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FB[KS], fa[T][KS], acc[MT0 + T][NT], 0, 0, 0); \
+    else                                                                                                     \
+      acc[MT0 + T][NT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[T][KS], FB[KS], acc[MT0 + T][NT], 0, 0, 0); \
+  } while (0)
+  // 8 MFMAs at priority 1.  DMA: the phase's two direct-to-LDS pieces are issued from INSIDE the section (after the 2nd and
+  // the 4th MFMA) when OASR_PP_DMA_IN_MMA: a piece costs ~60 cycles of issue among bare MFMAs, which the 256 cycles of
+  // matrix-pipe time cover, against 100-185 cycles in a read section already carrying 8-12 ds_read_b128
+  // (MI355X_MICROARCH.md, "LDS-DMA piece issue cost") -- there it made the read section longer than the partner's MFMAs.
+#define OASR_PP_MMA(MT0, NT, FB, DO_STAGE, IMG, T, BUFP)                                                     \
   do {                                                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     __builtin_amdgcn_s_setprio(1);                                                                           \
-    _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_) {   \
-      if (SWAP)                                                                                              \
-        acc[MT0 + t_][NT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FB[ks_], fa[t_][ks_], acc[MT0 + t_][NT], 0, 0, 0); \
-      else                                                                                                   \
-        acc[MT0 + t_][NT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t_][ks_], FB[ks_], acc[MT0 + t_][NT], 0, 0, 0); \
+    OASR_PP_MFMA1(MT0, NT, FB, 0, 0);                                                                        \
+    OASR_PP_MFMA1(MT0, NT, FB, 0, 1);                                                                        \
+    if (DMA_IN_MMA && (DO_STAGE)) {                                                                          \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
+      const __amdgpu_buffer_rsrc_t rs_ = make_rsrc((IMG) < 2 ? baseA + (T) * stepA : baseB + (T) * stepB);   \
+      glds16(rs_, (BUFP) + (IMG) * HALF + wave * 1024, off[IMG][0]);                                         \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
     }                                                                                                        \
+    OASR_PP_MFMA1(MT0, NT, FB, 1, 0);                                                                        \
+    OASR_PP_MFMA1(MT0, NT, FB, 1, 1);                                                                        \
+    if (DMA_IN_MMA && (DO_STAGE)) {                                                                          \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
+      const __amdgpu_buffer_rsrc_t rs_ = make_rsrc((IMG) < 2 ? baseA + (T) * stepA : baseB + (T) * stepB);   \
+      glds16(rs_, (BUFP) + (IMG) * HALF + wave * 1024 + 8192, off[IMG][1]);                                  \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
+    }                                                                                                        \
+    OASR_PP_MFMA1(MT0, NT, FB, 2, 0);                                                                        \
+    OASR_PP_MFMA1(MT0, NT, FB, 2, 1);                                                                        \
+    OASR_PP_MFMA1(MT0, NT, FB, 3, 0);                                                                        \
+    OASR_PP_MFMA1(MT0, NT, FB, 3, 1);                                                                        \
     __builtin_amdgcn_s_setprio(0);                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
   } while (0)
@@ -854,41 +880,46 @@ __global__ __launch_bounds__(512, 2) void oasr_gemm_pp_kernel(GemmArgs p) {
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int i = 0; i < 2; ++i) fa[i][ks] = fast_frag<TA, 256>(cur + aoff, i * 32, ks, lane);
-    if (next1) OASR_PP_STAGE(0, t + 1, oth);
+    if (!DMA_IN_MMA && next1) OASR_PP_STAGE(0, t + 1, oth);
     OASR_PP_BARRIER();
-    OASR_PP_MMA(0, 0, fb0);
+    OASR_PP_MMA(0, 0, fb0, next1, 0, t + 1, oth);
     OASR_PP_BARRIER();
     // ---- phase 1
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) fb1[ks] = fast_frag<TB, 256>(cur + boff, bsub + 32, ks, lane);
-    if (next1) OASR_PP_STAGE(1, t + 1, oth);
+    if (!DMA_IN_MMA && next1) OASR_PP_STAGE(1, t + 1, oth);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // B images of `cur` are dead before this phase's barrier
     OASR_PP_BARRIER();
-    OASR_PP_MMA(0, 1, fb1);
+    OASR_PP_MMA(0, 1, fb1, next1, 1, t + 1, oth);
     OASR_PP_BARRIER();
     // ---- phase 2
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int i = 0; i < 2; ++i) fa[i][ks] = fast_frag<TA, 256>(cur + aoff, 64 + i * 32, ks, lane);
-    if (next2) OASR_PP_STAGE(2, t + 2, cur);
+    if (!DMA_IN_MMA && next2) OASR_PP_STAGE(2, t + 2, cur);
     OASR_PP_BARRIER();
-    OASR_PP_MMA(2, 1, fb1);
+    OASR_PP_MMA(2, 1, fb1, next2, 2, t + 2, cur);
     OASR_PP_BARRIER();
-    // ---- phase 3
-    if (next2) {
+    // ---- phase 3: everything of tile t+1 (this wave's pieces) must have landed before the barrier that ends the tile
+    if (DMA_IN_MMA) {
+      // outstanding, oldest first: [B0 B1](t+1) [A0 A1](t+1) B0(t+2) -> all but the last two pieces
+      if (next2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (next2) {
       OASR_PP_STAGE(3, t + 2, cur);
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // everything but tile t+2's B has landed (this wave's pieces)
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     OASR_PP_BARRIER();
-    OASR_PP_MMA(2, 0, fb0);
+    OASR_PP_MMA(2, 0, fb0, next2, 3, t + 2, cur);
     OASR_PP_BARRIER();
   }
   if (wm == 0) OASR_PP_BARRIER();  // re-join: the trailing half has finished its LDS reads after this
 #undef OASR_PP_STAGE
 #undef OASR_PP_MMA
+#undef OASR_PP_MFMA1
   fast_epilogue<SWAP, CSUM>(p, acc, smem, m0, n0, wm, wn, wave, lane);
 }
 
@@ -1005,12 +1036,12 @@ int launch_fast_cfg(const GemmArgs& a, hipStream_t stream) {
   return OASR_OK;
 }
 
-template <bool TA, bool TB, bool SWAP, bool CSUM = false>
-int launch_pp_cfg(const GemmArgs& a, hipStream_t stream) {
+template <bool TA, bool TB, bool SWAP, bool CSUM, bool DMA>
+int launch_pp_variant(const GemmArgs& a, hipStream_t stream) {
   static bool attr = false;
   const int lds = 2 * 4 * 128 * 64 * 2;
   if (!attr) {
-    OASR_CHECK_HIP(hipFuncSetAttribute((const void*)oasr_gemm_pp_kernel<TA, TB, SWAP, CSUM>,
+    OASR_CHECK_HIP(hipFuncSetAttribute((const void*)oasr_gemm_pp_kernel<TA, TB, SWAP, CSUM, DMA>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr = true;
   }
@@ -1028,15 +1059,24 @@ int launch_pp_cfg(const GemmArgs& a, hipStream_t stream) {
     e0 = g_prof.events[2 * idx];
     e1 = g_prof.events[2 * idx + 1];
     auto tf = [](bool b) { return b ? "true" : "false"; };
-    static const std::string name =
-        std::string("oasr_gemm_pp_kernel<") + tf(TA) + ", " + tf(TB) + ", " + tf(SWAP) + ", " + tf(CSUM) + ">";
+    static const std::string name = std::string("oasr_gemm_pp_kernel<") + tf(TA) + ", " + tf(TB) + ", " + tf(SWAP) + ", " + tf(CSUM) +
+                                    ", " + tf(DMA) + ">";
     g_prof.recs.push_back({(TA ? 2 : 0) + (TB ? 1 : 0), 2.0 * (double)a.M * (double)a.N * (double)a.K, name.c_str()});
     OASR_CHECK_HIP(hipEventRecord(e0, stream));
   }
-  hipLaunchKernelGGL((oasr_gemm_pp_kernel<TA, TB, SWAP, CSUM>), grid, dim3(512), lds, stream, a);
+  hipLaunchKernelGGL((oasr_gemm_pp_kernel<TA, TB, SWAP, CSUM, DMA>), grid, dim3(512), lds, stream, a);
   OASR_LAUNCH_CHECK();
   if (e1) OASR_CHECK_HIP(hipEventRecord(e1, stream));
   return OASR_OK;
+}
+template <bool TA, bool TB, bool SWAP, bool CSUM = false>
+int launch_pp_cfg(const GemmArgs& a, hipStream_t stream) {
+  // Where the direct-to-LDS pieces are issued: between the MFMAs (+3..5 % on the NT forward shapes at M = 192000,
+  // profiles/r02_gemm_dma_placement_ab.txt) or in the fragment-read section (level or better when an operand is read
+  // through ds_read_b64_tr_b16: those read sections are longer and hide the issue).  g_pp_dma_in_mma: -1 = this rule,
+  // 0 / 1 = forced (scripts/gemm_stagger_ab.py variant).
+  const bool in_mma = g_pp_dma_in_mma < 0 ? (!TA && !TB) : g_pp_dma_in_mma != 0;
+  return in_mma ? launch_pp_variant<TA, TB, SWAP, CSUM, true>(a, stream) : launch_pp_variant<TA, TB, SWAP, CSUM, false>(a, stream);
 }
 
 // Geometry choice for bf16-output GEMMs, from interleaved A/B runs on the OLMoASR-medium shapes (scripts/gemm_ab.py,
@@ -1140,6 +1180,7 @@ int launch_t(const GemmArgs& a, hipStream_t stream) {
 
 }  // namespace
 
+void gemm_set_variant(int dma_in_mma) { g_pp_dma_in_mma = dma_in_mma < 0 ? -1 : (dma_in_mma != 0); }
 void gemm_set_stagger(int sleeps, int phases) {  // sleeps < 0: stagger off everywhere (A/B baseline)
   g_stagger = sleeps;
   g_stagger_phases = phases < 2 ? 2 : phases;

@@ -71,6 +71,7 @@ int launch_gemm(const GemmArgsF& a, hipStream_t stream);  // fp32 validation ker
 // bench-only: time every GEMM launch with HIP events on its stream; collect() sums per variant (2*ta+tb)
 void gemm_profile_enable(int on);
 void gemm_force_general(int on);  // tests: disable the direct-to-LDS fast path
+void gemm_set_variant(int dma_in_mma);  // experiments: ping-pong kernel issues its DMA pieces between the MFMAs
 void gemm_set_stagger(int sleeps, int phases);  // experiments: first-wave phase stagger of the ping-pong kernel
 int gemm_profile_collect(double ms[4], double flops[4], long count[4], char* by_symbol, int cap);
 template <typename T>

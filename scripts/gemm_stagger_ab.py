@@ -39,6 +39,17 @@ def main():
         ("NN dgrad      N=1024 K=4096", lambda: ops.gemm(x, w[:, :d], M, d, 4 * d, tb=True, out=out[:, :d]), 2.0 * M * 4 * d * d),
         ("NN dgrad dgelu N=4096 K=1024", lambda: ops.gemm(x[:, :d], w[:d], M, 4 * d, d, tb=True, dgelu_u=pre, dgelu_deriv=True, out=out), 2.0 * M * 4 * d * d),
     ]
+    if len(sys.argv) > 1 and sys.argv[1] == "variant":  # A/B of where the ping-pong kernel issues its DMA pieces
+        print(f"{'case':34s}  dma-in-read: ms TF/s | dma-in-mma: ms TF/s  (x2, interleaved)")
+        for name, fn, flops in cases:
+            row = f"{name:34s} "
+            for v in (0, 1, 0, 1):
+                N.lib().oasr_gemm_set_variant(v)
+                ms = timeit(fn)
+                row += f"{ms:7.3f} {flops / ms / 1e9:6.0f} | "
+            print(row, flush=True)
+        N.lib().oasr_gemm_set_variant(-1)
+        return
     settings = [(0, 2), (2, 2), (5, 2), (2, 4), (3, 4), (1, 8)]
     print(f"{'case':34s} " + " ".join(f"s{a}p{b}: ms TF/s " for a, b in settings))
     for name, fn, flops in cases:

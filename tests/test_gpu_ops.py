@@ -144,6 +144,35 @@ def test_gemm_layouts(M, N, K, ta, tb, gemm_path):
     close(out, Af @ Bf.t(), name=f"gemm {M}x{N}x{K} ta={ta} tb={tb}")
 
 
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
+def test_gemm_pingpong_dma_placement_variants_are_bit_identical(ta, tb):
+    """The 256x256 kernel issues its direct-to-LDS pieces either in the fragment-read section or between the MFMAs
+    (per-layout default); both schedules must produce the same bits."""
+    from olmoasr_amd import _native as N
+    M, N_, K = 2560, 1024, 1024
+    A = rnd(K, M, seed=1) if ta else rnd(M, K, seed=1)
+    B = rnd(K, N_, seed=2, scale=0.05) if tb else rnd(N_, K, seed=2, scale=0.05)
+    outs = []
+    try:
+        N.lib().oasr_gemm_force_general(4)  # force the ping-pong kernel
+        for v in (0, 1):
+            N.lib().oasr_gemm_set_variant(v)
+            if ta:  # wgrad layout: fp32 atomic output
+                o = torch.zeros(M, N_, device=DEV)
+                ops().gemm(A, B, M, N_, K, ta=ta, tb=tb, out_f32=o, atomic=True, split_k=1)
+            else:
+                o = torch.full((M, N_), float("nan"), device=DEV, dtype=BF)
+                ops().gemm(A, B, M, N_, K, ta=ta, tb=tb, out=o)
+            outs.append(o)
+    finally:
+        N.lib().oasr_gemm_force_general(0)
+        N.lib().oasr_gemm_set_variant(-1)
+    assert torch.equal(outs[0], outs[1])
+    Af = A.float().t() if ta else A.float()
+    Bf = B.float().t() if tb else B.float()
+    close(outs[1], Af @ Bf.t(), name="dma-in-mma variant")
+
+
 def test_gemm_epilogues(gemm_path):
     M, N, K = 300, 256, 192
     A, B = rnd(M, K, seed=3), rnd(N, K, seed=4, scale=0.1)
