@@ -28,7 +28,16 @@ constexpr int TILE = 64 * 64 * 2;  // one 64x64 bf16 tile
 
 typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
 
-__device__ __forceinline__ int tile_addr(int row, int c16) { return row * 128 + ((c16 ^ ((row >> 1) & 7)) << 4); }
+// Bank-conflict swizzle of a [64 rows][128 B] tile: chunk c16 of row r lives at chunk c16 ^ f((r >> 1) & 7), f(x) = x ^ ((x & 1) << 2).
+//  * ds_read_b128 (frag_rows) is served in 16-lane groups whose rows cover every value of (r >> 1) & 7 exactly twice (once per
+//    row parity = bank half): any bijection of that value keeps the 16 x 4 banks distinct;
+//  * ds_read_b64_tr_b16 (frag_cols) is served in 32-lane groups = 4 consecutive rows x 4 consecutive chunks: rows r and r + 2 share
+//    the bank half, so their chunk sets must be disjoint, i.e. f must differ in bit 2 between (r >> 1) and (r >> 1) + 1.  The plain
+//    XOR with (r >> 1) & 7 did not (measured: 20-25 % of the LDS cycles of the three kernels were conflicts).
+__device__ __forceinline__ int tile_addr(int row, int c16) {
+  const int x = (row >> 1) & 7;
+  return row * 128 + ((c16 ^ x ^ ((x & 1) << 2)) << 4);
+}
 
 // cooperative 64x64 tile: each of 256 threads moves 2 x 16 bytes.  Bounds-checked buffer loads: the descriptor covers
 // rows [0, rmax) of this (batch, head) slice, so rows past the end read as zeros (their scores are masked, and zero V
