@@ -47,7 +47,7 @@ struct GemmProfile {
 GemmProfile g_prof;
 bool g_force_general = false;
 int g_stagger = 0, g_stagger_phases = 2;  // experiment hook (oasr_gemm_set_stagger)
-int g_pp_dma_in_mma = -1;                 // ping-pong kernel variant (oasr_gemm_set_variant): -1 = per-layout default
+int g_pp_dma_in_mma = -1;                 // ping-pong kernel variant (oasr_gemm_set_variant): -1 = default
 int g_fast_geometry = 0;  // 0 = heuristic, 1 = force 256x128 (4 waves), 2 = force 256x256 (8 waves, 2 stages)  // tests: run the register-staged general kernel even where the fast path applies
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -740,8 +740,14 @@ __global__ __launch_bounds__(128 * NWN, (NWN == 2 && !SWAP) ? 3 : 2) void oasr_g
 //        retired its reads (lgkmcnt(0)) before its first barrier (B1 in phase 1 -> B restaged in phase 2).
 #define OASR_PP_BARRIER() asm volatile("s_barrier" ::: "memory")
 
-template <bool TA, bool TB, bool SWAP, bool CSUM, bool DMA_IN_MMA>
+template <bool TA, bool TB, bool SWAP, bool CSUM, int VAR>
 __global__ __launch_bounds__(512, 2) void oasr_gemm_pp_kernel(GemmArgs p) {
+  // VAR bit 0: the direct-to-LDS pieces are issued between the MFMAs (else in the fragment-read section);
+  //     bit 1: every MFMA section is pinned between its two barriers.  Without the pin hipcc sinks most of a section's MFMAs
+  //            below the closing s_barrier (the asm-volatile barrier orders memory, not register-only instructions, and the
+  //            conditional DMA issue splits the basic block the sched_barrier fences act in): the ISA of round 1's kernel has
+  //            1 + 7 MFMAs around the first barrier pair instead of 8 inside it.
+  constexpr bool DMA_IN_MMA = (VAR & 1) != 0, PIN = (VAR & 2) != 0;
   constexpr int HALF = 128 * 64 * 2, BUF = 4 * HALF;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -845,6 +851,7 @@ __global__ __launch_bounds__(512, 2) void oasr_gemm_pp_kernel(GemmArgs p) {
   do {                                                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     __builtin_amdgcn_s_setprio(1);                                                                           \
+    if (PIN) asm volatile("" : "+v"(acc[MT0][NT]), "+v"(acc[MT0 + 1][NT]));                                  \
     OASR_PP_MFMA1(MT0, NT, FB, 0, 0);                                                                        \
     OASR_PP_MFMA1(MT0, NT, FB, 0, 1);                                                                        \
     if (DMA_IN_MMA && (DO_STAGE)) {                                                                          \
@@ -865,10 +872,107 @@ __global__ __launch_bounds__(512, 2) void oasr_gemm_pp_kernel(GemmArgs p) {
     OASR_PP_MFMA1(MT0, NT, FB, 2, 1);                                                                        \
     OASR_PP_MFMA1(MT0, NT, FB, 3, 0);                                                                        \
     OASR_PP_MFMA1(MT0, NT, FB, 3, 1);                                                                        \
+    if (PIN) asm volatile("" : "+v"(acc[MT0][NT]), "+v"(acc[MT0 + 1][NT]));                                  \
     __builtin_amdgcn_s_setprio(0);                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
   } while (0)
 
+  if (VAR & 4) {
+    // Two sections of 16 MFMAs per K-tile (4 barriers instead of 8): S0 = rows 0-63 of this wave's 128 x 64 block against
+    // both column halves, S1 = rows 64-127.  Staging (hazards as in the header, with "phase" = section):
+    //   S0 read : A image 0 of tile t+1 -> oth (its last reader, the leading group, is past its own S1 MFMAs);
+    //             lgkmcnt(0) BEFORE the barrier, so the B images of `cur` are dead once both groups passed it
+    //   S0 MFMA : A image 1 of tile t+1 -> oth, between the MFMAs (the trailing group finished reading it one barrier ago)
+    //   S1 read : B images of tile t+2 -> cur; vmcnt(4): everything of tile t+1 has landed, only those 4 pieces are in flight
+    for (int t = 0; t < nt; ++t) {
+      char* cur = smem + (t & 1) * BUF;
+      char* oth = smem + ((t & 1) ^ 1) * BUF;
+      const bool next1 = t + 1 < nt, next2 = t + 2 < nt;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        fb0[ks] = fast_frag<TB, 256>(cur + boff, bsub, ks, lane);
+        fb1[ks] = fast_frag<TB, 256>(cur + boff, bsub + 32, ks, lane);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i][ks] = fast_frag<TA, 256>(cur + aoff, i * 32, ks, lane);
+      if (next1) OASR_PP_STAGE(0, t + 1, oth);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      OASR_PP_BARRIER();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      asm volatile("" : "+v"(acc[0][0]), "+v"(acc[1][0]), "+v"(acc[0][1]), "+v"(acc[1][1]));
+      OASR_PP_MFMA1(0, 0, fb0, 0, 0);
+      OASR_PP_MFMA1(0, 0, fb0, 0, 1);
+      OASR_PP_MFMA1(0, 1, fb1, 0, 0);
+      OASR_PP_MFMA1(0, 1, fb1, 0, 1);
+      if (next1) {
+        __builtin_amdgcn_sched_barrier(0);
+        const __amdgpu_buffer_rsrc_t rs_ = make_rsrc(baseA + (t + 1) * stepA);
+        glds16(rs_, oth + 1 * HALF + wave * 1024, off[1][0]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      OASR_PP_MFMA1(0, 0, fb0, 1, 0);
+      OASR_PP_MFMA1(0, 0, fb0, 1, 1);
+      OASR_PP_MFMA1(0, 1, fb1, 1, 0);
+      OASR_PP_MFMA1(0, 1, fb1, 1, 1);
+      if (next1) {
+        __builtin_amdgcn_sched_barrier(0);
+        const __amdgpu_buffer_rsrc_t rs_ = make_rsrc(baseA + (t + 1) * stepA);
+        glds16(rs_, oth + 1 * HALF + wave * 1024 + 8192, off[1][1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int ks = 2; ks < 4; ++ks) {
+        OASR_PP_MFMA1(0, 0, fb0, ks, 0);
+        OASR_PP_MFMA1(0, 0, fb0, ks, 1);
+        OASR_PP_MFMA1(0, 1, fb1, ks, 0);
+        OASR_PP_MFMA1(0, 1, fb1, ks, 1);
+      }
+      asm volatile("" : "+v"(acc[0][0]), "+v"(acc[1][0]), "+v"(acc[0][1]), "+v"(acc[1][1]));
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      OASR_PP_BARRIER();
+      // ---- S1
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i][ks] = fast_frag<TA, 256>(cur + aoff, 64 + i * 32, ks, lane);
+      if (next2) {
+        OASR_PP_STAGE(2, t + 2, cur);
+        if (DMA_IN_MMA) {  // B image 1 of tile t+2 goes out between this section's MFMAs: only B image 0's 2 pieces are newer
+          asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+          OASR_PP_STAGE(3, t + 2, cur);
+          asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        }
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      OASR_PP_BARRIER();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      asm volatile("" : "+v"(acc[2][0]), "+v"(acc[3][0]), "+v"(acc[2][1]), "+v"(acc[3][1]));
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        OASR_PP_MFMA1(2, 0, fb0, ks, 0);
+        OASR_PP_MFMA1(2, 0, fb0, ks, 1);
+        OASR_PP_MFMA1(2, 1, fb1, ks, 0);
+        OASR_PP_MFMA1(2, 1, fb1, ks, 1);
+        if (DMA_IN_MMA && next2 && ks < 2) {
+          __builtin_amdgcn_sched_barrier(0);
+          const __amdgpu_buffer_rsrc_t rs_ = make_rsrc(baseB + (t + 2) * stepB);
+          glds16(rs_, cur + 3 * HALF + wave * 1024 + ks * 8192, off[3][ks]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      asm volatile("" : "+v"(acc[2][0]), "+v"(acc[3][0]), "+v"(acc[2][1]), "+v"(acc[3][1]));
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      OASR_PP_BARRIER();
+    }
+  } else
   for (int t = 0; t < nt; ++t) {
     char* cur = smem + (t & 1) * BUF;
     char* oth = smem + ((t & 1) ^ 1) * BUF;
@@ -1036,7 +1140,7 @@ int launch_fast_cfg(const GemmArgs& a, hipStream_t stream) {
   return OASR_OK;
 }
 
-template <bool TA, bool TB, bool SWAP, bool CSUM, bool DMA>
+template <bool TA, bool TB, bool SWAP, bool CSUM, int DMA>
 int launch_pp_variant(const GemmArgs& a, hipStream_t stream) {
   static bool attr = false;
   const int lds = 2 * 4 * 128 * 64 * 2;
@@ -1060,7 +1164,7 @@ int launch_pp_variant(const GemmArgs& a, hipStream_t stream) {
     e1 = g_prof.events[2 * idx + 1];
     auto tf = [](bool b) { return b ? "true" : "false"; };
     static const std::string name = std::string("oasr_gemm_pp_kernel<") + tf(TA) + ", " + tf(TB) + ", " + tf(SWAP) + ", " + tf(CSUM) +
-                                    ", " + tf(DMA) + ">";
+                                    ", " + std::to_string(DMA) + ">";
     g_prof.recs.push_back({(TA ? 2 : 0) + (TB ? 1 : 0), 2.0 * (double)a.M * (double)a.N * (double)a.K, name.c_str()});
     OASR_CHECK_HIP(hipEventRecord(e0, stream));
   }
@@ -1072,11 +1176,21 @@ int launch_pp_variant(const GemmArgs& a, hipStream_t stream) {
 template <bool TA, bool TB, bool SWAP, bool CSUM = false>
 int launch_pp_cfg(const GemmArgs& a, hipStream_t stream) {
   // Where the direct-to-LDS pieces are issued: between the MFMAs (+3..5 % on the NT forward shapes at M = 192000,
-  // profiles/r02_gemm_dma_placement_ab.txt) or in the fragment-read section (level or better when an operand is read
+  // profiles/r02_gemm_variants_ab.txt) or in the fragment-read section (level or better when an operand is read
   // through ds_read_b64_tr_b16: those read sections are longer and hide the issue).  g_pp_dma_in_mma: -1 = this rule,
   // 0 / 1 = forced (scripts/gemm_stagger_ab.py variant).
-  const bool in_mma = g_pp_dma_in_mma < 0 ? (!TA && !TB) : g_pp_dma_in_mma != 0;
-  return in_mma ? launch_pp_variant<TA, TB, SWAP, CSUM, true>(a, stream) : launch_pp_variant<TA, TB, SWAP, CSUM, false>(a, stream);
+  // Default (profiles/r02_gemm_variants_ab.txt, M = 192000): two pinned 16-MFMA sections per K-tile with the DMA pieces spread
+  // over read and MFMA sections (7) -- +8 % on the NT forward shapes at K = 1024, +16..19 % on the NN dgrads whose B fragments
+  // come through ds_read_b64_tr_b16 -- except the long-K NT shapes, where four pinned 8-MFMA sections (2) are 2 % ahead.
+  const int var = g_pp_dma_in_mma >= 0 ? g_pp_dma_in_mma : ((!TA && !TB && a.K >= 4096) ? 2 : 7);
+  switch (var & 7) {
+    case 1: return launch_pp_variant<TA, TB, SWAP, CSUM, 1>(a, stream);
+    case 2: return launch_pp_variant<TA, TB, SWAP, CSUM, 2>(a, stream);
+    case 3: return launch_pp_variant<TA, TB, SWAP, CSUM, 3>(a, stream);
+    case 6: return launch_pp_variant<TA, TB, SWAP, CSUM, 6>(a, stream);
+    case 7: return launch_pp_variant<TA, TB, SWAP, CSUM, 7>(a, stream);
+    default: return launch_pp_variant<TA, TB, SWAP, CSUM, 0>(a, stream);
+  }
 }
 
 // Geometry choice for bf16-output GEMMs, from interleaved A/B runs on the OLMoASR-medium shapes (scripts/gemm_ab.py,
@@ -1180,7 +1294,7 @@ int launch_t(const GemmArgs& a, hipStream_t stream) {
 
 }  // namespace
 
-void gemm_set_variant(int dma_in_mma) { g_pp_dma_in_mma = dma_in_mma < 0 ? -1 : (dma_in_mma != 0); }
+void gemm_set_variant(int v) { g_pp_dma_in_mma = v < 0 ? -1 : (v & 7); }
 void gemm_set_stagger(int sleeps, int phases) {  // sleeps < 0: stagger off everywhere (A/B baseline)
   g_stagger = sleeps;
   g_stagger_phases = phases < 2 ? 2 : phases;

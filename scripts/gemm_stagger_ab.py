@@ -40,10 +40,10 @@ def main():
         ("NN dgrad dgelu N=4096 K=1024", lambda: ops.gemm(x[:, :d], w[:d], M, 4 * d, d, tb=True, dgelu_u=pre, dgelu_deriv=True, out=out), 2.0 * M * 4 * d * d),
     ]
     if len(sys.argv) > 1 and sys.argv[1] == "variant":  # A/B of where the ping-pong kernel issues its DMA pieces
-        print(f"{'case':34s}  dma-in-read: ms TF/s | dma-in-mma: ms TF/s  (x2, interleaved)")
+        print(f"{'case':34s}  variants 2 6 7 2 6 7 (bit 0 = DMA between the MFMAs, bit 1 = MFMA sections pinned, bit 2 = two 16-MFMA sections per K-tile): ms TF/s")
         for name, fn, flops in cases:
             row = f"{name:34s} "
-            for v in (0, 1, 0, 1):
+            for v in (2, 6, 7, 2, 6, 7):
                 N.lib().oasr_gemm_set_variant(v)
                 ms = timeit(fn)
                 row += f"{ms:7.3f} {flops / ms / 1e9:6.0f} | "
