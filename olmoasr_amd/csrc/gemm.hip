@@ -1237,7 +1237,8 @@ int launch_fast_t(const GemmArgs& a, hipStream_t stream) {
   }();
   const int geom = g_fast_geometry ? g_fast_geometry : env_geom;
   const bool big = geom == 2;  // (the 256x256 / 2-stage geometry lost to 256x128 on every measured shape incl. small split-K outputs: scripts/wgrad_sweep.py)
-  if (geom == 3 || (geom == 0 && !atomic_only && prefer_pingpong(a))) {  // 256x256 ping-pong kernel
+  if (geom == 3 || (geom == 0 && !atomic_only && prefer_pingpong(a)) ||
+      (geom == 0 && atomic_only && a.atomic_on_pp && (a.M % 256) == 0 && (a.N % 256) == 0)) {  // 256x256 ping-pong kernel
     if (atomic_only) return launch_pp_cfg<TA, TB, false>(a, stream);
     if (a.colsum && !TA && TB) return launch_pp_cfg<false, true, true, true>(a, stream);
     const int rc = launch_pp_cfg<TA, TB, true>(a, stream);

@@ -63,6 +63,7 @@ struct GemmArgsT {
   int raster_gm;  // fast path: tile rows per L2 group (0 = choose from residency)
   int dgelu_deriv;  // dgelu_u already holds GELU'(u) (written by an act == 2 forward)
   int stagger, stagger_phases;  // ping-pong kernel: first-wave phase stagger in units of s_sleep(127) (0 = off)
+  int atomic_on_pp;             // split-K / atomic output on the 256x256 ping-pong kernel instead of the 256x128 one
 };
 typedef GemmArgsT<bf16_t> GemmArgs;
 typedef GemmArgsT<float> GemmArgsF;
