@@ -1182,7 +1182,12 @@ int launch_pp_cfg(const GemmArgs& a, hipStream_t stream) {
   // Default (profiles/r02_gemm_variants_ab.txt, M = 192000): two pinned 16-MFMA sections per K-tile with the DMA pieces spread
   // over read and MFMA sections (7) -- +8 % on the NT forward shapes at K = 1024, +16..19 % on the NN dgrads whose B fragments
   // come through ds_read_b64_tr_b16 -- except the long-K NT shapes, where four pinned 8-MFMA sections (2) are 2 % ahead.
-  const int var = g_pp_dma_in_mma >= 0 ? g_pp_dma_in_mma : ((!TA && !TB && a.K >= 4096) ? 2 : 7);
+  static const int env_var = [] {
+    const char* e = getenv("OASR_PP_VARIANT");  // experiments: force one variant for a whole process
+    return e ? atoi(e) : -1;
+  }();
+  const int forced = g_pp_dma_in_mma >= 0 ? g_pp_dma_in_mma : env_var;
+  const int var = forced >= 0 ? forced : ((CSUM || (!TA && !TB && a.K >= 4096)) ? 2 : 7);  // (CSUM: whole-step A/B, same box)
   switch (var & 7) {
     case 1: return launch_pp_variant<TA, TB, SWAP, CSUM, 1>(a, stream);
     case 2: return launch_pp_variant<TA, TB, SWAP, CSUM, 2>(a, stream);
