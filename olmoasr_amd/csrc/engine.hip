@@ -345,15 +345,16 @@ struct Runner {
       }
     }
     g.split_k = (int)split;
-    // Long token dimensions (the encoder's 192k rows per micro-batch): with its MFMA sections pinned the 256x256 ping-pong
-    // loop beats the 256x128 kernel on three of the four weight shapes (scripts/wgrad_sweep.py, TOKENS=192000, round 2:
-    // [1024x1024] 1030 vs 937 TF/s at split 16, [4096x1024] 1148 vs 1113 at split 8, [1024x4096] 1155 vs 1052 at split 4;
-    // [3072x1024] level) -- one workgroup per CU, so the split is chosen to give 256-512 workgroups.
-    if (M >= 150000 && x.rpb == 0 && (N % 256) == 0 && (K % 256) == 0) {
+    // With its MFMA sections pinned the 256x256 ping-pong loop beats the 256x128 kernel on the square and the 4:1 weight shapes
+    // (scripts/wgrad_sweep.py, profiles/r02_wgrad_sweep.txt; TF/s pp vs 256x128): 192k tokens [1024x1024] 1071 vs 972 (split 16),
+    // [4096x1024] 1157 vs 1117 (8), [1024x4096] 1158 vs 1064 (4); 57k tokens [4096x1024] 1032 vs 956 (4), [1024x4096] 1131 vs 996
+    // (4); [3072x1024] and the 57k-token square stay on the 256x128 kernel.  One workgroup per CU: splits give 256-512 workgroups.
+    if (M >= 40000 && x.rpb == 0 && (N % 256) == 0 && (K % 256) == 0) {
       const long t256 = (long)(N / 256) * (K / 256);
+      const bool long_tokens = M >= 150000;
       int pp_split = 0;
-      if (t256 == 16) pp_split = 16;
-      else if (t256 == 64) pp_split = N > K ? 8 : 4;
+      if (t256 == 16 && long_tokens) pp_split = 16;
+      else if (t256 == 64) pp_split = (long_tokens && N > K) ? 8 : 4;
       if (pp_split) {
         g.atomic_on_pp = 1;
         g.split_k = pp_split;
