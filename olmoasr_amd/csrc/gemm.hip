@@ -832,7 +832,7 @@ __global__ __launch_bounds__(512, 2) void oasr_gemm_pp_kernel(GemmArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   OASR_PP_BARRIER();
-  if (wm == 1) OASR_PP_BARRIER();  // the upper half trails by one barrier from here on
+  if (wm == 1 && !(VAR & 8)) OASR_PP_BARRIER();  // the upper half trails by one barrier from here on (VAR bit 3: lockstep experiment)
 
   const int aoff = wm * HALF, boff = (2 + (wn >> 1)) * HALF, bsub = (wn & 1) * 64;
   bf16x8_t fa[2][4], fb0[4], fb1[4];
@@ -1020,7 +1020,7 @@ __global__ __launch_bounds__(512, 2) void oasr_gemm_pp_kernel(GemmArgs p) {
     OASR_PP_MMA(2, 0, fb0, next2, 3, t + 2, cur);
     OASR_PP_BARRIER();
   }
-  if (wm == 0) OASR_PP_BARRIER();  // re-join: the trailing half has finished its LDS reads after this
+  if (wm == 0 && !(VAR & 8)) OASR_PP_BARRIER();  // re-join: the trailing half has finished its LDS reads after this
 #undef OASR_PP_STAGE
 #undef OASR_PP_MMA
 #undef OASR_PP_MFMA1
@@ -1188,12 +1188,13 @@ int launch_pp_cfg(const GemmArgs& a, hipStream_t stream) {
   }();
   const int forced = g_pp_dma_in_mma >= 0 ? g_pp_dma_in_mma : env_var;
   const int var = forced >= 0 ? forced : ((CSUM || (!TA && !TB && a.K >= 4096)) ? 2 : 7);  // (CSUM: whole-step A/B, same box)
-  switch (var & 7) {
+  switch (var & 15) {
     case 1: return launch_pp_variant<TA, TB, SWAP, CSUM, 1>(a, stream);
     case 2: return launch_pp_variant<TA, TB, SWAP, CSUM, 2>(a, stream);
     case 3: return launch_pp_variant<TA, TB, SWAP, CSUM, 3>(a, stream);
     case 6: return launch_pp_variant<TA, TB, SWAP, CSUM, 6>(a, stream);
     case 7: return launch_pp_variant<TA, TB, SWAP, CSUM, 7>(a, stream);
+    case 15: return launch_pp_variant<TA, TB, SWAP, CSUM, 15>(a, stream);
     default: return launch_pp_variant<TA, TB, SWAP, CSUM, 0>(a, stream);
   }
 }
@@ -1300,7 +1301,7 @@ int launch_t(const GemmArgs& a, hipStream_t stream) {
 
 }  // namespace
 
-void gemm_set_variant(int v) { g_pp_dma_in_mma = v < 0 ? -1 : (v & 7); }
+void gemm_set_variant(int v) { g_pp_dma_in_mma = v < 0 ? -1 : (v & 15); }
 void gemm_set_stagger(int sleeps, int phases) {  // sleeps < 0: stagger off everywhere (A/B baseline)
   g_stagger = sleeps;
   g_stagger_phases = phases < 2 ? 2 : phases;

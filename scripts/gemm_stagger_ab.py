@@ -40,10 +40,10 @@ def main():
         ("NN dgrad dgelu N=4096 K=1024", lambda: ops.gemm(x[:, :d], w[:d], M, 4 * d, d, tb=True, dgelu_u=pre, dgelu_deriv=True, out=out), 2.0 * M * 4 * d * d),
     ]
     if len(sys.argv) > 1 and sys.argv[1] == "variant":  # A/B of where the ping-pong kernel issues its DMA pieces
-        print(f"{'case':34s}  variants 2 6 7 2 6 7 (bit 0 = DMA between the MFMAs, bit 1 = MFMA sections pinned, bit 2 = two 16-MFMA sections per K-tile): ms TF/s")
+        print(f"{'case':34s}  variants 7 15 7 15 (bit 3 = both wave groups in lockstep, no ping-pong offset) (bit 0 = DMA between the MFMAs, bit 1 = MFMA sections pinned, bit 2 = two 16-MFMA sections per K-tile): ms TF/s")
         for name, fn, flops in cases:
             row = f"{name:34s} "
-            for v in (2, 6, 7, 2, 6, 7):
+            for v in (7, 15, 7, 15):
                 N.lib().oasr_gemm_set_variant(v)
                 ms = timeit(fn)
                 row += f"{ms:7.3f} {flops / ms / 1e9:6.0f} | "
