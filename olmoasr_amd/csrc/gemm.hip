@@ -1179,15 +1179,16 @@ int launch_pp_cfg(const GemmArgs& a, hipStream_t stream) {
   // profiles/r02_gemm_variants_ab.txt) or in the fragment-read section (level or better when an operand is read
   // through ds_read_b64_tr_b16: those read sections are longer and hide the issue).  g_pp_dma_in_mma: -1 = this rule,
   // 0 / 1 = forced (scripts/gemm_stagger_ab.py variant).
-  // Default (profiles/r02_gemm_variants_ab.txt, M = 192000): two pinned 16-MFMA sections per K-tile with the DMA pieces spread
-  // over read and MFMA sections (7) -- +8 % on the NT forward shapes at K = 1024, +16..19 % on the NN dgrads whose B fragments
-  // come through ds_read_b64_tr_b16 -- except the long-K NT shapes, where four pinned 8-MFMA sections (2) are 2 % ahead.
+  // Default (profiles/r02_gemm_variants_ab.txt, r02_step_gemm_variants_same_box.txt): two pinned 16-MFMA sections per K-tile with
+  // the DMA pieces spread over read and MFMA sections (7): +8 % on the NT forward shapes at K = 1024, +16..19 % on the NN dgrads
+  // whose B fragments come through ds_read_b64_tr_b16.  The fused-colsum dgrad keeps four pinned 8-MFMA sections (2), which won
+  // the whole-step A/B for it.  (NT at K = 4096 is 2 % faster on 2; not worth a second instantiation per layout.)
   static const int env_var = [] {
     const char* e = getenv("OASR_PP_VARIANT");  // experiments: force one variant for a whole process
     return e ? atoi(e) : -1;
   }();
   const int forced = g_pp_dma_in_mma >= 0 ? g_pp_dma_in_mma : env_var;
-  const int var = forced >= 0 ? forced : ((CSUM || (!TA && !TB && a.K >= 4096)) ? 2 : 7);  // (CSUM: whole-step A/B, same box)
+  const int var = forced >= 0 ? forced : (CSUM ? 2 : 7);
   switch (var & 15) {
     case 1: return launch_pp_variant<TA, TB, SWAP, CSUM, 1>(a, stream);
     case 2: return launch_pp_variant<TA, TB, SWAP, CSUM, 2>(a, stream);
