@@ -179,7 +179,7 @@ struct Plan {
   int32_t* n_valid;
   // backward temporaries
   T *ga, *gb, *gc, *gln, *gqkv, *go, *gu, *gxa, *gkv, *gq, *gA2;
-  float *delta, *tmp_w1p, *tmp_w2p, *cs_scratch;
+  float *delta, *tmp_w1p, *tmp_w2p, *cs_scratch, *gemm_cs_scratch;
 };
 
 static void plan_attn(Arena& A, AttnSave& s, long M, long Mkv, int d, int B, int H, long Tq, bool cross, bool train) {
@@ -264,6 +264,7 @@ static void make_plan(const oasr_ctx* c, Arena& A, Plan& p, int B, int S, bool t
     p.gA2 = A.template act<T>(Me * 3 * d);
     p.delta = A.f32((long)B * c->H * c->Te);
     p.cs_scratch = A.f32(attn_colsum_scratch_floats(B, c->H, c->Te, c->Te));  // (the largest of the three attention shapes)
+    p.gemm_cs_scratch = A.f32((size_t)2 * cdiv(Mmax, 256) * 4 * d + 64);
     p.tmp_w1p = A.f32((long)d * 256);
     p.tmp_w2p = A.f32((long)d * 3 * d);
   }
@@ -275,6 +276,7 @@ struct Runner {
   int B, S;
   const int32_t* text_len;
   bool train = false;  // the training forward saves GELU'(u) in place of u (GemmArgs.act == 2)
+  float* cs_scratch = nullptr;  // partial rows of fused bias-gradient column sums (GemmArgs.colsum_scratch)
 
   int linear(const T* x, long M, int K, const T* W, int N, const float* bias, int act, const T* resid, T* out,
              T* out_pre) {
@@ -311,6 +313,7 @@ struct Runner {
     g.out = dx;
     g.ldc = K;
     g.colsum = colsum;
+    g.colsum_scratch = colsum ? cs_scratch : nullptr;
     return launch_gemm(g, st);
   }
   // dW[N,K] += dy[M,N]^T . x[M,K]   (fp32 atomics, split over the token dimension)
@@ -1026,6 +1029,7 @@ static int oasr_train_fwd_bwd_s_impl(oasr_ctx* c, const float* mel, const int64_
   Engine<T>::make_plan(c, A, p, B, S, true);
   typename Engine<T>::Runner r{c, (hipStream_t)stream, B, S, text_len};
   r.train = true;
+  r.cs_scratch = p.gemm_cs_scratch;
   hipStream_t st = r.st;
 
   // ---------------- forward ----------------

@@ -572,8 +572,14 @@ __device__ __forceinline__ void fast_epilogue_rows(const GemmArgs& p, f32x16_t (
       cs[e] = t;
     }
     if (lane < 8 && n_ok) {
+      if (p.colsum_scratch) {  // one partial row per 128-row wave block, written exactly once: no atomics
+        float* dst = p.colsum_scratch + (long)(mrow0 >> 7) * p.N + nn;
+        *(f32x4_t*)dst = f32x4_t{cs[0], cs[1], cs[2], cs[3]};
+        *(f32x4_t*)(dst + 4) = f32x4_t{cs[4], cs[5], cs[6], cs[7]};
+      } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) unsafeAtomicAdd(p.colsum + nn + e, cs[e]);
+        for (int e = 0; e < 8; ++e) unsafeAtomicAdd(p.colsum + nn + e, cs[e]);
+      }
     }
   }
 }
@@ -1247,7 +1253,11 @@ int launch_fast_t(const GemmArgs& a, hipStream_t stream) {
   if (geom == 3 || (geom == 0 && !atomic_only && prefer_pingpong(a)) ||
       (geom == 0 && atomic_only && a.atomic_on_pp && (a.M % 256) == 0 && (a.N % 256) == 0)) {  // 256x256 ping-pong kernel
     if (atomic_only) return launch_pp_cfg<TA, TB, false>(a, stream);
-    if (a.colsum && !TA && TB) return launch_pp_cfg<false, true, true, true>(a, stream);
+    if (a.colsum && !TA && TB) {
+      const int rc = launch_pp_cfg<false, true, true, true>(a, stream);
+      if (rc || !a.colsum_scratch) return rc;  // (without scratch the kernel used atomics)
+      return launch_colsum_accum(a.colsum_scratch, a.N, 2L * cdiv(a.M, 256), a.N, a.colsum, stream);
+    }
     const int rc = launch_pp_cfg<TA, TB, true>(a, stream);
     return (rc || !a.colsum) ? rc : launch_colsum_accum(a.out, a.ldc, a.M, a.N, a.colsum, stream);
   }
@@ -1260,7 +1270,11 @@ int launch_fast_t(const GemmArgs& a, hipStream_t stream) {
     return (rc || !a.colsum) ? rc : launch_colsum_accum(a.out, a.ldc, a.M, a.N, a.colsum, stream);
   }
   if (a.colsum) {
-    if (!TA && TB) return launch_fast_cfg<false, true, 128, 2, 1, true, true>(a, stream);  // dgrad + fused bias gradient
+    if (!TA && TB) {  // dgrad + fused bias gradient
+      const int rc = launch_fast_cfg<false, true, 128, 2, 1, true, true>(a, stream);
+      if (rc || !a.colsum_scratch) return rc;
+      return launch_colsum_accum(a.colsum_scratch, a.N, 2L * cdiv(a.M, 256), a.N, a.colsum, stream);
+    }
     const int rc = launch_fast_cfg<TA, TB, 128, 2, 1, true>(a, stream);
     return rc ? rc : launch_colsum_accum(a.out, a.ldc, a.M, a.N, a.colsum, stream);
   }

@@ -64,6 +64,8 @@ struct GemmArgsT {
   int dgelu_deriv;  // dgelu_u already holds GELU'(u) (written by an act == 2 forward)
   int stagger, stagger_phases;  // ping-pong kernel: first-wave phase stagger in units of s_sleep(127) (0 = off)
   int atomic_on_pp;             // split-K / atomic output on the 256x256 ping-pong kernel instead of the 256x128 one
+  float* colsum_scratch;        // optional, with colsum on the direct-to-LDS kernels: fp32 [2 * ceil(M/256)][N] partial rows (one per
+                                // 128-row wave block) that the launcher reduces into colsum -- instead of fp32 atomics from every wave
 };
 typedef GemmArgsT<bf16_t> GemmArgs;
 typedef GemmArgsT<float> GemmArgsF;

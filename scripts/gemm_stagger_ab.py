@@ -39,6 +39,16 @@ def main():
         ("NN dgrad      N=1024 K=4096", lambda: ops.gemm(x, w[:, :d], M, d, 4 * d, tb=True, out=out[:, :d]), 2.0 * M * 4 * d * d),
         ("NN dgrad dgelu N=4096 K=1024", lambda: ops.gemm(x[:, :d], w[:d], M, 4 * d, d, tb=True, dgelu_u=pre, dgelu_deriv=True, out=out), 2.0 * M * 4 * d * d),
     ]
+    if len(sys.argv) > 1 and sys.argv[1] == "colsum":  # what the fused bias-gradient column sums cost the GELU' dgrad
+        cs = torch.zeros(4 * d, device=DEV)
+        a = lambda: ops.gemm(x[:, :d], w[:d], M, 4 * d, d, tb=True, dgelu_u=pre, dgelu_deriv=True, out=out)
+        b = lambda: ops.gemm(x[:, :d], w[:d], M, 4 * d, d, tb=True, dgelu_u=pre, dgelu_deriv=True, out=out, colsum=cs)
+        for v in (2, 7):
+            N.lib().oasr_gemm_set_variant(v)
+            for _ in range(2):
+                print(f"variant {v}: dgelu dgrad {timeit(a):.3f} ms, with fused colsum {timeit(b):.3f} ms", flush=True)
+        N.lib().oasr_gemm_set_variant(-1)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "variant":  # A/B of where the ping-pong kernel issues its DMA pieces
         print(f"{'case':34s}  variants 7 15 7 15 (bit 3 = both wave groups in lockstep, no ping-pong offset) (bit 0 = DMA between the MFMAs, bit 1 = MFMA sections pinned, bit 2 = two 16-MFMA sections per K-tile): ms TF/s")
         for name, fn, flops in cases:
