@@ -60,6 +60,7 @@ def _declare(lib):
         "oasr_decode_step_workspace_bytes": (sz, [vp, i32]),
         "oasr_decode_begin": (i32, [vp, vp, i32, vp, vp]),
         "oasr_decode_step": (i32, [vp, vp, i32, i32, vp, vp, vp, sz, vp]),
+        "oasr_decode_check": (i32, [vp, i32, vp, vp]),
         "oasr_decode_logits": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, sz, vp]),
         "oasr_destroy": (None, [vp]),
         "oasr_param_count": (i32, [vp]),
@@ -93,6 +94,7 @@ def _declare(lib):
         "oasr_gemm_force_general": (i32, [i32]),
         "oasr_gemm_set_stagger": (i32, [i32, i32]),
         "oasr_gemm_set_variant": (i32, [i32]),
+        "oasr_decode_set_fused": (i32, [i32]),
         "oasr_profile_gemm_collect": (i32, [vp, vp, vp, C.c_char_p, i32]),
     }
     for name, (res, args) in sig.items():

@@ -48,6 +48,8 @@ GemmProfile g_prof;
 bool g_force_general = false;
 int g_stagger = 0, g_stagger_phases = 2;  // experiment hook (oasr_gemm_set_stagger)
 int g_pp_dma_in_mma = -1;                 // ping-pong kernel variant (oasr_gemm_set_variant): -1 = default
+int g_pp_persistent = -1;                 // ping-pong kernel launched persistent: -1 = default rule, 0 / 1 forced
+int g_epi_flags = -1;                     // epilogue memory policy (GemmArgs::epi_flags): -1 = default
 int g_fast_geometry = 0;  // 0 = heuristic, 1 = force 256x128 (4 waves), 2 = force 256x256 (8 waves, 2 stages)  // tests: run the register-staged general kernel even where the fast path applies
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -420,6 +422,15 @@ __host__ __device__ __forceinline__ bool fast_rows_ok(const GemmArgs& p) {
          (!p.resid || (p.ldr % 8) == 0) && (!p.dgelu_u || (p.ldu % 8) == 0) && !(p.resid && p.dgelu_u);
 }
 
+// 16-byte global accesses of the epilogue, optionally non-temporal (streaming: the output / side-input bytes are touched once
+// and should not displace the operand panels the main loops re-read from L2)
+__device__ __forceinline__ void store16(bf16_t* ptr, const u32x4_t& v, bool nt) {
+  if (nt) __builtin_nontemporal_store(v, (u32x4_t*)ptr);
+  else *(u32x4_t*)ptr = v;
+}
+__device__ __forceinline__ u32x4_t load16(const bf16_t* ptr, bool nt) {
+  return nt ? __builtin_nontemporal_load((const u32x4_t*)ptr) : *(const u32x4_t*)ptr;
+}
 // stg: this wave's staging tile, 8-row groups of 1 KiB placed GS bytes apart; bias_lds: 64 floats of wave-private LDS.
 template <bool CSUM, int GS = 1024, bool PF = true>
 __device__ __forceinline__ void fast_epilogue_rows(const GemmArgs& p, f32x16_t (&acc)[4][2], char* stg, float* bias_lds,
@@ -428,6 +439,7 @@ __device__ __forceinline__ void fast_epilogue_rows(const GemmArgs& p, f32x16_t (
   const bool has_bias = p.bias != nullptr, has_side = p.dgelu_u != nullptr || p.resid != nullptr, has_u = p.dgelu_u != nullptr;
   const bool has_pre = p.out_pre != nullptr, has_out = p.out != nullptr, gelu = p.act != 0, has_pos = p.pos != nullptr;
   const bool save_deriv = p.act == 2, u_is_deriv = p.dgelu_deriv != 0;
+  const bool nt_st = (p.epi_flags & 1) != 0, nt_ld = (p.epi_flags & 2) != 0;
   const bf16_t* side = has_u ? p.dgelu_u : p.resid;  // at most one of the two (fast_rows_ok)
   const long lds_ = has_u ? p.ldu : p.ldr;
   const int ch = lane & 7, nn = ncol0 + ch * 8;
@@ -441,7 +453,7 @@ __device__ __forceinline__ void fast_epilogue_rows(const GemmArgs& p, f32x16_t (
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int mm = mrow0 + i * 8 + (lane >> 3);
-      if (n_ok && mm < p.M) sd[i] = *(const u32x4_t*)(side + (long)mm * lds_ + nn);
+      if (n_ok && mm < p.M) sd[i] = load16(side + (long)mm * lds_ + nn, nt_ld);
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -479,7 +491,7 @@ __device__ __forceinline__ void fast_epilogue_rows(const GemmArgs& p, f32x16_t (
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int mm = mrow0 + (mt + (PF ? 1 : 0)) * 32 + i * 8 + (lane >> 3);
-        if (n_ok && mm < p.M) sn[i] = *(const u32x4_t*)(side + (long)mm * lds_ + nn);
+        if (n_ok && mm < p.M) sn[i] = load16(side + (long)mm * lds_ + nn, nt_ld);
       }
     }
     // pass B
@@ -489,7 +501,7 @@ __device__ __forceinline__ void fast_epilogue_rows(const GemmArgs& p, f32x16_t (
       const int mm = mrow0 + mt * 32 + r2;
       const bool ok = n_ok && mm < p.M;
       const u32x4_t pre = *(lds_u32x4_ptr)(size_t)(rbase + i * GS);  // rows r2 = i*8 + (lane >> 3): (r2 & 7) == lane >> 3
-      if (has_pre && !save_deriv && ok) *(u32x4_t*)(p.out_pre + (long)mm * p.ldc + nn) = pre;
+      if (has_pre && !save_deriv && ok) store16(p.out_pre + (long)mm * p.ldc + nn, pre, nt_st);
       u32x4_t fin = pre;
       if (gelu || has_side || has_pos) {
         float x[8];
@@ -506,7 +518,7 @@ __device__ __forceinline__ void fast_epilogue_rows(const GemmArgs& p, f32x16_t (
             u32x4_t dpk;
 #pragma unroll
             for (int e = 0; e < 4; ++e) dpk[e] = pack_bf2(dv[2 * e], dv[2 * e + 1]);
-            *(u32x4_t*)(p.out_pre + (long)mm * p.ldc + nn) = dpk;
+            store16(p.out_pre + (long)mm * p.ldc + nn, dpk, nt_st);
           }
         } else if (gelu) {
 #pragma unroll
@@ -553,7 +565,7 @@ __device__ __forceinline__ void fast_epilogue_rows(const GemmArgs& p, f32x16_t (
           cs[2 * e + 1] += bf_hi(fin[e]);
         }
       }
-      if (has_out && ok) *(u32x4_t*)(p.out + (long)mm * p.ldc + nn) = fin;
+      if (has_out && ok) store16(p.out + (long)mm * p.ldc + nn, fin, nt_st);
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -587,12 +599,12 @@ __device__ __forceinline__ void fast_epilogue_rows(const GemmArgs& p, f32x16_t (
 // Epilogue shared by the direct-to-LDS kernels: each wave owns a 128 x 64 block of the output tile as acc[4][2]
 // 32x32 MFMA blocks (rows m0 + wm*128 + mt*32, columns n0 + wn*64 + nt*32).  All waves of the workgroup must be past
 // their last main-loop LDS read (the staging tiles alias the operand images).
+// stg: this wave's 4 KiB staging tile, bias_lds: this wave's 64 floats.
 template <bool SWAP, bool CSUM, bool PF = true>
-__device__ __forceinline__ void fast_epilogue(const GemmArgs& p, f32x16_t (&acc)[4][2], char* smem, int m0, int n0, int wm,
-                                              int wn, int wave, int lane) {
+__device__ __forceinline__ void fast_epilogue(const GemmArgs& p, f32x16_t (&acc)[4][2], char* stg, float* bias_lds, int m0, int n0,
+                                              int wm, int wn, int lane) {
   if (SWAP) {  // bf16 outputs (the host routes anything fast_rows_ok() rejects to the general kernel)
-    fast_epilogue_rows<CSUM, 1024, PF>(p, acc, smem + wave * 8192, (float*)(smem + wave * 8192 + 4096), m0 + wm * 128,
-                                       n0 + wn * 64, lane);
+    fast_epilogue_rows<CSUM, 1024, PF>(p, acc, stg, bias_lds, m0 + wm * 128, n0 + wn * 64, lane);
     return;
   }
   const int h = lane >> 5;
@@ -719,7 +731,7 @@ __global__ __launch_bounds__(128 * NWN, (NWN == 2 && !SWAP) ? 3 : 2) void oasr_g
     __syncthreads();  // stage fully consumed (and, with two stages, the prefetched tile has landed)
   }
 
-  fast_epilogue<SWAP, CSUM, true>(p, acc, smem, m0, n0, wm, wn, wave, lane);
+  fast_epilogue<SWAP, CSUM, true>(p, acc, smem + wave * 8192, (float*)(smem + wave * 8192 + 4096), m0, n0, wm, wn, lane);
 }
 
 
@@ -760,37 +772,55 @@ __global__ __launch_bounds__(512, 2) void oasr_gemm_pp_kernel(GemmArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
-  int tm, tn, ksplit;
-  {
-    const int ntile = tiles_m * tiles_n;
-    if (!SWAP && (p.split_k & 7) == 0 && gridDim.y == 1) {  // split-K range tied to the XCD (see the kernel above)
-      const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-      const int s8 = p.split_k >> 3;
-      const int t = j % ntile;
-      ksplit = xcd * s8 + j / ntile;
-      tm = t / tiles_n;
-      tn = t - tm * tiles_n;
-    } else {
-      const int bid = xcd_remap(blockIdx.x, gridDim.x);
-      // groups of 8 tile rows, walked rows-first: the 32 tiles an XCD runs at once are 8 row panels x 4 column panels
-      // (12 operand panels through its L2 instead of 2 x 16 = 18: -6 % on the N = 4096 layers, scripts/gemm_ab.py)
-      int gm = p.raster_gm > 0 ? p.raster_gm : 8;
-      gm = gm < 1 ? 1 : (gm > 16 ? 16 : gm);
-      const int per_group = gm * tiles_n;
-      const int group = bid / per_group, in_group = bid - group * per_group;
-      const int first_m = group * gm;
-      const int gsz = min(gm, tiles_m - first_m);
-      tm = first_m + in_group % gsz;
-      tn = in_group / gsz;
-      ksplit = blockIdx.y;
-    }
-  }
-  const int m0 = tm * 256, n0 = tn * 256;
   const int kt_total = p.K / BK;
   const int per = (kt_total + p.split_k - 1) / p.split_k;
-  const int kt0 = ksplit * per;
-  const int nt = min(kt_total, kt0 + per) - kt0;  // K-tiles of this workgroup
-  if (nt <= 0) return;
+  const long stepA = TA ? (long)BK * p.A.ld : BK, stepB = TB ? (long)BK * p.B.ld : BK;
+  // PERSISTENT launches (p.vgrid > gridDim.x, one workgroup per CU): workgroup w walks the virtual blocks w, w + gridDim.x, ...
+  // of the grid a plain launch would have used -- gridDim.x is a multiple of 8, so the XCD a virtual block lands on, and with it
+  // the rasterisation below, is exactly that of the plain launch.
+  const int vgrid = p.vgrid > 0 ? p.vgrid : (int)gridDim.x;
+  int m0, n0, nt;
+  unsigned off[4][2];  // staging offsets: image i (0,1 = A halves; 2,3 = B halves), 2 pieces per wave
+  const bf16_t *baseA, *baseB;
+#define OASR_PP_TILE(V)                                                                                      \
+  do {                                                                                                       \
+    int tm_, tn_, ksplit_;                                                                                   \
+    const int ntile_ = tiles_m * tiles_n;                                                                    \
+    if (!SWAP && (p.split_k & 7) == 0 && gridDim.y == 1) { /* split-K range tied to the XCD (see the kernel above) */ \
+      const int xcd_ = (V) & 7, j_ = (V) >> 3;                                                               \
+      const int s8_ = p.split_k >> 3;                                                                        \
+      const int t_ = j_ % ntile_;                                                                            \
+      ksplit_ = xcd_ * s8_ + j_ / ntile_;                                                                    \
+      tm_ = t_ / tiles_n;                                                                                    \
+      tn_ = t_ - tm_ * tiles_n;                                                                              \
+    } else {                                                                                                 \
+      const int bid_ = xcd_remap((V), vgrid);                                                                \
+      /* groups of 8 tile rows, walked rows-first: the 32 tiles an XCD runs at once are 8 row panels x 4 column panels */ \
+      /* (12 operand panels through its L2 instead of 2 x 16 = 18: -6 % on the N = 4096 layers, scripts/gemm_ab.py) */ \
+      int gm_ = p.raster_gm > 0 ? p.raster_gm : 8;                                                           \
+      gm_ = gm_ < 1 ? 1 : (gm_ > 16 ? 16 : gm_);                                                             \
+      const int per_group_ = gm_ * tiles_n;                                                                  \
+      const int group_ = bid_ / per_group_, in_group_ = bid_ - group_ * per_group_;                          \
+      const int first_m_ = group_ * gm_;                                                                     \
+      const int gsz_ = min(gm_, tiles_m - first_m_);                                                         \
+      tm_ = first_m_ + in_group_ % gsz_;                                                                     \
+      tn_ = in_group_ / gsz_;                                                                                \
+      ksplit_ = blockIdx.y;                                                                                  \
+    }                                                                                                        \
+    m0 = tm_ * 256;                                                                                          \
+    n0 = tn_ * 256;                                                                                          \
+    const int kt0_ = ksplit_ * per;                                                                          \
+    nt = min(kt_total, kt0_ + per) - kt0_; /* K-tiles of this output tile */                                 \
+    fast_offsets<TA, 128, 2, 8>(p.A, p.M, m0, lane, wave, off[0], m0);                                       \
+    fast_offsets<TA, 128, 2, 8>(p.A, p.M, m0 + 128, lane, wave, off[1], m0);                                 \
+    fast_offsets<TB, 128, 2, 8>(p.B, p.N, n0, lane, wave, off[2], n0);                                       \
+    fast_offsets<TB, 128, 2, 8>(p.B, p.N, n0 + 128, lane, wave, off[3], n0);                                 \
+    baseA = (TA ? p.A.ptr + m0 : p.A.ptr + (long)m0 * p.A.ld) + (long)kt0_ * stepA;                         \
+    baseB = (TB ? p.B.ptr + n0 : p.B.ptr + (long)n0 * p.B.ld) + (long)kt0_ * stepB;                         \
+  } while (0)
+  int v = blockIdx.x;
+  OASR_PP_TILE(v);
+  if (nt <= 0) return;  // (uneven split-K; the host never launches those persistent)
   // Phase stagger of the first wave of workgroups (one per CU): with equal-length tiles every CU reaches its epilogue at
   // the same moment and the 256 x 128 KiB of output must drain to HBM in one burst while the matrix cores idle; delaying
   // the CUs of each XCD by k/phases of a tile period spreads the stores under the other CUs' main loops.
@@ -798,16 +828,6 @@ __global__ __launch_bounds__(512, 2) void oasr_gemm_pp_kernel(GemmArgs p) {
     const int ph = (blockIdx.x >> 3) % p.stagger_phases;
     for (int i = 0; i < ph * p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
   }
-
-  // staging offsets: image i (0,1 = A halves; 2,3 = B halves), 2 pieces per wave
-  unsigned off[4][2];
-  fast_offsets<TA, 128, 2, 8>(p.A, p.M, m0, lane, wave, off[0], m0);
-  fast_offsets<TA, 128, 2, 8>(p.A, p.M, m0 + 128, lane, wave, off[1], m0);
-  fast_offsets<TB, 128, 2, 8>(p.B, p.N, n0, lane, wave, off[2], n0);
-  fast_offsets<TB, 128, 2, 8>(p.B, p.N, n0 + 128, lane, wave, off[3], n0);
-  const bf16_t* baseA = (TA ? p.A.ptr + m0 : p.A.ptr + (long)m0 * p.A.ld) + (long)kt0 * (TA ? (long)BK * p.A.ld : BK);
-  const bf16_t* baseB = (TB ? p.B.ptr + n0 : p.B.ptr + (long)n0 * p.B.ld) + (long)kt0 * (TB ? (long)BK * p.B.ld : BK);
-  const long stepA = TA ? (long)BK * p.A.ld : BK, stepB = TB ? (long)BK * p.B.ld : BK;
 
 #define OASR_PP_STAGE(IMG, T, BUFP)                                                                          \
   do {                                                                                                       \
@@ -817,25 +837,33 @@ __global__ __launch_bounds__(512, 2) void oasr_gemm_pp_kernel(GemmArgs p) {
     glds16(rs_, d_ + 8192, off[IMG][1]);                                                                     \
   } while (0)
 
+  // prologue of an output tile: all of K-tile 0 into buffer P0, the B images of K-tile 1 into the other buffer
+#define OASR_PP_PROLOGUE(P0, P1)      \
+  do {                                \
+    OASR_PP_STAGE(0, 0, P0);          \
+    OASR_PP_STAGE(1, 0, P0);          \
+    OASR_PP_STAGE(2, 0, P0);          \
+    OASR_PP_STAGE(3, 0, P0);          \
+    if (nt > 1) {                     \
+      OASR_PP_STAGE(2, 1, P1);        \
+      OASR_PP_STAGE(3, 1, P1);        \
+    }                                 \
+  } while (0)
   f32x16_t acc[4][2];
+  int parity = 0;     // buffer that holds K-tile 0 of the current output tile
+  bool first = true;  // first output tile of this workgroup (its prologue was not issued from an epilogue)
+  OASR_PP_PROLOGUE(smem, smem + BUF);
+for (;;) {  // output tiles of this workgroup (one iteration unless the launch is persistent)
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // prologue: all of tile 0, B of tile 1
-  OASR_PP_STAGE(0, 0, smem);
-  OASR_PP_STAGE(1, 0, smem);
-  OASR_PP_STAGE(2, 0, smem);
-  OASR_PP_STAGE(3, 0, smem);
-  if (nt > 1) {
-    OASR_PP_STAGE(2, 1, smem + BUF);
-    OASR_PP_STAGE(3, 1, smem + BUF);
+  if (first && nt > 1) {
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {  // later tiles: the prologue pieces are older than the previous epilogue's stores, so the count is drained
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   }
   OASR_PP_BARRIER();
   if (wm == 1 && !(VAR & 8)) OASR_PP_BARRIER();  // the upper half trails by one barrier from here on (VAR bit 3: lockstep experiment)
@@ -891,8 +919,8 @@ __global__ __launch_bounds__(512, 2) void oasr_gemm_pp_kernel(GemmArgs p) {
     //   S0 MFMA : A image 1 of tile t+1 -> oth, between the MFMAs (the trailing group finished reading it one barrier ago)
     //   S1 read : B images of tile t+2 -> cur; vmcnt(4): everything of tile t+1 has landed, only those 4 pieces are in flight
     for (int t = 0; t < nt; ++t) {
-      char* cur = smem + (t & 1) * BUF;
-      char* oth = smem + ((t & 1) ^ 1) * BUF;
+      char* cur = smem + ((t & 1) ^ parity) * BUF;
+      char* oth = smem + ((t & 1) ^ parity ^ 1) * BUF;
       const bool next1 = t + 1 < nt, next2 = t + 2 < nt;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -980,8 +1008,8 @@ __global__ __launch_bounds__(512, 2) void oasr_gemm_pp_kernel(GemmArgs p) {
     }
   } else
   for (int t = 0; t < nt; ++t) {
-    char* cur = smem + (t & 1) * BUF;
-    char* oth = smem + ((t & 1) ^ 1) * BUF;
+    char* cur = smem + ((t & 1) ^ parity) * BUF;
+    char* oth = smem + ((t & 1) ^ parity ^ 1) * BUF;
     const bool next1 = t + 1 < nt, next2 = t + 2 < nt;
     // ---- phase 0
 #pragma unroll
@@ -1027,10 +1055,31 @@ __global__ __launch_bounds__(512, 2) void oasr_gemm_pp_kernel(GemmArgs p) {
     OASR_PP_BARRIER();
   }
   if (wm == 0 && !(VAR & 8)) OASR_PP_BARRIER();  // re-join: the trailing half has finished its LDS reads after this
+  // Persistent launch: the NEXT output tile's prologue is issued before this tile's epilogue, into the buffer the epilogue does
+  // not stage through (K-tile 0 -> buffer parity ^ 1, K-tile 1's B images -> the upper half of buffer `parity`; the epilogue's
+  // wave-private staging tiles live in the lower half of buffer `parity`, the bias rows behind both buffers).  The operand fetch
+  // latency, the workgroup relaunch and the drain of this tile's stores then overlap instead of adding up per tile.
+  const int em0 = m0, en0 = n0;
+  char* const stg = smem + parity * BUF + wave * 4096;
+  const int vn = v + (int)gridDim.x;
+  const bool has_next = vn < vgrid;
+  if (has_next) {
+    OASR_PP_TILE(vn);
+    parity ^= 1;
+    OASR_PP_PROLOGUE(smem + parity * BUF, smem + (parity ^ 1) * BUF);
+  }
+  fast_epilogue<SWAP, CSUM>(p, acc, stg, (float*)(smem + 2 * BUF + wave * 256), em0, en0, wm, wn, lane);
+  if (!has_next) break;
+  v = vn;
+  asm volatile("" : "+s"(v));  // re-derive the tile's offsets here instead of keeping 8 VGPRs live across the epilogue
+  OASR_PP_TILE(v);
+  first = false;
+}
 #undef OASR_PP_STAGE
+#undef OASR_PP_PROLOGUE
+#undef OASR_PP_TILE
 #undef OASR_PP_MMA
 #undef OASR_PP_MFMA1
-  fast_epilogue<SWAP, CSUM>(p, acc, smem, m0, n0, wm, wn, wave, lane);
 }
 
 
@@ -1149,7 +1198,7 @@ int launch_fast_cfg(const GemmArgs& a, hipStream_t stream) {
 template <bool TA, bool TB, bool SWAP, bool CSUM, int DMA>
 int launch_pp_variant(const GemmArgs& a, hipStream_t stream) {
   static bool attr = false;
-  const int lds = 2 * 4 * 128 * 64 * 2;
+  const int lds = 2 * 4 * 128 * 64 * 2 + 8 * 256;  // two K-tile buffers + the epilogue's per-wave bias rows
   if (!attr) {
     OASR_CHECK_HIP(hipFuncSetAttribute((const void*)oasr_gemm_pp_kernel<TA, TB, SWAP, CSUM, DMA>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -1158,6 +1207,26 @@ int launch_pp_variant(const GemmArgs& a, hipStream_t stream) {
   const int tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
   dim3 grid(tiles, a.split_k);
   if (!SWAP && (a.split_k & 7) == 0) grid = dim3(tiles * a.split_k, 1);
+  // Persistent launch (one workgroup per CU walking the same virtual grid, next tile's prologue issued ahead of the epilogue):
+  // opt-in (OASR_PP_PERSISTENT=1 or oasr_gemm_set_variant() bits 4-5).  Measured level with plain launches on every layer shape
+  // (profiles/r02_gemm_tile_cost_model.txt): the chip is at its power budget in these kernels (effective clock 1.53 GHz of 2.4,
+  // profiles/r02_gemm_effective_clock.txt), so cycles saved between tiles come back as a lower clock, and plain launches keep the
+  // hardware's dynamic tile dispatch (robust when RCCL kernels hold CUs).
+  static const int n_cu = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+    n &= ~7;  // (the virtual-block -> XCD correspondence needs a multiple of 8)
+    return n >= 8 ? n : 8;
+  }();
+  static const int env_persist = [] {
+    const char* e = getenv("OASR_PP_PERSISTENT");
+    return e ? atoi(e) : -1;
+  }();
+  GemmArgs pa = a;
+  pa.vgrid = (int)grid.x;
+  const int want = g_pp_persistent >= 0 ? g_pp_persistent : env_persist;
+  const bool can_persist = grid.y == 1 && (int)grid.x > n_cu && ((a.K / BK) % a.split_k) == 0;
+  if (can_persist && want == 1) grid = dim3(n_cu, 1);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (g_prof.on) {
     const size_t idx = g_prof.recs.size();
@@ -1174,7 +1243,7 @@ int launch_pp_variant(const GemmArgs& a, hipStream_t stream) {
     g_prof.recs.push_back({(TA ? 2 : 0) + (TB ? 1 : 0), 2.0 * (double)a.M * (double)a.N * (double)a.K, name.c_str()});
     OASR_CHECK_HIP(hipEventRecord(e0, stream));
   }
-  hipLaunchKernelGGL((oasr_gemm_pp_kernel<TA, TB, SWAP, CSUM, DMA>), grid, dim3(512), lds, stream, a);
+  hipLaunchKernelGGL((oasr_gemm_pp_kernel<TA, TB, SWAP, CSUM, DMA>), grid, dim3(512), lds, stream, pa);
   OASR_LAUNCH_CHECK();
   if (e1) OASR_CHECK_HIP(hipEventRecord(e1, stream));
   return OASR_OK;
@@ -1316,7 +1385,13 @@ int launch_t(const GemmArgs& a, hipStream_t stream) {
 
 }  // namespace
 
-void gemm_set_variant(int v) { g_pp_dma_in_mma = v < 0 ? -1 : (v & 15); }
+// v < 0: defaults.  bits 0-3: kernel variant (8 = the per-layout default); bits 4-5: 0 = default launch rule, 1 = never
+// persistent, 2 = persistent whenever possible.  (24 = default kernels, plain launches; 40 = default kernels, persistent)
+void gemm_set_variant(int v) {
+  g_pp_dma_in_mma = (v < 0 || (v & 15) == 8) ? -1 : (v & 15);
+  g_pp_persistent = v < 0 ? -1 : (((v >> 4) & 3) == 0 ? -1 : ((v >> 4) & 3) - 1);
+  g_epi_flags = v < 0 ? -1 : ((v >> 6) & 3);  // bit 6: non-temporal output stores, bit 7: non-temporal side-input loads
+}
 void gemm_set_stagger(int sleeps, int phases) {  // sleeps < 0: stagger off everywhere (A/B baseline)
   g_stagger = sleeps;
   g_stagger_phases = phases < 2 ? 2 : phases;
@@ -1324,6 +1399,11 @@ void gemm_set_stagger(int sleeps, int phases) {  // sleeps < 0: stagger off ever
 
 int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   OASR_REQUIRE(a.A.ptr && a.B.ptr, "gemm: null operand");
+  if (g_epi_flags >= 0 && a.epi_flags != g_epi_flags + 256) {
+    GemmArgs b = a;
+    b.epi_flags = g_epi_flags + 256;  // (+256: marks the override as applied)
+    return launch_gemm(b, stream);
+  }
   if (g_stagger > 0 && a.stagger == 0) {
     GemmArgs b = a;
     b.stagger = g_stagger;

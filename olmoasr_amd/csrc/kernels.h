@@ -64,6 +64,8 @@ struct GemmArgsT {
   int dgelu_deriv;  // dgelu_u already holds GELU'(u) (written by an act == 2 forward)
   int stagger, stagger_phases;  // ping-pong kernel: first-wave phase stagger in units of s_sleep(127) (0 = off)
   int atomic_on_pp;             // split-K / atomic output on the 256x256 ping-pong kernel instead of the 256x128 one
+  int vgrid;                    // set by the launcher: blocks of the virtual grid a persistent ping-pong launch walks
+  int epi_flags;                // epilogue memory policy: bit 0 non-temporal output stores, bit 1 non-temporal side-input loads
   float* colsum_scratch;        // optional, with colsum on the direct-to-LDS kernels: fp32 [2 * ceil(M/256)][N] partial rows (one per
                                 // 128-row wave block) that the launcher reduces into colsum -- instead of fp32 atomics from every wave
 };
@@ -130,6 +132,27 @@ int launch_attention_fwd(const AttnArgs& a, hipStream_t s);
 int launch_attention_bwd(const AttnArgs& a, hipStream_t s);
 int launch_attention_fwd(const AttnArgsF& a, hipStream_t s);  // fp32 validation kernels (o_lo unused: O is fp32)
 int launch_attention_bwd(const AttnArgsF& a, hipStream_t s);
+
+// ---- one-launch KV-cached decoder step (decode_fused.hip) -----------------------------------------------
+struct FusedDecLayer {  // device-resident table, one entry per decoder block
+  const float *ln1_g, *ln1_b, *bqkv, *bo, *ln2_g, *ln2_b, *bcq, *bco, *ln3_g, *ln3_b, *b1, *b2;
+  const bf16_t *wqkv, *wo, *wcq, *wco, *w1, *w2;  // [3d,d] fused q|k|v, [d,d] x3, [4d,d], [d,4d]
+  bf16_t* self_qkv;                               // cache [B, S_max, 3d]
+  const bf16_t* cross_kv;                         // cache [B, Te, 2d]
+};
+struct FusedDecArgs {
+  int B, d, H, L, S_max, Te, pos, V;
+  long n_embed;                      // rows of the token embedding table
+  const int64_t* tok;                // [B] token at position pos
+  const float *E, *pos_emb;          // fp32 token embedding, positional row of `pos`
+  const float *lnf_g, *lnf_b;
+  const bf16_t* Wemb;                // bf16 token embedding [V, d] (logits weight)
+  bf16_t *r0, *r1, *r2, *o, *q, *hg; // workspace: residual stream x3 [B,d], attention out, cross query, MLP hidden [B,4d]
+  float* logits;                     // [B, V]
+  unsigned *counter, *err;           // adjacent words: device-wide barrier counter, bail-out flag
+  const FusedDecLayer* layers;
+};
+int launch_decode_fused(const FusedDecArgs& a, hipStream_t s);
 
 // ---- elementwise / reductions -------------------------------------------------------------------------
 int launch_cast_f32_bf16(const float* src, bf16_t* dst, long n, hipStream_t s);

@@ -253,6 +253,8 @@ def decode(model, mel: torch.Tensor, options: Optional[DecodingOptions] = None, 
         return max(cands, key=score)
 
     results = []
+    if state is not None:
+        model.kv_cache_check(state)
     tok_cpu, sums = tokens.cpu(), sum_logprobs.cpu()
     for a in range(n_audio):
         if beam:

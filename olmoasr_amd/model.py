@@ -474,6 +474,12 @@ class OLMoASR(nn.Module):
         state["pos"] += 1
         return out
 
+    def kv_cache_check(self, state) -> None:
+        """Synchronises and raises if a one-launch decode step since kv_cache_begin abandoned its device-wide barrier
+        (oasr_decode_check); call once per decoded window, before reading the tokens back."""
+        with torch.cuda.device(state["cache"].device):
+            N.check(N.lib().oasr_decode_check(self._ctx, state["B"], N.ptr(state["cache"]), N.stream_ptr()), "oasr_decode_check")
+
     def install_kv_cache_hooks(self, cache: Optional[dict] = None):
         """olmoasr/model.py:925-964.  The reference hooks every key/value Linear and keeps their outputs in a dict; here the
         engine owns ONE cache buffer (self-attention K/V rows per position, cross-attention K/V once per window), so the

@@ -49,6 +49,17 @@ def main():
                 print(f"variant {v}: dgelu dgrad {timeit(a):.3f} ms, with fused colsum {timeit(b):.3f} ms", flush=True)
         N.lib().oasr_gemm_set_variant(-1)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "persist":  # plain launches (24) against persistent ones (40), default kernels
+        print(f"{'case':34s}  launch plain persistent plain persistent: ms TF/s")
+        for name, fn, flops in cases:
+            row = f"{name:34s} "
+            for v in (24, 40, 24, 40):
+                N.lib().oasr_gemm_set_variant(v)
+                ms = timeit(fn)
+                row += f"{ms:7.3f} {flops / ms / 1e9:6.0f} | "
+            print(row, flush=True)
+        N.lib().oasr_gemm_set_variant(-1)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "variant":  # A/B of where the ping-pong kernel issues its DMA pieces
         print(f"{'case':34s}  variants 7 15 7 15 (bit 3 = both wave groups in lockstep, no ping-pong offset) (bit 0 = DMA between the MFMAs, bit 1 = MFMA sections pinned, bit 2 = two 16-MFMA sections per K-tile): ms TF/s")
         for name, fn, flops in cases:

@@ -152,7 +152,8 @@ def _dp_worker(rank, world, port, q, algo):
         norm, params = _step_from_flat(sd, names, flat, inv)
         lt = torch.tensor([loss])
         dist.all_reduce(lt)
-        q.put((rank, "ok", norm, float(lt) / world, {k: v for k, v in list(params.items())[:3]}, float(sum(p.double().sum() for p in params.values()))))
+        # (numpy, pickled by value: torch tensors travel as file descriptors the parent can only fetch while this process lives)
+        q.put((rank, "ok", norm, float(lt) / world, {k: v.numpy().copy() for k, v in list(params.items())[:3]}, float(sum(p.double().sum() for p in params.values()))))
     except Exception as e:  # pragma: no cover
         import traceback
         q.put((rank, "err: " + traceback.format_exc(), 0, 0, None, 0))
@@ -191,7 +192,7 @@ def test_data_parallel_step_world2_equals_world1(algo):
         assert abs(norm - norm1) < 1e-5 * norm1, (norm, norm1)
         assert abs(loss - (l0 + l1)) < 1e-5
         for k, v in head.items():
-            assert torch.allclose(v, params1[k], atol=2e-6), k
+            assert torch.allclose(torch.from_numpy(v), params1[k], atol=2e-6), k
         assert abs(checksum - float(sum(p.double().sum() for p in params1.values()))) < 1e-2
     assert res[0][2] == res[1][2]  # both ranks hold bit-identical results after the exchange
 
@@ -242,7 +243,7 @@ def _zero_worker(rank, world, port, q):
             if step == 2:
                 g.copy_(torch.randn(n, generator=torch.Generator().manual_seed(20 + rank)) * 1024.0)
             stats = opt.step(step=step, lr=1e-2, inv_loss_scale=1.0 / (1024.0 * opt.grad_divisor))
-            outs.append((p.clone(), float(stats[0])))
+            outs.append((p.numpy().copy(), float(stats[0])))  # numpy: pickled by value
         q.put((rank, "ok", outs, opt.off, opt.len))
     except Exception:
         import traceback
@@ -274,7 +275,7 @@ def test_zero1_sharded_step_equals_replicated_step():
         ref.step(0, n, m, v, ref.sumsq(0, n), step=step, lr=1e-2, inv_loss_scale=1.0 / 2048.0, max_grad_norm=1.0, betas=(0.9, 0.98), eps=1e-6,
                  weight_decay=0.1)
         for rank, _, outs, off, ln in res:
-            got, sumsq = outs[step - 1]
+            got, sumsq = torch.from_numpy(outs[step - 1][0]), outs[step - 1][1]
             assert torch.allclose(got, p, atol=1e-6, rtol=0), (step, rank, float((got - p).abs().max()))
             assert abs(sumsq - float(ref.sumsq(0, n)[0])) < 1e-3 * sumsq
     assert res[0][3] == 0 and res[1][3] == res[0][4] and res[1][3] + res[1][4] == n  # the two ranges tile the arena

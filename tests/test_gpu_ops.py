@@ -144,6 +144,55 @@ def test_gemm_layouts(M, N, K, ta, tb, gemm_path):
     close(out, Af @ Bf.t(), name=f"gemm {M}x{N}x{K} ta={ta} tb={tb}")
 
 
+@pytest.mark.parametrize("layout", ["nt_resid", "nt_gelu", "nn", "tn_splitk"])
+def test_gemm_pingpong_persistent_launch_matches_plain(layout):
+    """Persistent launches of the 256x256 kernel (one workgroup per CU walking the plain launch's grid, next tile's prologue
+    issued ahead of the epilogue) must produce the plain launch's bits (fp32 atomic outputs: its values)."""
+    from olmoasr_amd import _native as N
+    if layout == "tn_splitk":
+        M, N_, K = 2048, 2048, 4096   # 64 tiles x 8 K-ranges = 512 virtual blocks
+        A, B = rnd(K, M, seed=1), rnd(K, N_, seed=2, scale=0.05)
+    else:
+        M, N_, K = 256 * 40 + 64, 2048, 512  # 41 x 8 = 328 virtual blocks (uneven rounds, ragged last row panel)
+        A = rnd(M, K, seed=1)
+        B = rnd(K, N_, seed=2, scale=0.05) if layout == "nn" else rnd(N_, K, seed=2, scale=0.05)
+    bias = torch.randn(N_, device=DEV)
+    resid = rnd(M, N_, seed=3)
+    outs = []
+    try:
+        N.lib().oasr_gemm_force_general(4)  # force the ping-pong kernel
+        for v in (24, 40):                  # default kernels: plain launch / persistent launch
+            N.lib().oasr_gemm_set_variant(v)
+            if layout == "tn_splitk":
+                o = torch.zeros(M, N_, device=DEV)
+                ops().gemm(A, B, M, N_, K, ta=True, tb=True, out_f32=o, atomic=True, split_k=8)
+                outs.append((o,))
+            elif layout == "nt_gelu":
+                o = torch.full((M, N_), float("nan"), device=DEV, dtype=BF)
+                pre = torch.full((M, N_), float("nan"), device=DEV, dtype=BF)
+                ops().gemm(A, B, M, N_, K, bias=bias, act=2, out=o, out_pre=pre)
+                outs.append((o, pre))
+            else:
+                o = torch.full((M, N_), float("nan"), device=DEV, dtype=BF)
+                cs = torch.zeros(N_, device=DEV)
+                ops().gemm(A, B, M, N_, K, tb=(layout == "nn"), bias=bias, resid=resid, out=o)
+                outs.append((o, cs))
+    finally:
+        N.lib().oasr_gemm_force_general(0)
+        N.lib().oasr_gemm_set_variant(-1)
+    for a, b in zip(outs[0], outs[1]):
+        if layout == "tn_splitk":
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-3)
+        else:
+            assert torch.equal(a, b)
+    if layout == "tn_splitk":
+        close(outs[1][0], A.float().t() @ B.float(), name="persistent wgrad")
+    elif layout != "nt_gelu":
+        Bf = B.float() if layout == "nn" else B.float().t()
+        ref = (A.float() @ Bf + bias).bfloat16().float() + resid.float()
+        close(outs[1][0], ref, name="persistent " + layout)
+
+
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
 def test_gemm_pingpong_dma_placement_variants_are_bit_identical(ta, tb):
     """The 256x256 kernel issues its direct-to-LDS pieces either in the fragment-read section or between the MFMAs
