@@ -16,7 +16,10 @@ int oasr_profile_gemm(int enable);
 /* experiments on the 256x256 kernel.  v < 0: defaults.  bits 0-3: schedule variant (8 = per-layout default); bits 4-5: 1 = plain
  * launches, 2 = persistent launches (next tile's prologue ahead of the epilogue); bit 6 / 7: non-temporal epilogue stores / side loads */
 int oasr_gemm_set_variant(int v);
-int oasr_decode_set_fused(int on); /* tests / A-B: 0 = multi-launch decode step, 1 = one-launch step, -1 = default (OASR_DECODE_FUSED) */
+/* tests / A-B of the KV-cached step: 0 = multi-launch with LayerNorm folded into the projections (the default up to 4 sequences),
+ * 1 = one persistent launch (opt-in, OASR_DECODE_FUSED=1), 2 = multi-launch with separate LayerNorm kernels (the default above 4),
+ * -1 = default.  All three are bit-identical (tests/test_gpu_decode_fused.py). */
+int oasr_decode_set_fused(int mode);
 int oasr_gemm_set_stagger(int sleeps, int phases); /* experiments: first-wave phase stagger of the 256x256 kernel (0 = off) */
 int oasr_gemm_force_general(int on); /* tests: route every GEMM through the register-staged general kernel */
 int oasr_profile_gemm_collect(double* ms4, double* flops4, int64_t* count4, char* by_symbol /* "symbol\tlaunches\tms\tflops\n"... or NULL */, int cap);

@@ -889,20 +889,22 @@ char* kv_tail(const oasr_ctx* c, void* cache, int B) {
   const size_t per_layer = ((size_t)3 * B * c->S_max * c->d + (size_t)B * c->Te * 2 * c->d) * (c->f32 ? 4 : 2);
   return (char*)cache + per_layer * c->L_dec;
 }
-// The one-launch step (decode_fused.hip) serves the bf16 engine for up to 32 sequences; OASR_DECODE_FUSED=0 or
-// oasr_decode_set_fused(0) keeps the multi-launch path (A/B, and the reference the parity test compares it with).
+// The one-launch step (decode_fused.hip) serves the bf16 engine for up to 32 sequences.  It is OPT-IN (OASR_DECODE_FUSED=1 or
+// oasr_decode_set_fused(1)): bit-identical to the multi-launch step, but measured slower on the 8-XCD MI355X -- every device-wide
+// barrier needs an L2 write-back + invalidate per workgroup (1.7 ms per step at B = 1 against 1.0 ms; scripts/decode_step_probe.py,
+// profiles/r02_decode_step.txt).  What it did give the default path: its LayerNorm-in-the-operand-load projections, as launches.
 int g_decode_fused = -1;
 bool fused_step_ok(const oasr_ctx* c, int B, int pos) {
   static const int env = [] {
     const char* e = getenv("OASR_DECODE_FUSED");
-    return e ? atoi(e) : 1;
+    return e ? atoi(e) : 0;
   }();
   const int want = g_decode_fused >= 0 ? g_decode_fused : env;
-  return want != 0 && !c->f32 && B <= 32 && c->d % 64 == 0 && c->d <= 2048 && c->H * 64 == c->d && pos + 1 <= 1536 && c->Te <= 1536;
+  return want == 1 && !c->f32 && B <= 32 && c->d % 64 == 0 && c->d <= 2048 && c->H * 64 == c->d && pos + 1 <= 1536 && c->Te <= 1536;
 }
 }  // namespace
 extern "C" int oasr_decode_set_fused(int on) {
-  g_decode_fused = on < 0 ? -1 : (on != 0);
+  g_decode_fused = on < 0 ? -1 : on;  // 0 = multi-launch with LayerNorm folded into the projections (default for B <= 4), 1 = one launch, 2 = multi-launch, separate LayerNorm kernels (default above)
   return OASR_OK;
 }
 
@@ -1021,11 +1023,23 @@ static int oasr_decode_step_impl(oasr_ctx* c, const int64_t* tokens_last, int B,
   // token + positional embedding of position pos: S = 1 per sequence, positional row offset by pos
   RC(launch_embedding_fwd(tokens_last, c->P(c->tok_emb), c->P(c->dec_pos) + (size_t)pos * d, x, B, 1, d, c->V, st));
   T* cur = x;
+  // a few sequences on the bf16 engine: every LayerNorm rides in the operand load of the projection that consumes it and the
+  // logits leave as fp32 (8 launches per layer instead of 11; bit-identical to the separate kernels below).  Measured
+  // (profiles/r02_decode_step.txt): -5 % per step at B = 1, but every workgroup recomputes the B row statistics, which loses
+  // from B = 16 on (+20 %) -- so only small batches take it (mode 0 forces it for the A/B and the bit-identity test).
+  bool folded = false;
+  if constexpr (std::is_same<T, bf16_t>::value)
+    folded = d % 64 == 0 && d <= 2048 && g_decode_fused != 2 && (B <= 4 || (g_decode_fused == 0 && B <= 32));
   for (int i = 0; i < c->L_dec; ++i) {
     const BlockP& bp = c->dec[i];
     KvLayer<T> kl = kv_layer<T>(c, kv_cache, B, i);
-    RC(launch_layernorm_fwd(cur, c->P(bp.attn_ln_w), c->P(bp.attn_ln_b), ln, mean, rstd, B, d, st));
-    {  // q | k | v of this position in one launch, straight into the cache: output row b lands at [b, pos, 0:3d]
+    if (!folded) RC(launch_layernorm_fwd(cur, c->P(bp.attn_ln_w), c->P(bp.attn_ln_b), ln, mean, rstd, B, d, st));
+    if constexpr (std::is_same<T, bf16_t>::value) {
+      if (folded)
+        RC(launch_decode_proj(cur, B, d, c->template Wt<bf16_t>(bp.attn.qw), 3 * d, c->P(bp.attn_ln_w), c->P(bp.attn_ln_b),
+                              c->aux(bp.attn.fused_bias), 0, nullptr, 0, kl.qkv + (size_t)pos * 3 * d, (long)S_max * 3 * d, nullptr, 0, st));
+    }
+    if (!folded) {  // q | k | v of this position in one launch, straight into the cache: output row b lands at [b, pos, 0:3d]
       GemmArgsT<T> g = gemm_defaults_t<T>();
       g.A = plain_view(ln, d);
       g.B = plain_view(c->template Wt<T>(bp.attn.qw), d);  // query | key | value weights are adjacent in the arena
@@ -1056,8 +1070,15 @@ static int oasr_decode_step_impl(oasr_ctx* c, const int64_t* tokens_last, int B,
     a.Tk = pos + 1;
     RC(launch_attention_fwd(a, st));
     RC(r.linear(o, B, d, c->template Wt<T>(bp.attn.ow), d, c->P(bp.attn.ob), 0, cur, x2, nullptr));
-    RC(launch_layernorm_fwd(x2, c->P(bp.cln_w), c->P(bp.cln_b), ln, mean, rstd, B, d, st));
-    RC(r.linear(ln, B, d, c->template Wt<T>(bp.cattn.qw), d, c->P(bp.cattn.qb), 0, nullptr, q, nullptr));
+    if constexpr (std::is_same<T, bf16_t>::value) {
+      if (folded)
+        RC(launch_decode_proj(x2, B, d, c->template Wt<bf16_t>(bp.cattn.qw), d, c->P(bp.cln_w), c->P(bp.cln_b), c->P(bp.cattn.qb), 0,
+                              nullptr, 0, q, d, nullptr, 0, st));
+    }
+    if (!folded) {
+      RC(launch_layernorm_fwd(x2, c->P(bp.cln_w), c->P(bp.cln_b), ln, mean, rstd, B, d, st));
+      RC(r.linear(ln, B, d, c->template Wt<T>(bp.cattn.qw), d, c->P(bp.cattn.qb), 0, nullptr, q, nullptr));
+    }
     a.q = q;
     a.ldq = d;
     a.bsq = d;
@@ -1068,10 +1089,22 @@ static int oasr_decode_step_impl(oasr_ctx* c, const int64_t* tokens_last, int B,
     a.Tk = c->Te;
     RC(launch_attention_fwd(a, st));
     RC(r.linear(o, B, d, c->template Wt<T>(bp.cattn.ow), d, c->P(bp.cattn.ob), 0, x2, x3, nullptr));
-    RC(launch_layernorm_fwd(x3, c->P(bp.mlp_ln_w), c->P(bp.mlp_ln_b), ln, mean, rstd, B, d, st));
-    RC(r.linear(ln, B, d, c->template Wt<T>(bp.w1), 4 * d, c->P(bp.b1), 1, nullptr, hg, u));
+    if constexpr (std::is_same<T, bf16_t>::value) {
+      if (folded)
+        RC(launch_decode_proj(x3, B, d, c->template Wt<bf16_t>(bp.w1), 4 * d, c->P(bp.mlp_ln_w), c->P(bp.mlp_ln_b), c->P(bp.b1), 1, nullptr,
+                              0, hg, 4 * d, nullptr, 0, st));
+    }
+    if (!folded) {
+      RC(launch_layernorm_fwd(x3, c->P(bp.mlp_ln_w), c->P(bp.mlp_ln_b), ln, mean, rstd, B, d, st));
+      RC(r.linear(ln, B, d, c->template Wt<T>(bp.w1), 4 * d, c->P(bp.b1), 1, nullptr, hg, u));
+    }
     RC(r.linear(hg, B, 4 * d, c->template Wt<T>(bp.w2), d, c->P(bp.b2), 0, x3, cur == x ? x2 : x, nullptr));
     cur = (cur == x) ? x2 : x;
+  }
+  if constexpr (std::is_same<T, bf16_t>::value) {
+    if (folded)
+      return launch_decode_proj(cur, B, d, c->template Wt<bf16_t>(c->tok_emb), c->V, c->P(c->dec_ln_w), c->P(c->dec_ln_b), nullptr, 0, nullptr,
+                                0, nullptr, 0, logits_out, c->V, st);
   }
   RC(launch_layernorm_fwd(cur, c->P(c->dec_ln_w), c->P(c->dec_ln_b), ln, mean, rstd, B, d, st));
   RC(r.linear(ln, B, d, c->template Wt<T>(c->tok_emb), c->Vp, nullptr, 0, nullptr, logits, nullptr));

@@ -153,6 +153,10 @@ struct FusedDecArgs {
   const FusedDecLayer* layers;
 };
 int launch_decode_fused(const FusedDecArgs& a, hipStream_t s);
+// LayerNorm (optional: ln_g != null) + Linear + bias (+ GELU) (+ residual) of M <= 32 token rows in one launch: bf16 `out` and / or
+// fp32 `out_f32` (the bf16-rounded Linear output, widened: logits).  Bit-identical to layernorm_fwd + the skinny GEMM.
+int launch_decode_proj(const bf16_t* x, int M, int K, const bf16_t* W, int N, const float* ln_g, const float* ln_b, const float* bias,
+                       int gelu, const bf16_t* resid, long ldr, bf16_t* out, long ldc, float* out_f32, long ldf, hipStream_t s);
 
 // ---- elementwise / reductions -------------------------------------------------------------------------
 int launch_cast_f32_bf16(const float* src, bf16_t* dst, long n, hipStream_t s);

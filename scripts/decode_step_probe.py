@@ -11,11 +11,23 @@ from olmoasr_amd.model import OLMoASR  # noqa: E402
 
 
 def main():
-    B = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-    net = OLMoASR(VARIANT_TO_DIMS["small"], device="cuda", seed=0, inference=True)
+    from olmoasr_amd import _native as N
+    net = OLMoASR(VARIANT_TO_DIMS[os.environ.get("OASR_PROBE_MODEL", "small")], device="cuda", seed=0, inference=True)
+    for B in [int(a) for a in sys.argv[1:]] or [20]:
+        for fused in (2, 0, 1):
+            N.lib().oasr_decode_set_fused(fused)
+            print("--- " + {0: "multi-launch step, LayerNorm folded into the projections (default)", 1: "one persistent launch (opt-in)",
+                            2: "multi-launch step, separate LayerNorm kernels (round-2 start)"}[fused])
+            probe(net, B)
+            net.kv_cache_check(probe.state)
+    N.lib().oasr_decode_set_fused(-1)
+
+
+def probe(net, B):
     mel = torch.randn(B, 80, 3000, device="cuda")
     xa = net.embed_audio(mel)
     st = net.kv_cache_begin(xa)
+    probe.state = st
     tok = torch.full((B,), 50257, device="cuda", dtype=torch.int64)
     for _ in range(5):
         net.kv_cache_step(st, tok)

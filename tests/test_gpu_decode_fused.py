@@ -1,0 +1,75 @@
+"""The one-launch KV-cached decoder step (csrc/decode_fused.hip: one persistent kernel per token, phases separated by a
+device-wide barrier) against the multi-launch step it replaces and against the cache-less decoder.
+Reference semantics: TextDecoder.forward with the kv_cache hooks, olmoasr/model.py:786-817, 925-964."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _dims(mo_dims):
+    from olmoasr_amd.config.model_dims import ModelDimensions
+    return ModelDimensions(**{k: getattr(mo_dims, k) for k in ModelDimensions.__dataclass_fields__})
+
+
+def _steps(net, xa, toks, mode):
+    """mode: 0 = multi-launch, LayerNorm folded into the projections (default); 1 = one persistent launch; 2 = multi-launch with
+    separate LayerNorm / logits-widening kernels."""
+    from olmoasr_amd import _native as N
+    N.lib().oasr_decode_set_fused(mode)
+    try:
+        st = net.kv_cache_begin(xa)
+        out = [net.kv_cache_step(st, toks[:, p]) for p in range(toks.shape[1])]
+        net.kv_cache_check(st)
+        return torch.stack(out, 1)
+    finally:
+        N.lib().oasr_decode_set_fused(-1)
+
+
+@pytest.mark.parametrize("width,heads,layers,B,inference", [(384, 6, 4, 2, True), (384, 6, 2, 7, False), (768, 12, 2, 16, True),
+                                                            (512, 8, 3, 32, True), (1024, 16, 1, 1, False)])
+def test_step_engines_are_bit_identical(tiny_case, width, heads, layers, B, inference):
+    """Same rounding points, same skinny-GEMM accumulation scheme, same attention kernel body: the two step engines must agree
+    to the last bit on every position; both must track the cache-less decoder to bf16 accumulation-order noise."""
+    from olmoasr_amd.model import OLMoASR
+    from oracle import model_oracle as mo
+    dims = mo.Dims(80, 1500, width, heads, 1, 51864, 448, width, heads, layers)
+    net = OLMoASR(_dims(dims), device=DEV, seed=5 + layers, inference=inference)
+    mel = tiny_case["mel"].to(DEV)
+    mel = mel.repeat((B + 1) // 2, 1, 1)[:B] * torch.linspace(1.0, 0.8, B, device=DEV)[:, None, None]
+    xa = net.embed_audio(mel)
+    g = torch.Generator().manual_seed(B)
+    toks = torch.randint(0, 50000, (B, 9), generator=g).to(DEV)
+    toks[:, 0] = 50257
+    multi = _steps(net, xa, toks, 2)
+    folded = _steps(net, xa, toks, 0)
+    fused = _steps(net, xa, toks, 1)
+    assert torch.isfinite(fused).all() and torch.isfinite(folded).all()
+    assert torch.equal(folded, multi), float((folded - multi).abs().max())
+    assert torch.equal(fused, multi), float((fused - multi).abs().max())
+    scale = float(multi.abs().max())
+    full = net.logits(toks, xa)
+    assert float((fused - full).abs().max()) < 0.08 + 0.02 * scale
+    # a second window on the same buffers (barrier state is reset by kv_cache_begin / every launch)
+    again = _steps(net, xa, toks, 1)
+    assert torch.equal(again, fused)
+
+
+def test_decode_through_every_step_engine(tiny_case):
+    from olmoasr_amd import _native as N
+    from olmoasr_amd.decoding import DecodingOptions, decode
+    from olmoasr_amd.model import OLMoASR
+    from oracle import model_oracle as mo
+    dims = mo.Dims(80, 1500, 384, 6, 2, 51864, 448, 384, 6, 2)
+    net = OLMoASR(_dims(dims), device=DEV, seed=11, inference=True)
+    mel = tiny_case["mel"].to(DEV)
+    r_f = decode(net, mel, DecodingOptions(sample_len=6, use_kv_cache=True, without_timestamps=True))
+    for mode in (1, 2):
+        N.lib().oasr_decode_set_fused(mode)
+        try:
+            r_m = decode(net, mel, DecodingOptions(sample_len=6, use_kv_cache=True, without_timestamps=True))
+        finally:
+            N.lib().oasr_decode_set_fused(-1)
+        for a, b in zip(r_f, r_m):
+            assert a.tokens == b.tokens and abs(a.avg_logprob - b.avg_logprob) < 1e-6
