@@ -240,7 +240,10 @@ def decode(model, mel: torch.Tensor, options: Optional[DecodingOptions] = None, 
             sum_logprobs = sum_logprobs + cur * alive
             nxt = torch.where(alive, nxt, torch.full_like(nxt, EOT))
             tokens = torch.cat([tokens, nxt[:, None]], dim=1)
-            completed = bool((tokens[:, -1] == EOT).all())
+            # The all-rows-finished test is a device -> host sync.  Finished rows only ever append eot and add 0 to their score, so
+            # testing every 8th step decodes at most 7 surplus positions and changes no result -- but lets the host run ahead of
+            # the GPU in between (a KV-cached step is ~1 ms of GPU time behind ~0.9 ms of enqueue).
+            completed = bool((tokens[:, -1] == EOT).all()) if (not cached or i % 8 == 7 or i == sample_len - 1) else False
         if completed or tokens.shape[-1] > dims.n_text_ctx:
             break
 
