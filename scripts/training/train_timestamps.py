@@ -11,9 +11,12 @@ What is kept from the reference loop (citations into /root/reference/scripts/tra
   GradScaler semantics (enabled for bf16 too, :2349: scale 65536, x2 every 2000 clean steps, x0.5 + skipped step on
   inf/nan) * per-step clip(1.0)+AdamW :1509-1512 * throughput metric audio_min_per_GPU_second :1525-1527 * loss
   all-reduce every train_log_freq :1553 * checkpoint dict keys and file names :930-972.
-What is replaced: DataLoader/tokenizer/W&B/eval plumbing (out of scope) -> a seeded synthetic dataset
-with the reference's token layout, sharded like DistributedSampler (:633-638); model/loss/backward/optimizer/DDP -> the
-HIP engine (olmoasr_amd).  Data is int16 PCM on the device; log-mel runs on the GPU.
+What is replaced: tokenizer/W&B/eval plumbing (out of scope); model/loss/backward/optimizer/DDP -> the HIP
+engine (olmoasr_amd).  Data: ``--samples_dicts_dir DIR --synthetic False`` reads the reference's shard files (:577-604, :2255-2266)
+through the on-device input path (olmoasr_amd/data.py: DistributedSampler order, int16 clips via pinned ring slots and a copy
+stream, log-mel on the GPU, ``text_len`` instead of the [448, 448] mask -- SURVEY.md section 8f-1; tokens come pre-tokenised or from
+a ``text_fn`` plug because the whisper tokenizer is not vendored); the default is a seeded synthetic dataset with the reference's
+token layout, sharded like DistributedSampler (:633-638).
 """
 import ast
 import glob
@@ -45,7 +48,7 @@ REFERENCE_FLAGS = dict(
     num_workers=10, prefetch_factor=2, pin_memory=True, shuffle=True, persistent_workers=True, run_eval=False, train_log_freq=20000,
     eval_freq=20000, ckpt_freq=2500, verbose=False, precision="bfloat16", hardware="MI355X", async_eval=False, eval_script_path=None,
     eval_wandb_log=False, eval_on_gpu=True)
-IGNORED_FLAGS = ("samples_dicts_dir", "eval_dir", "eval_batch_size", "pin_memory", "shuffle", "persistent_workers", "eval_freq", "verbose",
+IGNORED_FLAGS = ("eval_dir", "eval_batch_size", "pin_memory", "persistent_workers", "eval_freq", "verbose",
                  "async_eval", "eval_script_path", "eval_wandb_log", "eval_on_gpu", "job_type", "log_dir")
 NATIVE_FLAGS = dict(  # additions of this implementation
     synthetic=True, n_synthetic=4096, timestamps=False, seed=0, bucket_cap_mb=128.0, reducer="allreduce", resume=False,
@@ -374,7 +377,19 @@ def main(argv=None):
             if c >= len(mine):
                 c = 0
 
-    loader = SynthLoader(batch_order(cursor), dev, workers=workers, depth=max(1, int(args.prefetch_factor)), timestamps=bool(args.timestamps))
+    # --samples_dicts_dir (with --synthetic False): the reference's shard files through the on-device input path (olmoasr_amd/data.py)
+    real_data = bool(args.samples_dicts_dir) and not bool(args.synthetic)
+    if real_data:
+        from olmoasr_amd import data
+        shards = data.AudioTextShards(data.load_samples_dicts(args.samples_dicts_dir))
+        per_rank = -(-len(shards) // world_size)  # DistributedSampler pads every rank's share to ceil(n / world)
+        if rank == 0:
+            print(json.dumps({"event": "data", "samples": len(shards), "per_rank": per_rank, "shuffle": bool(args.shuffle)}), flush=True)
+        loader = data.ShardLoader(shards, data.epoch_batches(len(shards), rank, world_size, args.train_batch_size, epoch, cursor, bool(args.shuffle)),
+                                  dev, batch=args.train_batch_size, workers=workers, depth=max(1, int(args.prefetch_factor)))
+    else:
+        per_rank = len(mine)
+        loader = SynthLoader(batch_order(cursor), dev, workers=workers, depth=max(1, int(args.prefetch_factor)), timestamps=bool(args.timestamps))
     held_out = [args.n_synthetic + i for i in range(8)]  # evaluate(): clips outside every rank's training shard
     while global_step < args.train_steps:
         start_step = time.time()
@@ -382,10 +397,10 @@ def main(argv=None):
         log_now = ((global_step + 1) % args.train_log_freq) == 0  # gen_pred condition of the reference (:1480)
         preds, tgts = [], []
         for i in range(accum):
-            cursor += args.train_batch_size
-            if cursor >= len(mine):
-                cursor, epoch = 0, epoch + 1
             pcm, ti, ty, tl = next(loader)
+            cursor += args.train_batch_size  # (position in this rank's epoch order; a short last batch also ends the epoch)
+            if cursor >= per_rank:
+                cursor, epoch = 0, epoch + 1
             mel = ops.log_mel(pcm)
             last = i == accum - 1
             _, logits = net.loss_and_backward(mel, ti, ty, tl, loss_scale=scaler.scale, accumulation_steps=accum, loss_out=loss_buf,
