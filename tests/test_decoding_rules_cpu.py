@@ -1,5 +1,6 @@
 """CPU tests of the token-level logit filters of olmoasr_amd.decoding (no device needed): ApplyTimestampRules as
 whisper.decoding defines them, with the English-only ids the reference's Dataset writes."""
+import pytest
 import torch
 
 from olmoasr_amd.decoding import EOT, NO_TIMESTAMPS, SOT, TIMESTAMP_BEGIN, _timestamp_rules
@@ -79,3 +80,77 @@ def test_suppress_lists_agree():
     assert suppress_list(DecodingOptions(suppress_tokens="-1,7", non_speech_tokens=(1, 2))) == \
         do.suppress_list(do.Options(suppress_tokens=(-1, 7), non_speech_tokens=(1, 2))) == [1, 2, 7, 50257, 50357, 50358, 50359, 50360, 50361]
     assert suppress_list(DecodingOptions(suppress_tokens=None)) == []
+
+
+# ---- an implementation independent of ours: transformers' generation processors (installed offline) ------------------------------
+# openai-whisper is not vendored, so whisper.decoding's ApplyTimestampRules / SuppressTokens / SuppressBlank cannot be imported;
+# transformers ships its own restatement of the same rules for WhisperForConditionalGeneration.  Both of ours (the oracle's and the
+# product's) must mask exactly the logits it masks.
+def _hf_timestamp_processor(sample_begin, max_initial_index):
+    from types import SimpleNamespace
+    from transformers.generation.logits_process import WhisperTimeStampLogitsProcessor
+    cfg = SimpleNamespace(no_timestamps_token_id=50362, eos_token_id=50256, bos_token_id=50256, max_initial_timestamp_index=max_initial_index,
+                          _detect_timestamp_from_logprob=True)
+    return WhisperTimeStampLogitsProcessor(cfg, begin_index=sample_begin)
+
+
+def _random_history(g, n, length, sample_begin):
+    """Token rows [n, sample_begin + length] that exercise every branch: text runs, single and paired timestamps, repeats."""
+    rows = []
+    for _ in range(n):
+        seq, t = [50257] * sample_begin, 50363 + int(torch.randint(0, 40, (1,), generator=g))
+        while len(seq) < sample_begin + length:
+            kind = int(torch.randint(0, 4, (1,), generator=g))
+            if kind == 0:
+                seq.append(int(torch.randint(0, 50256, (1,), generator=g)))
+            elif kind == 1:
+                seq.append(t)
+            elif kind == 2:
+                t += int(torch.randint(0, 30, (1,), generator=g))
+                seq += [t, t]
+            else:
+                t += int(torch.randint(1, 30, (1,), generator=g))
+                seq.append(min(t, 51863))
+        rows.append(seq[:sample_begin + length])
+    return torch.tensor(rows, dtype=torch.int64)
+
+
+@pytest.mark.parametrize("length", [0, 1, 2, 3, 7, 16])
+@pytest.mark.parametrize("max_initial_index", [None, 50])
+def test_timestamp_rules_equal_transformers_processor(length, max_initial_index):
+    import torch as T
+    from olmoasr_amd import decoding as dec
+    from oracle import decode_oracle as do
+    g = T.Generator().manual_seed(100 + length)
+    sample_begin, n, V = 1, 24, 51864
+    tokens = _random_history(g, n, length, sample_begin)
+    logits = T.randn(n, V, generator=g) * 3.0
+    logits[: n // 2, 50363:] += 6.0  # half the rows: enough timestamp mass to trigger the "sample a timestamp" rule
+    want = _hf_timestamp_processor(sample_begin, max_initial_index)(tokens, logits.clone())
+    a, b = logits.clone(), logits.clone()
+    do.apply_timestamp_rules(a, tokens, sample_begin, max_initial_index)
+    dec._timestamp_rules(b, tokens, sample_begin, max_initial_index)
+    for got, name in ((a, "oracle"), (b, "product")):
+        assert T.equal(T.isinf(got), T.isinf(want)), name
+        assert T.equal(got[~T.isinf(got)], want[~T.isinf(want)]), name
+
+
+def test_suppress_processors_equal_transformers():
+    """SuppressTokens = transformers' SuppressTokensLogitsProcessor on our suppress list; SuppressBlank = its
+    SuppressTokensAtBeginLogitsProcessor([blank, eot]) at the first sampled position only."""
+    import torch as T
+    from transformers.generation.logits_process import SuppressTokensAtBeginLogitsProcessor, SuppressTokensLogitsProcessor
+    from olmoasr_amd import decoding as dec
+    opt = dec.DecodingOptions()
+    sup = dec.suppress_list(opt)
+    g = T.Generator().manual_seed(3)
+    logits = T.randn(4, 51864, generator=g)
+    want = SuppressTokensLogitsProcessor(sup)(T.zeros(4, 2, dtype=T.long), logits.clone())
+    mask = T.zeros(51864)
+    mask[sup] = -float("inf")
+    assert T.equal(logits + mask, want)
+    begin = SuppressTokensAtBeginLogitsProcessor([220, 50256], begin_index=2)
+    first = T.zeros(51864)
+    first[[220, 50256]] = -float("inf")
+    assert T.equal(logits + first, begin(T.zeros(4, 2, dtype=T.long), logits.clone()))          # at sample_begin
+    assert T.equal(logits, begin(T.zeros(4, 3, dtype=T.long), logits.clone()))                  # later: untouched
