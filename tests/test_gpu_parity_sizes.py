@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 BF = torch.bfloat16
 
-SIZES = [("base", 2), ("small", 2), ("medium", 1)]
+SIZES = [("base", 2), ("small", 2), ("medium", 1), ("large", 1)]  # large = BASELINE configs[3] (large-v2 shares its dims)
 
 
 def _dims(mo_dims):
