@@ -123,6 +123,15 @@ int oasr_train_fwd_bwd(oasr_ctx*, const float* mel, const int64_t* tokens, const
 int oasr_train_fwd_bwd_s(oasr_ctx*, const float* mel, const int64_t* tokens, const int64_t* targets, const int32_t* text_len, int B,
                          int S, float loss_scale, float inv_accum, float* loss_out, int accumulate_loss, float* logits_out,
                          void** seg_events, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same micro-step cut at the logits, for torch.autograd: OLMoASR.forward in training mode (olmoasr/model.py:856-887) followed by
+ * the CALLER's loss and .backward() (train_timestamps.py:1440-1454 unchanged).  train_fwd: fp32 logits [B, S, rows], every saved
+ * activation stays in the workspace.  train_bwd: dlogits = d(loss)/d(logits), fp32, same shape -> parameter gradients ACCUMULATED into
+ * the bound arena (seg_events as above).  Same B, S, tokens, text_len for the pair; the workspace must not be reused in between. */
+int oasr_train_fwd(oasr_ctx*, const float* mel, const int64_t* tokens, const int32_t* text_len, int B, int S, float* logits_out,
+                   void* workspace, size_t workspace_bytes, void* stream);
+int oasr_train_bwd(oasr_ctx*, const int64_t* tokens, const int32_t* text_len, const float* dlogits, int B, int S, void** seg_events,
+                   void* workspace, size_t workspace_bytes, void* stream);
 int oasr_zero_grad(oasr_ctx*, void* stream);
 
 /* scaler.unscale_ + clip_grad_norm_(max_norm) + AdamW.step + bf16 shadow refresh (train_timestamps.py:1509-1512).

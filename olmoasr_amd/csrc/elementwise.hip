@@ -213,6 +213,14 @@ __global__ __launch_bounds__(256) void logits_to_f32_kernel(const bf16_t* __rest
     out[i] = bf2f(lg[r * ld + col]);
   }
 }
+// d(loss)/d(logits) handed in by torch.autograd (fp32 [rows, V]) -> the engine's padded bf16 [rows, ld] buffer (padding columns zero)
+__global__ __launch_bounds__(256) void dlogits_from_f32_kernel(const float* __restrict__ src, int V, long ld, bf16_t* __restrict__ dst, long total) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / ld;
+    const int col = (int)(i - r * ld);
+    dst[i] = col < V ? f2bf_dev(src[r * V + col]) : (bf16_t)0;
+  }
+}
 __global__ __launch_bounds__(256) void dgelu_mul_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ u, bf16_t* __restrict__ out,
                                                        long n8) {
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
@@ -304,6 +312,13 @@ int launch_axpy_f32(const float* src, float* dst, long n, float a, hipStream_t s
 int launch_dgelu_mul(const bf16_t* dy, const bf16_t* u, bf16_t* out, long n, hipStream_t s) {
   OASR_REQUIRE(dy && u && out && n % 8 == 0, "dgelu_mul: bad args");
   hipLaunchKernelGGL(dgelu_mul_kernel, dim3(grid_for(n / 8)), dim3(256), 0, s, dy, u, out, n / 8);
+  OASR_LAUNCH_CHECK();
+  return OASR_OK;
+}
+int launch_dlogits_from_f32(const float* src, int V, long rows, long ld, bf16_t* dst, hipStream_t s) {
+  OASR_REQUIRE(src && dst && V <= ld, "dlogits_from_f32: bad args");
+  const long total = rows * ld;
+  hipLaunchKernelGGL(dlogits_from_f32_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, s, src, V, ld, dst, total);
   OASR_LAUNCH_CHECK();
   return OASR_OK;
 }

@@ -267,6 +267,10 @@ static void make_plan(const oasr_ctx* c, Arena& A, Plan& p, int B, int S, bool t
     p.gemm_cs_scratch = A.f32((size_t)2 * cdiv(Mmax, 256) * 4 * d + 64);
     p.tmp_w1p = A.f32((long)d * 256);
     p.tmp_w2p = A.f32((long)d * 3 * d);
+    // the residual stream entering each block (block_fwd records the same pointers): a plan re-made for a backward-only call
+    // (oasr_train_bwd) must be complete without having run the forward
+    for (int i = 0; i < c->L_enc; ++i) p.enc[i].x_in = i ? p.enc[i - 1].x_out : p.x0;
+    for (int i = 0; i < c->L_dec; ++i) p.dec[i].x_in = i ? p.dec[i - 1].x_out : p.dx0;
   }
 }
 
@@ -1148,33 +1152,14 @@ extern "C" int oasr_train_fwd_bwd(oasr_ctx* c, const float* mel, const int64_t* 
 // rounded up, the loss, every gradient and therefore the optimizer step are those of the full padded context: positions
 // past the last real token only ever see ignore_index targets, and no real query attends to them (causal mask), so
 // the reference spends their share of the decoder on exact zeros (train_timestamps.py:318-329 pads every sample to 448).
+// The backward half of a training micro-step: p.logits holds d(loss)/d(logits) (bf16 engine: bf16 [Md, Vp]) on entry -- written in
+// place by the fused cross-entropy (oasr_train_fwd_bwd*) or converted from the caller's fp32 tensor (oasr_train_bwd, the
+// torch.autograd path) -- and every saved activation of the forward is still in the workspace.
 template <typename T>
-static int oasr_train_fwd_bwd_s_impl(oasr_ctx* c, const float* mel, const int64_t* tokens, const int64_t* targets,
-                                    const int32_t* text_len, int B, int S, float loss_scale, float inv_accum, float* loss_out,
-                                    int accumulate_loss, float* logits_out, void** ev, void* workspace, size_t workspace_bytes,
-                                    void* stream) {
-  RC(check_bound(c, true));
-  OASR_REQUIRE(S > 0 && S <= c->S_max, "oasr_train_fwd_bwd: S=%d outside (0, n_text_ctx=%d]", S, c->S_max);
-  OASR_REQUIRE(mel && tokens && targets && text_len && loss_out && workspace && B > 0, "oasr_train_fwd_bwd: bad args");
-  OASR_REQUIRE(workspace_bytes >= oasr_workspace_bytes(c, B, S, OASR_MODE_TRAIN), "oasr_train_fwd_bwd: workspace too small");
+static int train_backward(oasr_ctx* c, typename Engine<T>::Runner& r, typename Engine<T>::Plan& p, const int64_t* tokens, int B, int S, void** ev) {
   const int d = c->d;
   const long Md = (long)B * S, Me = (long)B * c->Te, M1 = (long)B * c->T1;
-  Arena A(workspace, workspace_bytes);
-  typename Engine<T>::Plan p;
-  Engine<T>::make_plan(c, A, p, B, S, true);
-  typename Engine<T>::Runner r{c, (hipStream_t)stream, B, S, text_len};
-  r.train = true;
-  r.cs_scratch = p.gemm_cs_scratch;
   hipStream_t st = r.st;
-
-  // ---------------- forward ----------------
-  RC(r.encoder_fwd(p, mel));
-  RC(r.decoder_fwd(p, tokens));
-  if (logits_out) RC(launch_logits_to_f32(p.logits, c->Vp, Md, c->V, logits_out, st));
-  RC(launch_count_valid(targets, Md, PAD_ID, p.n_valid, st));
-  RC(launch_cross_entropy(p.logits, c->Vp, c->V, targets, Md, PAD_ID, loss_scale * inv_accum, p.n_valid, p.row_loss, 1, st));
-  RC(launch_loss_reduce(p.row_loss, Md, p.n_valid, inv_accum, loss_out, accumulate_loss, st));
-
   // ---------------- backward: decoder ----------------
   int seg = 0;
   // tied logits: dE += dlogits^T . lnf ; d(lnf) = dlogits . E
@@ -1286,6 +1271,82 @@ static int oasr_train_fwd_bwd_s_impl(oasr_ctx* c, const float* mel, const int64_
     return OASR_ESTATE;
   }
   return OASR_OK;
+}
+
+template <typename T>
+static int oasr_train_fwd_bwd_s_impl(oasr_ctx* c, const float* mel, const int64_t* tokens, const int64_t* targets,
+                                    const int32_t* text_len, int B, int S, float loss_scale, float inv_accum, float* loss_out,
+                                    int accumulate_loss, float* logits_out, void** ev, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+  RC(check_bound(c, true));
+  OASR_REQUIRE(S > 0 && S <= c->S_max, "oasr_train_fwd_bwd: S=%d outside (0, n_text_ctx=%d]", S, c->S_max);
+  OASR_REQUIRE(mel && tokens && targets && text_len && loss_out && workspace && B > 0, "oasr_train_fwd_bwd: bad args");
+  OASR_REQUIRE(workspace_bytes >= oasr_workspace_bytes(c, B, S, OASR_MODE_TRAIN), "oasr_train_fwd_bwd: workspace too small");
+  const long Md = (long)B * S;
+  Arena A(workspace, workspace_bytes);
+  typename Engine<T>::Plan p;
+  Engine<T>::make_plan(c, A, p, B, S, true);
+  typename Engine<T>::Runner r{c, (hipStream_t)stream, B, S, text_len};
+  r.train = true;
+  r.cs_scratch = p.gemm_cs_scratch;
+  hipStream_t st = r.st;
+  // ---------------- forward ----------------
+  RC(r.encoder_fwd(p, mel));
+  RC(r.decoder_fwd(p, tokens));
+  if (logits_out) RC(launch_logits_to_f32(p.logits, c->Vp, Md, c->V, logits_out, st));
+  RC(launch_count_valid(targets, Md, PAD_ID, p.n_valid, st));
+  RC(launch_cross_entropy(p.logits, c->Vp, c->V, targets, Md, PAD_ID, loss_scale * inv_accum, p.n_valid, p.row_loss, 1, st));
+  RC(launch_loss_reduce(p.row_loss, Md, p.n_valid, inv_accum, loss_out, accumulate_loss, st));
+  return train_backward<T>(c, r, p, tokens, B, S, ev);
+}
+
+// ---- the same micro-step cut at the logits, for torch.autograd (OLMoASR.forward in training mode, olmoasr/model.py:856-887 followed
+// by the caller's own loss, train_timestamps.py:1440-1454): oasr_train_fwd returns fp32 logits [B, S, rows] and leaves every saved
+// activation in the workspace; oasr_train_bwd takes d(loss)/d(logits) (fp32, same shape; rounded to the engine's activation type
+// exactly where autocast's backward would round it) and accumulates the parameter gradients into the bound arena.  The workspace
+// must not be used for anything else in between; B, S, tokens and text_len must be the forward's.
+template <typename T>
+static int oasr_train_fwd_impl(oasr_ctx* c, const float* mel, const int64_t* tokens, const int32_t* text_len, int B, int S,
+                               float* logits_out, void* workspace, size_t workspace_bytes, void* stream) {
+  Arena A(workspace, workspace_bytes);
+  typename Engine<T>::Plan p;
+  Engine<T>::make_plan(c, A, p, B, S, true);
+  typename Engine<T>::Runner r{c, (hipStream_t)stream, B, S, text_len};
+  r.train = true;
+  r.cs_scratch = p.gemm_cs_scratch;
+  RC(r.encoder_fwd(p, mel));
+  RC(r.decoder_fwd(p, tokens));
+  return launch_logits_to_f32(p.logits, c->Vp, (long)B * S, c->V, logits_out, r.st);
+}
+template <typename T>
+static int oasr_train_bwd_impl(oasr_ctx* c, const int64_t* tokens, const int32_t* text_len, const float* dlogits, int B, int S, void** ev,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+  Arena A(workspace, workspace_bytes);
+  typename Engine<T>::Plan p;
+  Engine<T>::make_plan(c, A, p, B, S, true);
+  typename Engine<T>::Runner r{c, (hipStream_t)stream, B, S, text_len};
+  r.train = true;
+  r.cs_scratch = p.gemm_cs_scratch;
+  RC(launch_dlogits_from_f32(dlogits, c->V, (long)B * S, c->Vp, p.logits, r.st));
+  return train_backward<T>(c, r, p, tokens, B, S, ev);
+}
+extern "C" int oasr_train_fwd(oasr_ctx* c, const float* mel, const int64_t* tokens, const int32_t* text_len, int B, int S, float* logits_out,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+  RC(check_bound(c, true));
+  OASR_REQUIRE(S > 0 && S <= c->S_max, "oasr_train_fwd: S=%d outside (0, n_text_ctx=%d]", S, c->S_max);
+  OASR_REQUIRE(mel && tokens && text_len && logits_out && workspace && B > 0, "oasr_train_fwd: bad args");
+  OASR_REQUIRE(workspace_bytes >= oasr_workspace_bytes(c, B, S, OASR_MODE_TRAIN), "oasr_train_fwd: workspace too small");
+  return c->f32 ? oasr_train_fwd_impl<float>(c, mel, tokens, text_len, B, S, logits_out, workspace, workspace_bytes, stream)
+                : oasr_train_fwd_impl<bf16_t>(c, mel, tokens, text_len, B, S, logits_out, workspace, workspace_bytes, stream);
+}
+extern "C" int oasr_train_bwd(oasr_ctx* c, const int64_t* tokens, const int32_t* text_len, const float* dlogits, int B, int S, void** ev,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+  RC(check_bound(c, true));
+  OASR_REQUIRE(S > 0 && S <= c->S_max, "oasr_train_bwd: S=%d outside (0, n_text_ctx=%d]", S, c->S_max);
+  OASR_REQUIRE(tokens && text_len && dlogits && workspace && B > 0, "oasr_train_bwd: bad args");
+  OASR_REQUIRE(workspace_bytes >= oasr_workspace_bytes(c, B, S, OASR_MODE_TRAIN), "oasr_train_bwd: workspace too small");
+  return c->f32 ? oasr_train_bwd_impl<float>(c, tokens, text_len, dlogits, B, S, ev, workspace, workspace_bytes, stream)
+                : oasr_train_bwd_impl<bf16_t>(c, tokens, text_len, dlogits, B, S, ev, workspace, workspace_bytes, stream);
 }
 extern "C" int oasr_train_fwd_bwd_s(oasr_ctx* c, const float* mel, const int64_t* tokens, const int64_t* targets,
                                     const int32_t* text_len, int B, int S, float loss_scale, float inv_accum, float* loss_out,

@@ -396,6 +396,13 @@ __global__ __launch_bounds__(256) void dgelu_mul_f32_kernel(const float* __restr
                                                            long n) {
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = dy[i] * dgelu_exact(u[i]);
 }
+__global__ __launch_bounds__(256) void dlogits_copy_f32_kernel(const float* __restrict__ src, int V, long ld, float* __restrict__ dst, long total) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / ld;
+    const int col = (int)(i - r * ld);
+    dst[i] = col < V ? src[r * V + col] : 0.f;
+  }
+}
 __global__ __launch_bounds__(256) void logits_copy_f32_kernel(const float* __restrict__ lg, long ld, int V, float* __restrict__ out, long total) {
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const long r = i / V;
@@ -537,6 +544,13 @@ int launch_conv2_col2im_dgelu(const float* dA, const float* u1, float* dpre1, in
 int launch_dgelu_mul(const float* dy, const float* u, float* out, long n, hipStream_t s) {
   OASR_REQUIRE(dy && u && out, "dgelu_mul(f32): bad args");
   hipLaunchKernelGGL(dgelu_mul_f32_kernel, dim3(grid_for(n)), dim3(256), 0, s, dy, u, out, n);
+  OASR_LAUNCH_CHECK();
+  return OASR_OK;
+}
+int launch_dlogits_from_f32(const float* src, int V, long rows, long ld, float* dst, hipStream_t s) {
+  OASR_REQUIRE(src && dst && V <= ld, "dlogits_from_f32(f32): bad args");
+  const long total = rows * ld;
+  hipLaunchKernelGGL(dlogits_copy_f32_kernel, dim3(grid_for(total)), dim3(256), 0, s, src, V, ld, dst, total);
   OASR_LAUNCH_CHECK();
   return OASR_OK;
 }

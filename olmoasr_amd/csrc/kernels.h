@@ -193,6 +193,8 @@ int launch_dgelu_mul(const bf16_t* dy, const bf16_t* u, bf16_t* out, long n, hip
 int launch_dgelu_mul(const float* dy, const float* u, float* out, long n, hipStream_t s);
 int launch_logits_to_f32(const bf16_t* logits, long ld, long rows, int V, float* out, hipStream_t s);
 int launch_logits_to_f32(const float* logits, long ld, long rows, int V, float* out, hipStream_t s);
+int launch_dlogits_from_f32(const float* src, int V, long rows, long ld, bf16_t* dst, hipStream_t s);  // fp32 [rows, V] -> padded [rows, ld]
+int launch_dlogits_from_f32(const float* src, int V, long rows, long ld, float* dst, hipStream_t s);
 
 // ---- loss -------------------------------------------------------------------------------------------------
 // logits bf16 [rows][ld] (first V entries valid).  Writes, in place, dlogits = (softmax - onehot) * gscale / n_valid

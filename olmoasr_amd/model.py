@@ -87,6 +87,54 @@ class _EngineKV:
         return _EngineKV(m, {"cache": cache, "ws": ws, "B": Bn, "pos": self.state["pos"]})
 
 
+class _TrainStep(torch.autograd.Function):
+    """OLMoASR.forward with a grad_fn: oasr_train_fwd keeps the saved activations in the model's workspace, backward hands
+    d(loss)/d(logits) to oasr_train_bwd, which accumulates into the flat gradient arena (= every ``p.grad``).  Gradients do not
+    travel through autograd's per-parameter AccumulateGrad nodes, so ``torch.nn.parallel.DistributedDataParallel``'s hooks never
+    fire: data parallelism is ``olmoasr_amd.ddp.GradReducer`` on the arena."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, mel, tokens, text_len):
+        N.require_gpu(mel, "mel")
+        N.require_gpu(tokens, "tokens")
+        B, S = tokens.shape
+        assert mel.shape == (B, model.dims.n_mels, 2 * model.dims.n_audio_ctx), "incorrect audio shape"
+        model._sync_for_autograd()
+        mel = mel.float().contiguous()
+        tokens = tokens.to(torch.int64).contiguous()
+        text_len = (torch.full((B,), S, dtype=torch.int32, device=mel.device) if text_len is None else text_len.to(torch.int32).contiguous())
+        ws = model._ws(B, S, 1)
+        logits = torch.empty(B, S, model._n_rows, device=mel.device, dtype=torch.float32)
+        with torch.cuda.device(mel.device):
+            N.check(N.lib().oasr_train_fwd(model._ctx, N.ptr(mel), N.ptr(tokens), N.ptr(text_len), B, S, N.ptr(logits), N.ptr(ws), ws.numel(),
+                                           N.stream_ptr()), "oasr_train_fwd")
+        model._autograd_gen = getattr(model, "_autograd_gen", 0) + 1
+        ctx.model, ctx.gen = model, model._autograd_gen
+        ctx.save_for_backward(tokens, text_len)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        model = ctx.model
+        if ctx.gen != model._autograd_gen:
+            raise RuntimeError("OLMoASR.backward: the activations of this forward are gone -- the engine keeps ONE forward's activations "
+                               "(in the model's workspace) and a later training-mode forward or a previous backward through this graph "
+                               "used them; run forward and backward in pairs (gradient accumulation: forward/backward per micro-batch)")
+        tokens, text_len = ctx.saved_tensors
+        B, S = tokens.shape
+        dlogits = dlogits.float().contiguous()
+        ws = model._ws(B, S, 1)
+        seg = getattr(model, "_autograd_segment_events", None)
+        ev = None
+        if seg is not None:
+            ev = (C.c_void_p * len(seg))(*[e.cuda_event for e in seg])
+        with torch.cuda.device(dlogits.device):
+            N.check(N.lib().oasr_train_bwd(model._ctx, N.ptr(tokens), N.ptr(text_len), N.ptr(dlogits), B, S, ev, N.ptr(ws), ws.numel(),
+                                           N.stream_ptr()), "oasr_train_bwd")
+        model._autograd_gen += 1  # consumed
+        return None, None, None, None, None
+
+
 class _HookHandle:
     """RemovableHandle stand-in returned by install_kv_cache_hooks (there are no module hooks to remove)."""
 
@@ -305,6 +353,8 @@ class OLMoASR(nn.Module):
             for name, off, numel, shape in self._table:
                 mod, attr = self._module_and_attr(name)
                 mod._parameters[attr].grad = self._gflat[off:off + numel].view(shape)
+        self._param_views = [(self._module_and_attr(name)[0]._parameters[self._module_and_attr(name)[1]], off, numel, shape)
+                             for name, off, numel, shape in self._table]
 
     def _apply(self, fn, recurse=True):
         """.to()/.cuda()/.float(): move the flat arenas, then re-point every parameter view (nn.Module._apply would
@@ -402,15 +452,52 @@ class OLMoASR(nn.Module):
                                          N.ptr(ws), ws.numel(), N.stream_ptr()), "oasr_forward")
         return logits, xa
 
-    @torch.no_grad()
     def forward(self, mel: Tensor, tokens: Tensor, padding_mask: Optional[Tensor] = None, verbose: bool = False) -> Tensor:
         """logits fp32 [B, S, n_vocab+1] (reference model.py:856-887).  ``padding_mask`` is the reference's
-        [B,S,S] additive mask (or an int32 [B] text_len tensor)."""
+        [B,S,S] additive mask (or an int32 [B] text_len tensor).
+
+        With autograd enabled on a module in training mode (``model.train()``, the nn.Module default) the logits carry a grad_fn, as
+        the reference's do: the caller's own loss and ``.backward()`` (train_timestamps.py:1440-1454 unchanged, GradScaler
+        included) run the engine's backward from d(loss)/d(logits) and ACCUMULATE into ``p.grad`` of every parameter (views of the
+        flat gradient arena).  ``loss_and_backward`` is the fused form of the same step (cross-entropy inside, no fp32 logits)."""
         text_len = None
         if padding_mask is not None:
             text_len = padding_mask.to(torch.int32) if padding_mask.dim() == 1 else self._text_len_from_mask(padding_mask)
             text_len = text_len.to(mel.device).contiguous()
-        return self._forward_impl(mel, tokens, text_len)[0]
+        if torch.is_grad_enabled() and self.training and not self.inference:
+            return _TrainStep.apply(self._autograd_anchor(), self, mel, tokens, text_len)
+        with torch.no_grad():
+            return self._forward_impl(mel, tokens, text_len)[0]
+
+    # ---- torch.autograd bridge -------------------------------------------------------------------------------------------
+    def _autograd_anchor(self) -> Tensor:
+        a = getattr(self, "_anchor", None)
+        if a is None or a.device != self._flat.device:
+            a = self._anchor = torch.zeros((), device=self._flat.device, requires_grad=True)
+        return a
+
+    def _sync_for_autograd(self):
+        """What a torch training loop may have done to the parameters since the last engine call: ``optimizer.step()`` wrote the fp32
+        masters in place (-> refresh the bf16 compute copies), ``zero_grad(set_to_none=True)`` dropped ``p.grad`` (-> those gradients
+        are reset: zero their arena ranges and re-attach the views)."""
+        self.enable_grad_arena()
+        ver, dropped = 0, False
+        for p, off, numel, shape in self._param_views:
+            ver += p._version
+            if p.grad is None:
+                dropped = True
+        if dropped:
+            if all(p.grad is None for p, *_ in self._param_views):
+                self.zero_grad()
+            for p, off, numel, shape in self._param_views:
+                if p.grad is None:
+                    g = self._gflat[off:off + numel].view(shape)
+                    g.zero_()
+                    p.grad = g
+        if ver != getattr(self, "_param_version", None):
+            if getattr(self, "_param_version", None) is not None:
+                self.refresh_shadow()
+            self._param_version = ver
 
     @torch.no_grad()
     def embed_audio(self, mel: Tensor) -> Tensor:

@@ -39,7 +39,7 @@ def test_fp32_forward_logits_within_1e3(net32, oracle, tiny_case, golden_dir):
     from oracle import model_oracle as mo
     c = tiny_case
     pm = mo.build_padding_mask(c["text_len"])
-    logits = net32(c["mel"].to(DEV), c["tokens"].to(DEV), pm.to(DEV)).cpu()
+    logits = net32(c["mel"].to(DEV), c["tokens"].to(DEV), pm.to(DEV)).detach().cpu()  # (training mode: the logits carry a grad_fn, as the reference's do)
     assert logits.shape == (2, 448, 51865) and logits.dtype == torch.float32
     valid = torch.arange(448)[None, :] < c["text_len"][:, None].long()
     err = (logits - oracle["logits"]).abs()

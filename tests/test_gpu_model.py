@@ -55,7 +55,7 @@ def test_forward_logits_vs_oracle_and_golden(native_tiny, oracle_tiny, tiny_case
     envelope = float(g["bf16_vs_fp32_maxabs"])  # reference-bf16 vs reference-fp32 on the same inputs
     from oracle import model_oracle as mo
     pm = mo.build_padding_mask(c["text_len"])
-    logits = native_tiny(c["mel"].to(DEV), c["tokens"].to(DEV), pm.to(DEV)).cpu()
+    logits = native_tiny(c["mel"].to(DEV), c["tokens"].to(DEV), pm.to(DEV)).detach().cpu()  # (training mode: grad_fn attached)
     assert logits.shape == (2, 448, 51865) and logits.dtype == torch.float32
     ref = oracle_tiny["logits"]
     err = (logits - ref).abs()
