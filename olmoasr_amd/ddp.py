@@ -119,6 +119,50 @@ class GradReducer:
         main.wait_stream(self.comm_stream)
 
 
+class DistributedDataParallel(torch.nn.Module):
+    """``torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank])`` (train_timestamps.py:2330) for the native model,
+    on top of its autograd bridge: constructor = parameter broadcast from rank 0 (``_sync_module_states``), ``forward`` = the wrapped
+    module's, and after every backward the gradient arena is all-reduced to the MEAN over ranks (bucketed in completion order on a
+    side stream, each bucket waiting only for its own segments' events, i.e. overlapped with the rest of the backward) -- so
+    ``p.grad`` holds what torch's DDP would leave there, ``state_dict()`` keys carry the ``module.`` prefix (:935), and the reference's
+    loop runs unchanged.  Like torch's class it reduces on EVERY backward unless inside ``no_sync()``; under gradient accumulation
+    without ``no_sync`` the already-averaged part is averaged again (a no-op: it is identical on all ranks), as in torch.
+    The fused path (``loss_and_backward`` + ``GradReducer`` + ``optim_step``) does one exchange per window and no extra pass."""
+
+    def __init__(self, module, device_ids=None, output_device=None, bucket_cap_mb: float = 25.0, process_group=None, algo: str = "allreduce", **_ignored):
+        super().__init__()
+        self.module = module
+        broadcast_parameters(module.flat_params, group=process_group)
+        module.refresh_shadow()
+        self.reducer = GradReducer(module.flat_grads, module.grad_segments, bucket_cap_mb=bucket_cap_mb, group=process_group, algo=algo,
+                                   force=dist.is_initialized())
+        self.require_backward_grad_sync = True
+        module._autograd_post_backward = self._after_backward
+
+    def _after_backward(self):
+        if not self.require_backward_grad_sync:
+            return
+        self.reducer.reduce()
+        if self.reducer.world > 1:
+            self.reducer.flat.mul_(1.0 / self.reducer.world)
+
+    def forward(self, *args, **kwargs):
+        self.module._autograd_segment_events = self.reducer.segment_events() if self.require_backward_grad_sync else None
+        return self.module(*args, **kwargs)
+
+    def no_sync(self):
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            old, self.require_backward_grad_sync = self.require_backward_grad_sync, False
+            try:
+                yield
+            finally:
+                self.require_backward_grad_sync = old
+        return ctx()
+
+
 def broadcast_parameters(flat_params: torch.Tensor, src: int = 0, group: Optional[dist.ProcessGroup] = None):
     """DDP constructor's ``_sync_module_states`` (C2) on the flat arena."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:

@@ -91,7 +91,8 @@ class _TrainStep(torch.autograd.Function):
     """OLMoASR.forward with a grad_fn: oasr_train_fwd keeps the saved activations in the model's workspace, backward hands
     d(loss)/d(logits) to oasr_train_bwd, which accumulates into the flat gradient arena (= every ``p.grad``).  Gradients do not
     travel through autograd's per-parameter AccumulateGrad nodes, so ``torch.nn.parallel.DistributedDataParallel``'s hooks never
-    fire: data parallelism is ``olmoasr_amd.ddp.GradReducer`` on the arena."""
+    fire: data parallelism is ``olmoasr_amd.ddp.DistributedDataParallel`` (same constructor call; all-reduces the arena after every
+    backward) or, on the fused path, ``olmoasr_amd.ddp.GradReducer``."""
 
     @staticmethod
     def forward(ctx, anchor, model, mel, tokens, text_len):
@@ -132,6 +133,9 @@ class _TrainStep(torch.autograd.Function):
             N.check(N.lib().oasr_train_bwd(model._ctx, N.ptr(tokens), N.ptr(text_len), N.ptr(dlogits), B, S, ev, N.ptr(ws), ws.numel(),
                                            N.stream_ptr()), "oasr_train_bwd")
         model._autograd_gen += 1  # consumed
+        post = getattr(model, "_autograd_post_backward", None)
+        if post is not None:
+            post()  # ddp.DistributedDataParallel: bucketed all-reduce of the arena, overlapped through the segment events
         return None, None, None, None, None
 
 

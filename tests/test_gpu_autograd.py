@@ -103,3 +103,45 @@ def test_one_forward_per_backward_is_enforced_and_eval_mode_has_no_graph(tiny_ca
     net.train()
     with torch.no_grad():
         assert not net(c["mel"].to(DEV), c["tokens"].to(DEV)).requires_grad
+
+
+def test_ddp_wrapper_runs_the_reference_loop_lines(tiny_case, tmp_path):
+    """``model = DDP(model, device_ids=[local_rank])`` (train_timestamps.py:2330) with olmoasr_amd.ddp.DistributedDataParallel: one rank
+    over RCCL (the collectives really run), the reference's lines, state_dict keys prefixed ``module.``; results equal the unwrapped
+    model's (mean over one rank), with and without ``no_sync`` under gradient accumulation."""
+    import torch.distributed as dist
+    from olmoasr_amd import ddp
+    from olmoasr_amd.model import OLMoASR
+    c = tiny_case
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", init_method=f"file://{tmp_path}/rdzv", rank=0, world_size=1, device_id=torch.device(DEV, 0))
+    try:
+        plain = OLMoASR(_dims(c["dims"]), device=DEV, seed=0, compute_dtype="float32")
+        plain.load_state_dict(c["sd"])
+        base = OLMoASR(_dims(c["dims"]), device=DEV, seed=0, compute_dtype="float32")
+        base.load_state_dict(c["sd"])
+        model = ddp.DistributedDataParallel(base, device_ids=[0])
+        assert all(k.startswith("module.") for k in model.state_dict())
+        plain.zero_grad()
+        for _ in range(2):
+            loss, _ = _ref_loss(plain, c, accum=2)
+            loss.backward()
+        want = {n: p.grad.clone() for n, p in plain.named_parameters()}
+        for use_no_sync in (False, True):
+            model.zero_grad()
+            if use_no_sync:
+                with model.no_sync():
+                    loss, _ = _ref_loss(model, c, accum=2)
+                    loss.backward()
+            else:
+                loss, _ = _ref_loss(model, c, accum=2)
+                loss.backward()
+            loss, _ = _ref_loss(model, c, accum=2)
+            loss.backward()
+            torch.cuda.synchronize()
+            for n, p in base.named_parameters():
+                assert torch.allclose(p.grad, want[n], atol=1e-6, rtol=1e-5), (use_no_sync, n)
+    finally:
+        if created:
+            dist.destroy_process_group()
