@@ -145,3 +145,25 @@ def test_ddp_wrapper_runs_the_reference_loop_lines(tiny_case, tmp_path):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_autograd_path_with_a_short_decoder_context(tiny_case):
+    """model(mel, tokens[:, :S]) for S < 448 (the reference's forward takes any S <= n_text_ctx, model.py:716-732): same loss and
+    gradients as the fused step over the same span (``text_ctx=S``), which in turn equal the full padded context (tests elsewhere)."""
+    from olmoasr_amd.model import OLMoASR
+    c = tiny_case
+    S = 224
+    assert int(c["text_len"].max()) <= S
+    net = OLMoASR(_dims(c["dims"]), device=DEV, seed=0, compute_dtype="float32")
+    net.load_state_dict(c["sd"])
+    net.zero_grad()
+    lf, _ = net.loss_and_backward(c["mel"].to(DEV), c["tokens"].to(DEV), c["targets"].to(DEV), c["text_len"].to(DEV), text_ctx=S)
+    fused = {n: p.grad.clone() for n, p in net.named_parameters()}
+    net.zero_grad()
+    logits = net(c["mel"].to(DEV), c["tokens"].to(DEV)[:, :S], c["text_len"].to(DEV))
+    assert logits.shape == (2, S, PAD + 1)
+    loss = F.cross_entropy(logits.view(-1, PAD + 1), c["targets"].to(DEV)[:, :S].reshape(-1), ignore_index=PAD)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(lf)) < 1e-5
+    for n, p in net.named_parameters():
+        assert float((p.grad - fused[n]).norm() / (fused[n].norm() + 1e-20)) < 2e-5, n
