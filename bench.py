@@ -41,29 +41,43 @@ class PowerSampler:
         self.files = {}
         cards = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
         cards = [c for c in cards if os.path.exists(os.path.join(c, "freq1_input"))]
-        if cards:
-            base = cards[min(index, len(cards) - 1)]
-            for key, names in (("power_uw", ("power1_average", "power1_input")), ("cap_uw", ("power1_cap",)), ("sclk_hz", ("freq1_input",))):
-                for n in names:
-                    if os.path.exists(os.path.join(base, n)):
-                        self.files[key] = os.path.join(base, n)
-                        break
-        self.samples, self._stop, self._thread = [], False, None
+        base = None
+        try:  # the visible device's PCI address picks its sysfs node (a box may expose more cards than the job can see)
+            pr = torch.cuda.get_device_properties(index)
+            want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}."
+            for c in cards:
+                if os.path.basename(os.path.realpath(os.path.join(c, "..", ".."))).lower().startswith(want):
+                    base = c
+        except Exception:
+            base = None
+        self.matched_by = "pci address" if base else "busiest card"
+        self.candidates = [base] if base else cards  # no match: sample every card and report the one drawing the most power
+        self.samples, self._stop, self._thread = {c: [] for c in self.candidates}, False, None
 
-    def _read(self, key):
+    @staticmethod
+    def _file(base, names):
+        for n in names:
+            if os.path.exists(os.path.join(base, n)):
+                return os.path.join(base, n)
+        return None
+
+    @staticmethod
+    def _read(path):
         try:
-            return float(open(self.files[key]).read().strip())
+            return float(open(path).read().strip())
         except Exception:
             return None
 
     def _run(self):
+        files = {c: (self._file(c, ("power1_average", "power1_input")), self._file(c, ("freq1_input",))) for c in self.candidates}
         while not self._stop:
-            self.samples.append((self._read("power_uw"), self._read("sclk_hz")))
+            for c, (pf, ff) in files.items():
+                self.samples[c].append((self._read(pf) if pf else None, self._read(ff) if ff else None))
             time.sleep(0.05)
 
     def start(self):
         import threading
-        if "power_uw" in self.files or "sclk_hz" in self.files:
+        if self.candidates:
             self._thread = threading.Thread(target=self._run, daemon=True)
             self._thread.start()
 
@@ -72,13 +86,19 @@ class PowerSampler:
             return None
         self._stop = True
         self._thread.join()
-        pw = [p for p, _ in self.samples if p]
-        ck = [c for _, c in self.samples if c]
-        cap = self._read("cap_uw") if "cap_uw" in self.files else None
-        return {"samples": len(self.samples), "package_power_w_avg": round(sum(pw) / len(pw) / 1e6, 1) if pw else None,
+
+        def avg_power(c):
+            pw = [p for p, _ in self.samples[c] if p]
+            return sum(pw) / len(pw) if pw else 0.0
+        best = max(self.candidates, key=avg_power)
+        pw = [p for p, _ in self.samples[best] if p]
+        ck = [c for _, c in self.samples[best] if c]
+        capf = self._file(best, ("power1_cap",))
+        cap = self._read(capf) if capf else None
+        return {"samples": len(self.samples[best]), "package_power_w_avg": round(sum(pw) / len(pw) / 1e6, 1) if pw else None,
                 "package_power_w_max": round(max(pw) / 1e6, 1) if pw else None, "power_cap_w": round(cap / 1e6, 1) if cap else None,
                 "sclk_ghz_avg": round(sum(ck) / len(ck) / 1e9, 3) if ck else None, "sclk_ghz_min": round(min(ck) / 1e9, 3) if ck else None,
-                "source": "amdgpu hwmon sysfs, 50 ms period, one profiled step"}
+                "device_matched_by": self.matched_by, "source": "amdgpu hwmon sysfs, 50 ms period, one profiled step"}
 
 PAD_ID = 51864
 
