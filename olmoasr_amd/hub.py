@@ -71,8 +71,15 @@ def load_model(name: str, device: Optional[Union[str, torch.device]] = None, dow
     if name in MODEL2LINK:
         root = Path(download_root).expanduser() if download_root else Path.home() / ".cache" / "olmoasr"
         path = root / f"OLMoASR-{name}.pt"
-        if not path.is_file():
-            raise RuntimeError(f"{path} not found and this environment has no network to fetch {MODEL2LINK[name]}")
+        if not path.is_file():  # olmoasr/__init__.py:44-94: fetch into the cache directory, drop a partial file on failure
+            import urllib.request
+            root.mkdir(parents=True, exist_ok=True)
+            try:
+                urllib.request.urlretrieve(MODEL2LINK[name], path)
+            except Exception as e:
+                if path.exists():
+                    path.unlink()
+                raise RuntimeError(f"{path} not found and downloading {MODEL2LINK[name]} failed: {e}") from e
     elif os.path.isfile(name):
         path = Path(name)
     else:

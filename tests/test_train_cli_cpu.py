@@ -127,3 +127,15 @@ def test_reference_pickled_dims_load_here(tmp_path):
         for nm in names:
             sys.modules.pop(nm, None)
         sys.modules.update(saved)
+
+
+def test_load_model_by_name_without_network_fails_loudly_and_leaves_no_partial_file(tmp_path):
+    """olmoasr.load_model("tiny") downloads into the cache (olmoasr/__init__.py:44-94); offline the error names the URL and nothing
+    half-written stays behind."""
+    import pytest
+    from olmoasr_amd import hub
+    with pytest.raises(RuntimeError, match="OLMoASR-tiny.en.pt"):
+        hub.load_model("tiny", device="cpu", download_root=str(tmp_path))
+    assert not list(tmp_path.glob("*.pt"))
+    with pytest.raises(RuntimeError, match="available models"):
+        hub.load_model("no-such-model", device="cpu")
