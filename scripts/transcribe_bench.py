@@ -22,20 +22,23 @@ def main():
     variant = sys.argv[1] if len(sys.argv) > 1 else "small"
     seconds = int(sys.argv[2]) if len(sys.argv) > 2 else 600
     bw = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+    opts = dict(GREEDY)
+    if len(sys.argv) > 4 and sys.argv[4] == "ts":  # the reference's default: timestamp tokens on, windows strictly sequential (seek depends on them)
+        opts["without_timestamps"] = False
     dev = torch.device("cuda", 0)
     net = OLMoASR(VARIANT_TO_DIMS[variant], device=dev, seed=0, inference=True)
     g = torch.Generator().manual_seed(0)
     audio = (torch.randn(seconds * 16000, generator=g) * 0.1).clamp_(-1, 1)
-    net.transcribe(audio[:16000 * 60], batch_windows=bw, **GREEDY)  # warm-up (workspaces, tables)
+    net.transcribe(audio[:16000 * 60], batch_windows=bw, **opts)  # warm-up (workspaces, tables)
     torch.cuda.synchronize()
     t0 = time.time()
-    out = net.transcribe(audio, batch_windows=bw, **GREEDY)
+    out = net.transcribe(audio, batch_windows=bw, **opts)
     torch.cuda.synchronize()
     dt = time.time() - t0
     ntok = sum(len(s["tokens"]) for s in out["segments"])
-    print(json.dumps({"config": f"OLMoASR-{variant} greedy transcribe, {seconds} s synthetic audio, {bw} windows per decode batch, KV cache",
+    print(json.dumps({"config": f"OLMoASR-{variant} greedy transcribe, {seconds} s synthetic audio, {bw} windows per decode batch, KV cache" + (", timestamp tokens (sequential windows)" if not opts["without_timestamps"] else ""),
                       "audio_seconds_per_second": round(seconds / dt, 1), "wall_s": round(dt, 3), "windows": len(out["segments"]),
-                      "tokens": ntok, "ms_per_decode_step": round(1000 * dt / max(1, ntok / bw), 3)}))
+                      "tokens": ntok, "ms_per_decode_step": round(1000 * dt / max(1, ntok / (bw if opts["without_timestamps"] else 1)), 3)}))
 
 
 if __name__ == "__main__":
