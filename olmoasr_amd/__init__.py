@@ -9,7 +9,7 @@ from .config.model_dims import VARIANT_TO_DIMS, ModelDimensions  # noqa: E402,F4
 
 def __getattr__(name):
     """Lazy re-exports mirroring ``olmoasr/__init__.py:17-21`` (torch/HIP are only touched when used)."""
-    if name in ("log_mel_spectrogram", "pad_or_trim", "N_SAMPLES", "N_FRAMES", "SAMPLE_RATE", "HOP_LENGTH", "N_FFT"):
+    if name in ("log_mel_spectrogram", "pad_or_trim", "load_audio", "N_SAMPLES", "N_FRAMES", "SAMPLE_RATE", "HOP_LENGTH", "N_FFT"):
         from . import audio
         return getattr(audio, name)
     if name == "OLMoASR":

@@ -39,7 +39,8 @@ def transcribe(model, audio, *, verbose: Optional[bool] = None,
                prepend_punctuations: str = "", append_punctuations: str = "", clip_timestamps: Union[str, Sequence[float]] = "0",
                hallucination_silence_threshold: Optional[float] = None, batch_windows: int = 16, **decode_options):
     if isinstance(audio, str):
-        raise NotImplementedError("audio file decoding (ffmpeg) is out of scope: pass a waveform array/tensor")
+        from .audio import load_audio
+        audio = load_audio(audio)
     if word_timestamps or initial_prompt is not None or hallucination_silence_threshold is not None:
         warnings.warn("word_timestamps / initial_prompt / hallucination_silence_threshold need the tokenizer's text and are ignored")
     if not torch.is_tensor(audio):

@@ -105,3 +105,26 @@ def test_text_fn_plug_and_timestamp_mode_use_the_full_clip(tmp_path):
     assert sh.load(0)[0].shape[0] == 80000
     with pytest.raises(ValueError, match="n_text_ctx"):
         data.AudioTextShards([s], text_fn=lambda d: (list(range(460)), False, None)).load(0)
+
+
+def test_load_audio_reads_wave_and_npy_without_ffmpeg(tmp_path):
+    """whisper.audio.load_audio's contract (mono float32 in [-1, 1] at 16 kHz) for the codec-free formats."""
+    import wave
+    from olmoasr_amd.audio import load_audio
+    t = np.arange(16000) / 16000.0
+    tone = (0.5 * np.sin(2 * np.pi * 440.0 * t) * 32767).astype(np.int16)
+    with wave.open(str(tmp_path / "mono16k.wav"), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(tone.tobytes())
+    a = load_audio(str(tmp_path / "mono16k.wav"))
+    assert a.dtype == np.float32 and a.shape == (16000,) and np.array_equal(a, tone.astype(np.float32) / 32768.0)
+    t8 = np.arange(8000) / 8000.0
+    st = np.stack([(0.5 * np.sin(2 * np.pi * 440.0 * t8) * 32767).astype(np.int16)] * 2, axis=1)
+    with wave.open(str(tmp_path / "stereo8k.wav"), "wb") as w:
+        w.setnchannels(2); w.setsampwidth(2); w.setframerate(8000); w.writeframes(st.tobytes())
+    b = load_audio(str(tmp_path / "stereo8k.wav"))
+    assert b.shape == (16000,) and float(np.abs(b[200:-200] - a[200:-200]).max()) < 2e-2  # channel mean + 8 -> 16 kHz polyphase
+    np.save(tmp_path / "clip.npy", tone)
+    assert np.array_equal(load_audio(str(tmp_path / "clip.npy")), a)
+    with pytest.raises(RuntimeError, match="Failed to load audio"):
+        (tmp_path / "x.mp3").write_bytes(b"not audio")
+        load_audio(str(tmp_path / "x.mp3"))
