@@ -63,3 +63,21 @@ def test_training_from_shards_with_shuffle_and_a_short_last_batch(tmp_path):
                    "--synthetic=False", "--shuffle=True"])
     assert len(log) == 4 and all(not r["found_inf"] and r["train_loss"] == r["train_loss"] for r in log)
     assert log[-1]["train_loss"] < log[0]["train_loss"]
+
+
+def test_transcribe_accepts_a_wave_file_path(tmp_path):
+    """model.transcribe("file.wav") (olmoasr/transcribe.py:147-148 via whisper.audio.load_audio) == transcribe(samples)."""
+    import wave
+    import numpy as np
+    from olmoasr_amd.config.model_dims import ModelDimensions
+    from olmoasr_amd.model import OLMoASR
+    g = torch.Generator().manual_seed(0)
+    pcm = (torch.randn(16000 * 35, generator=g) * 0.1).clamp_(-1, 1)
+    i16 = torch.round(pcm * 32767).to(torch.int16).numpy()
+    with wave.open(str(tmp_path / "a.wav"), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(i16.tobytes())
+    net = OLMoASR(ModelDimensions(80, 1500, 384, 6, 1, 51864, 448, 384, 6, 1), device=DEV, seed=3, inference=True)
+    opts = dict(temperature=0.0, logprob_threshold=None, no_speech_threshold=None, sample_len=6)
+    a = net.transcribe(str(tmp_path / "a.wav"), **opts)
+    b = net.transcribe(i16.astype(np.float32) / 32768.0, **opts)
+    assert a["tokens"] == b["tokens"] and len(a["segments"]) == len(b["segments"]) >= 2
