@@ -84,3 +84,36 @@ def test_greedy_decode_oracle_equals_transformers_forward_plus_processors(pair):
         body = tokens[b, 2:].tolist()
         body = body[:body.index(50256)] if 50256 in body else body
         assert r.tokens == body, (b, r.tokens, body)
+
+
+def test_timestamp_mode_greedy_equals_transformers_forward_plus_processors(pair):
+    """The reference's default decoding mode (timestamp tokens on): SuppressBlank, SuppressTokens, ApplyTimestampRules in whisper's order,
+    here as transformers' three processors around transformers' forward."""
+    from types import SimpleNamespace
+    from transformers.generation.logits_process import (SuppressTokensAtBeginLogitsProcessor, SuppressTokensLogitsProcessor,
+                                                        WhisperTimeStampLogitsProcessor)
+    from oracle import decode_oracle as do
+    mo, dims, sd, hf, mel = pair
+    L = 9
+    opt = do.Options(sample_len=L)
+    want_oracle = do.decode(sd, dims, mel, opt)
+    sup = SuppressTokensLogitsProcessor(do.suppress_list(opt))
+    begin = SuppressTokensAtBeginLogitsProcessor([220, 50256], begin_index=1)
+    cfg = SimpleNamespace(no_timestamps_token_id=50362, eos_token_id=50256, bos_token_id=50256, max_initial_timestamp_index=50,
+                          _detect_timestamp_from_logprob=True)
+    ts = WhisperTimeStampLogitsProcessor(cfg, begin_index=1)
+    tokens = torch.tensor([[50257]] * mel.shape[0])
+    done = torch.zeros(mel.shape[0], dtype=torch.bool)
+    with torch.no_grad():
+        for _ in range(L):
+            logits = hf(input_features=mel, decoder_input_ids=tokens).logits[:, -1].float()
+            logits = ts(tokens, sup(tokens, begin(tokens, logits)))
+            nxt = logits.argmax(-1)
+            nxt = torch.where(done, torch.full_like(nxt, 50256), nxt)
+            tokens = torch.cat([tokens, nxt[:, None]], 1)
+            done |= nxt == 50256
+    for b, r in enumerate(want_oracle):
+        body = tokens[b, 1:].tolist()
+        body = body[:body.index(50256)] if 50256 in body else body
+        assert r.tokens == body, (b, r.tokens, body)
+        assert body[0] >= 50363  # the first sampled token is a timestamp
