@@ -30,7 +30,9 @@ if ROOT not in sys.path:
 
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16, MI355X_MICROARCH.md "Chip-level parameters"
 
-SUSTAINED_GEMM_TFLOPS = 1307.0  # measured: the layer GEMM alone at the 1400 W package cap (profiles/r02_gpu_power_under_gemm.txt)
+SUSTAINED_GEMM_TFLOPS = 1484.0  # measured: the best dense bf16 GEMM seen at the 1400 W package cap on these boxes -- hipBLASLt's 4-wave
+#                                 256x256x64 stream-K kernel, 1.83 GHz (profiles/r02_gemm_vs_vendor.txt)
+OWN_SUSTAINED_GEMM_TFLOPS = 1307.0  # this repo's layer GEMM alone at the same cap, 1.65 GHz (profiles/r02_gpu_power_under_gemm.txt)
 
 
 class PowerSampler:
@@ -411,10 +413,12 @@ def main():
                 "by_layout_tflops": {layouts[k]: round(fl[k] / ms[k] / 1e9, 1) for k in range(4) if cnt[k]},
                 "gemm_ms_per_step": round(sum(ms), 2)}
         # The MI355X clocks to its 1400 W package budget: `frac` above is priced against the 2.4 GHz datasheet peak as
-        # the contract asks; this block says where the board actually was during the profiled step, and what the same kernel sustains
-        # when it alone holds the package at its cap (profiles/r02_gpu_power_under_gemm.txt: 1307 TFLOP/s at 1400 W, 1.65 GHz).
+        # the contract asks; this block says where the board actually was during the profiled step, and what a dense bf16 GEMM sustains
+        # when it alone holds the package at its cap: the vendor library's best kernel (the practical ceiling) and this repo's own.
         roof["power_limited"] = {"sampled_during_profiled_step": power, "sustained_gemm_ceiling_tflops": SUSTAINED_GEMM_TFLOPS,
-                                 "ceiling_source": "profiles/r02_gpu_power_under_gemm.txt (scripts/gpu_power_probe.sh: 14 s of the N=K=4096 layer GEMM, rocm-smi: 1399-1400 W of 1400 W, sclk 1.65 GHz) -- NOT measured in this run",
+                                 "ceiling_source": "profiles/r02_gemm_vs_vendor.txt (hipBLASLt MT256x256x64 stream-K via torch.matmul, N=K=4096, 6 s back to back: 1398-1400 W of 1400 W, sclk 1.83 GHz) -- NOT measured in this run",
+                                 "own_kernel_sustained_tflops": OWN_SUSTAINED_GEMM_TFLOPS,
+                                 "own_source": "profiles/r02_gpu_power_under_gemm.txt (this repo's ping-pong kernel, same shape: 1399-1400 W, sclk 1.65 GHz) -- NOT measured in this run",
                                  "frac_of_sustained_ceiling": round(achieved / SUSTAINED_GEMM_TFLOPS, 4)}
 
     out = None
