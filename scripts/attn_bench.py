@@ -44,6 +44,19 @@ def main():
         tb = timeit(lambda: ops.attention_bwd(q, k, v, o, lse, d_o, kv_len, causal, o_lo=o_lo), iters)
         print(f"{name:14s} Tq={Tq} Tk={Tk}: fwd {tf:7.3f} ms {flops / tf / 1e9:7.1f} TF/s | bwd {tb:7.3f} ms {2.5 * flops / tb / 1e9:7.1f} TF/s (algorithmic 2.5x)",
               flush=True)
+        if os.environ.get("OASR_ATTN_VS_SDPA") and kv_len is None:
+            # the vendor's flash attention (torch SDPA -> AOTriton / CK on ROCm) on the same problem, [B, H, T, 64] layout, no mask
+            import torch.nn.functional as F
+            qs, ks, vs = (t.permute(0, 2, 1, 3).contiguous().requires_grad_(True) for t in (q, k, v))
+            go = d_o.unflatten(2, (H, 64)).permute(0, 2, 1, 3).contiguous()
+            try:
+                with torch.nn.attention.sdpa_kernel([torch.nn.attention.SDPBackend.FLASH_ATTENTION]):
+                    ts = timeit(lambda: F.scaled_dot_product_attention(qs, ks, vs, is_causal=False), iters)
+                    out = F.scaled_dot_product_attention(qs, ks, vs, is_causal=False)
+                    tsb = timeit(lambda: torch.autograd.grad(out, (qs, ks, vs), go, retain_graph=True), iters)
+                print(f"{'':14s} torch SDPA (flash backend): fwd {ts:7.3f} ms {flops / ts / 1e9:7.1f} TF/s | bwd {tsb:7.3f} ms {2.5 * flops / tsb / 1e9:7.1f} TF/s", flush=True)
+            except Exception as e:  # backend not available for this shape on this build
+                print(f"{'':14s} torch SDPA flash backend unavailable: {str(e)[:120]}", flush=True)
 
 
 if __name__ == "__main__":
