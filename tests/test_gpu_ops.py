@@ -189,8 +189,12 @@ def test_gemm_pingpong_persistent_launch_matches_plain(layout):
         close(outs[1][0], A.float().t() @ B.float(), name="persistent wgrad")
     elif layout != "nt_gelu":
         Bf = B.float() if layout == "nn" else B.float().t()
-        ref = (A.float() @ Bf + bias).bfloat16().float() + resid.float()
-        close(outs[1][0], ref, name="persistent " + layout)
+        pre = (A.float() @ Bf + bias).bfloat16().float()
+        ref = pre + resid.float()
+        # one bf16 ulp of the larger addend: where pre and the residual cancel, the fp32 reference product (vendor GEMM, box dependent)
+        # may round `pre` to the neighbouring bf16 value
+        ulp = torch.maximum(pre.abs(), resid.float().abs()) * 2.0 ** -7
+        assert bool(((outs[1][0].float() - ref).abs() <= ulp + 1e-2 * ref.abs() + 1e-3).all()), "persistent " + layout
 
 
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
