@@ -279,3 +279,78 @@ def test_zero1_sharded_step_equals_replicated_step():
             assert torch.allclose(got, p, atol=1e-6, rtol=0), (step, rank, float((got - p).abs().max()))
             assert abs(sumsq - float(ref.sumsq(0, n)[0])) < 1e-3 * sumsq
     assert res[0][3] == 0 and res[1][3] == res[0][4] and res[1][3] + res[1][4] == n  # the two ranges tile the arena
+
+
+# ---- ddp.DistributedDataParallel (the reference's DDP(model, device_ids=[...]) call) under gloo, world 2, on a stand-in module -----------
+class _ArenaModule(torch.nn.Module):
+    """What the wrapper needs of OLMoASR: flat parameter / gradient arenas, their segments, refresh_shadow, and an autograd-free backward that
+    writes the arena and then fires ``_autograd_post_backward`` (model.py::_TrainStep.backward does exactly that on the GPU)."""
+
+    def __init__(self, n, rank):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.full((n,), float(rank + 1)))
+        self.flat_params = self.w.data
+        self.flat_grads = torch.zeros(n)
+        self.grad_segments = [(0, n // 4), (n // 4, n - n // 4)]
+        self.refreshed = 0
+
+    def refresh_shadow(self):
+        self.refreshed += 1
+
+    def forward(self, x):
+        return x
+
+    def fake_backward(self, g):
+        self.flat_grads += g
+        post = getattr(self, "_autograd_post_backward", None)
+        if post is not None:
+            post()
+
+
+def _wrapper_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 1001
+        base = _ArenaModule(n, rank)
+        model = ddp.DistributedDataParallel(base, device_ids=[rank], bucket_cap_mb=1000 * 4 / (1 << 20))
+        assert torch.equal(base.flat_params, torch.ones(n)) and base.refreshed == 1          # rank 0's parameters everywhere
+        assert list(model.state_dict()) == ["module.w"]
+        g = [torch.randn(n, generator=torch.Generator().manual_seed(10 * r + k)) for r in range(world) for k in range(2)]
+        mine = [g[2 * rank], g[2 * rank + 1]]
+        mean = [sum(g[2 * r + k] for r in range(world)) / world for k in range(2)]
+        # two micro-batches without no_sync: reduced after each backward; the already-averaged part stays put
+        model(torch.zeros(1))
+        base.fake_backward(mine[0])
+        assert torch.allclose(base.flat_grads, mean[0], atol=1e-6)
+        model(torch.zeros(1))
+        base.fake_backward(mine[1])
+        assert torch.allclose(base.flat_grads, mean[0] + mean[1], atol=1e-6)
+        # the same window with no_sync on the first micro-batch: one exchange, same result
+        base.flat_grads.zero_()
+        with model.no_sync():
+            model(torch.zeros(1))
+            base.fake_backward(mine[0])
+            assert torch.equal(base.flat_grads, mine[0])
+        model(torch.zeros(1))
+        base.fake_backward(mine[1])
+        assert torch.allclose(base.flat_grads, mean[0] + mean[1], atol=1e-6)
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ddp_wrapper_world2_mean_allreduce_and_no_sync():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_wrapper_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(30)
+    assert all(r[1] == "ok" for r in res), res
