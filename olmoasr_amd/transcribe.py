@@ -68,10 +68,10 @@ def transcribe(model, audio, *, verbose: Optional[bool] = None,
         for t in temperatures:
             kwargs = {**decode_options}
             if t > 0:
-                kwargs.pop("beam_size", None)   # disable beam_size and patience when t > 0
+                kwargs.pop("beam_size", None)   # sampling temperatures run without the beam (:201-204)
                 kwargs.pop("patience", None)
             else:
-                kwargs.pop("best_of", None)     # disable best_of when t == 0
+                kwargs.pop("best_of", None)     # and the greedy/beam pass without best_of (:205-207)
             out = decode(model, segments[todo], DecodingOptions(**kwargs, temperature=t))
             still = []
             for j, r in zip(todo, out):
@@ -79,7 +79,7 @@ def transcribe(model, audio, *, verbose: Optional[bool] = None,
                 needs_fallback = logprob_threshold is not None and r.avg_logprob < logprob_threshold
                 if (no_speech_threshold is not None and r.no_speech_prob > no_speech_threshold and logprob_threshold is not None
                         and r.avg_logprob < logprob_threshold):
-                    needs_fallback = False      # silence
+                    needs_fallback = False      # a quiet window is accepted as it is (:223-229)
                 if needs_fallback:
                     still.append(j)
             todo = still
@@ -122,12 +122,12 @@ def transcribe(model, audio, *, verbose: Optional[bool] = None,
         segment_duration = segment_size * HOP_LENGTH / SAMPLE_RATE
         tokens = list(result.tokens)
 
-        if no_speech_threshold is not None:  # no voice activity check (:305-320)
+        if no_speech_threshold is not None:  # windows judged silent are stepped over whole (:305-320)
             should_skip = result.no_speech_prob > no_speech_threshold
             if logprob_threshold is not None and result.avg_logprob > logprob_threshold:
-                should_skip = False          # don't skip if the logprob is high enough, despite the no_speech_prob
+                should_skip = False          # ... unless the decoder was confident about what it wrote
             if should_skip:
-                seek += segment_size         # fast-forward to the next segment boundary
+                seek += segment_size
                 continue
 
         current_segments: List[dict] = []
@@ -140,7 +140,7 @@ def transcribe(model, audio, *, verbose: Optional[bool] = None,
         is_ts = [t >= TIMESTAMP_BEGIN for t in tokens]
         single_timestamp_ending = is_ts[-2:] == [False, True]
         consecutive = [i + 1 for i in range(len(tokens) - 1) if is_ts[i] and is_ts[i + 1]]
-        if len(consecutive) > 0:  # the output contains two consecutive timestamp tokens
+        if len(consecutive) > 0:  # <|t|><|t'|> pairs close segments (:348-386)
             slices = list(consecutive)
             if single_timestamp_ending:
                 slices.append(len(tokens))
@@ -151,18 +151,18 @@ def transcribe(model, audio, *, verbose: Optional[bool] = None,
                                                     end=time_offset + (sliced[-1] - TIMESTAMP_BEGIN) * time_precision, toks=sliced))
                 last_slice = current_slice
             if single_timestamp_ending:
-                seek += segment_size  # single timestamp at the end means no speech after the last timestamp
-            else:                     # otherwise, ignore the unfinished segment and seek to the last timestamp
+                seek += segment_size  # output closed by a lone timestamp: the rest of the window holds nothing
+            else:                     # open tail: resume from the last closed timestamp, the tail is decoded again
                 seek += (tokens[last_slice - 1] - TIMESTAMP_BEGIN) * input_stride
         else:
             duration = segment_duration
             stamps = [t for t in tokens if t >= TIMESTAMP_BEGIN]
             if len(stamps) > 0 and stamps[-1] != TIMESTAMP_BEGIN:
-                duration = (stamps[-1] - TIMESTAMP_BEGIN) * time_precision  # no consecutive timestamps but it has one: use the last
+                duration = (stamps[-1] - TIMESTAMP_BEGIN) * time_precision  # a lone timestamp bounds the segment (:388-399)
             current_segments.append(new_segment(start=time_offset, end=time_offset + duration, toks=tokens))
             seek += segment_size
 
-        # if a segment is instantaneous or does not contain text, clear it (text == token ids below eot here)
+        # zero-length segments and segments without a text token keep their slot but lose their tokens (:494-499)
         for seg in current_segments:
             if seg["start"] == seg["end"] or not any(t < EOT for t in seg["tokens"]):
                 seg["tokens"] = []

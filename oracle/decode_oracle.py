@@ -293,6 +293,7 @@ def transcribe(sd, dims, mel_padded: torch.Tensor, *, temperature=(0.0, 0.2, 0.4
         for s in current:  # "instantaneous or does not contain text" (:494-499); text == tokens below eot here
             if s["start"] == s["end"] or not any(t < EOT for t in s["tokens"]):
                 s["tokens"] = []
-        all_segments.extend({"id": len(all_segments) + i, **s} for i, s in enumerate(current))
+        base_id = len(all_segments)  # ids continue across windows (:501-508); evaluated before the list grows
+        all_segments.extend({"id": base_id + i, **s} for i, s in enumerate(current))
         all_tokens.extend(t for s in current for t in s["tokens"])
     return {"tokens": all_tokens, "segments": all_segments, "seeks": seeks}

@@ -65,3 +65,12 @@ def load():
     inf_model = importlib.import_module("olmoasr.inf_model")
     dims = importlib.import_module("olmoasr.config.model_dims")
     return model, inf_model, dims
+
+
+def load_transcribe():
+    """The UNMODIFIED ``/root/reference/olmoasr/transcribe.py`` as a module (its ``whisper.*`` imports are the stand-ins
+    registered by ``load()``).  The caller patches the module globals it needs (``log_mel_spectrogram``, ``pad_or_trim``,
+    ``get_tokenizer``, ``DecodingOptions``) -- see tests/test_oracle_transcribe_ref_cpu.py, the pin of
+    ``oracle.decode_oracle.transcribe`` against the reference's own seek loop (transcribe.py:147-517)."""
+    load()
+    return importlib.import_module("olmoasr.transcribe")

@@ -1,0 +1,162 @@
+"""Harness that pins ``oracle.decode_oracle.transcribe`` to the reference's OWN long-form driver.  TEST INFRASTRUCTURE ONLY.
+
+``olmoasr/transcribe.py:47-523`` is in the reference tree and is executed here UNMODIFIED (``ref_import.load_transcribe``);
+only the names it imports from the un-vendored ``whisper`` package are supplied:
+
+  log_mel_spectrogram(audio, n_mels, padding)  -> the padded mel handed in as ``audio`` (transcribe.py:148)
+  pad_or_trim(x, 3000)                         -> zero pad / cut of the last axis (whisper.audio.pad_or_trim, :295)
+  get_tokenizer(...)                           -> .eot / .timestamp_begin / .encode / .decode(ids) (text = the ids, spelled)
+  DecodingOptions(**kwargs)                    -> a plain namespace (:212)
+  model.decode(segment, options)               -> the SAME callable the oracle's transcribe() is given
+
+so the two seek loops (clip handling :177-186, temperature fallback :193-233, no-speech skip :305-320, timestamp-driven
+seek and segment cutting :348-408, the "instantaneous or empty" rule :494-499, ids :501-512) run on identical decode
+results and must produce identical seeks, segments and token streams.
+
+Two kinds of decode callables:
+  * ``scripted_decode(seed)`` -- a deterministic function of (window start, window size, temperature) that emits token
+    patterns from a small grammar (closed <|t|>..<|t'|> pairs, an open tail, a single closing timestamp, no timestamps,
+    nothing at all) with random avg_logprob / no_speech_prob: every branch of the loop is reached within a few cases.
+    The window start is read back from the mel itself (frame f of the padded mel carries f in band 0).
+  * ``model_decode(sd, dims, ...)`` -- ``decode_oracle.decode`` on a real (tiny) model.
+"""
+import random
+import types
+from typing import Callable, List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+from . import decode_oracle as do
+
+N_FRAMES = 3000
+
+
+def index_mel(content_frames: int) -> torch.Tensor:
+    """[80, content + 3000] 'mel' whose band 0 holds the frame index + 1 (0 = the zero padding of pad_or_trim)."""
+    mel = torch.zeros(80, content_frames + N_FRAMES)
+    mel[0] = torch.arange(1, content_frames + N_FRAMES + 1, dtype=torch.float32)
+    return mel
+
+
+def scripted_decode(seed: int) -> Callable:
+    """decode(segment [80,3000], temperature, options-dict) -> decode_oracle.Result, a pure function of its arguments."""
+    def decode(segment: torch.Tensor, temperature: float, kw: dict) -> do.Result:
+        seek = int(segment[0, 0].item()) - 1
+        size = int((segment[0] > 0).sum().item())
+        rng = random.Random(hash((seed, seek, size, round(temperature * 10), bool(kw.get("beam_size")), bool(kw.get("best_of")))) & 0xFFFFFFFF)
+        toks: List[int] = []
+        kind = rng.choice(["pairs", "pairs", "pairs_open", "pairs_single_end", "single_ts", "no_ts", "empty", "only_ts", "zero_len"])
+        t = rng.randrange(0, 40)
+        text = lambda: [rng.randrange(0, 50256) for _ in range(rng.randrange(1, 5))]  # noqa: E731
+        if kind in ("pairs", "pairs_open", "pairs_single_end"):
+            for _ in range(rng.randrange(1, 4)):
+                t2 = min(1500, t + rng.randrange(1, 500))
+                toks += [do.TIMESTAMP_BEGIN + t] + text() + [do.TIMESTAMP_BEGIN + t2]
+                t = min(1500, t2 + rng.randrange(0, 20))
+            if kind == "pairs_open":
+                toks += [do.TIMESTAMP_BEGIN + t] + text()
+            elif kind == "pairs_single_end":
+                toks += [do.TIMESTAMP_BEGIN + t] + text() + [do.TIMESTAMP_BEGIN + min(1500, t + rng.randrange(1, 99))]
+                toks = toks[:-1] if rng.random() < 0.5 else toks
+                toks += text() + [do.TIMESTAMP_BEGIN + min(1500, t + 120)]
+        elif kind == "single_ts":
+            toks = [do.TIMESTAMP_BEGIN + t] + text() + ([do.TIMESTAMP_BEGIN + t + rng.randrange(0, 3)] if rng.random() < 0.7 else [])
+        elif kind == "no_ts":
+            toks = text()
+        elif kind == "only_ts":
+            toks = [do.TIMESTAMP_BEGIN + t, do.TIMESTAMP_BEGIN + t + rng.randrange(0, 2)]
+        elif kind == "zero_len":
+            toks = [do.TIMESTAMP_BEGIN + t] + text() + [do.TIMESTAMP_BEGIN + t] + [do.TIMESTAMP_BEGIN + t + 7] + text() + [do.TIMESTAMP_BEGIN + t + 9]
+        lp = rng.choice([-0.2, -0.6, -0.99, -1.0, -1.01, -1.4, -2.5]) + 0.3 * temperature
+        return do.Result(tokens=toks, avg_logprob=lp, no_speech_prob=rng.choice([0.01, 0.3, 0.59, 0.6, 0.61, 0.9]),
+                         temperature=temperature, sum_logprob=lp * (len(toks) + 1))
+    return decode
+
+
+def model_decode(sd, dims, logit_bias: Optional[torch.Tensor] = None) -> Callable:
+    def decode(segment: torch.Tensor, temperature: float, kw: dict) -> do.Result:
+        kw = {k: v for k, v in kw.items() if k in do.Options.__dataclass_fields__}
+        return do.decode(sd, dims, segment[None], do.Options(temperature=temperature, logit_bias=logit_bias, **kw))[0]
+    return decode
+
+
+def run_oracle(decode: Callable, mel_padded: torch.Tensor, **kw) -> dict:
+    """decode_oracle.transcribe with its model call replaced by ``decode`` (same replacement the reference side gets)."""
+    saved = do.decode
+
+    def shim(sd, dims, seg, opt):
+        fields = {k: getattr(opt, k) for k in opt.__dataclass_fields__ if k not in ("temperature", "logit_bias")}
+        passed = {k: v for k, v in fields.items() if k in shim.kw}  # only what transcribe() forwarded
+        return [decode(seg[0], opt.temperature, passed)]
+    tkw = {k: kw.pop(k) for k in list(kw) if k in ("temperature", "logprob_threshold", "no_speech_threshold", "clip_timestamps")}
+    shim.kw = dict(kw)
+    do.decode = shim
+    try:
+        return do.transcribe(None, None, mel_padded, **tkw, **kw)
+    finally:
+        do.decode = saved
+
+
+def run_reference(decode: Callable, mel_padded: torch.Tensor, **kw) -> dict:
+    """The reference's transcribe() itself (needs /root/reference)."""
+    from . import ref_import
+    rt = ref_import.load_transcribe()
+
+    class Tok:
+        eot, timestamp_begin = do.EOT, do.TIMESTAMP_BEGIN
+
+        def encode(self, s):
+            return [int(x) for x in s.split()]
+
+        def decode(self, ids):
+            return " ".join(str(int(i)) for i in ids)
+
+    class Opt(types.SimpleNamespace):
+        pass
+
+    def ref_decode(segment, options):
+        d = dict(vars(options))
+        t = d.pop("temperature")
+        d.pop("language", None), d.pop("fp16", None)
+        r = decode(segment, t, d)
+        return types.SimpleNamespace(tokens=list(r.tokens), avg_logprob=r.avg_logprob, no_speech_prob=r.no_speech_prob,
+                                     temperature=r.temperature, compression_ratio=1.0)
+
+    model = types.SimpleNamespace(dims=types.SimpleNamespace(n_mels=80, n_audio_ctx=1500, n_text_ctx=448), device=torch.device("cpu"),
+                                  is_multilingual=False, num_languages=0, decode=ref_decode)
+    rt.log_mel_spectrogram = lambda audio, n_mels=80, padding=0: audio
+    rt.pad_or_trim = lambda x, length: F.pad(x, (0, length - x.shape[-1])) if x.shape[-1] < length else x[..., :length]
+    rt.get_tokenizer = lambda *a, **k: Tok()
+    rt.DecodingOptions = Opt
+    if "clip_timestamps" in kw:
+        kw["clip_timestamps"] = list(kw["clip_timestamps"])
+    out = rt.transcribe(model, mel_padded, verbose=None, compression_ratio_threshold=None, **kw)
+    toks = [t for s in out["segments"] for t in s["tokens"]]
+    return {"segments": out["segments"], "tokens": toks, "text": out["text"]}
+
+
+def comparable(out: dict) -> dict:
+    """The fields both sides define, JSON-ready."""
+    keys = ("id", "seek", "start", "end", "tokens", "temperature", "avg_logprob", "no_speech_prob")
+    return {"tokens": [int(t) for t in out["tokens"]],
+            "segments": [{k: ([int(t) for t in s[k]] if k == "tokens" else s[k]) for k in keys} for s in out["segments"]]}
+
+
+def scripted_cases() -> List[dict]:
+    """(seed, content_frames, transcribe kwargs) of the committed fixture (tests/golden/transcribe_ref.json)."""
+    cases = []
+    for seed in range(40):
+        rng = random.Random(1000 + seed)
+        kw: dict = dict(temperature=rng.choice([0.0, (0.0, 0.2, 0.4), (0.0, 0.2, 0.4, 0.6, 0.8, 1.0)]),
+                        logprob_threshold=rng.choice([-1.0, -1.0, None, -0.5]), no_speech_threshold=rng.choice([0.6, 0.6, None]))
+        content = rng.choice([700, 2999, 3000, 3001, 9000, 12345, 20000])
+        if rng.random() < 0.3:
+            pts = sorted(rng.sample(range(0, content // 100), rng.choice([1, 2, 3, 4])))
+            kw["clip_timestamps"] = [float(p) for p in pts]
+        if rng.random() < 0.4:
+            kw["beam_size"], kw["best_of"] = 5, 5
+        if rng.random() < 0.3:
+            kw["without_timestamps"] = True
+        cases.append(dict(seed=seed, content_frames=content, kw=kw))
+    return cases
