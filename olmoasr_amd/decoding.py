@@ -12,8 +12,8 @@ reference": it ships no tests or vectors for decoding.
   DecodingTask.run:  initial tokens [sot] (+ [notimestamps] when without_timestamps) -- the English-only specials the
   reference's Dataset writes (train_timestamps.py:345-506); up to sample_len (= n_text_ctx // 2) steps of
       logits = decoder(tokens, audio_features)[:, -1]          (every row the head has: the training model's pad class too)
-      SuppressBlank (blank " " and eot at the first sampled position), SuppressTokens ("-1" = caller-supplied non-speech
-      symbol ids + transcribe/translate/sot/sot_prev/sot_lm/no_speech), ApplyTimestampRules (unless without_timestamps)
+      SuppressBlank (blank " " and eot at the first sampled position), SuppressTokens ("-1" = the tokenizer's non-speech
+      symbol ids, NON_SPEECH_TOKENS_EN, + transcribe/translate/sot/sot_prev/sot_lm/no_speech), ApplyTimestampRules (unless without_timestamps)
       GreedyDecoder (argmax, or Categorical(logits / T) with best_of samples) or BeamSearchDecoder (beam_size, patience)
   then MaximumLikelihoodRanker (sum_logprob / length, or the length_penalty form) and avg_logprob = sum / (len + 1);
   no_speech_prob = softmax(logits at the sot position)[no_speech].
@@ -37,6 +37,18 @@ NO_SPEECH = 50361
 NO_TIMESTAMPS = 50362
 TIMESTAMP_BEGIN = 50363  # <|0.00|>; id = TIMESTAMP_BEGIN + ms // 20 (train_timestamps.py:236)
 BLANK = 220              # GPT-2 BPE id of " ": what whisper's SuppressBlank masks (tokenizer.encode(" "))
+# whisper.tokenizer.Tokenizer.non_speech_tokens evaluated on the GPT-2 (English-only) vocabulary: what suppress_tokens="-1" -- the
+# default of DecodingOptions, hence of the reference's DecodingOptions(language="en", without_timestamps=True) at
+# train_timestamps.py:1916 and of transcribe() -- expands to.  The rule: every symbol of  " # ( ) * + / : ; < = > @ [ \ ] ^ _ ` { | } ~
+# and the bracket / dash / music-note strings that encodes to ONE token, bare and with a leading space, plus the first token of " -"
+# and " '".  A constant of the vocabulary (ids 0..93 are the printable ASCII bytes '!'..'~': '"' = 1, '#' = 2, '(' = 7, ...); the same
+# 84 ids ship as the ``suppress_tokens`` of every openai/whisper-*.en config and as transformers'
+# ``models/whisper/configuration_whisper.py::NON_SPEECH_TOKENS`` (minus its four specials), against which the tests pin this table.
+NON_SPEECH_TOKENS_EN = (
+    1, 2, 7, 8, 9, 10, 14, 25, 26, 27, 28, 29, 31, 58, 59, 60, 61, 62, 63, 90, 91, 92, 93, 357, 366, 438, 532, 685, 705, 796, 930,
+    1058, 1220, 1267, 1279, 1303, 1343, 1377, 1391, 1635, 1782, 1875, 2162, 2361, 2488, 3467, 4008, 4211, 4600, 4808, 5299, 5855,
+    6329, 7203, 9609, 9959, 10563, 10786, 11420, 11709, 11907, 13163, 13697, 13700, 14808, 15306, 16410, 16791, 17992, 19203, 19510,
+    20724, 22305, 22935, 27007, 30109, 30420, 33409, 34949, 40283, 40493, 40549, 47282, 49146)
 
 
 @dataclass(frozen=True)
@@ -57,7 +69,7 @@ class DecodingOptions:
     max_initial_timestamp: Optional[float] = 1.0
     fp16: bool = True
     # --- not in whisper: what its tokenizer would have supplied, and engine switches -----------------------------------
-    non_speech_tokens: Sequence[int] = ()            # tokenizer.non_speech_tokens (ids of the symbols "-1" expands to)
+    non_speech_tokens: Optional[Sequence[int]] = None  # what "-1" expands to; None = NON_SPEECH_TOKENS_EN (the tokenizer's list)
     initial_tokens: Optional[Sequence[int]] = None   # override of the sot sequence
     suppress_mask: Optional[torch.Tensor] = None     # extra additive mask [rows] (0 / -inf)
     seed: Optional[int] = None                       # sampling generator seed (temperature > 0)
@@ -85,7 +97,7 @@ def suppress_list(options: DecodingOptions) -> List[int]:
         sup = [int(t) for t in sup.split(",") if t.strip()]
     sup = list(sup)
     if -1 in sup:
-        sup = [t for t in sup if t >= 0] + list(options.non_speech_tokens)
+        sup = [t for t in sup if t >= 0] + list(NON_SPEECH_TOKENS_EN if options.non_speech_tokens is None else options.non_speech_tokens)
     sup += [TRANSCRIBE, TRANSLATE, SOT, SOT_PREV, SOT_LM, NO_SPEECH]
     return sorted(set(sup))
 

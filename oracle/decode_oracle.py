@@ -28,6 +28,12 @@ EOT, SOT, TRANSLATE, TRANSCRIBE, SOT_LM, SOT_PREV, NO_SPEECH, NO_TIMESTAMPS, TIM
     50256, 50257, 50357, 50358, 50359, 50360, 50361, 50362, 50363)
 BLANK = 220  # GPT-2 BPE id of " " (tokenizer.encode(" ")), what SuppressBlank masks at the first sampled position
 N_FRAMES, HOP_LENGTH, SAMPLE_RATE, FRAMES_PER_SECOND = 3000, 160, 16000, 100
+# Tokenizer.non_speech_tokens on the GPT-2 English vocabulary (what suppress_tokens="-1" expands to).  The oracle's own copy of the
+# constant, pinned in tests/test_decoding_rules_cpu.py against transformers' configuration_whisper.NON_SPEECH_TOKENS.
+NON_SPEECH_EN = tuple(int(t) for t in """1 2 7 8 9 10 14 25 26 27 28 29 31 58 59 60 61 62 63 90 91 92 93 357 366 438 532 685 705 796 930 1058 1220
+1267 1279 1303 1343 1377 1391 1635 1782 1875 2162 2361 2488 3467 4008 4211 4600 4808 5299 5855 6329 7203 9609 9959 10563 10786 11420 11709
+11907 13163 13697 13700 14808 15306 16410 16791 17992 19203 19510 20724 22305 22935 27007 30109 30420 33409 34949 40283 40493 40549 47282
+49146""".split())
 
 
 @dataclass
@@ -39,7 +45,7 @@ class Options:  # whisper.decoding.DecodingOptions (token-level fields)
     patience: Optional[float] = None
     length_penalty: Optional[float] = None
     suppress_tokens: Optional[Sequence[int]] = (-1,)   # "-1": the non-speech symbol list + the specials
-    non_speech_tokens: Sequence[int] = ()              # tokenizer.non_speech_tokens (needs the tokenizer: caller-supplied)
+    non_speech_tokens: Sequence[int] = NON_SPEECH_EN   # tokenizer.non_speech_tokens
     suppress_blank: bool = True
     without_timestamps: bool = False
     max_initial_timestamp: Optional[float] = 1.0

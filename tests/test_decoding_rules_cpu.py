@@ -76,7 +76,16 @@ def test_product_rules_equal_the_oracle_restatement_on_random_states():
 def test_suppress_lists_agree():
     from olmoasr_amd.decoding import DecodingOptions, suppress_list
     from oracle import decode_oracle as do
-    assert suppress_list(DecodingOptions()) == do.suppress_list(do.Options()) == [50257, 50357, 50358, 50359, 50360, 50361]
+    specials = [50257, 50357, 50358, 50359, 50360, 50361]
+    assert suppress_list(DecodingOptions(non_speech_tokens=())) == do.suppress_list(do.Options(non_speech_tokens=())) == specials
+    # the default ("-1") expands to the tokenizer's non-speech symbol list; independent source: transformers' constant for the
+    # English-only checkpoints (= the suppress_tokens of openai/whisper-*.en), which also carries sot / sot_lm / sot_prev / no_speech
+    from transformers.models.whisper.configuration_whisper import NON_SPEECH_TOKENS
+    from olmoasr_amd.decoding import NON_SPEECH_TOKENS_EN
+    assert sorted(NON_SPEECH_TOKENS_EN) == sorted(do.NON_SPEECH_EN) == [t for t in NON_SPEECH_TOKENS if t < 50257] and len(NON_SPEECH_TOKENS_EN) == 84
+    assert set(NON_SPEECH_TOKENS) - set(NON_SPEECH_TOKENS_EN) == {50257, 50359, 50360, 50361}
+    assert suppress_list(DecodingOptions()) == do.suppress_list(do.Options()) == sorted(list(NON_SPEECH_TOKENS_EN) + specials)
+    assert all(ord(c) - 33 in NON_SPEECH_TOKENS_EN for c in '"#()*+/:;<=>@[\\]^_`{|}~')  # ids 0..93 = printable ASCII bytes
     assert suppress_list(DecodingOptions(suppress_tokens="-1,7", non_speech_tokens=(1, 2))) == \
         do.suppress_list(do.Options(suppress_tokens=(-1, 7), non_speech_tokens=(1, 2))) == [1, 2, 7, 50257, 50357, 50358, 50359, 50360, 50361]
     assert suppress_list(DecodingOptions(suppress_tokens=None)) == []
