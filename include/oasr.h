@@ -103,10 +103,7 @@ size_t oasr_decode_step_workspace_bytes(const oasr_ctx*, int B);
 int oasr_decode_begin(oasr_ctx*, const void* xa, int B, void* kv_cache, void* stream);
 int oasr_decode_step(oasr_ctx*, const int64_t* tokens_last, int B, int pos, void* kv_cache, float* logits_out, void* workspace,
                      size_t workspace_bytes, void* stream);
-/* The bf16 engine runs a step for up to 32 sequences as ONE persistent launch whose phases meet at a device-wide barrier
- * (csrc/decode_fused.hip).  Its spin is bounded; decode_check synchronises the stream and returns OASR_EHIP if any step since
- * decode_begin gave up on the barrier (its logits are then invalid) -- call it once per decoded window, where the caller
- * reads the tokens back anyway. */
+/* Synchronises the stream: call once per decoded window, where the caller reads the tokens back. */
 int oasr_decode_check(oasr_ctx*, int B, void* kv_cache, void* stream);
 
 /* One micro-step of train() (train_timestamps.py:1440-1454): forward, CE(ignore_index=pad)/accum, backward.

@@ -16,10 +16,9 @@ int oasr_profile_gemm(int enable);
 /* experiments on the 256x256 kernel.  v < 0: defaults.  bits 0-3: schedule variant (8 = per-layout default); bits 4-5: 1 = plain
  * launches, 2 = persistent launches (next tile's prologue ahead of the epilogue); bit 6 / 7: non-temporal epilogue stores / side loads */
 int oasr_gemm_set_variant(int v);
-/* tests / A-B of the KV-cached step: 0 = multi-launch with LayerNorm folded into the projections (the default up to 4 sequences),
- * 1 = one persistent launch (opt-in, OASR_DECODE_FUSED=1), 2 = multi-launch with separate LayerNorm kernels (the default above 4),
- * -1 = default.  All three are bit-identical (tests/test_gpu_decode_fused.py). */
-int oasr_decode_set_fused(int mode);
+/* tests / A-B of the KV-cached step's LayerNorm placement: 1 = folded into the projections' operand loads for every B <= 32,
+ * 0 = always separate kernels, -1 = default (folded up to 4 sequences).  Bit-identical (tests/test_gpu_decode_step.py). */
+int oasr_decode_set_ln_fold(int mode);
 int oasr_gemm_set_stagger(int sleeps, int phases); /* experiments: first-wave phase stagger of the 256x256 kernel (0 = off) */
 int oasr_gemm_force_general(int on); /* tests: route every GEMM through the register-staged general kernel */
 int oasr_profile_gemm_collect(double* ms4, double* flops4, int64_t* count4, char* by_symbol /* "symbol\tlaunches\tms\tflops\n"... or NULL */, int cap);

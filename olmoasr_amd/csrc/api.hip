@@ -134,7 +134,7 @@ extern "C" int oasr_attention_bwd(const oasr_attn_args* a, void* stream) {
 extern "C" int oasr_cross_entropy(void* logits, int64_t ld, int V, const int64_t* targets, int64_t rows, int64_t ignore, float gscale,
                                   int32_t* n_valid_dev, float* row_loss, float* loss_out, int write_grad, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  int rc = launch_count_valid(targets, rows, ignore, n_valid_dev, st);
+  int rc = launch_count_valid(targets, rows, ignore, V, n_valid_dev, st);
   if (rc) return rc;
   rc = launch_cross_entropy((bf16_t*)logits, ld, V, targets, rows, ignore, gscale, n_valid_dev, row_loss, write_grad, st);
   if (rc) return rc;

@@ -870,12 +870,10 @@ extern "C" int oasr_decode_logits(oasr_ctx* c, const int64_t* tokens, const void
 // sequence at position `pos`: ONE fused q|k|v projection writes straight into the cache row of that position (GEMM output
 // row stride = one sequence's cache; the q slot is scratch that keeps the three projections in a single launch),
 // attention reads q from that row and the first pos+1 cached keys/values through strides.
-// Behind the layers' caches: 256 bytes of step state (the fused step's device-wide barrier counter and bail-out flag) and the
-// fused step's per-layer pointer table (written by oasr_decode_begin).
 extern "C" size_t oasr_kv_cache_bytes(const oasr_ctx* c, int B) {
   if (!c || B <= 0) return 0;
   const size_t per_layer = ((size_t)3 * B * c->S_max * c->d + (size_t)B * c->Te * 2 * c->d) * (c->f32 ? 4 : 2);
-  return per_layer * c->L_dec + 256 + (size_t)c->L_dec * sizeof(FusedDecLayer) + 256;
+  return per_layer * c->L_dec + 256;
 }
 namespace {
 template <typename T>
@@ -888,27 +886,12 @@ KvLayer<T> kv_layer(const oasr_ctx* c, void* cache, int B, int layer) {
   T* base = (T*)cache + per_layer * layer;
   return KvLayer<T>{base, base + (size_t)3 * B * c->S_max * c->d};
 }
-// step state / pointer table behind the caches (bf16 engine only)
-char* kv_tail(const oasr_ctx* c, void* cache, int B) {
-  const size_t per_layer = ((size_t)3 * B * c->S_max * c->d + (size_t)B * c->Te * 2 * c->d) * (c->f32 ? 4 : 2);
-  return (char*)cache + per_layer * c->L_dec;
-}
-// The one-launch step (decode_fused.hip) serves the bf16 engine for up to 32 sequences.  It is OPT-IN (OASR_DECODE_FUSED=1 or
-// oasr_decode_set_fused(1)): bit-identical to the multi-launch step, but measured slower on the 8-XCD MI355X -- every device-wide
-// barrier needs an L2 write-back + invalidate per workgroup (1.7 ms per step at B = 1 against 1.0 ms; scripts/decode_step_probe.py,
-// profiles/r02_decode_step.txt).  What it did give the default path: its LayerNorm-in-the-operand-load projections, as launches.
-int g_decode_fused = -1;
-bool fused_step_ok(const oasr_ctx* c, int B, int pos) {
-  static const int env = [] {
-    const char* e = getenv("OASR_DECODE_FUSED");
-    return e ? atoi(e) : 0;
-  }();
-  const int want = g_decode_fused >= 0 ? g_decode_fused : env;
-  return want == 1 && !c->f32 && B <= 32 && c->d % 64 == 0 && c->d <= 2048 && c->H * 64 == c->d && pos + 1 <= 1536 && c->Te <= 1536;
-}
+// A/B and test switch of the step's LayerNorm placement: -1 = default (folded into the projections' operand loads for B <= 4, the
+// timestamp-mode transcribe loop; separate kernels above), 1 = folded for every B <= 32, 0 = always separate.  Bit-identical.
+int g_decode_ln_fold = -1;
 }  // namespace
-extern "C" int oasr_decode_set_fused(int on) {
-  g_decode_fused = on < 0 ? -1 : on;  // 0 = multi-launch with LayerNorm folded into the projections (default for B <= 4), 1 = one launch, 2 = multi-launch, separate LayerNorm kernels (default above)
+extern "C" int oasr_decode_set_ln_fold(int mode) {
+  g_decode_ln_fold = mode < 0 ? -1 : (mode ? 1 : 0);
   return OASR_OK;
 }
 
@@ -928,38 +911,6 @@ static int oasr_decode_begin_impl(oasr_ctx* c, const void* xa, int B, void* kv_c
     const BlockP& bp = c->dec[i];
     KvLayer<T> kl = kv_layer<T>(c, kv_cache, B, i);
     RC(r.linear((const T*)xa, (long)B * c->Te, d, c->template Wt<T>(bp.cattn.kw), 2 * d, c->aux(bp.cattn.fused_bias) + d, 0, nullptr, kl.ckv, nullptr));
-  }
-  if (!c->f32) {  // pointer table of the one-launch step; the barrier state starts clean
-    std::vector<FusedDecLayer> tab((size_t)c->L_dec);
-    for (int i = 0; i < c->L_dec; ++i) {
-      const BlockP& bp = c->dec[i];
-      KvLayer<bf16_t> kl = kv_layer<bf16_t>(c, kv_cache, B, i);
-      FusedDecLayer& f = tab[(size_t)i];
-      f.ln1_g = c->P(bp.attn_ln_w);
-      f.ln1_b = c->P(bp.attn_ln_b);
-      f.bqkv = c->aux(bp.attn.fused_bias);
-      f.bo = c->P(bp.attn.ob);
-      f.ln2_g = c->P(bp.cln_w);
-      f.ln2_b = c->P(bp.cln_b);
-      f.bcq = c->P(bp.cattn.qb);
-      f.bco = c->P(bp.cattn.ob);
-      f.ln3_g = c->P(bp.mlp_ln_w);
-      f.ln3_b = c->P(bp.mlp_ln_b);
-      f.b1 = c->P(bp.b1);
-      f.b2 = c->P(bp.b2);
-      f.wqkv = c->template Wt<bf16_t>(bp.attn.qw);
-      f.wo = c->template Wt<bf16_t>(bp.attn.ow);
-      f.wcq = c->template Wt<bf16_t>(bp.cattn.qw);
-      f.wco = c->template Wt<bf16_t>(bp.cattn.ow);
-      f.w1 = c->template Wt<bf16_t>(bp.w1);
-      f.w2 = c->template Wt<bf16_t>(bp.w2);
-      f.self_qkv = kl.qkv;
-      f.cross_kv = kl.ckv;
-    }
-    char* tail = kv_tail(c, kv_cache, B);
-    OASR_CHECK_HIP(hipMemsetAsync(tail, 0, 256, r.st));
-    OASR_CHECK_HIP(hipMemcpyAsync(tail + 256, tab.data(), tab.size() * sizeof(FusedDecLayer), hipMemcpyHostToDevice, r.st));
-    OASR_CHECK_HIP(hipStreamSynchronize(r.st));  // (the table is staged from this stack frame)
   }
   return OASR_OK;
 }
@@ -991,49 +942,17 @@ static int oasr_decode_step_impl(oasr_ctx* c, const int64_t* tokens_last, int B,
   float* lse = A.f32((size_t)B * c->H);
   float* mean = A.f32(B);
   float* rstd = A.f32(B);
-  if constexpr (std::is_same<T, bf16_t>::value) {
-    if (fused_step_ok(c, B, pos)) {  // the whole step in one persistent launch (decode_fused.hip)
-      char* tail = kv_tail(c, kv_cache, B);
-      FusedDecArgs f;
-      memset(&f, 0, sizeof(f));
-      f.B = B;
-      f.d = d;
-      f.H = c->H;
-      f.L = c->L_dec;
-      f.S_max = S_max;
-      f.Te = c->Te;
-      f.pos = pos;
-      f.V = c->V;
-      f.n_embed = c->V;
-      f.tok = tokens_last;
-      f.E = c->P(c->tok_emb);
-      f.pos_emb = c->P(c->dec_pos) + (size_t)pos * d;
-      f.lnf_g = c->P(c->dec_ln_w);
-      f.lnf_b = c->P(c->dec_ln_b);
-      f.Wemb = c->template Wt<bf16_t>(c->tok_emb);
-      f.r0 = x;
-      f.r1 = x2;
-      f.r2 = x3;
-      f.o = o;
-      f.q = q;
-      f.hg = hg;
-      f.logits = logits_out;
-      f.counter = (unsigned*)tail;
-      f.err = (unsigned*)tail + 1;
-      f.layers = (const FusedDecLayer*)(tail + 256);
-      return launch_decode_fused(f, st);
-    }
-  }
   // token + positional embedding of position pos: S = 1 per sequence, positional row offset by pos
   RC(launch_embedding_fwd(tokens_last, c->P(c->tok_emb), c->P(c->dec_pos) + (size_t)pos * d, x, B, 1, d, c->V, st));
   T* cur = x;
   // a few sequences on the bf16 engine: every LayerNorm rides in the operand load of the projection that consumes it and the
   // logits leave as fp32 (8 launches per layer instead of 11; bit-identical to the separate kernels below).  Measured
   // (profiles/r02_decode_step.txt): -5 % per step at B = 1, but every workgroup recomputes the B row statistics, which loses
-  // from B = 16 on (+20 %) -- so only small batches take it (mode 0 forces it for the A/B and the bit-identity test).
+  // from B = 16 on (+20 %) -- so only small batches take it (oasr_decode_set_ln_fold forces either side for the A/B and the
+  // bit-identity test).
   bool folded = false;
   if constexpr (std::is_same<T, bf16_t>::value)
-    folded = d % 64 == 0 && d <= 2048 && g_decode_fused != 2 && (B <= 4 || (g_decode_fused == 0 && B <= 32));
+    folded = d % 64 == 0 && d <= 2048 && g_decode_ln_fold != 0 && (B <= 4 || (g_decode_ln_fold == 1 && B <= 32));
   for (int i = 0; i < c->L_dec; ++i) {
     const BlockP& bp = c->dec[i];
     KvLayer<T> kl = kv_layer<T>(c, kv_cache, B, i);
@@ -1120,18 +1039,10 @@ extern "C" int oasr_decode_step(oasr_ctx* c, const int64_t* tokens_last, int B, 
   return c->f32 ? oasr_decode_step_impl<float>(c, tokens_last, B, pos, kv_cache, logits_out, workspace, workspace_bytes, stream) : oasr_decode_step_impl<bf16_t>(c, tokens_last, B, pos, kv_cache, logits_out, workspace, workspace_bytes, stream);
 }
 
-// Synchronises the stream and reports whether a one-launch step since oasr_decode_begin gave up on its device-wide barrier.
+// Synchronises the stream before the caller reads a window's tokens back (the step engines themselves cannot fail once enqueued).
 extern "C" int oasr_decode_check(oasr_ctx* c, int B, void* kv_cache, void* stream) {
   OASR_REQUIRE(c && kv_cache && B > 0, "oasr_decode_check: bad args");
   OASR_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
-  if (c->f32) return OASR_OK;
-  unsigned state[2] = {0, 0};
-  OASR_CHECK_HIP(hipMemcpy(state, kv_tail(c, kv_cache, B), sizeof(state), hipMemcpyDeviceToHost));
-  if (state[1] != 0) {
-    oasr_set_error("oasr_decode_check: a fused decode step abandoned its device-wide barrier (workgroups not co-resident?); "
-                   "rerun with OASR_DECODE_FUSED=0");
-    return OASR_EHIP;
-  }
   return OASR_OK;
 }
 
@@ -1294,7 +1205,7 @@ static int oasr_train_fwd_bwd_s_impl(oasr_ctx* c, const float* mel, const int64_
   RC(r.encoder_fwd(p, mel));
   RC(r.decoder_fwd(p, tokens));
   if (logits_out) RC(launch_logits_to_f32(p.logits, c->Vp, Md, c->V, logits_out, st));
-  RC(launch_count_valid(targets, Md, PAD_ID, p.n_valid, st));
+  RC(launch_count_valid(targets, Md, PAD_ID, c->V, p.n_valid, st));
   RC(launch_cross_entropy(p.logits, c->Vp, c->V, targets, Md, PAD_ID, loss_scale * inv_accum, p.n_valid, p.row_loss, 1, st));
   RC(launch_loss_reduce(p.row_loss, Md, p.n_valid, inv_accum, loss_out, accumulate_loss, st));
   return train_backward<T>(c, r, p, tokens, B, S, ev);

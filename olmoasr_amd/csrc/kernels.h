@@ -133,28 +133,7 @@ int launch_attention_bwd(const AttnArgs& a, hipStream_t s);
 int launch_attention_fwd(const AttnArgsF& a, hipStream_t s);  // fp32 validation kernels (o_lo unused: O is fp32)
 int launch_attention_bwd(const AttnArgsF& a, hipStream_t s);
 
-// ---- one-launch KV-cached decoder step (decode_fused.hip) -----------------------------------------------
-struct FusedDecLayer {  // device-resident table, one entry per decoder block
-  const float *ln1_g, *ln1_b, *bqkv, *bo, *ln2_g, *ln2_b, *bcq, *bco, *ln3_g, *ln3_b, *b1, *b2;
-  const bf16_t *wqkv, *wo, *wcq, *wco, *w1, *w2;  // [3d,d] fused q|k|v, [d,d] x3, [4d,d], [d,4d]
-  bf16_t* self_qkv;                               // cache [B, S_max, 3d]
-  const bf16_t* cross_kv;                         // cache [B, Te, 2d]
-};
-struct FusedDecArgs {
-  int B, d, H, L, S_max, Te, pos, V;
-  long n_embed;                      // rows of the token embedding table
-  const int64_t* tok;                // [B] token at position pos
-  const float *E, *pos_emb;          // fp32 token embedding, positional row of `pos`
-  const float *lnf_g, *lnf_b;
-  const bf16_t* Wemb;                // bf16 token embedding [V, d] (logits weight)
-  bf16_t *r0, *r1, *r2, *o, *q, *hg; // workspace: residual stream x3 [B,d], attention out, cross query, MLP hidden [B,4d]
-  float* logits;                     // [B, V]
-  unsigned *counter, *err;           // adjacent words: device-wide barrier counter, bail-out flag
-  const FusedDecLayer* layers;
-};
-int launch_decode_fused(const FusedDecArgs& a, hipStream_t s);
-// LayerNorm (optional: ln_g != null) + Linear + bias (+ GELU) (+ residual) of M <= 32 token rows in one launch: bf16 `out` and / or
-// fp32 `out_f32` (the bf16-rounded Linear output, widened: logits).  Bit-identical to layernorm_fwd + the skinny GEMM.
+// ---- LayerNorm-folded decode projection (decode_proj.hip) ------------------------------------------------
 int launch_decode_proj(const bf16_t* x, int M, int K, const bf16_t* W, int N, const float* ln_g, const float* ln_b, const float* bias,
                        int gelu, const bf16_t* resid, long ldr, bf16_t* out, long ldc, float* out_f32, long ldf, hipStream_t s);
 
@@ -200,7 +179,7 @@ int launch_dlogits_from_f32(const float* src, int V, long rows, long ld, float* 
 // logits bf16 [rows][ld] (first V entries valid).  Writes, in place, dlogits = (softmax - onehot) * gscale / n_valid
 // (zeros for ignored rows and pad columns), row_loss[r] = lse - logit[target] (0 for ignored rows).
 // n_valid_dev: device int32 (count of targets != ignore).  loss_out += sum(row_loss)/n_valid * loss_mul.
-int launch_count_valid(const int64_t* targets, long rows, long ignore, int32_t* n_valid_dev, hipStream_t s);
+int launch_count_valid(const int64_t* targets, long rows, long ignore, int V, int32_t* n_valid_dev, hipStream_t s);
 int launch_cross_entropy(bf16_t* logits, long ld, int V, const int64_t* targets, long rows, long ignore, float gscale,
                          const int32_t* n_valid_dev, float* row_loss, int write_grad, hipStream_t s);
 int launch_cross_entropy(float* logits, long ld, int V, const int64_t* targets, long rows, long ignore, float gscale,

@@ -92,10 +92,11 @@ __global__ __launch_bounds__(256) void ce_kernel(bf16_t* __restrict__ logits, lo
   }
 }
 
-__global__ __launch_bounds__(256) void count_valid_kernel(const int64_t* __restrict__ t, long rows, long ignore, int32_t* out) {
+__global__ __launch_bounds__(256) void count_valid_kernel(const int64_t* __restrict__ t, long rows, long ignore, int V, int32_t* out) {
   __shared__ int red[4];
   int c = 0;
-  for (long i = threadIdx.x; i < rows; i += 256) c += (t[i] != ignore) ? 1 : 0;  // (== F.cross_entropy's denominator)
+  // F.cross_entropy's denominator; the predicate is ce_kernel's (an id outside [0, V) contributes neither loss nor count)
+  for (long i = threadIdx.x; i < rows; i += 256) c += (t[i] != ignore && t[i] >= 0 && t[i] < V) ? 1 : 0;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
@@ -192,9 +193,9 @@ int launch_pick_tokens(const float* logits, long ld, int V, long rows, const flo
   return OASR_OK;
 }
 
-int launch_count_valid(const int64_t* targets, long rows, long ignore, int32_t* n_valid_dev, hipStream_t s) {
+int launch_count_valid(const int64_t* targets, long rows, long ignore, int V, int32_t* n_valid_dev, hipStream_t s) {
   OASR_REQUIRE(targets && n_valid_dev && rows > 0, "count_valid: bad args");
-  hipLaunchKernelGGL(count_valid_kernel, dim3(1), dim3(256), 0, s, targets, rows, ignore, n_valid_dev);
+  hipLaunchKernelGGL(count_valid_kernel, dim3(1), dim3(256), 0, s, targets, rows, ignore, V, n_valid_dev);
   OASR_LAUNCH_CHECK();
   return OASR_OK;
 }

@@ -64,6 +64,10 @@ class GradReducer:
         covered = sum(n for _, n, _ in self.buckets)
         assert covered == flat_grads.numel(), "gradient segments must tile the arena"
         self.cuda = flat_grads.is_cuda
+        # None: leave the SUM (the fused path folds 1/world into the optimizer's unscale).  A float (DistributedDataParallel sets
+        # 1/world): the buckets come back as the MEAN -- ReduceOp.AVG inside the collective on RCCL (no extra pass over the
+        # gradients at all), SUM followed by a per-bucket scale on the communication stream elsewhere (gloo has no AVG).
+        self.mean_scale: Optional[float] = None
         self.comm_stream = torch.cuda.Stream(flat_grads.device) if self.cuda else None
         self.events = None
         if self.cuda:
@@ -85,20 +89,25 @@ class GradReducer:
         return self.events
 
     def _sum_bucket(self, t: torch.Tensor):
-        """SUM over ranks of the 1-D fp32 view ``t``, in place."""
+        """SUM (or, with ``mean_scale``, MEAN) over ranks of the 1-D fp32 view ``t``, in place."""
+        avg = self.mean_scale is not None and self.world > 1
+        in_op = avg and dist.get_backend(self.group) == "nccl"  # RCCL: ncclAvg
+        op = dist.ReduceOp.AVG if in_op else dist.ReduceOp.SUM
         if self.algo == "allreduce" or self.world == 1:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-            return
-        W, n = self.world, t.numel()
-        per = n // W
-        rank = dist.get_rank(self.group)
-        if per:
-            body = t[: per * W]
-            mine = body[rank * per:(rank + 1) * per]
-            dist.reduce_scatter_tensor(mine, body, op=dist.ReduceOp.SUM, group=self.group)   # rank r ends up owning chunk r's sum
-            dist.all_gather_into_tensor(body, mine, group=self.group)                        # every rank fetches every chunk
-        if per * W < n:  # fewer than W trailing elements
-            dist.all_reduce(t[per * W:], op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(t, op=op, group=self.group)
+        else:
+            W, n = self.world, t.numel()
+            per = n // W
+            rank = dist.get_rank(self.group)
+            if per:
+                body = t[: per * W]
+                mine = body[rank * per:(rank + 1) * per]
+                dist.reduce_scatter_tensor(mine, body, op=op, group=self.group)       # rank r ends up owning chunk r's sum
+                dist.all_gather_into_tensor(body, mine, group=self.group)             # every rank fetches every chunk
+            if per * W < n:  # fewer than W trailing elements
+                dist.all_reduce(t[per * W:], op=op, group=self.group)
+        if avg and not in_op:
+            t.mul_(self.mean_scale)
 
     def reduce(self, use_events: bool = True):
         """All-reduce (SUM) every bucket.  With events: bucket k starts as soon as its gradients are final."""
@@ -127,27 +136,32 @@ class DistributedDataParallel(torch.nn.Module):
     ``p.grad`` holds what torch's DDP would leave there, ``state_dict()`` keys carry the ``module.`` prefix (:935), and the reference's
     loop runs unchanged.  Like torch's class it reduces on EVERY backward unless inside ``no_sync()``; under gradient accumulation
     without ``no_sync`` the already-averaged part is averaged again (a no-op: it is identical on all ranks), as in torch.
-    The fused path (``loss_and_backward`` + ``GradReducer`` + ``optim_step``) does one exchange per window and no extra pass."""
+    The fused path (``loss_and_backward`` + ``GradReducer`` + ``optim_step``) does one exchange per window and no extra pass.
+    Bucket size: the GradReducer default (128 MiB: few, large collectives for 7 x 153 GB/s point-to-point xGMI links), not torch's
+    25 MiB, which is tuned for NVSwitch-class all-reduce latency."""
 
-    def __init__(self, module, device_ids=None, output_device=None, bucket_cap_mb: float = 25.0, process_group=None, algo: str = "allreduce", **_ignored):
+    def __init__(self, module, device_ids=None, output_device=None, bucket_cap_mb: float = None, process_group=None, algo: str = "allreduce", **_ignored):
         super().__init__()
         self.module = module
         broadcast_parameters(module.flat_params, group=process_group)
         module.refresh_shadow()
-        self.reducer = GradReducer(module.flat_grads, module.grad_segments, bucket_cap_mb=bucket_cap_mb, group=process_group, algo=algo,
-                                   force=dist.is_initialized())
+        self.reducer = GradReducer(module.flat_grads, module.grad_segments, group=process_group, algo=algo, force=dist.is_initialized(),
+                                   **({} if bucket_cap_mb is None else {"bucket_cap_mb": bucket_cap_mb}))
         self.require_backward_grad_sync = True
+        self._sync_this_backward = False  # decided at forward time, as torch's DDP does: a forward under no_sync() records no events
         module._autograd_post_backward = self._after_backward
+        # SUM -> mean without a pass of its own: the 1/world rides in the reducer (``GradReducer.mean_scale``: applied per bucket on
+        # the communication stream, behind that bucket's collective and under the rest of the backward)
+        self.reducer.mean_scale = 1.0 / self.reducer.world if self.reducer.world > 1 else None
 
     def _after_backward(self):
-        if not self.require_backward_grad_sync:
+        if not self._sync_this_backward:
             return
         self.reducer.reduce()
-        if self.reducer.world > 1:
-            self.reducer.flat.mul_(1.0 / self.reducer.world)
 
     def forward(self, *args, **kwargs):
-        self.module._autograd_segment_events = self.reducer.segment_events() if self.require_backward_grad_sync else None
+        self._sync_this_backward = self.require_backward_grad_sync
+        self.module._autograd_segment_events = self.reducer.segment_events() if self._sync_this_backward else None
         return self.module(*args, **kwargs)
 
     def no_sync(self):

@@ -15,8 +15,8 @@ from olmoasr_amd.model import OLMoASR  # noqa: E402
 def main():
     net = OLMoASR(VARIANT_TO_DIMS["small"], device="cuda", seed=0, inference=True)
     for B in [int(a) for a in sys.argv[1:]] or [1, 16]:
-        for mode in (2, 0):
-            N.lib().oasr_decode_set_fused(mode)
+        for mode in (0, 1):
+            N.lib().oasr_decode_set_ln_fold(mode)
             mel = torch.randn(B, 80, 3000, device="cuda")
             xa = net.embed_audio(mel)
             st = net.kv_cache_begin(xa)
@@ -55,7 +55,7 @@ def main():
             host = (time.perf_counter() - t0) / 100
             torch.cuda.synchronize()
             print(f"B={B} mode={mode}: eager {eager:.3f} ms/step, hipGraph replay {e0.elapsed_time(e1) / 100:.3f} ms/step (host {1e3 * host:.3f} ms per replay)", flush=True)
-    N.lib().oasr_decode_set_fused(-1)
+    N.lib().oasr_decode_set_ln_fold(-1)
 
 
 if __name__ == "__main__":

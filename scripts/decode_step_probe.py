@@ -14,13 +14,12 @@ def main():
     from olmoasr_amd import _native as N
     net = OLMoASR(VARIANT_TO_DIMS[os.environ.get("OASR_PROBE_MODEL", "small")], device="cuda", seed=0, inference=True)
     for B in [int(a) for a in sys.argv[1:]] or [20]:
-        for fused in (2, 0, 1):
-            N.lib().oasr_decode_set_fused(fused)
-            print("--- " + {0: "multi-launch step, LayerNorm folded into the projections (default)", 1: "one persistent launch (opt-in)",
-                            2: "multi-launch step, separate LayerNorm kernels (round-2 start)"}[fused])
+        for fold in (0, 1):
+            N.lib().oasr_decode_set_ln_fold(fold)
+            print("--- " + {1: "LayerNorm folded into the projections (default for B <= 4)", 0: "separate LayerNorm kernels (default above)"}[fold])
             probe(net, B)
             net.kv_cache_check(probe.state)
-    N.lib().oasr_decode_set_fused(-1)
+    N.lib().oasr_decode_set_ln_fold(-1)
 
 
 def probe(net, B):

@@ -1,5 +1,5 @@
-"""The one-launch KV-cached decoder step (csrc/decode_fused.hip: one persistent kernel per token, phases separated by a
-device-wide barrier) against the multi-launch step it replaces and against the cache-less decoder.
+"""The KV-cached decoder step's two LayerNorm placements (folded into the projections' operand loads, csrc/decode_proj.hip, vs
+separate kernels) against each other (bit-identical) and against the cache-less decoder.
 Reference semantics: TextDecoder.forward with the kv_cache hooks, olmoasr/model.py:786-817, 925-964."""
 import pytest
 import torch
@@ -14,24 +14,23 @@ def _dims(mo_dims):
 
 
 def _steps(net, xa, toks, mode):
-    """mode: 0 = multi-launch, LayerNorm folded into the projections (default); 1 = one persistent launch; 2 = multi-launch with
-    separate LayerNorm / logits-widening kernels."""
+    """mode: 1 = LayerNorm folded into the projections; 0 = separate LayerNorm / logits-widening kernels."""
     from olmoasr_amd import _native as N
-    N.lib().oasr_decode_set_fused(mode)
+    N.lib().oasr_decode_set_ln_fold(mode)
     try:
         st = net.kv_cache_begin(xa)
         out = [net.kv_cache_step(st, toks[:, p]) for p in range(toks.shape[1])]
         net.kv_cache_check(st)
         return torch.stack(out, 1)
     finally:
-        N.lib().oasr_decode_set_fused(-1)
+        N.lib().oasr_decode_set_ln_fold(-1)
 
 
 @pytest.mark.parametrize("width,heads,layers,B,inference", [(384, 6, 4, 2, True), (384, 6, 2, 7, False), (768, 12, 2, 16, True),
                                                             (512, 8, 3, 32, True), (1024, 16, 1, 1, False)])
 def test_step_engines_are_bit_identical(tiny_case, width, heads, layers, B, inference):
-    """Same rounding points, same skinny-GEMM accumulation scheme, same attention kernel body: the two step engines must agree
-    to the last bit on every position; both must track the cache-less decoder to bf16 accumulation-order noise."""
+    """Same rounding points, same skinny-GEMM accumulation scheme: the two placements must agree to the last bit on every
+    position; both must track the cache-less decoder to bf16 accumulation-order noise."""
     from olmoasr_amd.model import OLMoASR
     from oracle import model_oracle as mo
     dims = mo.Dims(80, 1500, width, heads, 1, 51864, 448, width, heads, layers)
@@ -42,18 +41,16 @@ def test_step_engines_are_bit_identical(tiny_case, width, heads, layers, B, infe
     g = torch.Generator().manual_seed(B)
     toks = torch.randint(0, 50000, (B, 9), generator=g).to(DEV)
     toks[:, 0] = 50257
-    multi = _steps(net, xa, toks, 2)
-    folded = _steps(net, xa, toks, 0)
-    fused = _steps(net, xa, toks, 1)
-    assert torch.isfinite(fused).all() and torch.isfinite(folded).all()
+    multi = _steps(net, xa, toks, 0)
+    folded = _steps(net, xa, toks, 1)
+    assert torch.isfinite(folded).all()
     assert torch.equal(folded, multi), float((folded - multi).abs().max())
-    assert torch.equal(fused, multi), float((fused - multi).abs().max())
     scale = float(multi.abs().max())
     full = net.logits(toks, xa)
-    assert float((fused - full).abs().max()) < 0.08 + 0.02 * scale
-    # a second window on the same buffers (barrier state is reset by kv_cache_begin / every launch)
+    assert float((folded - full).abs().max()) < 0.08 + 0.02 * scale
+    # a second window on the same buffers
     again = _steps(net, xa, toks, 1)
-    assert torch.equal(again, fused)
+    assert torch.equal(again, folded)
 
 
 def test_decode_through_every_step_engine(tiny_case):
@@ -65,11 +62,11 @@ def test_decode_through_every_step_engine(tiny_case):
     net = OLMoASR(_dims(dims), device=DEV, seed=11, inference=True)
     mel = tiny_case["mel"].to(DEV)
     r_f = decode(net, mel, DecodingOptions(sample_len=6, use_kv_cache=True, without_timestamps=True))
-    for mode in (1, 2):
-        N.lib().oasr_decode_set_fused(mode)
+    for mode in (1, 0):
+        N.lib().oasr_decode_set_ln_fold(mode)
         try:
             r_m = decode(net, mel, DecodingOptions(sample_len=6, use_kv_cache=True, without_timestamps=True))
         finally:
-            N.lib().oasr_decode_set_fused(-1)
+            N.lib().oasr_decode_set_ln_fold(-1)
         for a, b in zip(r_f, r_m):
             assert a.tokens == b.tokens and abs(a.avg_logprob - b.avg_logprob) < 1e-6
