@@ -735,6 +735,151 @@ __global__ __launch_bounds__(128 * NWN, (NWN == 2 && !SWAP) ? 3 : 2) void oasr_g
 }
 
 
+#define OASR_PP_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+// ---- 256 x 128 x 64 "duo" kernel: TWO co-resident workgroups per CU --------------------------------------------------
+// Why: a CU's store path moves ~14-16 B/clk (MI355X_MICROARCH.md, "attention epilogue store tail": store-ISSUE bound), so the
+// 128 KiB of a 256 x 256 bf16 tile take >= 4.5 us to leave however idle HBM is -- 7.5 us measured with the launch/prologue, 14 us
+// with a residual read, 17 us with two outputs (profiles/r02_gemm_tile_cost_model.txt) -- against 24 us of K loop at K = 1024.
+// The ping-pong kernel owns the whole CU (128 KiB LDS, 8 x 256 VGPRs), so nothing runs under that tail.  Here a workgroup is
+// HALF a CU -- 4 waves (2 x 2, 128 x 64 outputs each: the ping-pong kernel's per-wave tile, fragment readers and LDS images),
+// 80 KiB of LDS, <= 256 VGPRs -- and two of them are resident: one's epilogue (and prologue) runs under the other's K loop, and
+// inside the loop the older workgroup's MFMA sections win the matrix pipe while the younger one reads and stages (VALU/MFMA
+// issue is arbitrated by priority, then age), so the two fall into the alternation the ping-pong kernel builds by hand.
+// LDS: the A image (256 x 64, 32 KiB) is double buffered; the B image (128 x 64, 16 KiB) is single: a wave reads ALL its B
+// fragments of a K-tile (64 columns x 64 k = 32 VGPRs) in the first read section, so the image is dead one barrier later and
+// tile t+1's B is staged into it under this tile's MFMAs.
+//   per K-tile:  S0 { ds_read B (8), A rows 0-63 (8); stage A(t+1) pieces 0-3 -> other A buffer; lgkmcnt(0); s_barrier;
+//                     16 MFMAs with the 4 B(t+1) pieces issued between them }
+//                S1 { ds_read A rows 64-127 (8); stage A(t+1) pieces 4-7; 16 MFMAs; vmcnt(0); s_barrier }
+// Hazards: A(t+1) lands in the buffer whose last readers (tile t-1, S1) are behind the closing barrier of t-1; B(t+1) is issued
+// after the S0 barrier, which every wave passes only with its B(t) reads retired; tile t+1 is read after its issuers' vmcnt(0)
+// and the closing barrier.  The vmcnt(0) is not a drain in the loop's critical path: the pieces it waits for were issued at
+// least one 16-MFMA section earlier, and the co-resident workgroup covers what is left.
+// Accumulation order per accumulator is that of the other direct-to-LDS kernels: results are bit-identical to theirs.
+template <bool TA, bool TB, bool CSUM>
+__global__ __launch_bounds__(256, 2) void oasr_gemm_duo_kernel(GemmArgs p) {
+  constexpr int NW = 4, FBN = 128;
+  constexpr int A_BYTES = FBM * 64 * 2, B_BYTES = FBN * 64 * 2;
+  constexpr int NIA = (A_BYTES / 1024) / NW, NIB = (B_BYTES / 1024) / NW;  // 8, 4 pieces per wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_m = (p.M + FBM - 1) / FBM, tiles_n = (p.N + FBN - 1) / FBN;
+  int tm, tn;
+  {  // groups of 8 tile rows walked rows-first: the 64 tiles an XCD runs at once are 8 A row panels x 8 column panels
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int gm = p.raster_gm > 0 ? p.raster_gm : 8;
+    gm = gm < 1 ? 1 : (gm > 16 ? 16 : gm);
+    const int per_group = gm * tiles_n;
+    const int group = bid / per_group, in_group = bid - group * per_group;
+    const int first_m = group * gm;
+    const int gsz = min(gm, tiles_m - first_m);
+    tm = first_m + in_group % gsz;
+    tn = in_group / gsz;
+  }
+  const int m0 = tm * FBM, n0 = tn * FBN;
+  const int nt = p.K / BK;
+
+  unsigned offA[NIA], offB[NIB];
+  fast_offsets<TA, FBM, NIA, NW>(p.A, p.M, m0, lane, wave, offA);
+  fast_offsets<TB, FBN, NIB, NW>(p.B, p.N, n0, lane, wave, offB);
+  const bf16_t* baseA = TA ? p.A.ptr + m0 : p.A.ptr + (long)m0 * p.A.ld;
+  const bf16_t* baseB = TB ? p.B.ptr + n0 : p.B.ptr + (long)n0 * p.B.ld;
+  const long stepA = TA ? (long)BK * p.A.ld : BK, stepB = TB ? (long)BK * p.B.ld : BK;
+  char* const sB = smem + 2 * A_BYTES;
+
+#define OASR_DUO_STAGE_A(T, DST, J0, J1)                                                  \
+  do {                                                                                    \
+    const __amdgpu_buffer_rsrc_t r_ = make_rsrc(baseA + (T) * stepA);                     \
+    _Pragma("unroll") for (int j_ = (J0); j_ < (J1); ++j_) glds16(r_, (DST) + (j_ * NW + wave) * 1024, offA[j_]); \
+  } while (0)
+#define OASR_DUO_STAGE_B(T, J0, J1)                                                       \
+  do {                                                                                    \
+    const __amdgpu_buffer_rsrc_t r_ = make_rsrc(baseB + (T) * stepB);                     \
+    _Pragma("unroll") for (int j_ = (J0); j_ < (J1); ++j_) glds16(r_, sB + (j_ * NW + wave) * 1024, offB[j_]); \
+  } while (0)
+#define OASR_DUO_MFMA(MT, NT, KS) acc[MT][NT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[NT][KS], fa[(MT) & 1][KS], acc[MT][NT], 0, 0, 0)
+
+  f32x16_t acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  OASR_DUO_STAGE_A(0, smem, 0, NIA);
+  OASR_DUO_STAGE_B(0, 0, NIB);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  OASR_PP_BARRIER();
+
+  bf16x8_t fa[2][4], fb[2][4];
+  for (int t = 0; t < nt; ++t) {
+    const char* sA = smem + (t & 1) * A_BYTES;
+    char* nA = smem + ((t & 1) ^ 1) * A_BYTES;
+    const bool next = t + 1 < nt;
+    // ---- S0
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j][ks] = fast_frag<TB, FBN * 2>(sB, wn * 64 + j * 32, ks, lane);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i][ks] = fast_frag<TA, FBM * 2>(sA, wm * 128 + i * 32, ks, lane);
+    if (next) OASR_DUO_STAGE_A(t + 1, nA, 0, NIA / 2);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // B(t) is dead for this wave before the barrier
+    OASR_PP_BARRIER();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    asm volatile("" : "+v"(acc[0][0]), "+v"(acc[1][0]), "+v"(acc[0][1]), "+v"(acc[1][1]));
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      OASR_DUO_MFMA(0, 0, ks);
+      OASR_DUO_MFMA(1, 0, ks);
+      OASR_DUO_MFMA(0, 1, ks);
+      OASR_DUO_MFMA(1, 1, ks);
+      if (next && ks < 2) {  // B(t+1) -> the (dead) B image, two pieces after each of the first two k-steps
+        __builtin_amdgcn_sched_barrier(0);
+        OASR_DUO_STAGE_B(t + 1, 2 * ks, 2 * ks + 2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    asm volatile("" : "+v"(acc[0][0]), "+v"(acc[1][0]), "+v"(acc[0][1]), "+v"(acc[1][1]));
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- S1
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i][ks] = fast_frag<TA, FBM * 2>(sA, wm * 128 + 64 + i * 32, ks, lane);
+    if (next) OASR_DUO_STAGE_A(t + 1, nA, NIA / 2, NIA);
+    __builtin_amdgcn_sched_barrier(0);  // (no explicit lgkmcnt here: hipcc's counted waits let the first MFMAs start under the later reads)
+    __builtin_amdgcn_s_setprio(1);
+    asm volatile("" : "+v"(acc[2][0]), "+v"(acc[3][0]), "+v"(acc[2][1]), "+v"(acc[3][1]));
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      OASR_DUO_MFMA(2, 0, ks);
+      OASR_DUO_MFMA(3, 0, ks);
+      OASR_DUO_MFMA(2, 1, ks);
+      OASR_DUO_MFMA(3, 1, ks);
+    }
+    asm volatile("" : "+v"(acc[2][0]), "+v"(acc[3][0]), "+v"(acc[2][1]), "+v"(acc[3][1]));
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile t+1 have landed
+    OASR_PP_BARRIER();
+  }
+#undef OASR_DUO_STAGE_A
+#undef OASR_DUO_STAGE_B
+#undef OASR_DUO_MFMA
+  // (the loop ended on a barrier: every LDS read is retired; the staging tiles alias the A buffers)
+  fast_epilogue<true, CSUM, true>(p, acc, smem + wave * 8192, (float*)(smem + wave * 8192 + 4096), m0, n0, wm, wn, lane);
+}
+
+
 // ---- 256 x 256 x 64 "ping-pong" kernel ---------------------------------------------------------------------------
 // 8 waves (2 along M x 4 along N, 128 x 64 outputs each), one workgroup per CU, 128 KiB of LDS = two K-tile buffers of
 // four 16 KiB half-tile images (A rows 0-127 / 128-255, B columns 0-127 / 128-255; each image is laid out exactly like
@@ -756,7 +901,6 @@ __global__ __launch_bounds__(128 * NWN, (NWN == 2 && !SWAP) ? 3 : 2) void oasr_g
 //        (two barrier events later even for the trailing wave group);
 //   WAR  an image is re-staged >= 2 phases after its last ds_read, or in the next phase when the reading phase
 //        retired its reads (lgkmcnt(0)) before its first barrier (B1 in phase 1 -> B restaged in phase 2).
-#define OASR_PP_BARRIER() asm volatile("s_barrier" ::: "memory")
 
 template <bool TA, bool TB, bool SWAP, bool CSUM, int VAR>
 __global__ __launch_bounds__(512, 2) void oasr_gemm_pp_kernel(GemmArgs p) {
@@ -1195,6 +1339,36 @@ int launch_fast_cfg(const GemmArgs& a, hipStream_t stream) {
   return OASR_OK;
 }
 
+template <bool TA, bool TB, bool CSUM = false>
+int launch_duo_cfg(const GemmArgs& a, hipStream_t stream) {
+  static bool attr = false;
+  const int lds = 2 * FBM * 64 * 2 + 128 * 64 * 2;  // two A images + one B image = 80 KiB: two workgroups per CU
+  if (!attr) {
+    OASR_CHECK_HIP(hipFuncSetAttribute((const void*)oasr_gemm_duo_kernel<TA, TB, CSUM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr = true;
+  }
+  const dim3 grid(cdiv(a.M, FBM) * cdiv(a.N, 128));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (g_prof.on) {
+    const size_t idx = g_prof.recs.size();
+    while (g_prof.events.size() < 2 * (idx + 1)) {
+      hipEvent_t e;
+      OASR_CHECK_HIP(hipEventCreate(&e));
+      g_prof.events.push_back(e);
+    }
+    e0 = g_prof.events[2 * idx];
+    e1 = g_prof.events[2 * idx + 1];
+    auto tf = [](bool b) { return b ? "true" : "false"; };
+    static const std::string name = std::string("oasr_gemm_duo_kernel<") + tf(TA) + ", " + tf(TB) + ", " + tf(CSUM) + ">";
+    g_prof.recs.push_back({(TA ? 2 : 0) + (TB ? 1 : 0), 2.0 * (double)a.M * (double)a.N * (double)a.K, name.c_str()});
+    OASR_CHECK_HIP(hipEventRecord(e0, stream));
+  }
+  hipLaunchKernelGGL((oasr_gemm_duo_kernel<TA, TB, CSUM>), grid, dim3(256), lds, stream, a);
+  OASR_LAUNCH_CHECK();
+  if (e1) OASR_CHECK_HIP(hipEventRecord(e1, stream));
+  return OASR_OK;
+}
+
 template <bool TA, bool TB, bool SWAP, bool CSUM, int DMA>
 int launch_pp_variant(const GemmArgs& a, hipStream_t stream) {
   static bool attr = false;
@@ -1319,6 +1493,20 @@ int launch_fast_t(const GemmArgs& a, hipStream_t stream) {
   }();
   const int geom = g_fast_geometry ? g_fast_geometry : env_geom;
   const bool big = geom == 2;  // (the 256x256 / 2-stage geometry lost to 256x128 on every measured shape incl. small split-K outputs: scripts/wgrad_sweep.py)
+  static const int env_duo_k = [] {
+    const char* e = getenv("OASR_GEMM_DUO_K");  // experiments: the duo kernel for every bf16-output GEMM with K <= this
+    return e ? atoi(e) : -1;
+  }();
+  const bool duo_rule = geom == 0 && !atomic_only && a.split_k == 1 && env_duo_k > 0 && a.K <= env_duo_k && prefer_pingpong(a);
+  if ((geom == 5 || duo_rule) && !atomic_only && a.split_k == 1) {  // 256x128 "duo" kernel (two workgroups per CU)
+    if (a.colsum && !TA && TB) {
+      const int rc = launch_duo_cfg<false, true, true>(a, stream);
+      if (rc || !a.colsum_scratch) return rc;
+      return launch_colsum_accum(a.colsum_scratch, a.N, 2L * cdiv(a.M, 256), a.N, a.colsum, stream);
+    }
+    const int rc = launch_duo_cfg<TA, TB>(a, stream);
+    return (rc || !a.colsum) ? rc : launch_colsum_accum(a.out, a.ldc, a.M, a.N, a.colsum, stream);
+  }
   if (geom == 3 || (geom == 0 && !atomic_only && prefer_pingpong(a)) ||
       (geom == 0 && atomic_only && a.atomic_on_pp && (a.M % 256) == 0 && (a.N % 256) == 0)) {  // 256x256 ping-pong kernel
     if (atomic_only) return launch_pp_cfg<TA, TB, false>(a, stream);
@@ -1505,5 +1693,5 @@ int gemm_profile_collect(double ms[4], double flops[4], long count[4], char* by_
 
 void gemm_force_general(int on) {
   g_force_general = (on == 1);
-  g_fast_geometry = on >= 2 ? on - 1 : 0;  // 2 -> force 256x128, 3 -> force 256x256 (2-stage), 4 -> force 256x256 ping-pong
+  g_fast_geometry = on >= 2 ? on - 1 : 0;  // 2 -> force 256x128, 3 -> force 256x256 (2-stage), 4 -> force 256x256 ping-pong, 6 -> force 256x128 duo
 }
