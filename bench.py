@@ -114,25 +114,20 @@ def train_flops_per_sample(d, L, T=1500, S=448, V=51865, F=3000, n_mels=80):
     return 3 * (conv + L * enc_layer + L * dec_layer + logits)
 
 
-def synth_batch(n, device, seed):
-    """Synthetic clips in the layout of SURVEY.md section 8(d), generated on the device: int16 PCM ~ N(0, 0.1) with a silent
-    tail, tokens [sot, notimestamps, body..., eot] padded with 51864 to 448."""
-    g = torch.Generator(device=device).manual_seed(seed)
-    pcm = (torch.randn(n, 480000, generator=g, device=device) * 0.1).clamp_(-1, 1).mul_(32767).round_().to(torch.int16)
-    sil = torch.randint(0, 240001, (n,), generator=g, device=device)
-    idx = torch.arange(480000, device=device)[None, :]
-    pcm.masked_fill_(idx >= (480000 - sil)[:, None], 0)
-    L = torch.randint(8, 221, (n,), generator=g, device=device)
-    body = torch.randint(0, 50256, (n, 449), generator=g, device=device)
-    pos = torch.arange(449, device=device)[None, :]
-    toks = torch.where(pos == 0, torch.full_like(body, 50257), body)
-    toks = torch.where(pos == 1, torch.full_like(body, 50362), toks)
-    toks = torch.where(pos == (L - 1)[:, None], torch.full_like(body, 50256), toks)
-    toks = torch.where(pos >= L[:, None], torch.full_like(body, PAD_ID), toks)
-    text_input = toks[:, :448].clone()
-    text_input = torch.where(pos[:, :448] >= (L - 1)[:, None], torch.full_like(text_input, PAD_ID), text_input)
-    text_y = toks[:, 1:449].contiguous()
-    return pcm, text_input.contiguous(), text_y, (L - 1).to(torch.int32)
+def synth_batch(indices, device):
+    """SURVEY.md section 8(d)'s generator, sample by sample on the host (olmoasr_amd/synth.py: seed 1234 + sample index, bit-equal
+    to oracle.model_oracle.synthetic_sample, tests/test_synth_cpu.py): int16 PCM ~ round(clip(N(0, 0.1)) * 32767) with a zeroed
+    tail of U{0..240000} samples, tokens [sot, notimestamps, body..., eot] padded with 51864 to 448.  Runs before the timed
+    region; the clips are resident in HBM when it starts."""
+    from concurrent.futures import ThreadPoolExecutor
+    from olmoasr_amd.synth import synth_sample
+    with ThreadPoolExecutor(max_workers=min(16, len(os.sched_getaffinity(0)))) as pool:
+        items = list(pool.map(synth_sample, [int(i) for i in indices]))
+    pcm = torch.stack([it[0] for it in items]).to(device)
+    ti = torch.stack([it[1] for it in items]).to(device)
+    ty = torch.stack([it[2] for it in items]).to(device)
+    tl = torch.tensor([it[3] for it in items], dtype=torch.int32).to(device)
+    return pcm, ti, ty, tl
 
 
 def _flush_c_stdio():
@@ -322,8 +317,8 @@ def main():
             mb = int(t)
     assert B % mb == 0
     accum = B // mb
-    # sample i of the global batch goes to rank i % world (DistributedSampler rule): seed per rank
-    pcm, ti, ty, tl = synth_batch(B, dev, seed=1234 + rank)
+    # sample i of the global batch goes to rank i % world (DistributedSampler rule, shuffle off)
+    pcm, ti, ty, tl = synth_batch(range(rank, B * world, world), dev)
     loss_buf = torch.zeros(1, device=dev)
     loss_scale = 65536.0  # GradScaler() initial scale; the reference keeps it enabled for bf16 (train_timestamps.py:2349)
     state = {"step": 0}
@@ -430,7 +425,8 @@ def main():
         out = {
             "metric": "audio-seconds/sec/node (train step)", "value": round(value, 1), "unit": "audio-seconds/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic (SURVEY 8d generator: sample i = seed 1234 + i on the host, sample i -> rank i mod world; random-init weights)",
             "config": {"workload": f"OLMoASR-{args.variant} bf16 train step, {B} x 30 s synthetic clips per GPU "
                                    f"({accum} micro-batches of {mb}, grad accumulation), global batch {world * B}",
                        "global_batch": world * B, "micro_batch": mb, "parallelism": f"dp{world}" + (f" ({args.reducer} gradient exchange, {args.bucket_mb:g} MiB buckets)" if world > 1 else ""),

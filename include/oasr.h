@@ -179,6 +179,14 @@ int oasr_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
  * and gen_pred's argmax over teacher-forced logits (scripts/training/train_timestamps.py:1096-1098). */
 int oasr_pick_tokens(const float* logits, int64_t ld, int V, int64_t rows, const float* mask, const float* mask2, int64_t* tok,
                      float* logprob, void* stream);
+/* The same pick in TIMESTAMP mode -- the reference's default for transcribe() (olmoasr/transcribe.py:212: DecodingOptions without
+ * without_timestamps) -- with whisper.decoding.ApplyTimestampRules evaluated on the device from the sampled history
+ * (history i64 [rows, history_ld], n_history tokens sampled so far per row; max_initial_index < 0: no limit on the first timestamp):
+ * pairs must be closed, text must follow a pair, timestamps do not decrease, the first token is a timestamp <= max_initial, and a
+ * timestamp is forced when the timestamp mass beats every text token.  Replaces ApplyTimestampRules.apply + GreedyDecoder.update. */
+int oasr_pick_tokens_ts(const float* logits, int64_t ld, int V, int64_t rows, const float* mask, const float* mask2,
+                        const int64_t* history, int64_t history_ld, int n_history, int timestamp_begin, int eot, int no_timestamps,
+                        int max_initial_index, int64_t* tok, float* logprob, void* stream);
 /* Measurement / test hooks (GEMM launch timing for bench.py, kernel-path forcing, hardware probes) are declared in
  * include/oasr_testing.h: they are exported by the same library but are not part of the product surface. */
 

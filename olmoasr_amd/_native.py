@@ -90,6 +90,7 @@ def _declare(lib):
         "oasr_cross_entropy": (i32, [vp, i64, i32, vp, i64, i64, f32, vp, vp, vp, i32, vp]),
         "oasr_cast_f32_bf16": (i32, [vp, vp, i64, vp]),
         "oasr_pick_tokens": (i32, [vp, i64, i32, i64, vp, vp, vp, vp, vp]),
+        "oasr_pick_tokens_ts": (i32, [vp, i64, i32, i64, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp, vp, vp]),
         "oasr_probe_tr16": (i32, [vp, vp, vp]),
         "oasr_probe_lds_oob": (i32, [vp, vp, vp]),
         "oasr_profile_gemm": (i32, [i32]),
@@ -97,6 +98,7 @@ def _declare(lib):
         "oasr_gemm_set_stagger": (i32, [i32, i32]),
         "oasr_gemm_set_variant": (i32, [i32]),
         "oasr_decode_set_ln_fold": (i32, [i32]),
+        "oasr_set_lane": (i32, [i32]),
         "oasr_profile_gemm_collect": (i32, [vp, vp, vp, C.c_char_p, i32]),
     }
     for name, (res, args) in sig.items():

@@ -190,6 +190,10 @@ int launch_loss_reduce(const float* row_loss, long rows, const int32_t* n_valid_
 // tok[r] = argmax_c (logits[r][c] + mask[c] + mask2[c]) (lowest index on ties), logprob[r] = log_softmax of that entry (optional)
 int launch_pick_tokens(const float* logits, long ld, int V, long rows, const float* mask, const float* mask2, int64_t* tok, float* logprob,
                        hipStream_t s);
+// + whisper's ApplyTimestampRules evaluated from the device-resident sampled history (loss.hip::pick_ts_kernel)
+int launch_pick_tokens_ts(const float* logits, long ld, int V, long rows, const float* mask, const float* mask2, const int64_t* hist,
+                          long hist_ld, int n_hist, int ts_begin, int eot, int no_ts, int max_initial_index, int64_t* tok, float* logprob,
+                          hipStream_t s);
 
 // ---- optimizer (flat fp32 arenas) ---------------------------------------------------------------------------
 // stats[0] = sum g^2 (of the *scaled* grads), stats[1] = found_inf flag (nonzero if any non-finite)

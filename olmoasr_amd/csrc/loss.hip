@@ -182,6 +182,119 @@ __global__ __launch_bounds__(256) void pick_kernel(const float* __restrict__ log
   }
 }
 
+
+// The same pick with whisper.decoding.ApplyTimestampRules folded in (timestamp mode is the reference's default for transcribe(),
+// olmoasr/transcribe.py:212; whisper/decoding.py ApplyTimestampRules.apply): the rules are a function of the row's sampled history,
+// which lives on the device (int64 [rows, hist_ld], n_hist tokens sampled so far), so the greedy loop needs no host round trip per
+// token.  Column c of row r is masked (-inf) when
+//   c == <|notimestamps|>;
+//   the last sampled token is a timestamp and  (the one before it too, or there is none)  -> c >= ts_begin   (text must follow a pair)
+//                                              (the one before it is text)                -> c <  eot         (a pair must be closed)
+//   a timestamp was sampled before: ts_begin <= c < last_ts (+ 1 unless the last token is an unpaired timestamp)   (monotonic, > 0 s)
+//   nothing sampled yet: c < ts_begin, and c > ts_begin + max_initial_index when that is >= 0;
+// then, on log_softmax of what is left: if logsumexp(timestamp part) > max(text part) every text column is masked too.
+// tok = argmax of the survivors (lowest index on ties), logprob = its log_softmax over the survivors (GreedyDecoder.update).
+// One pass: online (max, argmax, sum-exp) for the text part and the timestamp part separately.
+struct PickPart {
+  float m, s;
+  int i;
+};
+__device__ __forceinline__ void pick_merge(PickPart& a, const PickPart& b) {
+  if (b.m > a.m || (b.m == a.m && b.i < a.i)) {
+    a.s = a.s * __expf(a.m - b.m) + b.s;  // (a.m = -inf: exp(-inf) = 0; both -inf: handled by the caller's guard)
+    a.m = b.m;
+    a.i = b.i;
+  } else if (b.m > -INFINITY) {
+    a.s += b.s * __expf(b.m - a.m);
+  }
+}
+__device__ __forceinline__ PickPart pick_block_reduce(PickPart p, PickPart* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    PickPart q;
+    q.m = __shfl_xor(p.m, o, 64);
+    q.s = __shfl_xor(p.s, o, 64);
+    q.i = __shfl_xor(p.i, o, 64);
+    pick_merge(p, q);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wave] = p;
+  __syncthreads();
+  p = sh[0];
+#pragma unroll
+  for (int w = 1; w < 4; ++w) pick_merge(p, sh[w]);
+  return p;
+}
+__global__ __launch_bounds__(256) void pick_ts_kernel(const float* __restrict__ logits, long ld, int V, const float* __restrict__ mask,
+                                                     const float* __restrict__ mask2, const int64_t* __restrict__ hist, long hist_ld,
+                                                     int n_hist, int ts_begin, int eot, int no_ts, int max_initial_index,
+                                                     int64_t* __restrict__ tok, float* __restrict__ logprob) {
+  __shared__ PickPart sh[4];
+  __shared__ int sh_last[4];
+  const float* lr = logits + (long)blockIdx.x * ld;
+  const int64_t* h = hist + (long)blockIdx.x * hist_ld;
+  // position of the last sampled timestamp (history is at most n_text_ctx tokens)
+  int last_pos = -1;
+  for (int t = threadIdx.x; t < n_hist; t += 256)
+    if (h[t] >= ts_begin) last_pos = t;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) last_pos = max(last_pos, __shfl_xor(last_pos, o, 64));
+  if ((threadIdx.x & 63) == 0) sh_last[threadIdx.x >> 6] = last_pos;
+  __syncthreads();
+  last_pos = max(max(sh_last[0], sh_last[1]), max(sh_last[2], sh_last[3]));
+  const bool last_was_ts = n_hist >= 1 && h[n_hist - 1] >= ts_begin;
+  const bool pen_was_ts = n_hist < 2 || h[n_hist - 2] >= ts_begin;
+  int ts_lo = -1;  // timestamps below this are masked
+  if (last_pos >= 0) ts_lo = (int)h[last_pos] + ((last_was_ts && !pen_was_ts) ? 0 : 1);
+  const bool first = n_hist == 0;
+  const int ts_hi = (first && max_initial_index >= 0) ? ts_begin + max_initial_index : 0x7fffffff;  // timestamps above this are masked
+
+  PickPart text{-INFINITY, 0.f, 0x7fffffff}, stamp{-INFINITY, 0.f, 0x7fffffff};
+  for (int c = threadIdx.x; c < V; c += 256) {
+    float x = lr[c];
+    if (mask) x += mask[c];
+    if (mask2) x += mask2[c];
+    const bool is_ts = c >= ts_begin;
+    bool dead = c == no_ts;
+    if (last_was_ts) dead = dead || (pen_was_ts ? is_ts : c < eot);
+    if (is_ts) dead = dead || c < ts_lo || c > ts_hi;
+    else dead = dead || first;
+    if (dead || !(x > -INFINITY)) continue;
+    PickPart& p = is_ts ? stamp : text;
+    if (x > p.m) {  // strict: lowest index of this thread's stride
+      p.s = p.s * __expf(p.m - x) + 1.f;
+      p.m = x;
+      p.i = c;
+    } else {
+      p.s += __expf(x - p.m);
+    }
+  }
+  text = pick_block_reduce(text, sh);
+  stamp = pick_block_reduce(stamp, sh);
+  if (threadIdx.x == 0) {
+    const float M = fmaxf(text.m, stamp.m);
+    int pick = 0;
+    float lp = -INFINITY;
+    if (M > -INFINITY) {
+      const float st = text.m > -INFINITY ? text.s * __expf(text.m - M) : 0.f;
+      const float ss = stamp.m > -INFINITY ? stamp.s * __expf(stamp.m - M) : 0.f;
+      const float lse = __logf(st + ss);
+      const bool force = stamp.m > -INFINITY && (text.m == -INFINITY || (__logf(ss) - lse) > ((text.m - M) - lse));
+      if (force) {
+        pick = stamp.i;
+        lp = -__logf(stamp.s);
+      } else {
+        const bool from_text = text.m >= stamp.m;  // equal maxima: text ids are the lower ones
+        pick = from_text ? text.i : stamp.i;
+        lp = ((from_text ? text.m : stamp.m) - M) - lse;
+      }
+    }
+    tok[blockIdx.x] = pick;
+    if (logprob) logprob[blockIdx.x] = lp;
+  }
+}
+
 }  // namespace
 
 int launch_pick_tokens(const float* logits, long ld, int V, long rows, const float* mask, const float* mask2, int64_t* tok, float* logprob,
@@ -215,6 +328,18 @@ int launch_loss_reduce(const float* row_loss, long rows, const int32_t* n_valid_
                        hipStream_t s) {
   OASR_REQUIRE(row_loss && n_valid_dev && loss_out, "loss_reduce: null pointer");
   hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, s, row_loss, rows, n_valid_dev, mul, loss_out, accumulate);
+  OASR_LAUNCH_CHECK();
+  return OASR_OK;
+}
+
+int launch_pick_tokens_ts(const float* logits, long ld, int V, long rows, const float* mask, const float* mask2, const int64_t* hist,
+                          long hist_ld, int n_hist, int ts_begin, int eot, int no_ts, int max_initial_index, int64_t* tok, float* logprob,
+                          hipStream_t s) {
+  OASR_REQUIRE(logits && tok && V > 0 && ld >= V && n_hist >= 0 && (n_hist == 0 || (hist && hist_ld >= n_hist)), "pick_tokens_ts: bad args");
+  OASR_REQUIRE(0 <= eot && eot < ts_begin && ts_begin < V, "pick_tokens_ts: token ids out of range");
+  if (rows <= 0) return OASR_OK;
+  hipLaunchKernelGGL(pick_ts_kernel, dim3((unsigned)rows), dim3(256), 0, s, logits, ld, V, mask, mask2, hist, hist_ld, n_hist, ts_begin, eot,
+                     no_ts, max_initial_index, tok, logprob);
   OASR_LAUNCH_CHECK();
   return OASR_OK;
 }

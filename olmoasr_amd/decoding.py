@@ -103,28 +103,37 @@ def suppress_list(options: DecodingOptions) -> List[int]:
 
 
 def _timestamp_rules(logits: torch.Tensor, tokens: torch.Tensor, sample_begin: int, max_initial_index: Optional[int]):
-    """whisper.decoding.ApplyTimestampRules on logits [n, rows], in place."""
+    """whisper.decoding.ApplyTimestampRules on logits [n, rows], in place -- evaluated with tensor ops on the device the logits live
+    on (no per-row Python, no device -> host copy: the decode loop never waits for the GPU here).  The greedy path does not come
+    through here at all: ``oasr_pick_tokens_ts`` applies the same rules inside the pick kernel."""
     ninf = -float("inf")
+    n, rows = logits.shape
+    dev = logits.device
     logits[:, NO_TIMESTAMPS] = ninf
-    for k, seq in enumerate(tokens[:, sample_begin:].tolist()):
-        last_was_ts = len(seq) >= 1 and seq[-1] >= TIMESTAMP_BEGIN
-        penultimate_was_ts = len(seq) < 2 or seq[-2] >= TIMESTAMP_BEGIN
-        if last_was_ts:
-            if penultimate_was_ts:
-                logits[k, TIMESTAMP_BEGIN:] = ninf   # has to be non-timestamp
-            else:
-                logits[k, :EOT] = ninf               # cannot be normal text tokens
-        ts = [t for t in seq if t >= TIMESTAMP_BEGIN]
-        if ts:  # timestamps shouldn't decrease; also force each segment to have a nonzero length
-            last = ts[-1] if (last_was_ts and not penultimate_was_ts) else ts[-1] + 1
-            logits[k, TIMESTAMP_BEGIN:last] = ninf
-    if tokens.shape[1] == sample_begin:
-        logits[:, :TIMESTAMP_BEGIN] = ninf           # suppress generating non-timestamp tokens at the beginning
+    seq = tokens[:, sample_begin:].to(dev)
+    m = seq.shape[1]
+    cols = torch.arange(rows, device=dev)[None, :]
+    if m >= 1:
+        is_ts = seq >= TIMESTAMP_BEGIN
+        last_was_ts = is_ts[:, -1]
+        penultimate_was_ts = is_ts[:, -2] if m >= 2 else torch.ones(n, dtype=torch.bool, device=dev)
+        # a timestamp pair has to be followed by text; an opening timestamp + text has to be closed before more text ... :
+        dead = (last_was_ts & penultimate_was_ts)[:, None] & (cols >= TIMESTAMP_BEGIN)
+        dead |= (last_was_ts & ~penultimate_was_ts)[:, None] & (cols < EOT)
+        # ... and timestamps neither decrease nor close a zero-length segment
+        pos = torch.arange(1, m + 1, device=dev)[None, :]
+        last_pos = (is_ts * pos).max(dim=1).values                       # 1-based position of the last timestamp, 0 = none
+        last_ts = seq.gather(1, (last_pos - 1).clamp(min=0)[:, None])[:, 0]
+        lo = last_ts + (~(last_was_ts & ~penultimate_was_ts)).to(last_ts.dtype)
+        dead |= (last_pos > 0)[:, None] & (cols >= TIMESTAMP_BEGIN) & (cols < lo[:, None])
+        logits.masked_fill_(dead, ninf)
+    else:
+        logits[:, :TIMESTAMP_BEGIN] = ninf           # the first sampled token is a timestamp ...
         if max_initial_index is not None:
-            logits[:, TIMESTAMP_BEGIN + max_initial_index + 1:] = ninf
+            logits[:, TIMESTAMP_BEGIN + max_initial_index + 1:] = ninf  # ... no later than max_initial_timestamp
     logprobs = torch.log_softmax(logits.float(), dim=-1)
     force = logprobs[:, TIMESTAMP_BEGIN:].logsumexp(dim=-1) > logprobs[:, :TIMESTAMP_BEGIN].max(dim=-1).values
-    logits[force, :TIMESTAMP_BEGIN] = ninf            # timestamp mass beats every text token: sample a timestamp
+    logits[:, :TIMESTAMP_BEGIN].masked_fill_(force[:, None], ninf)  # the timestamp mass beats every text token: sample a timestamp
 
 
 @torch.no_grad()

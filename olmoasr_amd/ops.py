@@ -154,3 +154,23 @@ def pick_tokens(logits, mask=None, mask2=None, want_logprob=True):
     N.check(N.lib().oasr_pick_tokens(N.ptr(logits), logits.stride(0), V, rows, N.ptr(mask), N.ptr(mask2), N.ptr(tok), N.ptr(lp),
                                      N.stream_ptr()), "oasr_pick_tokens")
     return tok, lp
+
+
+def pick_tokens_ts(logits, history, n_history, *, timestamp_begin, eot, no_timestamps, max_initial_index=None, mask=None, mask2=None):
+    """``pick_tokens`` with whisper's ApplyTimestampRules evaluated on the device: ``history`` int64 [rows, >= n_history] holds the
+    tokens sampled so far (after the sot sequence).  Returns (ids int64 [rows], log_softmax of the pick over the surviving columns)."""
+    N.require_gpu(logits, "logits")
+    assert logits.dtype == torch.float32 and logits.dim() == 2 and logits.stride(1) == 1
+    rows, V = logits.shape
+    assert n_history == 0 or (history.dtype == torch.int64 and history.dim() == 2 and history.shape[0] == rows and history.stride(1) == 1
+                              and history.shape[1] >= n_history and history.device == logits.device)
+    tok = torch.empty(rows, device=logits.device, dtype=torch.int64)
+    lp = torch.empty(rows, device=logits.device, dtype=torch.float32)
+    for m in (mask, mask2):
+        assert m is None or (m.dtype == torch.float32 and m.numel() == V and m.is_contiguous())
+    N.check(N.lib().oasr_pick_tokens_ts(N.ptr(logits), logits.stride(0), V, rows, N.ptr(mask), N.ptr(mask2),
+                                        N.ptr(history) if n_history else None, history.stride(0) if n_history else 0, int(n_history),
+                                        int(timestamp_begin), int(eot), int(no_timestamps),
+                                        -1 if max_initial_index is None else int(max_initial_index), N.ptr(tok), N.ptr(lp), N.stream_ptr()),
+            "oasr_pick_tokens_ts")
+    return tok, lp

@@ -58,8 +58,10 @@ class NativeBackend:
 
 
 class ShardedOptimizer:
-    def __init__(self, flat_params: torch.Tensor, flat_grads: torch.Tensor, backend, group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, flat_params: torch.Tensor, flat_grads: torch.Tensor, backend, group: Optional[dist.ProcessGroup] = None,
+                 force: bool = False):
         self.p, self.g, self.backend, self.group = flat_params, flat_grads, backend, group
+        self.force = force and dist.is_initialized()  # run the collectives even at world_size 1 (single-GPU rehearsal over RCCL)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         n = flat_params.numel()
@@ -79,18 +81,19 @@ class ShardedOptimizer:
         """``inv_loss_scale`` must already contain 1 / world (the reduced gradients are SUMs, like GradReducer's).  Returns the
         global stats tensor [sum g^2 (scaled), found_inf]."""
         W, per, n = self.world, self.per, self.p.numel()
-        if W > 1:
+        comm = W > 1 or self.force
+        if comm:
             body = self.g[: per * W]
             dist.reduce_scatter_tensor(body[self.rank * per:(self.rank + 1) * per], body, op=dist.ReduceOp.SUM, group=self.group)
             if per * W < n:  # the tail belongs to the last rank
                 dist.reduce(self.g[per * W:], dst=dist.get_global_rank(self.group, W - 1) if self.group else W - 1, op=dist.ReduceOp.SUM,
                             group=self.group)
         stats = self.backend.sumsq(self.off, self.len)
-        if W > 1:
+        if comm:
             dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=self.group)
         self.backend.step(self.off, self.len, self.m, self.v, stats, step=step, lr=lr, inv_loss_scale=inv_loss_scale,
                           max_grad_norm=max_grad_norm, betas=betas, eps=eps, weight_decay=weight_decay)
-        if W > 1:
+        if comm:
             body = self.p[: per * W]
             dist.all_gather_into_tensor(body, body[self.rank * per:(self.rank + 1) * per], group=self.group)
             if per * W < n:

@@ -52,6 +52,7 @@ IGNORED_FLAGS = ("eval_dir", "eval_batch_size", "pin_memory", "persistent_worker
                  "async_eval", "eval_script_path", "eval_wandb_log", "eval_on_gpu", "job_type", "log_dir")
 NATIVE_FLAGS = dict(  # additions of this implementation
     synthetic=True, n_synthetic=4096, timestamps=False, seed=0, bucket_cap_mb=128.0, reducer="allreduce", resume=False,
+    force_dist=False,  # run the RCCL group / bucketed exchange / sharded step even at world_size 1 (single-GPU rehearsal of the N > 1 path)
     zero_stage=0)  # zero_stage 1: AdamW moments sharded over the ranks (olmoasr_amd/zero.py; the reference's FSDP script's role)
 
 
@@ -336,9 +337,12 @@ def main(argv=None):
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world_size > 1:
+    force_dist = bool(args.force_dist) and world_size == 1
+    own_group = (world_size > 1 or force_dist) and not dist.is_initialized()
+    if own_group:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 400))
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world_size)  # RCCL over xGMI
 
     betas = tuple(args.betas)
     dims = VARIANT_TO_DIMS[args.model_variant]
@@ -348,11 +352,11 @@ def main(argv=None):
     sharded = None
     if int(args.zero_stage) == 1:
         from olmoasr_amd import zero
-        sharded = zero.ShardedOptimizer(net.flat_params, net.flat_grads, zero.NativeBackend(net))  # moments for the owned range only
+        sharded = zero.ShardedOptimizer(net.flat_params, net.flat_grads, zero.NativeBackend(net), force=force_dist)  # moments for the owned range only
     else:
         net.init_optimizer_state()
-    reducer = (ddp.GradReducer(net.flat_grads, net.grad_segments, bucket_cap_mb=args.bucket_cap_mb, algo=args.reducer)
-               if world_size > 1 and sharded is None else None)
+    reducer = (ddp.GradReducer(net.flat_grads, net.grad_segments, bucket_cap_mb=args.bucket_cap_mb, algo=args.reducer, force=force_dist)
+               if (world_size > 1 or force_dist) and sharded is None else None)
     scaler = GradScalerState()
     accum = accumulation_steps(args.eff_batch_size, world_size, args.train_batch_size)
     mine = ddp.shard_indices(args.n_synthetic, rank, world_size)
@@ -451,7 +455,7 @@ def main(argv=None):
     loader.close()
     if args.ckpt_freq and (global_step % args.ckpt_freq) != 0:
         save_ckpt(net, scaler, global_step, local_step, epoch, args, dims, rank, run_id, cursor, optimizer_steps, sharded=sharded)
-    if world_size > 1:
+    if own_group:
         dist.barrier()
         dist.destroy_process_group()
     return log
