@@ -20,8 +20,11 @@ reference": it ships no tests or vectors for decoding.
 
 Step engines: greedy / sampling run on the engine-owned KV cache (``kv_cache_begin/kv_cache_step`` = the reference's
 ``install_kv_cache_hooks`` (model.py:925-964) + a one-token decoder step; the per-step argmax + log-softmax gather with the
-suppress masks is one HIP kernel, ``oasr_pick_tokens``); beam search re-runs the decoder on the whole prefix each step
-(rows are re-gathered between steps), as does ``use_kv_cache=False`` (the pattern of notebooks/ow_decoding.py:42-72).
+suppress masks is one HIP kernel, ``oasr_pick_tokens`` -- in timestamp mode ``oasr_pick_tokens_ts``, which also applies
+ApplyTimestampRules from the device-resident token history, so the greedy loop never waits for the GPU); beam search runs on the
+same cache, its rows re-gathered in place between steps (``kv_cache_reorder`` = whisper's ``rearrange_kv_cache``,
+inf_model.py:422-453 hooks); ``use_kv_cache=False`` re-runs the decoder on the whole prefix each step (the pattern of
+notebooks/ow_decoding.py:42-72).
 """
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence, Union
@@ -191,7 +194,7 @@ def decode(model, mel: torch.Tensor, options: Optional[DecodingOptions] = None, 
     tokens = torch.tensor([init] * n, dtype=torch.int64, device=dev)
     sum_logprobs = torch.zeros(n, device=dev)
     finished = [dict() for _ in range(n_audio)] if beam else None
-    cached = options.use_kv_cache and not beam
+    cached = options.use_kv_cache
     state = None
     # position sot_index gives no_speech_prob; with the cache it is the logits returned while the prompt is being fed
     if cached:
@@ -211,9 +214,13 @@ def decode(model, mel: torch.Tensor, options: Optional[DecodingOptions] = None, 
         else:
             lg = model.logits(tokens, xa_g, last_only=True)
         fm = first_mask if i == 0 else None
-        simple = options.without_timestamps and not beam and options.temperature == 0
-        if simple:  # argmax + log-softmax gather + masks in ONE kernel
+        simple = not beam and options.temperature == 0
+        if simple and options.without_timestamps:  # argmax + log-softmax gather + masks in ONE kernel
             nxt, cur = ops.pick_tokens(lg, base_mask, fm)
+        elif simple:  # ... and, in timestamp mode, ApplyTimestampRules from the device-resident history in the same kernel
+            nxt, cur = ops.pick_tokens_ts(lg.float().contiguous(), tokens[:, sample_begin:], tokens.shape[1] - sample_begin,
+                                          timestamp_begin=TIMESTAMP_BEGIN, eot=EOT, no_timestamps=NO_TIMESTAMPS,
+                                          max_initial_index=max_init_idx, mask=base_mask, mask2=fm)
         else:
             lg = lg.float() + base_mask
             if fm is not None:
@@ -225,14 +232,16 @@ def decode(model, mel: torch.Tensor, options: Optional[DecodingOptions] = None, 
             top_lp, top_tok = logprobs.topk(beam + 1, dim=-1)
             top_lp, top_tok = top_lp.cpu(), top_tok.cpu()
             prev_sum, tok_cpu = sum_logprobs.cpu(), tokens.cpu()
-            next_tokens, new_sum = [], []
+            next_tokens, new_sum, sources = [], [], []
             for a in range(n_audio):
-                scores, newly = {}, {}
+                scores, newly, origin = {}, {}, {}
                 for j in range(beam):
                     idx = a * beam + j
                     prefix = tok_cpu[idx].tolist()
                     for lp, t in zip(top_lp[idx].tolist(), top_tok[idx].tolist()):
-                        scores[tuple(prefix + [t])] = float(prev_sum[idx]) + lp
+                        seq = tuple(prefix + [t])
+                        scores[seq] = float(prev_sum[idx]) + lp
+                        origin[seq] = idx
                 saved = 0
                 for seq in sorted(scores, key=scores.get, reverse=True):
                     if seq[-1] == EOT:
@@ -240,6 +249,7 @@ def decode(model, mel: torch.Tensor, options: Optional[DecodingOptions] = None, 
                     else:
                         new_sum.append(scores[seq])
                         next_tokens.append(list(seq))
+                        sources.append(origin[seq])
                         saved += 1
                         if saved == beam:
                             break
@@ -249,6 +259,8 @@ def decode(model, mel: torch.Tensor, options: Optional[DecodingOptions] = None, 
                     finished[a][seq] = newly[seq]
             tokens = torch.tensor(next_tokens, dtype=torch.int64, device=dev)
             sum_logprobs = torch.tensor(new_sum, device=dev)
+            if cached and sources != list(range(n)):  # PyTorchInference.rearrange_kv_cache: row j continues row sources[j]
+                model.kv_cache_reorder(state, sources)
             completed = all(len(f) >= max_candidates for f in finished)
         else:  # GreedyDecoder.update
             if not simple:

@@ -565,9 +565,25 @@ class OLMoASR(nn.Module):
         state["pos"] += 1
         return out
 
+    @torch.no_grad()
+    def kv_cache_reorder(self, state, source_indices) -> None:
+        """whisper's ``PyTorchInference.rearrange_kv_cache`` (beam search: row j continues the sequence that was row
+        source_indices[j]) on the engine-owned cache, IN PLACE: only the self-attention rows of the positions consumed so far
+        move (``pos * 3d`` elements per layer and sequence); the cross-attention K/V stay where they are, so every source must
+        belong to the same audio window as its destination -- beams never cross windows."""
+        B, L, d, pos = state["B"], self.dims.n_text_layer, self.dims.n_text_state, state["pos"]
+        idx = torch.as_tensor(source_indices, device=state["cache"].device, dtype=torch.long).reshape(-1)
+        assert idx.numel() == B
+        if pos == 0:
+            return
+        n_self, n_cross = 3 * B * self.dims.n_text_ctx * d, B * self.dims.n_audio_ctx * 2 * d
+        esz = 4 if self._act_dtype == torch.float32 else 2
+        flat = state["cache"][: (n_self + n_cross) * L * esz].view(self._act_dtype).view(L, n_self + n_cross)
+        rows = flat[:, :n_self].view(L, B, self.dims.n_text_ctx, 3 * d)[:, :, :pos]
+        rows.copy_(rows.index_select(1, idx))  # (index_select materialises the gathered rows before the copy back)
+
     def kv_cache_check(self, state) -> None:
-        """Synchronises and raises if a one-launch decode step since kv_cache_begin abandoned its device-wide barrier
-        (oasr_decode_check); call once per decoded window, before reading the tokens back."""
+        """Synchronises the stream (oasr_decode_check); call once per decoded window, before reading the tokens back."""
         with torch.cuda.device(state["cache"].device):
             N.check(N.lib().oasr_decode_check(self._ctx, state["B"], N.ptr(state["cache"]), N.stream_ptr()), "oasr_decode_check")
 

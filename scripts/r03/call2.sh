@@ -23,3 +23,5 @@ run lane7lo OASR_LANE=7 OASR_LANE_PRIO=1
 run base0b OASR_LANE=0
 run lane7b OASR_LANE=7
 python -m pytest tests/test_gpu_decode_parity.py tests/test_gpu_parity_sizes.py tests/test_gpu_decode_step.py -x -q > $O/pytest_new.log 2>&1; echo "pytest new rc=$?" | tee -a $O/summary.txt; tail -6 $O/pytest_new.log | tee -a $O/summary.txt
+python scripts/transcribe_bench.py small 600 20 > $O/transcribe_greedy.json 2>&1; tail -1 $O/transcribe_greedy.json | tee -a $O/summary.txt
+python scripts/transcribe_bench.py small 600 1 ts > $O/transcribe_ts.json 2>&1; tail -1 $O/transcribe_ts.json | tee -a $O/summary.txt

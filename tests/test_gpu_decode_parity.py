@@ -10,6 +10,8 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 DEV = "cuda"
 
 
@@ -324,3 +326,35 @@ def test_c5_small_dims_memorised_bf16_greedy_transcribe_is_exact():
     got32 = net32.transcribe(pcm, **kw)
     assert [s["tokens"] for s in got32["segments"]] == [s["tokens"] for s in want["segments"]]
     assert all(abs(a["avg_logprob"] - b["avg_logprob"]) < 2e-4 for a, b in zip(got32["segments"], want["segments"]))
+
+
+@pytest.mark.parametrize("length", [0, 1, 2, 5, 40])
+def test_pick_tokens_ts_kernel_equals_the_rules_then_argmax(length):
+    """oasr_pick_tokens_ts (ApplyTimestampRules + argmax + log-softmax of the pick in one kernel, history read on the device)
+    against the tensor form of the rules -- itself pinned to transformers' WhisperTimeStampLogitsProcessor on the CPU
+    (tests/test_decoding_rules_cpu.py) -- followed by torch argmax / log_softmax: same ids, same log-probabilities, on random
+    histories that reach every branch (pairs, open timestamps, repeats, text only), with and without the forced-timestamp rule,
+    with the suppress masks, for the inference and the training head."""
+    from olmoasr_amd import decoding as dec
+    from olmoasr_amd import ops
+    from test_decoding_rules_cpu import _random_history
+    g = torch.Generator().manual_seed(40 + length)
+    for rows_v in (51864, 51865):
+        n, sample_begin = 24, 1
+        tokens = _random_history(g, n, length, sample_begin).to(DEV)
+        logits = (torch.randn(n, rows_v, generator=g) * 3.0).to(DEV)
+        logits[: n // 2, dec.TIMESTAMP_BEGIN:] += 6.0  # half the rows: enough timestamp mass to force a timestamp
+        base = torch.zeros(rows_v, device=DEV)
+        base[dec.suppress_list(dec.DecodingOptions())] = -float("inf")
+        first = torch.zeros(rows_v, device=DEV)
+        first[[dec.BLANK, dec.EOT]] = -float("inf")
+        for max_init in (None, 50):
+            for fm in (None, first):
+                ref = logits + base + (fm if fm is not None else 0.0)
+                dec._timestamp_rules(ref, tokens, sample_begin, max_init)
+                want_tok = ref.argmax(-1)
+                want_lp = torch.log_softmax(ref.float(), -1).gather(1, want_tok[:, None])[:, 0]
+                tok, lp = ops.pick_tokens_ts(logits, tokens[:, sample_begin:], length, timestamp_begin=dec.TIMESTAMP_BEGIN, eot=dec.EOT,
+                                             no_timestamps=dec.NO_TIMESTAMPS, max_initial_index=max_init, mask=base, mask2=fm)
+                assert torch.equal(tok, want_tok), (length, rows_v, max_init, (tok != want_tok).nonzero().flatten().tolist())
+                assert float((lp - want_lp).abs().max()) < 2e-4
