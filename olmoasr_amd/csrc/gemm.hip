@@ -880,6 +880,174 @@ __global__ __launch_bounds__(256, 2) void oasr_gemm_duo_kernel(GemmArgs p) {
 }
 
 
+// ---- 256 x 256 x 64 "quad" kernel: FOUR waves, 128 x 128 outputs each, operands staged through registers -------------------
+// The form the vendor library's best kernel for these shapes has (profiles/r02_gemm_vs_vendor.txt: 4 waves x 128x128, one wave
+// per SIMD): a wave's 128 x 128 block reads 2 x 128 x 64 fragment elements per K-tile instead of the ping-pong kernel's
+// (128 + 64) x 64 for half the outputs -- two thirds of the LDS fragment bytes per MFMA -- and one wave per SIMD issues half the
+// wave-instructions.  With a lone wave on a SIMD nothing else covers a stall, so the stream itself has to keep the matrix pipe
+// fed: a direct-to-LDS piece occupies the issue port for ~60 cycles (MI355X_MICROARCH.md), longer than the 32-cycle shadow of a
+// 32x32x16 MFMA, which is why the operands go global -> VGPR -> LDS here: a 16-byte global load and a ds_write_b128 each fit
+// inside one shadow.  Per K-tile and wave: 64 MFMAs, 32 ds_read_b128 (fragments of k-step ks+1 under the MFMAs of ks), 16 global
+// loads (tile t+1, under k-steps 0-1) and 16 ds_write_b128 (under k-steps 2-3, into the other LDS buffer); ONE workgroup barrier
+// per K-tile.  The interleave is pinned with sched_group_barrier (the loop body is branch-free: the last iteration re-loads its
+// own tile into the dead buffer).  Accumulators: 16 x 16 = 256 registers; LDS 2 x 64 KiB.
+template <bool TRANS, int ROWS /*tile rows (M or N extent)*/>
+struct QuadStage {  // this thread's 8 x 16-byte pieces of a [ROWS x 64] (or [64 x ROWS]) operand tile
+  static_assert(ROWS == 256, "quad kernel tiles are 256 wide");
+  // !TRANS: piece p -> row = p*32 + (tid >> 3), chunk c16 = tid & 7      (8 lanes cover one 128-byte row segment)
+  //  TRANS: piece p -> k-row = p*8 + (tid >> 5), chunk c16 = tid & 31    (32 lanes cover one 512-byte k-row)
+  unsigned goff[8];  // byte offsets from the tile's base pointer
+  unsigned loff[8];  // byte offsets into the LDS image
+  __device__ __forceinline__ void init(const OperandView& v, int R, int row0, int tid) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      if (!TRANS) {
+        const int row = p * 32 + (tid >> 3), c16 = tid & 7;
+        int gr = row0 + row;
+        gr = gr < R ? gr : R - 1;  // (clamped rows only reach outputs that are never stored)
+        goff[p] = (unsigned)(((long)(gr - row0) * v.ld + c16 * 8) * 2);
+        loff[p] = (unsigned)(row * 128 + ((c16 ^ ((row >> 1) & 7)) << 4));
+      } else {
+        const int krow = p * 8 + (tid >> 5), c16 = tid & 31;
+        int col = row0 + c16 * 8;
+        col = col + 8 <= R ? col : R - 8;
+        goff[p] = (unsigned)(((long)krow * v.ld + (col - row0)) * 2);
+        loff[p] = (unsigned)(krow * 512 + ((c16 ^ ((krow & 3) << 2)) << 4));
+      }
+    }
+  }
+};
+
+template <bool TA, bool TB, bool CSUM>
+__global__ __launch_bounds__(256, 1) void oasr_gemm_quad_kernel(GemmArgs p) {
+  static_assert(!TA && !TB, "quad kernel: k-contiguous operands (the NT forward layout)");
+  constexpr int IMG = 256 * 64 * 2;  // one operand image: 32 KiB; buffer b = [A image | B image] at b * 64 KiB
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
+  int tm, tn;
+  {
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int gm = p.raster_gm > 0 ? p.raster_gm : 8;
+    gm = gm < 1 ? 1 : (gm > 16 ? 16 : gm);
+    const int per_group = gm * tiles_n;
+    const int group = bid / per_group, in_group = bid - group * per_group;
+    const int first_m = group * gm;
+    const int gsz = min(gm, tiles_m - first_m);
+    tm = first_m + in_group % gsz;
+    tn = in_group / gsz;
+  }
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int nt = p.K / BK;
+  QuadStage<false, 256> sa, sb;
+  sa.init(p.A, p.M, m0, tid);
+  sb.init(p.B, p.N, n0, tid);
+  const bf16_t* gA = p.A.ptr + (long)m0 * p.A.ld;
+  const bf16_t* gB = p.B.ptr + (long)n0 * p.B.ld;
+  // fragment read addresses (buffer 0): lane holds row (l & 31) of a 32-row block, 16-byte chunk ks*2 + (l >> 5), XOR-swizzled by
+  // (row >> 1) & 7 -- the XOR makes the k-step a per-lane term, so one address per k-step; blocks are +4096 immediates
+  unsigned adrA[4], adrB[4];
+  {
+    const int h = lane >> 5, ra_ = wm * 128 + (lane & 31), rb_ = wn * 128 + (lane & 31);
+    const unsigned base = (unsigned)(size_t)smem;  // LDS byte offset of the dynamic segment (the low half of the generic address)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      adrA[ks] = base + (unsigned)(ra_ * 128 + (((ks * 2 + h) ^ ((ra_ >> 1) & 7)) << 4));
+      adrB[ks] = base + (unsigned)(IMG + rb_ * 128 + (((ks * 2 + h) ^ ((rb_ >> 1) & 7)) << 4));
+    }
+  }
+
+  f32x16_t acc[2][4][2];  // [column half][mt][nt]: each half is the acc[4][2] block the shared epilogue takes
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.f;
+
+  u32x4_t ra[8], rb[8];
+  {
+    const __amdgpu_buffer_rsrc_t rsa = make_rsrc(gA), rsb = make_rsrc(gB);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsa, sa.goff[i], 0, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsb, sb.goff[i], 0, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      *(u32x4_t*)(smem + sa.loff[i]) = ra[i];
+      *(u32x4_t*)(smem + IMG + sb.loff[i]) = rb[i];
+    }
+  }
+  __syncthreads();
+
+  // One MFMA and at most one other memory instruction per slot, in exactly this order (sched_barrier(0) on both sides).
+  // Fragment reads are inline asm so that hipcc neither moves them next to their consumers nor waits for them early: the
+  // wait is the counted s_waitcnt in front of the k-step that consumes them, and it names the destinations ("+v") so that no
+  // MFMA can be scheduled above it (cdna_hip_programming.md section 5.7, form (ii)).
+  bf16x8_t fa[2][4], fb[2][4];
+#define OASR_QUAD_READ(DST, ADDR, BLK) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "i"((BLK) * 4096) : "memory")
+#define OASR_QUAD_WAIT(CNT, S)                                                                                                       \
+  asm volatile("s_waitcnt lgkmcnt(" #CNT ")"                                                                                         \
+               : "+v"(fa[S][0]), "+v"(fa[S][1]), "+v"(fa[S][2]), "+v"(fa[S][3]), "+v"(fb[S][0]), "+v"(fb[S][1]), "+v"(fb[S][2]), "+v"(fb[S][3]))
+#define OASR_QUAD_MFMA(C, MT, J) \
+  acc[(J) >> 1][MT][(J) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[C][J], fa[C][MT], acc[(J) >> 1][MT][(J) & 1], 0, 0, 0)
+#define OASR_QUAD_FENCE() __builtin_amdgcn_sched_barrier(0)
+  for (int t = 0; t < nt; ++t) {
+    const unsigned cur = (unsigned)(t & 1) << 16, nxt = cur ^ 0x10000u;
+    const int tn1 = t + 1 < nt ? t + 1 : t;  // branch-free body: the last iteration stages its own tile into the dead buffer
+    const __amdgpu_buffer_rsrc_t rsa = make_rsrc(gA + (long)tn1 * BK), rsb = make_rsrc(gB + (long)tn1 * BK);
+    {
+      const unsigned va = adrA[0] + cur, vb = adrB[0] + cur;
+      OASR_QUAD_READ(fa[0][0], va, 0);
+      OASR_QUAD_READ(fb[0][0], vb, 0);
+      OASR_QUAD_READ(fa[0][1], va, 1);
+      OASR_QUAD_READ(fb[0][1], vb, 1);
+      OASR_QUAD_READ(fa[0][2], va, 2);
+      OASR_QUAD_READ(fb[0][2], vb, 2);
+      OASR_QUAD_READ(fa[0][3], va, 3);
+      OASR_QUAD_READ(fb[0][3], vb, 3);
+    }
+    OASR_QUAD_WAIT(0, 0);
+    OASR_QUAD_FENCE();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int c = ks & 1, n = c ^ 1;
+      const unsigned va = adrA[(ks + 1) & 3] + cur, vb = adrB[(ks + 1) & 3] + cur;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int mt = q >> 2, j = q & 3;
+        OASR_QUAD_MFMA(c, mt, j);
+        OASR_QUAD_FENCE();
+        if (ks < 3 && q < 8) {  // fragments of k-step ks+1: A0 B0 A1 B1 ...
+          if ((q & 1) == 0) OASR_QUAD_READ(fa[n][q >> 1], va, q >> 1);
+          else OASR_QUAD_READ(fb[n][q >> 1], vb, q >> 1);
+        }
+        if (ks == 0 && q >= 8) ra[q - 8] = __builtin_amdgcn_raw_buffer_load_b128(rsa, sa.goff[q - 8], 0, 0);
+        if (ks == 1 && q >= 8) rb[q - 8] = __builtin_amdgcn_raw_buffer_load_b128(rsb, sb.goff[q - 8], 0, 0);
+        if (ks == 2 && q >= 8) *(u32x4_t*)(smem + (sa.loff[q - 8] | nxt)) = ra[q - 8];
+        if (ks == 3 && q < 8) *(u32x4_t*)(smem + ((IMG + sb.loff[q]) | nxt)) = rb[q];
+        OASR_QUAD_FENCE();
+      }
+      if (ks == 0 || ks == 1) OASR_QUAD_WAIT(0, n);  // the 8 reads were issued >= 8 MFMAs ago
+      if (ks == 2) OASR_QUAD_WAIT(8, n);              // ... and are older than the 8 LDS writes that followed them
+      OASR_QUAD_FENCE();
+    }
+    __syncthreads();
+  }
+#undef OASR_QUAD_READ
+#undef OASR_QUAD_WAIT
+#undef OASR_QUAD_MFMA
+#undef OASR_QUAD_FENCE
+  // epilogue: the wave's 128 x 128 block as two 128 x 64 halves through the shared row epilogue (staging tiles alias the A image)
+  fast_epilogue<true, CSUM, true>(p, acc[0], smem + wave * 8192, (float*)(smem + wave * 8192 + 4096), m0, n0 + wn * 64, wm, wn, lane);
+  fast_epilogue<true, CSUM, true>(p, acc[1], smem + wave * 8192, (float*)(smem + wave * 8192 + 4096), m0, n0 + wn * 64 + 64, wm, wn, lane);
+}
+
+
 // ---- 256 x 256 x 64 "ping-pong" kernel ---------------------------------------------------------------------------
 // 8 waves (2 along M x 4 along N, 128 x 64 outputs each), one workgroup per CU, 128 KiB of LDS = two K-tile buffers of
 // four 16 KiB half-tile images (A rows 0-127 / 128-255, B columns 0-127 / 128-255; each image is laid out exactly like
@@ -1369,6 +1537,36 @@ int launch_duo_cfg(const GemmArgs& a, hipStream_t stream) {
   return OASR_OK;
 }
 
+template <bool TA, bool TB, bool CSUM = false>
+int launch_quad_cfg(const GemmArgs& a, hipStream_t stream) {
+  static bool attr = false;
+  const int lds = 2 * 2 * 256 * 64 * 2;  // two K-tile buffers of an A and a B image: 128 KiB
+  if (!attr) {
+    OASR_CHECK_HIP(hipFuncSetAttribute((const void*)oasr_gemm_quad_kernel<TA, TB, CSUM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr = true;
+  }
+  const dim3 grid(cdiv(a.M, 256) * cdiv(a.N, 256));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (g_prof.on) {
+    const size_t idx = g_prof.recs.size();
+    while (g_prof.events.size() < 2 * (idx + 1)) {
+      hipEvent_t e;
+      OASR_CHECK_HIP(hipEventCreate(&e));
+      g_prof.events.push_back(e);
+    }
+    e0 = g_prof.events[2 * idx];
+    e1 = g_prof.events[2 * idx + 1];
+    auto tf = [](bool b) { return b ? "true" : "false"; };
+    static const std::string name = std::string("oasr_gemm_quad_kernel<") + tf(TA) + ", " + tf(TB) + ", " + tf(CSUM) + ">";
+    g_prof.recs.push_back({(TA ? 2 : 0) + (TB ? 1 : 0), 2.0 * (double)a.M * (double)a.N * (double)a.K, name.c_str()});
+    OASR_CHECK_HIP(hipEventRecord(e0, stream));
+  }
+  hipLaunchKernelGGL((oasr_gemm_quad_kernel<TA, TB, CSUM>), grid, dim3(256), lds, stream, a);
+  OASR_LAUNCH_CHECK();
+  if (e1) OASR_CHECK_HIP(hipEventRecord(e1, stream));
+  return OASR_OK;
+}
+
 template <bool TA, bool TB, bool SWAP, bool CSUM, int DMA>
 int launch_pp_variant(const GemmArgs& a, hipStream_t stream) {
   static bool attr = false;
@@ -1497,7 +1695,20 @@ int launch_fast_t(const GemmArgs& a, hipStream_t stream) {
     const char* e = getenv("OASR_GEMM_DUO_K");  // experiments: the duo kernel for every bf16-output GEMM with K <= this
     return e ? atoi(e) : -1;
   }();
-  const bool duo_rule = geom == 0 && !atomic_only && a.split_k == 1 && env_duo_k > 0 && a.K <= env_duo_k && prefer_pingpong(a);
+  static const int env_duo_n = [] {
+    const char* e = getenv("OASR_GEMM_DUO_N");  // ... and N <= this
+    return e ? atoi(e) : 0;
+  }();
+  const bool duo_rule = geom == 0 && !atomic_only && a.split_k == 1 && env_duo_k > 0 && a.K <= env_duo_k &&
+                        (env_duo_n <= 0 || a.N <= env_duo_n) && prefer_pingpong(a);
+  static const int env_quad = [] {
+    const char* e = getenv("OASR_GEMM_QUAD");  // experiments: 1 = the quad kernel for every NT bf16-output GEMM the ping-pong kernel would take
+    return e ? atoi(e) : 0;
+  }();
+  if ((geom == 6 || (geom == 0 && env_quad == 1 && prefer_pingpong(a))) && !atomic_only && a.split_k == 1 && !TA && !TB) {  // 256x256 "quad" kernel
+    const int rc = launch_quad_cfg<false, false>(a, stream);
+    return (rc || !a.colsum) ? rc : launch_colsum_accum(a.out, a.ldc, a.M, a.N, a.colsum, stream);
+  }
   if ((geom == 5 || duo_rule) && !atomic_only && a.split_k == 1) {  // 256x128 "duo" kernel (two workgroups per CU)
     if (a.colsum && !TA && TB) {
       const int rc = launch_duo_cfg<false, true, true>(a, stream);
@@ -1693,5 +1904,5 @@ int gemm_profile_collect(double ms[4], double flops[4], long count[4], char* by_
 
 void gemm_force_general(int on) {
   g_force_general = (on == 1);
-  g_fast_geometry = on >= 2 ? on - 1 : 0;  // 2 -> force 256x128, 3 -> force 256x256 (2-stage), 4 -> force 256x256 ping-pong, 6 -> force 256x128 duo
+  g_fast_geometry = on >= 2 ? on - 1 : 0;  // 2 -> force 256x128, 3 -> force 256x256 (2-stage), 4 -> force 256x256 ping-pong, 6 -> force 256x128 duo, 7 -> force 256x256 quad (NT / NN)
 }

@@ -14,6 +14,10 @@
 // dense DFT, same arithmetic.  The hann window is folded into the basis.  Power and the mel projection stay on chip (LDS), only
 // PCM is read and log-mel written: algorithmic HBM bytes = 2*n (i16) + 4*80*n/160 per clip.
 // The per-clip max (for the -8 floor) is an ordered-uint atomicMax; a second tiny pass applies it.
+#include <stdlib.h>
+
+#include <vector>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -180,6 +184,202 @@ __global__ __launch_bounds__(256) void logmel_main(const PCM* __restrict__ pcm, 
   if (lane == 0 && vmax > -1e29f) atomicMax(clipmax + b, f2ord(vmax));
 }
 
+// ---- FFT front end (the default) -----------------------------------------------------------------------------------------------
+// The dense DFT above spends 0.55 GFLOP per clip on the fp32 matrix pipe (3.5 us/clip at its peak, 6.7 measured) for a kernel
+// whose algorithmic HBM traffic (1.92 MB/clip) needs 0.3 us.  A 400-point real FFT needs ~10 kFLOP per frame = 30 MFLOP per clip:
+// a workgroup takes 32 frames of one clip through
+//     pack      z[n] = w[2n] x[2n] + i w[2n+1] x[2n+1], n < 200   (a real 400-point transform as a complex 200-point one)
+//     stage A   25 x radix-8 over n1 (n = 25 n1 + n2), twiddle W200^(n2 k1)                       -> A[k1][n2]
+//     stage B    8 x 25-point DFT over n2 as 5 x 5 (n2 = 5a + b, k2 = c + 5e; twiddle W25^(b c))   -> Z[k1 + 8 k2]
+//     unpack    X[k] = (Z[k] + conj Z[200-k]) / 2 - i W400^k (Z[k] - conj Z[200-k]) / 2, k <= 200 -> |X[k]|^2
+//     mel       80 triangular filters as sparse rows (402 non-zeros of 16080), log10, per-clip max
+// with every stage laid out as (32 frames) x (8 items per pass) over the 256 threads: the lane index is the frame, so all 32
+// lanes of a half-wave run the same butterfly on different frames -- no divergence, table reads are broadcasts, and every LDS
+// row stride (162 floats of samples, 201 complex / 201 floats per frame) is odd in its access width: conflict-free.  fp32 throughout
+// (twiddles rounded once from double): |error| ~ 1e-7 of the frame's amplitude, same as the k-ordered fmaf chains of the MFMA form.
+constexpr int XT = 32;                        // frames per workgroup
+constexpr int XNS = XT * HOP + (NFFT - HOP);  // 5360 samples
+constexpr int XROW = 201;                     // per-frame row length (complex for Z, float for the power spectrum)
+constexpr int XR0 = XT * XROW;                // region 0 (floats): samples (5426), later the power spectrum (6432)
+constexpr int XTAB = 400 + 402 + 204;         // W200 (200 complex) | W400 (201 complex) | hann[0..200]
+constexpr int XLDS_FLOATS = XR0 + 2 * XT * XROW + XTAB;
+
+struct cf {
+  float x, y;
+};
+__device__ __forceinline__ cf cadd(cf a, cf b) { return cf{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cf csub(cf a, cf b) { return cf{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cf cmul(cf a, cf b) { return cf{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ cf mni(cf a) { return cf{a.y, -a.x}; }  // -i a
+__device__ __forceinline__ cf pli(cf a) { return cf{-a.y, a.x}; }  // +i a
+__device__ __forceinline__ cf cscale(cf a, float s) { return cf{a.x * s, a.y * s}; }
+
+__device__ __forceinline__ void fft8(cf (&v)[8]) {  // forward, natural order in and out
+  constexpr float R2 = 0.70710678118654752f;
+  const cf a0 = cadd(v[0], v[4]), a1 = csub(v[0], v[4]), a2 = cadd(v[2], v[6]), a3 = csub(v[2], v[6]);
+  const cf a4 = cadd(v[1], v[5]), a5 = csub(v[1], v[5]), a6 = cadd(v[3], v[7]), a7 = csub(v[3], v[7]);
+  const cf E0 = cadd(a0, a2), E2 = csub(a0, a2), E1 = cadd(a1, mni(a3)), E3 = cadd(a1, pli(a3));
+  const cf O0 = cadd(a4, a6), O2 = csub(a4, a6), O1 = cadd(a5, mni(a7)), O3 = cadd(a5, pli(a7));
+  const cf w1 = cf{(O1.x + O1.y) * R2, (O1.y - O1.x) * R2};
+  const cf w2 = mni(O2);
+  const cf w3 = cf{(O3.y - O3.x) * R2, (-O3.x - O3.y) * R2};
+  v[0] = cadd(E0, O0);
+  v[1] = cadd(E1, w1);
+  v[2] = cadd(E2, w2);
+  v[3] = cadd(E3, w3);
+  v[4] = csub(E0, O0);
+  v[5] = csub(E1, w1);
+  v[6] = csub(E2, w2);
+  v[7] = csub(E3, w3);
+}
+__device__ __forceinline__ void dft5(cf x0, cf x1, cf x2, cf x3, cf x4, cf (&y)[5]) {  // forward
+  constexpr float C1 = 0.30901699437494742f, C2 = -0.80901699437494742f, S1 = 0.95105651629515357f, S2 = 0.58778525229247313f;
+  const cf t1 = cadd(x1, x4), t2 = cadd(x2, x3), t3 = csub(x1, x4), t4 = csub(x2, x3);
+  y[0] = cadd(x0, cadd(t1, t2));
+  const cf m1 = cf{x0.x + C1 * t1.x + C2 * t2.x, x0.y + C1 * t1.y + C2 * t2.y};
+  const cf m2 = cf{x0.x + C2 * t1.x + C1 * t2.x, x0.y + C2 * t1.y + C1 * t2.y};
+  const cf s1 = cf{S1 * t3.x + S2 * t4.x, S1 * t3.y + S2 * t4.y};
+  const cf s2 = cf{S2 * t3.x - S1 * t4.x, S2 * t3.y - S1 * t4.y};
+  y[1] = cadd(m1, mni(s1));
+  y[2] = cadd(m2, mni(s2));
+  y[3] = cadd(m2, pli(s2));
+  y[4] = cadd(m1, pli(s1));
+}
+__device__ __forceinline__ int xsamp_addr(int s) { return s + 2 * (s / HOP); }  // 162 floats between frames: 81 8-byte slots (odd)
+
+template <typename PCM>
+__global__ __launch_bounds__(256, 2) void logmel_fft(const PCM* __restrict__ pcm, int n_samples, int n_frames,
+                                                     const float* __restrict__ tab,      // [XTAB]
+                                                     const int* __restrict__ mel_idx,    // [80][2]: first bin, first weight
+                                                     const float* __restrict__ mel_val,  // concatenated non-zero weights
+                                                     float* __restrict__ out, unsigned* __restrict__ clipmax) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* samp = smem;             // region 0: samples, later the power spectrum [XT][XROW]
+  float* pw = smem;
+  cf* cb = (cf*)(smem + XR0);     // [XT][XROW] complex
+  float* tw = smem + XR0 + 2 * XT * XROW;
+  const cf* tw200 = (const cf*)tw;
+  const cf* tw400 = (const cf*)(tw + 400);
+  const float* win = tw + 802;
+  const int b = blockIdx.y, f0 = blockIdx.x * XT, tid = threadIdx.x;
+  const int f = tid & 31, j0 = tid >> 5;  // lane = frame, 8 items per pass
+  const PCM* clip = pcm + (long)b * n_samples;
+
+  for (int i = tid; i < XTAB; i += 256) tw[i] = tab[i];
+  // ---- samples of these 32 frames (reflect padding of torch.stft(center=True) at the clip's ends)
+  const long s_begin = (long)f0 * HOP - NFFT / 2;
+  const bool interior = s_begin >= 0 && s_begin + XNS <= n_samples && ((size_t)(clip + s_begin) & 15) == 0;
+  if (interior) {  // (wave-uniform) 16-byte loads; a vector never straddles a hop boundary (160 % 8 == 0), so its floats stay adjacent
+    constexpr int PER = 16 / (int)sizeof(PCM);  // 8 int16 / 4 float samples per load
+    for (int v = tid; v < XNS / PER; v += 256) {
+      const u32x4_t raw = *(const u32x4_t*)(clip + s_begin + (long)v * PER);
+      float* dst = samp + xsamp_addr(v * PER);
+      if (sizeof(PCM) == 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int w = (int)raw[i];
+          *(float2*)(dst + 2 * i) = float2{(float)(short)(w & 0xffff) * (1.0f / 32768.0f), (float)(w >> 16) * (1.0f / 32768.0f)};
+        }
+      } else {
+        *(float2*)dst = float2{__uint_as_float(raw[0]), __uint_as_float(raw[1])};
+        *(float2*)(dst + 2) = float2{__uint_as_float(raw[2]), __uint_as_float(raw[3])};
+      }
+    }
+  } else {
+    for (int s = tid; s < XNS; s += 256) {
+      long idx = s_begin + s;
+      if (idx < 0) idx = -idx;
+      if (idx >= n_samples) idx = 2L * (n_samples - 1) - idx;
+      idx = idx < 0 ? 0 : (idx >= n_samples ? n_samples - 1 : idx);
+      samp[xsamp_addr(s)] = load_pcm<PCM>(clip, idx);
+    }
+  }
+  __syncthreads();
+
+  // ---- stage A
+#pragma unroll 1
+  for (int it = 0; it < 4; ++it) {
+    const int n2 = it * 8 + j0;
+    if (n2 < 25) {
+      cf v[8];
+#pragma unroll
+      for (int n1 = 0; n1 < 8; ++n1) {
+        const int n = 25 * n1 + n2, i0 = 2 * n;
+        const float2 x = *(const float2*)(samp + xsamp_addr(f * HOP + i0));
+        const float w0 = win[i0 <= 200 ? i0 : NFFT - i0], w1 = win[i0 + 1 <= 200 ? i0 + 1 : NFFT - i0 - 1];
+        v[n1] = cf{x.x * w0, x.y * w1};
+      }
+      fft8(v);
+      cf* dst = cb + f * XROW + n2;
+      dst[0] = v[0];
+#pragma unroll
+      for (int k1 = 1; k1 < 8; ++k1) dst[k1 * 25] = cmul(v[k1], tw200[(n2 * k1) % 200]);
+    }
+  }
+  __syncthreads();
+
+  // ---- stage B: k1 = j0
+  {
+    const int k1 = j0;
+    cf a[25];
+    const cf* src = cb + f * XROW + k1 * 25;
+#pragma unroll
+    for (int i = 0; i < 25; ++i) a[i] = src[i];
+    __syncthreads();  // every thread holds its inputs: the rows can be overwritten in natural order
+    cf bm[5][5];      // [b][c]
+#pragma unroll
+    for (int bb = 0; bb < 5; ++bb) {
+      cf y[5];
+      dft5(a[bb], a[5 + bb], a[10 + bb], a[15 + bb], a[20 + bb], y);
+      bm[bb][0] = y[0];
+#pragma unroll
+      for (int c = 1; c < 5; ++c) bm[bb][c] = bb == 0 ? y[c] : cmul(y[c], tw200[8 * bb * c]);  // W25^(b c) = W200^(8 b c)
+    }
+    cf* dst = cb + f * XROW + k1;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      cf y[5];
+      dft5(bm[0][c], bm[1][c], bm[2][c], bm[3][c], bm[4][c], y);
+#pragma unroll
+      for (int e = 0; e < 5; ++e) dst[8 * (c + 5 * e)] = y[e];
+    }
+  }
+  __syncthreads();
+
+  // ---- unpack + power (the samples are dead: region 0 becomes pw)
+#pragma unroll 1
+  for (int it = 0; it < 26; ++it) {
+    const int k = it * 8 + j0;
+    if (k <= 200) {
+      const cf zk = cb[f * XROW + (k == 200 ? 0 : k)];
+      cf zm = cb[f * XROW + (k == 0 ? 0 : 200 - k)];
+      zm.y = -zm.y;
+      const cf e = cscale(cadd(zk, zm), 0.5f), o = cscale(mni(csub(zk, zm)), 0.5f);
+      const cf x = cadd(e, cmul(tw400[k], o));
+      pw[f * XROW + k] = x.x * x.x + x.y * x.y;
+    }
+  }
+  __syncthreads();
+
+  // ---- mel filters (sparse rows), log10, per-clip max, store
+  float vmax = -1e30f;
+  const int t = f0 + f;
+#pragma unroll 1
+  for (int it = 0; it < 10; ++it) {
+    const int m = it * 8 + j0;
+    const int lo = mel_idx[2 * m], p0 = mel_idx[2 * m + 1], cnt = mel_idx[2 * m + 3] - p0;  // ([80] carries the total)
+    float acc = 0.f;
+    for (int i = 0; i < cnt; ++i) acc = fmaf(pw[f * XROW + lo + i], mel_val[p0 + i], acc);
+    if (t < n_frames) {
+      const float v = log10f(fmaxf(acc, 1e-10f));
+      out[((long)b * NMEL + m) * n_frames + t] = v;
+      vmax = fmaxf(vmax, v);
+    }
+  }
+  vmax = wave_max(vmax);
+  if ((tid & 63) == 0 && vmax > -1e29f) atomicMax(clipmax + b, f2ord(vmax));
+}
+
 __global__ __launch_bounds__(256) void logmel_finalize(float* __restrict__ mel, const unsigned* __restrict__ clipmax,
                                                        long per_clip) {
   const int b = blockIdx.y;
@@ -200,6 +400,9 @@ __global__ __launch_bounds__(256) void logmel_finalize(float* __restrict__ mel, 
 struct MelTables {
   float* basis = nullptr;    // [208][416] (folded)
   float* melfilt = nullptr;  // [208][80]
+  float* fft_tab = nullptr;  // [XTAB] twiddles + window of the FFT kernel
+  int* mel_idx = nullptr;    // [81][2] (first bin, first weight) per filter, row 80 = (0, total)
+  float* mel_val = nullptr;  // non-zero filter weights, filter after filter
   int device = -1;
 };
 MelTables g_tables[16];
@@ -260,6 +463,41 @@ static int ensure_tables(int device, MelTables** t_out) {
     oasr_mel_filterbank(fb);
     for (int m = 0; m < NMEL; ++m)
       for (int f = 0; f < NFREQ; ++f) hf[(size_t)f * NMEL + m] = fb[m * NFREQ + f];
+    {  // FFT kernel tables
+      std::vector<float> ft((size_t)XTAB, 0.f);
+      for (int j = 0; j < 200; ++j) {
+        ft[(size_t)2 * j] = (float)cos(2.0 * PI * j / 200.0);
+        ft[(size_t)2 * j + 1] = (float)(-sin(2.0 * PI * j / 200.0));
+      }
+      for (int k = 0; k <= 200; ++k) {
+        ft[(size_t)400 + 2 * k] = (float)cos(2.0 * PI * k / 400.0);
+        ft[(size_t)400 + 2 * k + 1] = (float)(-sin(2.0 * PI * k / 400.0));
+      }
+      for (int j = 0; j <= 200; ++j) ft[(size_t)802 + j] = (float)(0.5 - 0.5 * cos(2.0 * PI * j / NFFT));
+      std::vector<int> idx((size_t)2 * (NMEL + 1), 0);
+      std::vector<float> val;
+      oasr_mel_filterbank(fb);
+      for (int m = 0; m < NMEL; ++m) {
+        int lo = NFREQ, hi = -1;
+        for (int f = 0; f < NFREQ; ++f)
+          if (fb[m * NFREQ + f] != 0.f) {
+            lo = f < lo ? f : lo;
+            hi = f;
+          }
+        if (hi < lo) lo = hi = 0;
+        idx[(size_t)2 * m] = lo;
+        idx[(size_t)2 * m + 1] = (int)val.size();
+        for (int f = lo; f <= hi; ++f) val.push_back(fb[m * NFREQ + f]);
+      }
+      idx[(size_t)2 * NMEL] = 0;
+      idx[(size_t)2 * NMEL + 1] = (int)val.size();
+      OASR_CHECK_HIP(hipMalloc((void**)&t.fft_tab, sizeof(float) * XTAB));
+      OASR_CHECK_HIP(hipMalloc((void**)&t.mel_idx, sizeof(int) * idx.size()));
+      OASR_CHECK_HIP(hipMalloc((void**)&t.mel_val, sizeof(float) * val.size()));
+      OASR_CHECK_HIP(hipMemcpy(t.fft_tab, ft.data(), sizeof(float) * XTAB, hipMemcpyHostToDevice));
+      OASR_CHECK_HIP(hipMemcpy(t.mel_idx, idx.data(), sizeof(int) * idx.size(), hipMemcpyHostToDevice));
+      OASR_CHECK_HIP(hipMemcpy(t.mel_val, val.data(), sizeof(float) * val.size(), hipMemcpyHostToDevice));
+    }
     OASR_CHECK_HIP(hipMalloc((void**)&t.basis, sizeof(float) * NK * NB));
     OASR_CHECK_HIP(hipMalloc((void**)&t.melfilt, sizeof(float) * NBH * NMEL));
     OASR_CHECK_HIP(hipMemcpy(t.basis, hb, sizeof(float) * NK * NB, hipMemcpyHostToDevice));
@@ -289,6 +527,36 @@ extern "C" int oasr_log_mel(const void* pcm, int pcm_dtype, int B, int n_samples
   if (rc) return rc;
   unsigned* clipmax = (unsigned*)workspace;
   OASR_CHECK_HIP(hipMemsetAsync(clipmax, 0, sizeof(unsigned) * B, stream));
+  static const bool use_mfma_dft = [] {
+    const char* e = getenv("OASR_LOGMEL");  // "mfma": the dense folded DFT on the fp32 matrix pipe (round 1-2 kernel; A/B and cross-check)
+    return e && strcmp(e, "mfma") == 0;
+  }();
+  const long per_clip = (long)NMEL * n_frames;
+  const dim3 g2((unsigned)((per_clip / 4 + 255) / 256 > 64 ? 64 : (per_clip / 4 + 255) / 256 + 1), B);
+  if (!use_mfma_dft) {
+    const size_t xlds = sizeof(float) * XLDS_FLOATS;
+    const dim3 xgrid(cdiv(n_frames, XT), B);
+    static bool attr16 = false, attr32 = false;
+    if (pcm_dtype == 1) {
+      if (!attr16) {
+        OASR_CHECK_HIP(hipFuncSetAttribute((const void*)logmel_fft<int16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)xlds));
+        attr16 = true;
+      }
+      hipLaunchKernelGGL(logmel_fft<int16_t>, xgrid, dim3(256), xlds, stream, (const int16_t*)pcm, n_samples, n_frames, t->fft_tab,
+                         t->mel_idx, t->mel_val, mel, clipmax);
+    } else {
+      if (!attr32) {
+        OASR_CHECK_HIP(hipFuncSetAttribute((const void*)logmel_fft<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)xlds));
+        attr32 = true;
+      }
+      hipLaunchKernelGGL(logmel_fft<float>, xgrid, dim3(256), xlds, stream, (const float*)pcm, n_samples, n_frames, t->fft_tab, t->mel_idx,
+                         t->mel_val, mel, clipmax);
+    }
+    OASR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(logmel_finalize, g2, dim3(256), 0, stream, mel, clipmax, per_clip);
+    OASR_LAUNCH_CHECK();
+    return OASR_OK;
+  }
   constexpr int SAMP_FLOATS = NS + 4 * (NS / HOP + 1);
   constexpr int REG0 = (SAMP_FLOATS > 4 * 16 * P_LD ? SAMP_FLOATS : 4 * 16 * P_LD);
   const size_t lds = sizeof(float) * (((REG0 + 3) & ~3) + KS * SLAB_LD);
@@ -311,8 +579,6 @@ extern "C" int oasr_log_mel(const void* pcm, int pcm_dtype, int B, int n_samples
                        t->melfilt, mel, clipmax);
   }
   OASR_LAUNCH_CHECK();
-  const long per_clip = (long)NMEL * n_frames;
-  dim3 g2((unsigned)((per_clip / 4 + 255) / 256 > 64 ? 64 : (per_clip / 4 + 255) / 256 + 1), B);
   hipLaunchKernelGGL(logmel_finalize, g2, dim3(256), 0, stream, mel, clipmax, per_clip);
   OASR_LAUNCH_CHECK();
   return OASR_OK;
