@@ -969,6 +969,10 @@ __global__ __launch_bounds__(256, 1) void oasr_gemm_quad_kernel(GemmArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.f;
 
+  // Register-staged operand pipeline, one K-tile deep in registers and one in LDS: while tile t is multiplied out of LDS buffer
+  // t & 1, tile t+1 (loaded a whole K-tile ago) moves from the staging registers into the other buffer, and each register is
+  // re-loaded with its piece of tile t+2 right behind the ds_write that freed it -- 16 global loads stay in flight for ~2k cycles,
+  // so no s_waitcnt vmcnt in the loop ever waits for memory.
   u32x4_t ra[8], rb[8];
   {
     const __amdgpu_buffer_rsrc_t rsa = make_rsrc(gA), rsb = make_rsrc(gB);
@@ -981,13 +985,21 @@ __global__ __launch_bounds__(256, 1) void oasr_gemm_quad_kernel(GemmArgs p) {
       *(u32x4_t*)(smem + sa.loff[i]) = ra[i];
       *(u32x4_t*)(smem + IMG + sb.loff[i]) = rb[i];
     }
+    const int t1 = nt > 1 ? 1 : 0;
+    const __amdgpu_buffer_rsrc_t rsa1 = make_rsrc(gA + (long)t1 * BK), rsb1 = make_rsrc(gB + (long)t1 * BK);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsa1, sa.goff[i], 0, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsb1, sb.goff[i], 0, 0);
   }
   __syncthreads();
 
-  // One MFMA and at most one other memory instruction per slot, in exactly this order (sched_barrier(0) on both sides).
+  // One MFMA and at most one LDS access + one global load per slot, in exactly this order (sched_barrier(0) on both sides).
   // Fragment reads are inline asm so that hipcc neither moves them next to their consumers nor waits for them early: the
   // wait is the counted s_waitcnt in front of the k-step that consumes them, and it names the destinations ("+v") so that no
-  // MFMA can be scheduled above it (cdna_hip_programming.md section 5.7, form (ii)).
+  // MFMA can be scheduled above it (cdna_hip_programming.md section 5.7, form (ii)).  The workgroup barrier of a K-tile sits in
+  // the MIDDLE of its last k-step, right behind the last staging write, and the first fragments of the next tile are read under
+  // the remaining 8 MFMAs: the top of a tile never waits for LDS either.
   bf16x8_t fa[2][4], fb[2][4];
 #define OASR_QUAD_READ(DST, ADDR, BLK) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "i"((BLK) * 4096) : "memory")
 #define OASR_QUAD_WAIT(CNT, S)                                                                                                       \
@@ -996,48 +1008,61 @@ __global__ __launch_bounds__(256, 1) void oasr_gemm_quad_kernel(GemmArgs p) {
 #define OASR_QUAD_MFMA(C, MT, J) \
   acc[(J) >> 1][MT][(J) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[C][J], fa[C][MT], acc[(J) >> 1][MT][(J) & 1], 0, 0, 0)
 #define OASR_QUAD_FENCE() __builtin_amdgcn_sched_barrier(0)
+  {
+    OASR_QUAD_READ(fa[0][0], adrA[0], 0);
+    OASR_QUAD_READ(fb[0][0], adrB[0], 0);
+    OASR_QUAD_READ(fa[0][1], adrA[0], 1);
+    OASR_QUAD_READ(fb[0][1], adrB[0], 1);
+    OASR_QUAD_READ(fa[0][2], adrA[0], 2);
+    OASR_QUAD_READ(fb[0][2], adrB[0], 2);
+    OASR_QUAD_READ(fa[0][3], adrA[0], 3);
+    OASR_QUAD_READ(fb[0][3], adrB[0], 3);
+  }
   for (int t = 0; t < nt; ++t) {
     const unsigned cur = (unsigned)(t & 1) << 16, nxt = cur ^ 0x10000u;
-    const int tn1 = t + 1 < nt ? t + 1 : t;  // branch-free body: the last iteration stages its own tile into the dead buffer
-    const __amdgpu_buffer_rsrc_t rsa = make_rsrc(gA + (long)tn1 * BK), rsb = make_rsrc(gB + (long)tn1 * BK);
-    {
-      const unsigned va = adrA[0] + cur, vb = adrB[0] + cur;
-      OASR_QUAD_READ(fa[0][0], va, 0);
-      OASR_QUAD_READ(fb[0][0], vb, 0);
-      OASR_QUAD_READ(fa[0][1], va, 1);
-      OASR_QUAD_READ(fb[0][1], vb, 1);
-      OASR_QUAD_READ(fa[0][2], va, 2);
-      OASR_QUAD_READ(fb[0][2], vb, 2);
-      OASR_QUAD_READ(fa[0][3], va, 3);
-      OASR_QUAD_READ(fb[0][3], vb, 3);
-    }
+    const int t2 = t + 2 < nt ? t + 2 : nt - 1;  // branch-free body: the last iterations re-stage the last tile into dead space
+    const __amdgpu_buffer_rsrc_t rsa = make_rsrc(gA + (long)t2 * BK), rsb = make_rsrc(gB + (long)t2 * BK);
     OASR_QUAD_WAIT(0, 0);
     OASR_QUAD_FENCE();
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int c = ks & 1, n = c ^ 1;
-      const unsigned va = adrA[(ks + 1) & 3] + cur, vb = adrB[(ks + 1) & 3] + cur;
+      // k-steps 0-2 read the fragments of the next k-step of THIS tile; k-step 3 (behind the barrier) those of k-step 0 of the next
+      const unsigned va = adrA[(ks + 1) & 3] + (ks < 3 ? cur : nxt), vb = adrB[(ks + 1) & 3] + (ks < 3 ? cur : nxt);
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int mt = q >> 2, j = q & 3;
         OASR_QUAD_MFMA(c, mt, j);
         OASR_QUAD_FENCE();
-        if (ks < 3 && q < 8) {  // fragments of k-step ks+1: A0 B0 A1 B1 ...
+        if (ks < 3 && q < 8) {  // A0 B0 A1 B1 ...
           if ((q & 1) == 0) OASR_QUAD_READ(fa[n][q >> 1], va, q >> 1);
           else OASR_QUAD_READ(fb[n][q >> 1], vb, q >> 1);
         }
-        if (ks == 0 && q >= 8) ra[q - 8] = __builtin_amdgcn_raw_buffer_load_b128(rsa, sa.goff[q - 8], 0, 0);
-        if (ks == 1 && q >= 8) rb[q - 8] = __builtin_amdgcn_raw_buffer_load_b128(rsb, sb.goff[q - 8], 0, 0);
-        if (ks == 2 && q >= 8) *(u32x4_t*)(smem + (sa.loff[q - 8] | nxt)) = ra[q - 8];
-        if (ks == 3 && q < 8) *(u32x4_t*)(smem + ((IMG + sb.loff[q]) | nxt)) = rb[q];
+        if (ks == 2 && q >= 8) {  // tile t+1: registers -> the other buffer; the freed register takes its piece of tile t+2
+          *(u32x4_t*)(smem + (sa.loff[q - 8] | nxt)) = ra[q - 8];
+          ra[q - 8] = __builtin_amdgcn_raw_buffer_load_b128(rsa, sa.goff[q - 8], 0, 0);
+        }
+        if (ks == 3 && q < 8) {
+          *(u32x4_t*)(smem + ((IMG + sb.loff[q]) | nxt)) = rb[q];
+          rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rsb, sb.goff[q], 0, 0);
+        }
+        if (ks == 3 && q == 7) {  // every wave's pieces of tile t+1 are in LDS, every read of this tile's buffer is retired
+          OASR_QUAD_FENCE();
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        if (ks == 3 && q >= 8 && q < 12) {  // two reads per slot: the last one is 4 MFMAs old at the top of the next tile
+          OASR_QUAD_READ(fa[n][q - 8], va, q - 8);
+          OASR_QUAD_READ(fb[n][q - 8], vb, q - 8);
+        }
         OASR_QUAD_FENCE();
       }
       if (ks == 0 || ks == 1) OASR_QUAD_WAIT(0, n);  // the 8 reads were issued >= 8 MFMAs ago
       if (ks == 2) OASR_QUAD_WAIT(8, n);              // ... and are older than the 8 LDS writes that followed them
       OASR_QUAD_FENCE();
     }
-    __syncthreads();
   }
+  OASR_QUAD_WAIT(0, 0);  // the look-ahead reads of the last iteration land in registers the epilogue is about to reuse
+  __syncthreads();
 #undef OASR_QUAD_READ
 #undef OASR_QUAD_WAIT
 #undef OASR_QUAD_MFMA

@@ -201,8 +201,11 @@ constexpr int XT = 32;                        // frames per workgroup
 constexpr int XNS = XT * HOP + (NFFT - HOP);  // 5360 samples
 constexpr int XROW = 201;                     // per-frame row length (complex for Z, float for the power spectrum)
 constexpr int XR0 = XT * XROW;                // region 0 (floats): samples (5426), later the power spectrum (6432)
-constexpr int XTAB = 400 + 402 + 204;         // W200 (200 complex) | W400 (201 complex) | hann[0..200]
-constexpr int XLDS_FLOATS = XR0 + 2 * XT * XROW + XTAB;
+// constant tables, one LDS slot re-filled per stage (80 KiB per workgroup = two workgroups per CU leaves 2.4 KiB for them):
+//   stage A/B: W200 (200 complex) | hann[0..200] (+3 pad);  unpack: W400 (201 complex);  mel: (first bin, first weight) x 81 | weights
+constexpr int XTAB_A = 400 + 204, XTAB_P = 402, XTAB_M_MAX = 604, XTAB_SLOT = 604;
+constexpr int XTAB_OFF_P = XTAB_A, XTAB_OFF_M = XTAB_A + XTAB_P, XTAB = XTAB_A + XTAB_P + XTAB_M_MAX;
+constexpr int XLDS_FLOATS = XR0 + 2 * XT * XROW + XTAB_SLOT;
 
 struct cf {
   float x, y;
@@ -249,23 +252,22 @@ __device__ __forceinline__ int xsamp_addr(int s) { return s + 2 * (s / HOP); }  
 
 template <typename PCM>
 __global__ __launch_bounds__(256, 2) void logmel_fft(const PCM* __restrict__ pcm, int n_samples, int n_frames,
-                                                     const float* __restrict__ tab,      // [XTAB]
-                                                     const int* __restrict__ mel_idx,    // [80][2]: first bin, first weight
-                                                     const float* __restrict__ mel_val,  // concatenated non-zero weights
+                                                     const float* __restrict__ tab,  // [XTAB]: the three stage tables
+                                                     int mel_words,                  // words of the mel table (162 + non-zeros)
                                                      float* __restrict__ out, unsigned* __restrict__ clipmax) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* samp = smem;             // region 0: samples, later the power spectrum [XT][XROW]
   float* pw = smem;
   cf* cb = (cf*)(smem + XR0);     // [XT][XROW] complex
   float* tw = smem + XR0 + 2 * XT * XROW;
-  const cf* tw200 = (const cf*)tw;
-  const cf* tw400 = (const cf*)(tw + 400);
-  const float* win = tw + 802;
+  const cf* tw200 = (const cf*)tw;  // stages A and B
+  const float* win = tw + 400;      // stage A
+  const cf* tw400 = (const cf*)tw;  // unpack (slot re-filled)
   const int b = blockIdx.y, f0 = blockIdx.x * XT, tid = threadIdx.x;
   const int f = tid & 31, j0 = tid >> 5;  // lane = frame, 8 items per pass
   const PCM* clip = pcm + (long)b * n_samples;
 
-  for (int i = tid; i < XTAB; i += 256) tw[i] = tab[i];
+  for (int i = tid; i < XTAB_A; i += 256) tw[i] = tab[i];
   // ---- samples of these 32 frames (reflect padding of torch.stft(center=True) at the clip's ends)
   const long s_begin = (long)f0 * HOP - NFFT / 2;
   const bool interior = s_begin >= 0 && s_begin + XNS <= n_samples && ((size_t)(clip + s_begin) & 15) == 0;
@@ -345,9 +347,11 @@ __global__ __launch_bounds__(256, 2) void logmel_fft(const PCM* __restrict__ pcm
     }
   }
   __syncthreads();
+  for (int i = tid; i < XTAB_P; i += 256) tw[i] = tab[XTAB_OFF_P + i];
+  __syncthreads();
 
   // ---- unpack + power (the samples are dead: region 0 becomes pw)
-#pragma unroll 1
+#pragma unroll 2
   for (int it = 0; it < 26; ++it) {
     const int k = it * 8 + j0;
     if (k <= 200) {
@@ -360,14 +364,18 @@ __global__ __launch_bounds__(256, 2) void logmel_fft(const PCM* __restrict__ pcm
     }
   }
   __syncthreads();
+  for (int i = tid; i < mel_words; i += 256) tw[i] = tab[XTAB_OFF_M + i];
+  __syncthreads();
 
   // ---- mel filters (sparse rows), log10, per-clip max, store
+  const int* mel_idx = (const int*)tw;  // [81][2]: first bin, first weight (row 80 carries the total)
+  const float* mel_val = tw + 162;
   float vmax = -1e30f;
   const int t = f0 + f;
 #pragma unroll 1
   for (int it = 0; it < 10; ++it) {
     const int m = it * 8 + j0;
-    const int lo = mel_idx[2 * m], p0 = mel_idx[2 * m + 1], cnt = mel_idx[2 * m + 3] - p0;  // ([80] carries the total)
+    const int lo = mel_idx[2 * m], p0 = mel_idx[2 * m + 1], cnt = mel_idx[2 * m + 3] - p0;
     float acc = 0.f;
     for (int i = 0; i < cnt; ++i) acc = fmaf(pw[f * XROW + lo + i], mel_val[p0 + i], acc);
     if (t < n_frames) {
@@ -400,9 +408,8 @@ __global__ __launch_bounds__(256) void logmel_finalize(float* __restrict__ mel, 
 struct MelTables {
   float* basis = nullptr;    // [208][416] (folded)
   float* melfilt = nullptr;  // [208][80]
-  float* fft_tab = nullptr;  // [XTAB] twiddles + window of the FFT kernel
-  int* mel_idx = nullptr;    // [81][2] (first bin, first weight) per filter, row 80 = (0, total)
-  float* mel_val = nullptr;  // non-zero filter weights, filter after filter
+  float* fft_tab = nullptr;  // [XTAB] stage tables of the FFT kernel (twiddles, window, sparse mel filters)
+  int mel_words = 0;         // used words of its mel table
   int device = -1;
 };
 MelTables g_tables[16];
@@ -469,11 +476,11 @@ static int ensure_tables(int device, MelTables** t_out) {
         ft[(size_t)2 * j] = (float)cos(2.0 * PI * j / 200.0);
         ft[(size_t)2 * j + 1] = (float)(-sin(2.0 * PI * j / 200.0));
       }
+      for (int j = 0; j <= 200; ++j) ft[(size_t)400 + j] = (float)(0.5 - 0.5 * cos(2.0 * PI * j / NFFT));
       for (int k = 0; k <= 200; ++k) {
-        ft[(size_t)400 + 2 * k] = (float)cos(2.0 * PI * k / 400.0);
-        ft[(size_t)400 + 2 * k + 1] = (float)(-sin(2.0 * PI * k / 400.0));
+        ft[(size_t)XTAB_OFF_P + 2 * k] = (float)cos(2.0 * PI * k / 400.0);
+        ft[(size_t)XTAB_OFF_P + 2 * k + 1] = (float)(-sin(2.0 * PI * k / 400.0));
       }
-      for (int j = 0; j <= 200; ++j) ft[(size_t)802 + j] = (float)(0.5 - 0.5 * cos(2.0 * PI * j / NFFT));
       std::vector<int> idx((size_t)2 * (NMEL + 1), 0);
       std::vector<float> val;
       oasr_mel_filterbank(fb);
@@ -491,12 +498,15 @@ static int ensure_tables(int device, MelTables** t_out) {
       }
       idx[(size_t)2 * NMEL] = 0;
       idx[(size_t)2 * NMEL + 1] = (int)val.size();
+      if (idx.size() + val.size() > (size_t)XTAB_M_MAX) {
+        oasr_set_error("log-mel: sparse filterbank (%zu words) exceeds its LDS slot", idx.size() + val.size());
+        return OASR_ESTATE;
+      }
+      memcpy(&ft[(size_t)XTAB_OFF_M], idx.data(), idx.size() * sizeof(int));
+      memcpy(&ft[(size_t)XTAB_OFF_M + idx.size()], val.data(), val.size() * sizeof(float));
+      t.mel_words = (int)(idx.size() + val.size());
       OASR_CHECK_HIP(hipMalloc((void**)&t.fft_tab, sizeof(float) * XTAB));
-      OASR_CHECK_HIP(hipMalloc((void**)&t.mel_idx, sizeof(int) * idx.size()));
-      OASR_CHECK_HIP(hipMalloc((void**)&t.mel_val, sizeof(float) * val.size()));
       OASR_CHECK_HIP(hipMemcpy(t.fft_tab, ft.data(), sizeof(float) * XTAB, hipMemcpyHostToDevice));
-      OASR_CHECK_HIP(hipMemcpy(t.mel_idx, idx.data(), sizeof(int) * idx.size(), hipMemcpyHostToDevice));
-      OASR_CHECK_HIP(hipMemcpy(t.mel_val, val.data(), sizeof(float) * val.size(), hipMemcpyHostToDevice));
     }
     OASR_CHECK_HIP(hipMalloc((void**)&t.basis, sizeof(float) * NK * NB));
     OASR_CHECK_HIP(hipMalloc((void**)&t.melfilt, sizeof(float) * NBH * NMEL));
@@ -543,14 +553,14 @@ extern "C" int oasr_log_mel(const void* pcm, int pcm_dtype, int B, int n_samples
         attr16 = true;
       }
       hipLaunchKernelGGL(logmel_fft<int16_t>, xgrid, dim3(256), xlds, stream, (const int16_t*)pcm, n_samples, n_frames, t->fft_tab,
-                         t->mel_idx, t->mel_val, mel, clipmax);
+                         t->mel_words, mel, clipmax);
     } else {
       if (!attr32) {
         OASR_CHECK_HIP(hipFuncSetAttribute((const void*)logmel_fft<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)xlds));
         attr32 = true;
       }
-      hipLaunchKernelGGL(logmel_fft<float>, xgrid, dim3(256), xlds, stream, (const float*)pcm, n_samples, n_frames, t->fft_tab, t->mel_idx,
-                         t->mel_val, mel, clipmax);
+      hipLaunchKernelGGL(logmel_fft<float>, xgrid, dim3(256), xlds, stream, (const float*)pcm, n_samples, n_frames, t->fft_tab, t->mel_words,
+                         mel, clipmax);
     }
     OASR_LAUNCH_CHECK();
     hipLaunchKernelGGL(logmel_finalize, g2, dim3(256), 0, stream, mel, clipmax, per_clip);
