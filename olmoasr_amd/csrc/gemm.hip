@@ -888,37 +888,12 @@ __global__ __launch_bounds__(256, 2) void oasr_gemm_duo_kernel(GemmArgs p) {
 // fed: a direct-to-LDS piece occupies the issue port for ~60 cycles (MI355X_MICROARCH.md), longer than the 32-cycle shadow of a
 // 32x32x16 MFMA, which is why the operands go global -> VGPR -> LDS here: a 16-byte global load and a ds_write_b128 each fit
 // inside one shadow.  Per K-tile and wave: 64 MFMAs, 32 ds_read_b128 (fragments of k-step ks+1 under the MFMAs of ks), 16 global
-// loads (tile t+1, under k-steps 0-1) and 16 ds_write_b128 (under k-steps 2-3, into the other LDS buffer); ONE workgroup barrier
-// per K-tile.  The interleave is pinned with sched_group_barrier (the loop body is branch-free: the last iteration re-loads its
-// own tile into the dead buffer).  Accumulators: 16 x 16 = 256 registers; LDS 2 x 64 KiB.
-template <bool TRANS, int ROWS /*tile rows (M or N extent)*/>
-struct QuadStage {  // this thread's 8 x 16-byte pieces of a [ROWS x 64] (or [64 x ROWS]) operand tile
-  static_assert(ROWS == 256, "quad kernel tiles are 256 wide");
-  // !TRANS: piece p -> row = p*32 + (tid >> 3), chunk c16 = tid & 7      (8 lanes cover one 128-byte row segment)
-  //  TRANS: piece p -> k-row = p*8 + (tid >> 5), chunk c16 = tid & 31    (32 lanes cover one 512-byte k-row)
-  unsigned goff[8];  // byte offsets from the tile's base pointer
-  unsigned loff[8];  // byte offsets into the LDS image
-  __device__ __forceinline__ void init(const OperandView& v, int R, int row0, int tid) {
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      if (!TRANS) {
-        const int row = p * 32 + (tid >> 3), c16 = tid & 7;
-        int gr = row0 + row;
-        gr = gr < R ? gr : R - 1;  // (clamped rows only reach outputs that are never stored)
-        goff[p] = (unsigned)(((long)(gr - row0) * v.ld + c16 * 8) * 2);
-        loff[p] = (unsigned)(row * 128 + ((c16 ^ ((row >> 1) & 7)) << 4));
-      } else {
-        const int krow = p * 8 + (tid >> 5), c16 = tid & 31;
-        int col = row0 + c16 * 8;
-        col = col + 8 <= R ? col : R - 8;
-        goff[p] = (unsigned)(((long)krow * v.ld + (col - row0)) * 2);
-        loff[p] = (unsigned)(krow * 512 + ((c16 ^ ((krow & 3) << 2)) << 4));
-      }
-    }
-  }
-};
-
-template <bool TA, bool TB, bool CSUM>
+// loads and 16 ds_write_b128 (under k-steps 2-3, into the other LDS buffer); ONE workgroup barrier per K-tile.  Every slot of the
+// stream is placed by hand (sched_barrier(0) fences, inline-asm fragment reads with counted waits); the loop body is branch-free
+// (the last iterations re-load the last tile into dead space).  Accumulators: 16 x 16 = 256 registers (AGPRs); LDS 2 x 64 KiB.
+// ABL (timing experiments only, results are garbage): bit 0 = no global loads / staging writes, bit 1 = no fragment reads,
+// bit 2 = no workgroup barrier, bit 3 = no MFMAs
+template <bool TA, bool TB, bool CSUM, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void oasr_gemm_quad_kernel(GemmArgs p) {
   static_assert(!TA && !TB, "quad kernel: k-contiguous operands (the NT forward layout)");
   constexpr int IMG = 256 * 64 * 2;  // one operand image: 32 KiB; buffer b = [A image | B image] at b * 64 KiB
@@ -941,11 +916,20 @@ __global__ __launch_bounds__(256, 1) void oasr_gemm_quad_kernel(GemmArgs p) {
   }
   const int m0 = tm * 256, n0 = tn * 256;
   const int nt = p.K / BK;
-  QuadStage<false, 256> sa, sb;
-  sa.init(p.A, p.M, m0, tid);
-  sb.init(p.B, p.N, n0, tid);
+  // Staging geometry (k-contiguous operands): piece i of this thread = row i*32 + (tid >> 3), 16-byte chunk tid & 7 of a 256 x 64
+  // image.  Global side: ONE per-lane byte offset per operand + a scalar offset per piece (rows past the operand's end are cut
+  // off by the buffer descriptor's range and read as zeros: they only reach outputs that are never stored).  LDS side: the XOR
+  // swizzle depends on (row >> 1) & 7, which the +32 rows of a piece leave alone: ONE per-lane address + 4 KiB immediates.
+  const int srow = tid >> 3, sc16 = tid & 7;
+  const unsigned voffA = (unsigned)(((long)srow * p.A.ld + sc16 * 8) * 2), voffB = (unsigned)(((long)srow * p.B.ld + sc16 * 8) * 2);
+  const unsigned pieceA = (unsigned)(32L * p.A.ld * 2), pieceB = (unsigned)(32L * p.B.ld * 2);  // bytes between pieces
+  const unsigned lw = (unsigned)(srow * 128 + ((sc16 ^ ((srow >> 1) & 7)) << 4));               // LDS offset of piece 0 in its image
   const bf16_t* gA = p.A.ptr + (long)m0 * p.A.ld;
   const bf16_t* gB = p.B.ptr + (long)n0 * p.B.ld;
+  const int rowsA = min(256, p.M - m0), rowsB = min(256, p.N - n0);
+  // descriptor of the operand tile at K-tile T: base advanced by T * 128 bytes, range = up to the end of the last valid row
+#define OASR_QUAD_RSRC(G, LD, ROWS, T) \
+  __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>((G) + (long)(T) * BK), 0, (int)((((long)(ROWS) - 1) * (LD) + (p.K - (T) * BK)) * 2), 0x00020000)
   // fragment read addresses (buffer 0): lane holds row (l & 31) of a 32-row block, 16-byte chunk ks*2 + (l >> 5), XOR-swizzled by
   // (row >> 1) & 7 -- the XOR makes the k-step a per-lane term, so one address per k-step; blocks are +4096 immediates
   unsigned adrA[4], adrB[4];
@@ -969,29 +953,36 @@ __global__ __launch_bounds__(256, 1) void oasr_gemm_quad_kernel(GemmArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.f;
 
-  // Register-staged operand pipeline, one K-tile deep in registers and one in LDS: while tile t is multiplied out of LDS buffer
-  // t & 1, tile t+1 (loaded a whole K-tile ago) moves from the staging registers into the other buffer, and each register is
-  // re-loaded with its piece of tile t+2 right behind the ds_write that freed it -- 16 global loads stay in flight for ~2k cycles,
-  // so no s_waitcnt vmcnt in the loop ever waits for memory.
-  u32x4_t ra[8], rb[8];
-  {
-    const __amdgpu_buffer_rsrc_t rsa = make_rsrc(gA), rsb = make_rsrc(gB);
+  // Register-staged operand pipeline, TWO K-tiles deep in registers and one in LDS: while tile t is multiplied out of LDS buffer
+  // t & 1, tile t+1 moves from staging set t & 1 ... into the other buffer, and each freed register is re-loaded with its piece
+  // of tile t+3 right behind the ds_write; the other set (tile t+2) stays in flight.  A load has two K-tiles (~2.5 us) to land:
+  // under full-chip load an HBM/MALL read takes 1.3-2.5 us (the one-tile-deep version of this loop ran at exactly its load
+  // latency: scripts/quad_probe.py ablations, profiles/r03_quad_ablation.txt).
+  // (The B operand -- weights, re-read by every row panel of an XCD and L2-resident -- keeps a one-tile flight: a second register
+  // set for it does not fit beside 64 fragment and 64 + 32 staging registers.)
+  u32x4_t xa[8], xb[8], ya[8];
+#define OASR_QUAD_LOAD_A(RA, T)                                                                                        \
+  do {                                                                                                                 \
+    const int t_ = (T) < nt ? (T) : nt - 1;                                                                            \
+    const __amdgpu_buffer_rsrc_t ra_ = OASR_QUAD_RSRC(gA, p.A.ld, rowsA, t_);                                          \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) RA[i_] = __builtin_amdgcn_raw_buffer_load_b128(ra_, voffA, i_ * pieceA, 0); \
+  } while (0)
+#define OASR_QUAD_LOAD_B(RB, T)                                                                                        \
+  do {                                                                                                                 \
+    const int t_ = (T) < nt ? (T) : nt - 1;                                                                            \
+    const __amdgpu_buffer_rsrc_t rb_ = OASR_QUAD_RSRC(gB, p.B.ld, rowsB, t_);                                          \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) RB[i_] = __builtin_amdgcn_raw_buffer_load_b128(rb_, voffB, i_ * pieceB, 0); \
+  } while (0)
+  OASR_QUAD_LOAD_A(xa, 0);
+  OASR_QUAD_LOAD_B(xb, 0);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsa, sa.goff[i], 0, 0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsb, sb.goff[i], 0, 0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      *(u32x4_t*)(smem + sa.loff[i]) = ra[i];
-      *(u32x4_t*)(smem + IMG + sb.loff[i]) = rb[i];
-    }
-    const int t1 = nt > 1 ? 1 : 0;
-    const __amdgpu_buffer_rsrc_t rsa1 = make_rsrc(gA + (long)t1 * BK), rsb1 = make_rsrc(gB + (long)t1 * BK);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsa1, sa.goff[i], 0, 0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsb1, sb.goff[i], 0, 0);
+  for (int i = 0; i < 8; ++i) {
+    *(u32x4_t*)(smem + lw + i * 4096) = xa[i];
+    *(u32x4_t*)(smem + IMG + lw + i * 4096) = xb[i];
   }
+  OASR_QUAD_LOAD_A(xa, 1);
+  OASR_QUAD_LOAD_B(xb, 1);
+  OASR_QUAD_LOAD_A(ya, 2);
   __syncthreads();
 
   // One MFMA and at most one LDS access + one global load per slot, in exactly this order (sched_barrier(0) on both sides).
@@ -1008,6 +999,50 @@ __global__ __launch_bounds__(256, 1) void oasr_gemm_quad_kernel(GemmArgs p) {
 #define OASR_QUAD_MFMA(C, MT, J) \
   acc[(J) >> 1][MT][(J) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[C][J], fa[C][MT], acc[(J) >> 1][MT][(J) & 1], 0, 0, 0)
 #define OASR_QUAD_FENCE() __builtin_amdgcn_sched_barrier(0)
+  // one K-tile: multiply out of buffer (T & 1); RA holds A of tile T+1 and is re-loaded with tile T+3, xb holds B of tile T+1
+  // and is re-loaded with tile T+2
+#define OASR_QUAD_TILE(RA, RB, T)                                                                                                    \
+  do {                                                                                                                               \
+    const unsigned cur = (unsigned)((T) & 1) << 16, nxt = cur ^ 0x10000u;                                                            \
+    const int t3 = (T) + 3 < nt ? (T) + 3 : nt - 1, t2 = (T) + 2 < nt ? (T) + 2 : nt - 1;                                            \
+    const __amdgpu_buffer_rsrc_t rsa = OASR_QUAD_RSRC(gA, p.A.ld, rowsA, t3), rsb = OASR_QUAD_RSRC(gB, p.B.ld, rowsB, t2);           \
+    const unsigned wa = lw + nxt, wb = lw + IMG + nxt;                                                                               \
+    OASR_QUAD_WAIT(0, 0);                                                                                                            \
+    OASR_QUAD_FENCE();                                                                                                               \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                                               \
+      const int c = ks & 1, n = c ^ 1;                                                                                               \
+      const unsigned va = adrA[(ks + 1) & 3] + (ks < 3 ? cur : nxt), vb = adrB[(ks + 1) & 3] + (ks < 3 ? cur : nxt);                 \
+      _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                                                               \
+        const int mt = q >> 2, j = q & 3;                                                                                            \
+        if (!(ABL & 8)) OASR_QUAD_MFMA(c, mt, j);                                                                                    \
+        OASR_QUAD_FENCE();                                                                                                           \
+        if (!(ABL & 2) && ks < 3 && q < 8) {                                                                                         \
+          if ((q & 1) == 0) OASR_QUAD_READ(fa[n][q >> 1], va, q >> 1);                                                               \
+          else OASR_QUAD_READ(fb[n][q >> 1], vb, q >> 1);                                                                            \
+        }                                                                                                                            \
+        if (!(ABL & 1) && ks == 2 && q >= 8) {                                                                                       \
+          *(u32x4_t*)(smem + wa + (q - 8) * 4096) = RA[q - 8];                                                                       \
+          RA[q - 8] = __builtin_amdgcn_raw_buffer_load_b128(rsa, voffA, (q - 8) * pieceA, 0);                                        \
+        }                                                                                                                            \
+        if (!(ABL & 1) && ks == 3 && q < 8) {                                                                                        \
+          *(u32x4_t*)(smem + wb + q * 4096) = RB[q];                                                                                 \
+          RB[q] = __builtin_amdgcn_raw_buffer_load_b128(rsb, voffB, q * pieceB, 0);                                                  \
+        }                                                                                                                            \
+        if (ks == 3 && q == 7) {                                                                                                     \
+          OASR_QUAD_FENCE();                                                                                                         \
+          if (!(ABL & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                            \
+        }                                                                                                                            \
+        if (!(ABL & 2) && ks == 3 && q >= 8 && q < 12) {                                                                             \
+          OASR_QUAD_READ(fa[n][q - 8], va, q - 8);                                                                                   \
+          OASR_QUAD_READ(fb[n][q - 8], vb, q - 8);                                                                                   \
+        }                                                                                                                            \
+        OASR_QUAD_FENCE();                                                                                                           \
+      }                                                                                                                              \
+      if (ks == 0 || ks == 1) OASR_QUAD_WAIT(0, n);                                                                                  \
+      if (ks == 2) OASR_QUAD_WAIT(8, n);                                                                                             \
+      OASR_QUAD_FENCE();                                                                                                             \
+    }                                                                                                                                \
+  } while (0)
   {
     OASR_QUAD_READ(fa[0][0], adrA[0], 0);
     OASR_QUAD_READ(fb[0][0], adrB[0], 0);
@@ -1018,51 +1053,16 @@ __global__ __launch_bounds__(256, 1) void oasr_gemm_quad_kernel(GemmArgs p) {
     OASR_QUAD_READ(fa[0][3], adrA[0], 3);
     OASR_QUAD_READ(fb[0][3], adrB[0], 3);
   }
-  for (int t = 0; t < nt; ++t) {
-    const unsigned cur = (unsigned)(t & 1) << 16, nxt = cur ^ 0x10000u;
-    const int t2 = t + 2 < nt ? t + 2 : nt - 1;  // branch-free body: the last iterations re-stage the last tile into dead space
-    const __amdgpu_buffer_rsrc_t rsa = make_rsrc(gA + (long)t2 * BK), rsb = make_rsrc(gB + (long)t2 * BK);
-    OASR_QUAD_WAIT(0, 0);
-    OASR_QUAD_FENCE();
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int c = ks & 1, n = c ^ 1;
-      // k-steps 0-2 read the fragments of the next k-step of THIS tile; k-step 3 (behind the barrier) those of k-step 0 of the next
-      const unsigned va = adrA[(ks + 1) & 3] + (ks < 3 ? cur : nxt), vb = adrB[(ks + 1) & 3] + (ks < 3 ? cur : nxt);
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int mt = q >> 2, j = q & 3;
-        OASR_QUAD_MFMA(c, mt, j);
-        OASR_QUAD_FENCE();
-        if (ks < 3 && q < 8) {  // A0 B0 A1 B1 ...
-          if ((q & 1) == 0) OASR_QUAD_READ(fa[n][q >> 1], va, q >> 1);
-          else OASR_QUAD_READ(fb[n][q >> 1], vb, q >> 1);
-        }
-        if (ks == 2 && q >= 8) {  // tile t+1: registers -> the other buffer; the freed register takes its piece of tile t+2
-          *(u32x4_t*)(smem + (sa.loff[q - 8] | nxt)) = ra[q - 8];
-          ra[q - 8] = __builtin_amdgcn_raw_buffer_load_b128(rsa, sa.goff[q - 8], 0, 0);
-        }
-        if (ks == 3 && q < 8) {
-          *(u32x4_t*)(smem + ((IMG + sb.loff[q]) | nxt)) = rb[q];
-          rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rsb, sb.goff[q], 0, 0);
-        }
-        if (ks == 3 && q == 7) {  // every wave's pieces of tile t+1 are in LDS, every read of this tile's buffer is retired
-          OASR_QUAD_FENCE();
-          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        }
-        if (ks == 3 && q >= 8 && q < 12) {  // two reads per slot: the last one is 4 MFMAs old at the top of the next tile
-          OASR_QUAD_READ(fa[n][q - 8], va, q - 8);
-          OASR_QUAD_READ(fb[n][q - 8], vb, q - 8);
-        }
-        OASR_QUAD_FENCE();
-      }
-      if (ks == 0 || ks == 1) OASR_QUAD_WAIT(0, n);  // the 8 reads were issued >= 8 MFMAs ago
-      if (ks == 2) OASR_QUAD_WAIT(8, n);              // ... and are older than the 8 LDS writes that followed them
-      OASR_QUAD_FENCE();
-    }
+  for (int t = 0; t < nt; t += 2) {
+    OASR_QUAD_TILE(xa, xb, t);
+    if (t + 1 < nt) OASR_QUAD_TILE(ya, xb, t + 1);
   }
   OASR_QUAD_WAIT(0, 0);  // the look-ahead reads of the last iteration land in registers the epilogue is about to reuse
   __syncthreads();
+#undef OASR_QUAD_TILE
+#undef OASR_QUAD_LOAD_A
+#undef OASR_QUAD_LOAD_B
+#undef OASR_QUAD_RSRC
 #undef OASR_QUAD_READ
 #undef OASR_QUAD_WAIT
 #undef OASR_QUAD_MFMA
@@ -1562,8 +1562,35 @@ int launch_duo_cfg(const GemmArgs& a, hipStream_t stream) {
   return OASR_OK;
 }
 
+template <int ABL>
+int launch_quad_abl(const GemmArgs& a, hipStream_t stream) {
+  static bool attr = false;
+  const int lds = 2 * 2 * 256 * 64 * 2;
+  if (!attr) {
+    OASR_CHECK_HIP(hipFuncSetAttribute((const void*)oasr_gemm_quad_kernel<false, false, false, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr = true;
+  }
+  hipLaunchKernelGGL((oasr_gemm_quad_kernel<false, false, false, ABL>), dim3(cdiv(a.M, 256) * cdiv(a.N, 256)), dim3(256), lds, stream, a);
+  OASR_LAUNCH_CHECK();
+  return OASR_OK;
+}
 template <bool TA, bool TB, bool CSUM = false>
 int launch_quad_cfg(const GemmArgs& a, hipStream_t stream) {
+  static const int env_abl = [] {
+    const char* e = getenv("OASR_QUAD_ABL");
+    return e ? atoi(e) : 0;
+  }();
+  if (env_abl && !CSUM) {
+    switch (env_abl) {
+      case 1: return launch_quad_abl<1>(a, stream);
+      case 2: return launch_quad_abl<2>(a, stream);
+      case 3: return launch_quad_abl<3>(a, stream);
+      case 4: return launch_quad_abl<4>(a, stream);
+      case 7: return launch_quad_abl<7>(a, stream);
+      case 8: return launch_quad_abl<8>(a, stream);
+      default: break;
+    }
+  }
   static bool attr = false;
   const int lds = 2 * 2 * 256 * 64 * 2;  // two K-tile buffers of an A and a B image: 128 KiB
   if (!attr) {

@@ -200,12 +200,13 @@ __global__ __launch_bounds__(256) void logmel_main(const PCM* __restrict__ pcm, 
 constexpr int XT = 32;                        // frames per workgroup
 constexpr int XNS = XT * HOP + (NFFT - HOP);  // 5360 samples
 constexpr int XROW = 201;                     // per-frame row length (complex for Z, float for the power spectrum)
-constexpr int XR0 = XT * XROW;                // region 0 (floats): samples (5426), later the power spectrum (6432)
-// constant tables, one LDS slot re-filled per stage (80 KiB per workgroup = two workgroups per CU leaves 2.4 KiB for them):
-//   stage A/B: W200 (200 complex) | hann[0..200] (+3 pad);  unpack: W400 (201 complex);  mel: (first bin, first weight) x 81 | weights
-constexpr int XTAB_A = 400 + 204, XTAB_P = 402, XTAB_M_MAX = 604, XTAB_SLOT = 604;
+constexpr int XR0 = XNS + 2 * (XNS / HOP + 1);  // region 0 (floats): the staged samples (pairs stay 8-byte aligned: +2 per hop)
+// constant tables, resident in LDS: W200 (200 complex) | hann[0..200] (+3 pad) | W400 (201 complex) | mel: (first bin, first weight) x 81 | weights
+// (the power spectrum overwrites the Z rows in place -- each thread holds its 26 values across a barrier -- so samples + Z + tables
+// fit 80 KiB: two workgroups per CU)
+constexpr int XTAB_A = 400 + 204, XTAB_P = 402, XTAB_M_MAX = 604;
 constexpr int XTAB_OFF_P = XTAB_A, XTAB_OFF_M = XTAB_A + XTAB_P, XTAB = XTAB_A + XTAB_P + XTAB_M_MAX;
-constexpr int XLDS_FLOATS = XR0 + 2 * XT * XROW + XTAB_SLOT;
+constexpr int XLDS_FLOATS = ((XR0 + 3) & ~3) + 2 * XT * XROW + XTAB;
 
 struct cf {
   float x, y;
@@ -254,20 +255,26 @@ template <typename PCM>
 __global__ __launch_bounds__(256, 2) void logmel_fft(const PCM* __restrict__ pcm, int n_samples, int n_frames,
                                                      const float* __restrict__ tab,  // [XTAB]: the three stage tables
                                                      int mel_words,                  // words of the mel table (162 + non-zeros)
+                                                     int max_span,                   // taps of the widest filter
                                                      float* __restrict__ out, unsigned* __restrict__ clipmax) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* samp = smem;             // region 0: samples, later the power spectrum [XT][XROW]
-  float* pw = smem;
-  cf* cb = (cf*)(smem + XR0);     // [XT][XROW] complex
-  float* tw = smem + XR0 + 2 * XT * XROW;
-  const cf* tw200 = (const cf*)tw;  // stages A and B
-  const float* win = tw + 400;      // stage A
-  const cf* tw400 = (const cf*)tw;  // unpack (slot re-filled)
-  const int b = blockIdx.y, f0 = blockIdx.x * XT, tid = threadIdx.x;
+  float* samp = smem;                       // region 0: samples
+  cf* cb = (cf*)(smem + ((XR0 + 3) & ~3));  // [XT][XROW] complex: A, then Z, then (as floats, same row stride) the power spectrum
+  float* pw = (float*)cb;
+  float* tw = smem + ((XR0 + 3) & ~3) + 2 * XT * XROW;
+  const cf* tw200 = (const cf*)tw;
+  const float* win = tw + 400;
+  const cf* tw400 = (const cf*)(tw + XTAB_OFF_P);
+  // 1-D grid, XCD-contiguous: neighbouring frame blocks of a clip run on the same XCD at the same time, so the 128-byte row
+  // segments they write (row pitch 12000 B: never line aligned) meet in ONE L2 and leave it as whole lines, and the 240 samples
+  // two neighbours share are fetched once
+  const int nblk = (n_frames + XT - 1) / XT;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int b = bid / nblk, f0 = (bid - b * nblk) * XT, tid = threadIdx.x;
   const int f = tid & 31, j0 = tid >> 5;  // lane = frame, 8 items per pass
   const PCM* clip = pcm + (long)b * n_samples;
 
-  for (int i = tid; i < XTAB_A; i += 256) tw[i] = tab[i];
+  for (int i = tid; i < (XTAB_OFF_M + mel_words + 3) / 4; i += 256) ((f32x4_t*)tw)[i] = ((const f32x4_t*)tab)[i];  // (XTAB floats allocated)
   // ---- samples of these 32 frames (reflect padding of torch.stft(center=True) at the clip's ends)
   const long s_begin = (long)f0 * HOP - NFFT / 2;
   const bool interior = s_begin >= 0 && s_begin + XNS <= n_samples && ((size_t)(clip + s_begin) & 15) == 0;
@@ -315,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void logmel_fft(const PCM* __restrict__ pcm
       cf* dst = cb + f * XROW + n2;
       dst[0] = v[0];
 #pragma unroll
-      for (int k1 = 1; k1 < 8; ++k1) dst[k1 * 25] = cmul(v[k1], tw200[(n2 * k1) % 200]);
+      for (int k1 = 1; k1 < 8; ++k1) dst[k1 * 25] = cmul(v[k1], tw200[n2 * k1]);  // (n2 k1 <= 168)
     }
   }
   __syncthreads();
@@ -347,45 +354,94 @@ __global__ __launch_bounds__(256, 2) void logmel_fft(const PCM* __restrict__ pcm
     }
   }
   __syncthreads();
-  for (int i = tid; i < XTAB_P; i += 256) tw[i] = tab[XTAB_OFF_P + i];
-  __syncthreads();
 
-  // ---- unpack + power (the samples are dead: region 0 becomes pw)
-#pragma unroll 2
-  for (int it = 0; it < 26; ++it) {
-    const int k = it * 8 + j0;
-    if (k <= 200) {
-      const cf zk = cb[f * XROW + (k == 200 ? 0 : k)];
-      cf zm = cb[f * XROW + (k == 0 ? 0 : 200 - k)];
-      zm.y = -zm.y;
-      const cf e = cscale(cadd(zk, zm), 0.5f), o = cscale(mni(csub(zk, zm)), 0.5f);
-      const cf x = cadd(e, cmul(tw400[k], o));
-      pw[f * XROW + k] = x.x * x.x + x.y * x.y;
+  // ---- unpack + power: every thread first computes its 26 bins of frame f into registers, then (behind a barrier: all reads of
+  // the Z rows are done) writes them over the row, as floats
+  {
+    float pv[26];
+#pragma unroll
+    for (int it = 0; it < 26; ++it) {
+      const int k = it * 8 + j0;
+      pv[it] = 0.f;
+      if (k <= 200) {
+        const cf zk = cb[f * XROW + (k == 200 ? 0 : k)];
+        cf zm = cb[f * XROW + (k == 0 ? 0 : 200 - k)];
+        zm.y = -zm.y;
+        const cf e = cscale(cadd(zk, zm), 0.5f), o = cscale(mni(csub(zk, zm)), 0.5f);
+        const cf x = cadd(e, cmul(tw400[k], o));
+        pv[it] = x.x * x.x + x.y * x.y;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 26; ++it) {
+      const int k = it * 8 + j0;
+      if (k <= 200) pw[f * (2 * XROW) + k] = pv[it];
     }
   }
-  __syncthreads();
-  for (int i = tid; i < mel_words; i += 256) tw[i] = tab[XTAB_OFF_M + i];
   __syncthreads();
 
   // ---- mel filters (sparse rows), log10, per-clip max, store
-  const int* mel_idx = (const int*)tw;  // [81][2]: first bin, first weight (row 80 carries the total)
-  const float* mel_val = tw + 162;
+  const int* mel_idx = (const int*)(tw + XTAB_OFF_M);  // [81][2]: first bin, first weight (row 80 carries the total)
+  const float* mel_val = tw + XTAB_OFF_M + 162;
   float vmax = -1e30f;
   const int t = f0 + f;
-#pragma unroll 1
-  for (int it = 0; it < 10; ++it) {
-    const int m = it * 8 + j0;
-    const int lo = mel_idx[2 * m], p0 = mel_idx[2 * m + 1], cnt = mel_idx[2 * m + 3] - p0;
-    float acc = 0.f;
-    for (int i = 0; i < cnt; ++i) acc = fmaf(pw[f * XROW + lo + i], mel_val[p0 + i], acc);
+  {
+    // this thread's 10 filters (m = 8 it + j0) advance together, one tap per step: 10 independent LDS-read + fma chains in flight
+    // instead of one serial chain per filter (each step is two LDS round trips; the filters have 2..14 taps)
+    int lo[10], p0[10], cnt[10];
+    float acc[10];
+#pragma unroll
+    for (int it = 0; it < 10; ++it) {
+      const int m = it * 8 + j0;
+      lo[it] = mel_idx[2 * m];
+      p0[it] = mel_idx[2 * m + 1];
+      cnt[it] = mel_idx[2 * m + 3] - p0[it];
+      acc[it] = 0.f;
+    }
+    const float* prow = pw + f * (2 * XROW);
+    // filters it and it + 5 advance together (two independent chains); the step count of a pair is the widest filter any lane of
+    // the wave holds for it (filter width grows with the index: ~44 steps in all instead of 10 x the global maximum)
+#pragma unroll
+    for (int a = 0; a < 5; ++a) {
+      int n = cnt[a] > cnt[a + 5] ? cnt[a] : cnt[a + 5];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) n = max(n, __shfl_xor(n, o, 64));
+      n = __builtin_amdgcn_readfirstlane(n);
+      for (int i = 0; i < n; i += 4) {  // 16 LDS reads in flight per trip (reads past a filter's end stay inside the row / the table)
+        float x0[4], w0[4], x1[4], w1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          x0[u] = prow[lo[a] + i + u];
+          w0[u] = mel_val[p0[a] + i + u];
+          x1[u] = prow[lo[a + 5] + i + u];
+          w1[u] = mel_val[p0[a + 5] + i + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          acc[a] = (i + u < cnt[a]) ? fmaf(x0[u], w0[u], acc[a]) : acc[a];
+          acc[a + 5] = (i + u < cnt[a + 5]) ? fmaf(x1[u], w1[u], acc[a + 5]) : acc[a + 5];
+        }
+      }
+    }
     if (t < n_frames) {
-      const float v = log10f(fmaxf(acc, 1e-10f));
-      out[((long)b * NMEL + m) * n_frames + t] = v;
-      vmax = fmaxf(vmax, v);
+#pragma unroll
+      for (int it = 0; it < 10; ++it) {
+        const float v = log10f(fmaxf(acc[it], 1e-10f));
+        out[((long)b * NMEL + it * 8 + j0) * n_frames + t] = v;
+        vmax = fmaxf(vmax, v);
+      }
     }
   }
+  // one ordered-uint atomicMax per workgroup (the tables are dead: their first words carry the four wave maxima)
   vmax = wave_max(vmax);
-  if ((tid & 63) == 0 && vmax > -1e29f) atomicMax(clipmax + b, f2ord(vmax));
+  __syncthreads();
+  if ((tid & 63) == 0) tw[tid >> 6] = vmax;
+  __syncthreads();
+  if (tid == 0) {
+    const float m4 = fmaxf(fmaxf(tw[0], tw[1]), fmaxf(tw[2], tw[3]));
+    if (m4 > -1e29f) atomicMax(clipmax + b, f2ord(m4));
+  }
 }
 
 __global__ __launch_bounds__(256) void logmel_finalize(float* __restrict__ mel, const unsigned* __restrict__ clipmax,
@@ -410,6 +466,7 @@ struct MelTables {
   float* melfilt = nullptr;  // [208][80]
   float* fft_tab = nullptr;  // [XTAB] stage tables of the FFT kernel (twiddles, window, sparse mel filters)
   int mel_words = 0;         // used words of its mel table
+  int mel_span = 0;          // taps of the widest filter
   int device = -1;
 };
 MelTables g_tables[16];
@@ -494,6 +551,7 @@ static int ensure_tables(int device, MelTables** t_out) {
         if (hi < lo) lo = hi = 0;
         idx[(size_t)2 * m] = lo;
         idx[(size_t)2 * m + 1] = (int)val.size();
+        t.mel_span = hi - lo + 1 > t.mel_span ? hi - lo + 1 : t.mel_span;
         for (int f = lo; f <= hi; ++f) val.push_back(fb[m * NFREQ + f]);
       }
       idx[(size_t)2 * NMEL] = 0;
@@ -545,7 +603,7 @@ extern "C" int oasr_log_mel(const void* pcm, int pcm_dtype, int B, int n_samples
   const dim3 g2((unsigned)((per_clip / 4 + 255) / 256 > 64 ? 64 : (per_clip / 4 + 255) / 256 + 1), B);
   if (!use_mfma_dft) {
     const size_t xlds = sizeof(float) * XLDS_FLOATS;
-    const dim3 xgrid(cdiv(n_frames, XT), B);
+    const dim3 xgrid((unsigned)(cdiv(n_frames, XT) * B));
     static bool attr16 = false, attr32 = false;
     if (pcm_dtype == 1) {
       if (!attr16) {
@@ -553,14 +611,14 @@ extern "C" int oasr_log_mel(const void* pcm, int pcm_dtype, int B, int n_samples
         attr16 = true;
       }
       hipLaunchKernelGGL(logmel_fft<int16_t>, xgrid, dim3(256), xlds, stream, (const int16_t*)pcm, n_samples, n_frames, t->fft_tab,
-                         t->mel_words, mel, clipmax);
+                         t->mel_words, t->mel_span, mel, clipmax);
     } else {
       if (!attr32) {
         OASR_CHECK_HIP(hipFuncSetAttribute((const void*)logmel_fft<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)xlds));
         attr32 = true;
       }
       hipLaunchKernelGGL(logmel_fft<float>, xgrid, dim3(256), xlds, stream, (const float*)pcm, n_samples, n_frames, t->fft_tab, t->mel_words,
-                         mel, clipmax);
+                         t->mel_span, mel, clipmax);
     }
     OASR_LAUNCH_CHECK();
     hipLaunchKernelGGL(logmel_finalize, g2, dim3(256), 0, stream, mel, clipmax, per_clip);
