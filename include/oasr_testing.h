@@ -19,9 +19,6 @@ int oasr_gemm_set_variant(int v);
 /* tests / A-B of the KV-cached step's LayerNorm placement: 1 = folded into the projections' operand loads for every B <= 32,
  * 0 = always separate kernels, -1 = default (folded up to 4 sequences).  Bit-identical (tests/test_gpu_decode_step.py). */
 int oasr_decode_set_ln_fold(int mode);
-/* the training step's side lane (engine.hip, oasr_ctx::Lane): bit 0 weight gradients, bit 1 forward cross K/V projections, bit 2 the
- * backward d(xa) chain; 0 = everything on the caller's stream; -1 = the default (OASR_LANE or the built-in rule) */
-int oasr_set_lane(int mode);
 int oasr_gemm_set_stagger(int sleeps, int phases); /* experiments: first-wave phase stagger of the 256x256 kernel (0 = off) */
 int oasr_gemm_force_general(int on); /* tests: route every GEMM through the register-staged general kernel */
 int oasr_profile_gemm_collect(double* ms4, double* flops4, int64_t* count4, char* by_symbol /* "symbol\tlaunches\tms\tflops\n"... or NULL */, int cap);

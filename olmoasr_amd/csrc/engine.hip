@@ -56,25 +56,6 @@ struct oasr_ctx {
   size_t sh_flat, sh_w1p, sh_w2p, sh_aux, sh_total;
   int64_t aux_floats;
   int f32 = 0;  // compute_dtype: 0 = bf16 production kernels, 1 = fp32 validation kernels (fp32ref.hip)
-  // Side lane of the training step: a second HIP stream that takes the work OFF the step's dependency chain -- every weight
-  // gradient of the backward (dW = dY^T X needs nothing but dY and a saved activation, and nothing in the backward needs dW), and
-  // the decoder's cross-attention K/V projections of the encoder output (all layers' inputs are ready when the encoder ends).
-  // The chain (dgrads, attention, LayerNorm) stays on the caller's stream; HIP events carry the dependencies both ways:
-  //   lane op      waits for the event recorded on the main stream behind the producer of its operands;
-  //   main writer  of a scratch buffer a lane op still reads waits for that op's completion event (`guards`);
-  //   segment events (the DDP reducer's "gradients of this segment are final") are recorded on the lane behind both streams;
-  //   the backward ends with the main stream waiting for the lane.
-  // What it buys: the chain's launches leave the chip partly idle -- the last partial round of every GEMM grid, the HBM-bound
-  // LayerNorm kernels, the VALU-bound attention backward whose matrix pipe idles two cycles in three -- and the lane's GEMM
-  // workgroups are dispatched into exactly those holes (a 256x128 wgrad workgroup fits beside an attention workgroup on a CU).
-  struct Lane {
-    hipStream_t st2 = nullptr;
-    std::vector<hipEvent_t> pool;
-    size_t next = 0;
-    std::vector<std::pair<const void*, hipEvent_t>> guards;  // (buffer a lane op reads, that op's completion event)
-    hipEvent_t last_done = nullptr;
-    std::vector<hipEvent_t> kv_done;  // forward: cross K/V of decoder layer i is ready
-  } lane;
   // compute copy of the weight at arena offset `off`: the bf16 shadow, or -- fp32 validation -- the master weights themselves
   template <typename T>
   const T* Wt(int64_t off) const;
@@ -300,59 +281,9 @@ struct Runner {
   const int32_t* text_len;
   bool train = false;  // the training forward saves GELU'(u) in place of u (GemmArgs.act == 2)
   float* cs_scratch = nullptr;  // partial rows of fused bias-gradient column sums (GemmArgs.colsum_scratch)
-  oasr_ctx::Lane* lane = nullptr;  // side lane (oasr_ctx::Lane), null = everything on `st`
-  int lane_mode = 0;               // bit 0: weight gradients, bit 1: forward cross K/V projections, bit 2: backward d(xa) chain
-
-  hipEvent_t lane_event() {
-    if (lane->next == lane->pool.size()) {
-      hipEvent_t e = nullptr;
-      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-      lane->pool.push_back(e);
-    }
-    return lane->pool[lane->next++];
-  }
-  // lane op prologue: the lane waits for everything enqueued on the main stream so far.  Returns the lane stream.
-  int lane_fork(hipStream_t* s2) {
-    hipEvent_t e = lane_event();
-    OASR_REQUIRE(e, "side lane: hipEventCreate failed");
-    OASR_CHECK_HIP(hipEventRecord(e, st));
-    OASR_CHECK_HIP(hipStreamWaitEvent(lane->st2, e, 0));
-    *s2 = lane->st2;
-    return OASR_OK;
-  }
-  // lane op epilogue: completion event; `reads`: scratch buffers of the op that the main stream will overwrite later
-  int lane_done(const void* read0, const void* read1 = nullptr, hipEvent_t* out = nullptr) {
-    hipEvent_t d = lane_event();
-    OASR_REQUIRE(d, "side lane: hipEventCreate failed");
-    OASR_CHECK_HIP(hipEventRecord(d, lane->st2));
-    lane->last_done = d;
-    if (read0) lane->guards.emplace_back(read0, d);
-    if (read1) lane->guards.emplace_back(read1, d);
-    if (out) *out = d;
-    return OASR_OK;
-  }
-  // before the main stream overwrites `ptr`: wait for the lane ops that still read it
-  int guard_write(const void* ptr) {
-    if (!lane) return OASR_OK;
-    for (size_t i = 0; i < lane->guards.size();) {
-      if (lane->guards[i].first == ptr) {
-        OASR_CHECK_HIP(hipStreamWaitEvent(st, lane->guards[i].second, 0));
-        lane->guards[i] = lane->guards.back();
-        lane->guards.pop_back();
-      } else {
-        ++i;
-      }
-    }
-    return OASR_OK;
-  }
-  int lane_join() {  // the main stream waits for everything the lane has been given
-    if (lane && lane->last_done) OASR_CHECK_HIP(hipStreamWaitEvent(st, lane->last_done, 0));
-    if (lane) lane->guards.clear();
-    return OASR_OK;
-  }
 
   int linear(const T* x, long M, int K, const T* W, int N, const float* bias, int act, const T* resid, T* out,
-             T* out_pre, hipStream_t on = nullptr) {
+             T* out_pre) {
     Gemm g = gemm_defaults_t<T>();
     g.A = plain_view(x, K);
     g.B = plain_view(W, K);
@@ -366,12 +297,11 @@ struct Runner {
     g.out = out;
     g.out_pre = out_pre;
     g.ldc = N;
-    return launch_gemm(g, on ? on : st);
+    return launch_gemm(g, st);
   }
   // dx[M,K] = dy[M,N] . W[N,K]  (* gelu'(u))  (+ resid)
   int dgrad(const T* dy, long M, int N, const T* W, int K, const T* dgelu_u, const T* resid, T* dx,
-            float* colsum = nullptr, bool u_is_deriv = false, hipStream_t on = nullptr) {
-    if (!on) RC(guard_write(dx));
+            float* colsum = nullptr, bool u_is_deriv = false) {
     Gemm g = gemm_defaults_t<T>();
     g.A = plain_view(dy, N);
     g.B = plain_view(W, K);
@@ -388,14 +318,10 @@ struct Runner {
     g.ldc = K;
     g.colsum = colsum;
     g.colsum_scratch = colsum ? cs_scratch : nullptr;
-    return launch_gemm(g, on ? on : st);
+    return launch_gemm(g, st);
   }
   // dW[N,K] += dy[M,N]^T . x[M,K]   (fp32 atomics, split over the token dimension)
-  // `on_lane`: the weight gradient leaves the chain (side lane); `dy_base`: the scratch buffer dy lives in (guarded until done)
-  int wgrad(const T* dy, long ldy, long M, int N, const View& x, int K, float* dW, long ldw, bool on_lane = false, const T* dy_base = nullptr) {
-    hipStream_t on = st;
-    const bool side = on_lane && lane && (lane_mode & 1);
-    if (side) RC(lane_fork(&on));
+  int wgrad(const T* dy, long ldy, long M, int N, const View& x, int K, float* dW, long ldw) {
     Gemm g = gemm_defaults_t<T>();
     g.A = plain_view(dy, ldy);
     g.ta = 1;
@@ -441,9 +367,7 @@ struct Runner {
         g.split_k = pp_split;
       }
     }
-    RC(launch_gemm(g, on));
-    if (side) RC(lane_done(dy_base ? dy_base : dy));
-    return OASR_OK;
+    return launch_gemm(g, st);
   }
   int attn_args(Attn& a, const AttnSave& s, bool cross, long Tq, long Tk, bool causal) {
     const int d = c->d;
@@ -477,7 +401,7 @@ struct Runner {
     return OASR_OK;
   }
 
-  int block_fwd(const BlockP& bp, BlockSave& s, const T* x_in, long M, long Tq, const T* xa, bool causal, hipEvent_t kv_ready = nullptr) {
+  int block_fwd(const BlockP& bp, BlockSave& s, const T* x_in, long M, long Tq, const T* xa, bool causal) {
     const int d = c->d;
     s.x_in = const_cast<T*>(x_in);
     RC(launch_layernorm_fwd(x_in, c->P(bp.attn_ln_w), c->P(bp.attn_ln_b), s.sa.ln, s.sa.mean, s.sa.rstd, M, d, st));
@@ -490,10 +414,7 @@ struct Runner {
     if (bp.cross) {
       RC(launch_layernorm_fwd(xm, c->P(bp.cln_w), c->P(bp.cln_b), s.ca.ln, s.ca.mean, s.ca.rstd, M, d, st));
       RC(linear(s.ca.ln, M, d, c->template Wt<T>(bp.cattn.qw), d, c->P(bp.cattn.qb), 0, nullptr, s.ca.qkv, nullptr));
-      if (kv_ready)  // this layer's cross K/V were projected on the side lane (decoder_fwd)
-        OASR_CHECK_HIP(hipStreamWaitEvent(st, kv_ready, 0));
-      else
-        RC(linear(xa, (long)B * c->Te, d, c->template Wt<T>(bp.cattn.kw), 2 * d, c->aux(bp.cattn.fused_bias) + d, 0, nullptr, s.ca.kv, nullptr));
+      RC(linear(xa, (long)B * c->Te, d, c->template Wt<T>(bp.cattn.kw), 2 * d, c->aux(bp.cattn.fused_bias) + d, 0, nullptr, s.ca.kv, nullptr));
       attn_args(a, s.ca, true, Tq, c->Te, false);
       RC(launch_attention_fwd(a, st));
       RC(linear(s.ca.o, M, d, c->template Wt<T>(bp.cattn.ow), d, c->P(bp.cattn.ob), 0, xm, s.x_mid2, nullptr));
@@ -588,20 +509,8 @@ struct Runner {
     const long Md = (long)B * S;
     RC(launch_embedding_fwd(tokens, c->P(c->tok_emb), c->P(c->dec_pos), p.dx0, B, S, d, c->V, st));
     const T* x = p.dx0;
-    const bool kv_lane = lane && (lane_mode & 2) && train;
-    if (kv_lane) {  // the cross K/V projections of EVERY layer depend on the encoder output only: off the chain, onto the lane
-      hipStream_t s2;
-      RC(lane_fork(&s2));
-      lane->kv_done.assign((size_t)c->L_dec, nullptr);
-      for (int i = 0; i < c->L_dec; ++i) {
-        const BlockP& bp = c->dec[i];
-        RC(linear(p.xa, (long)B * c->Te, d, c->template Wt<T>(bp.cattn.kw), 2 * d, c->aux(bp.cattn.fused_bias) + d, 0, nullptr, p.dec[i].ca.kv,
-                  nullptr, s2));
-        RC(lane_done(nullptr, nullptr, &lane->kv_done[(size_t)i]));
-      }
-    }
     for (int i = 0; i < c->L_dec; ++i) {
-      RC(block_fwd(c->dec[i], p.dec[i], x, Md, S, p.xa, true, kv_lane ? lane->kv_done[(size_t)i] : nullptr));
+      RC(block_fwd(c->dec[i], p.dec[i], x, Md, S, p.xa, true));
       x = p.dec[i].x_out;
     }
     RC(launch_layernorm_fwd(x, c->P(c->dec_ln_w), c->P(c->dec_ln_b), p.lnf, p.mean_f, p.rstd_f, Md, d, st));
@@ -621,14 +530,7 @@ struct Runner {
   }
 
   int record(void** ev, int idx) {
-    if (!(ev && ev[idx])) return OASR_OK;
-    if (lane && lane->last_done) {  // the segment's weight gradients come from the lane: record there, behind the main stream
-      hipStream_t s2;
-      RC(lane_fork(&s2));
-      OASR_CHECK_HIP(hipEventRecord((hipEvent_t)ev[idx], s2));
-    } else {
-      OASR_CHECK_HIP(hipEventRecord((hipEvent_t)ev[idx], st));
-    }
+    if (ev && ev[idx]) OASR_CHECK_HIP(hipEventRecord((hipEvent_t)ev[idx], st));
     return OASR_OK;
   }
 
@@ -642,11 +544,10 @@ struct Runner {
     const int d = c->d;
     const T* xm = bp.cross ? s.x_mid2 : s.x_mid;
     // ---- MLP -----------------------------------------------------------------------------------------------
-    RC(wgrad(dx_out, d, M, d, plain_view(s.hg, 4 * d), 4 * d, c->G(bp.w2), 4 * d, true));
+    RC(wgrad(dx_out, d, M, d, plain_view(s.hg, 4 * d), 4 * d, c->G(bp.w2), 4 * d));
     RC(dgrad(dx_out, M, d, c->template Wt<T>(bp.w2), 4 * d, s.u, nullptr, p.gu, c->G(bp.b1), true));  // s.u = GELU'(u); + fused mlp.0.bias gradient
-    RC(wgrad(p.gu, 4 * d, M, 4 * d, plain_view(s.ln2, d), d, c->G(bp.w1), d, true));
+    RC(wgrad(p.gu, 4 * d, M, 4 * d, plain_view(s.ln2, d), d, c->G(bp.w1), d));
     RC(dgrad(p.gu, M, 4 * d, c->template Wt<T>(bp.w1), d, nullptr, nullptr, p.gln));
-    RC(guard_write(scratch_a));
     RC(launch_layernorm_bwd(p.gln, xm, c->P(bp.mlp_ln_w), s.mean2, s.rstd2, dx_out, scratch_a, c->G(bp.mlp_ln_w), c->G(bp.mlp_ln_b),
                             c->G(bp.cross ? bp.cattn.ob : bp.attn.ob), M, d, st));
     const T* dx = scratch_a;
@@ -654,7 +555,7 @@ struct Runner {
     // ---- cross attention ---------------------------------------------------------------------------------------
     if (bp.cross) {
       const long Mkv = (long)B * c->Te;
-      RC(wgrad(dx, d, M, d, plain_view(s.ca.o, d), d, c->G(bp.cattn.ow), d, true));
+      RC(wgrad(dx, d, M, d, plain_view(s.ca.o, d), d, c->G(bp.cattn.ow), d));
       RC(dgrad(dx, M, d, c->template Wt<T>(bp.cattn.ow), d, nullptr, nullptr, p.go));
       Attn a;
       attn_args(a, s.ca, true, Tq, c->Te, false);
@@ -666,23 +567,12 @@ struct Runner {
       a.dq_colsum = c->G(bp.cattn.qb);  // query / value bias gradients = column sums of dq / dv, fused into the store epilogues
       a.dv_colsum = c->G(bp.cattn.vb);
       a.colsum_scratch = p.cs_scratch;
-      RC(guard_write(p.gq));
-      RC(guard_write(p.gkv));
       RC(launch_attention_bwd(a, st));
-      RC(wgrad(p.gq, d, M, d, plain_view(s.ca.ln, d), d, c->G(bp.cattn.qw), d, true));
-      RC(wgrad(p.gkv, 2 * d, Mkv, 2 * d, plain_view(p.xa, d), d, c->G(bp.cattn.kw), d, true));
-      // d(xa) accumulates over the decoder layers (bf16, like autograd's accumulation into xa.grad): a chain of its own (nothing
-      // in the decoder's backward reads it), so it can ride on the lane, in order
-      if (lane && (lane_mode & 4)) {
-        hipStream_t s2;
-        RC(lane_fork(&s2));
-        RC(dgrad(p.gkv, Mkv, 2 * d, c->template Wt<T>(bp.cattn.kw), d, nullptr, first_cross ? nullptr : p.gxa, p.gxa, nullptr, false, s2));
-        RC(lane_done(p.gkv));
-      } else {
-        RC(dgrad(p.gkv, Mkv, 2 * d, c->template Wt<T>(bp.cattn.kw), d, nullptr, first_cross ? nullptr : p.gxa, p.gxa));
-      }
+      RC(wgrad(p.gq, d, M, d, plain_view(s.ca.ln, d), d, c->G(bp.cattn.qw), d));
+      RC(wgrad(p.gkv, 2 * d, Mkv, 2 * d, plain_view(p.xa, d), d, c->G(bp.cattn.kw), d));
+      // d(xa) accumulates over the decoder layers (bf16, like autograd's accumulation into xa.grad)
+      RC(dgrad(p.gkv, Mkv, 2 * d, c->template Wt<T>(bp.cattn.kw), d, nullptr, first_cross ? nullptr : p.gxa, p.gxa));
       RC(dgrad(p.gq, M, d, c->template Wt<T>(bp.cattn.qw), d, nullptr, nullptr, p.gln));
-      RC(guard_write(nxt));
       RC(launch_layernorm_bwd(p.gln, s.x_mid, c->P(bp.cln_w), s.ca.mean, s.ca.rstd, dx, nxt, c->G(bp.cln_w), c->G(bp.cln_b),
                               c->G(bp.attn.ob), M, d, st));
       const T* t = dx;
@@ -690,7 +580,7 @@ struct Runner {
       nxt = const_cast<T*>(t);
     }
     // ---- self attention ----------------------------------------------------------------------------------------
-    RC(wgrad(dx, d, M, d, plain_view(s.sa.o, d), d, c->G(bp.attn.ow), d, true));
+    RC(wgrad(dx, d, M, d, plain_view(s.sa.o, d), d, c->G(bp.attn.ow), d));
     RC(dgrad(dx, M, d, c->template Wt<T>(bp.attn.ow), d, nullptr, nullptr, p.go));
     Attn a;
     attn_args(a, s.sa, false, Tq, Tq, causal);
@@ -702,11 +592,9 @@ struct Runner {
     a.dq_colsum = c->G(bp.attn.qb);
     a.dv_colsum = c->G(bp.attn.vb);
     a.colsum_scratch = p.cs_scratch;
-    RC(guard_write(p.gqkv));
     RC(launch_attention_bwd(a, st));
-    RC(wgrad(p.gqkv, 3 * d, M, 3 * d, plain_view(s.sa.ln, d), d, c->G(bp.attn.qw), d, true));
+    RC(wgrad(p.gqkv, 3 * d, M, 3 * d, plain_view(s.sa.ln, d), d, c->G(bp.attn.qw), d));
     RC(dgrad(p.gqkv, M, 3 * d, c->template Wt<T>(bp.attn.qw), d, nullptr, nullptr, p.gln));
-    RC(guard_write(nxt));
     RC(launch_layernorm_bwd(p.gln, s.x_in, c->P(bp.attn_ln_w), s.sa.mean, s.sa.rstd, dx, nxt, c->G(bp.attn_ln_w), c->G(bp.attn_ln_b),
                             dsum_next, M, d, st));
     *dx_in = nxt;
@@ -825,13 +713,7 @@ extern "C" oasr_ctx* oasr_create_ex2(const oasr_dims* dm, int embed_rows, int co
   c->sh_total = off;
   return c;
 }
-extern "C" void oasr_destroy(oasr_ctx* c) {
-  if (c) {
-    for (hipEvent_t e : c->lane.pool) (void)hipEventDestroy(e);
-    if (c->lane.st2) (void)hipStreamDestroy(c->lane.st2);
-  }
-  delete c;
-}
+extern "C" void oasr_destroy(oasr_ctx* c) { delete c; }
 extern "C" int oasr_compute_dtype(const oasr_ctx* c) { return c && c->f32 ? OASR_DTYPE_F32 : OASR_DTYPE_BF16; }
 extern "C" int oasr_param_count(const oasr_ctx* c) { return c ? (int)c->tensors.size() : 0; }
 extern "C" int64_t oasr_param_numel(const oasr_ctx* c) { return c ? c->numel : 0; }
@@ -1184,38 +1066,6 @@ extern "C" int oasr_train_fwd_bwd(oasr_ctx* c, const float* mel, const int64_t* 
 // The backward half of a training micro-step: p.logits holds d(loss)/d(logits) (bf16 engine: bf16 [Md, Vp]) on entry -- written in
 // place by the fused cross-entropy (oasr_train_fwd_bwd*) or converted from the caller's fp32 tensor (oasr_train_bwd, the
 // torch.autograd path) -- and every saved activation of the forward is still in the workspace.
-// OASR_LANE: bit 0 weight gradients, bit 1 forward cross K/V projections, bit 2 backward d(xa) chain (default: see below);
-// OASR_LANE_PRIO=1: the lane stream is created with the lowest priority (the chain's workgroups are dispatched first).
-static int g_lane_mode = -1;  // oasr_set_lane (tests / A-B): -1 = OASR_LANE or the default
-extern "C" int oasr_set_lane(int mode) {
-  g_lane_mode = mode < 0 ? -1 : mode;
-  return OASR_OK;
-}
-template <typename R>
-static int lane_setup(oasr_ctx* c, R& r) {
-  static const int env_mode = [] {
-    const char* e = getenv("OASR_LANE");
-    return e ? atoi(e) : 0;
-  }();
-  const int mode = g_lane_mode >= 0 ? g_lane_mode : env_mode;
-  if (!mode) return OASR_OK;
-  oasr_ctx::Lane& L = c->lane;
-  if (!L.st2) {
-    const char* pe = getenv("OASR_LANE_PRIO");
-    int least = 0, greatest = 0;
-    if (pe && atoi(pe) == 1 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess)
-      OASR_CHECK_HIP(hipStreamCreateWithPriority(&L.st2, hipStreamNonBlocking, least));
-    else
-      OASR_CHECK_HIP(hipStreamCreateWithFlags(&L.st2, hipStreamNonBlocking));
-  }
-  L.next = 0;
-  L.guards.clear();
-  L.last_done = nullptr;
-  r.lane = &L;
-  r.lane_mode = mode;
-  return OASR_OK;
-}
-
 template <typename T>
 static int train_backward(oasr_ctx* c, typename Engine<T>::Runner& r, typename Engine<T>::Plan& p, const int64_t* tokens, int B, int S, void** ev) {
   const int d = c->d;
@@ -1227,12 +1077,11 @@ static int train_backward(oasr_ctx* c, typename Engine<T>::Runner& r, typename E
   // (V = n_vocab + 1 is odd: the direct-to-LDS kernel wants a multiple of 8 rows, so the pad class gets its own 1-row GEMM)
   {
     const int v8 = c->V & ~7;
-    RC(r.wgrad(p.logits, c->Vp, Md, v8, plain_view(p.lnf, d), d, c->G(c->tok_emb), d, true));
-    if (v8 < c->V) RC(r.wgrad(p.logits + v8, c->Vp, Md, c->V - v8, plain_view(p.lnf, d), d, c->G(c->tok_emb) + (long)v8 * d, d, true, p.logits));
+    RC(r.wgrad(p.logits, c->Vp, Md, v8, plain_view(p.lnf, d), d, c->G(c->tok_emb), d));
+    if (v8 < c->V) RC(r.wgrad(p.logits + v8, c->Vp, Md, c->V - v8, plain_view(p.lnf, d), d, c->G(c->tok_emb) + (long)v8 * d, d));
   }
   RC(r.dgrad(p.logits, Md, c->Vp, c->template Wt<T>(c->tok_emb), d, nullptr, nullptr, p.gln));
   const T* x_last = c->L_dec ? p.dec[c->L_dec - 1].x_out : p.dx0;
-  RC(r.guard_write(p.ga));
   RC(launch_layernorm_bwd(p.gln, x_last, c->P(c->dec_ln_w), p.mean_f, p.rstd_f, nullptr, p.ga, c->G(c->dec_ln_w), c->G(c->dec_ln_b),
                           c->L_dec ? c->G(c->dec[c->L_dec - 1].b2) : nullptr, Md, d, st));
   RC(r.record(ev, seg++));
@@ -1261,8 +1110,6 @@ static int train_backward(oasr_ctx* c, typename Engine<T>::Runner& r, typename E
   // ---------------- backward: encoder ----------------
   const T* xe_last = c->L_enc ? p.enc[c->L_enc - 1].x_out : p.x0;
   if (c->L_dec == 0) OASR_CHECK_HIP(hipMemsetAsync(p.gxa, 0, (size_t)Me * d * sizeof(T), st));
-  if (r.lane && (r.lane_mode & 4)) RC(r.lane_join());  // d(xa) was accumulated on the lane
-  RC(r.guard_write(p.ga));
   RC(launch_layernorm_bwd(p.gxa, xe_last, c->P(c->enc_lnp_w), p.mean_p, p.rstd_p, nullptr, p.ga, c->G(c->enc_lnp_w), c->G(c->enc_lnp_b),
                           c->L_enc ? c->G(c->enc[c->L_enc - 1].b2) : nullptr, Me, d, st));
   RC(r.record(ev, seg++));
@@ -1302,7 +1149,6 @@ static int train_backward(oasr_ctx* c, typename Engine<T>::Runner& r, typename E
     RC(launch_unpack_conv_grad(p.tmp_w2p, c->G(c->conv2_w), d, d, 3 * d, st));
     RC(launch_colsum_accum(p.gln, d, Me, d, c->G(c->conv2_b), st));
     RC(r.dgrad(p.gln, Me, d, c->template w2p<T>(), 3 * d, nullptr, nullptr, p.gA2));
-    RC(r.guard_write(p.gu));
     RC(launch_conv2_col2im_dgelu(p.gA2, p.u1, p.gu, B, c->T1, d, st));  // gu = d(u1) [B*3000, d]
     OASR_CHECK_HIP(hipMemsetAsync(p.tmp_w1p, 0, (size_t)d * 256 * 4, st));
     // conv1 weight gradient, same trick: windows of 3*n_mels (+ junk up to 256, whose gradient columns are never
@@ -1331,7 +1177,6 @@ static int train_backward(oasr_ctx* c, typename Engine<T>::Runner& r, typename E
     RC(launch_colsum_accum(p.gu, d, M1, d, c->G(c->conv1_b), st));
   }
   RC(r.record(ev, seg++));
-  RC(r.lane_join());  // every weight gradient is in the arena (and the saved activations are free) once the main stream passes this
   if (seg != (int)c->segments.size()) {
     oasr_set_error("internal: segment count mismatch %d vs %zu", seg, c->segments.size());
     return OASR_ESTATE;
@@ -1355,7 +1200,6 @@ static int oasr_train_fwd_bwd_s_impl(oasr_ctx* c, const float* mel, const int64_
   typename Engine<T>::Runner r{c, (hipStream_t)stream, B, S, text_len};
   r.train = true;
   r.cs_scratch = p.gemm_cs_scratch;
-  RC(lane_setup(c, r));
   hipStream_t st = r.st;
   // ---------------- forward ----------------
   RC(r.encoder_fwd(p, mel));
@@ -1381,7 +1225,6 @@ static int oasr_train_fwd_impl(oasr_ctx* c, const float* mel, const int64_t* tok
   typename Engine<T>::Runner r{c, (hipStream_t)stream, B, S, text_len};
   r.train = true;
   r.cs_scratch = p.gemm_cs_scratch;
-  RC(lane_setup(c, r));
   RC(r.encoder_fwd(p, mel));
   RC(r.decoder_fwd(p, tokens));
   return launch_logits_to_f32(p.logits, c->Vp, (long)B * S, c->V, logits_out, r.st);
@@ -1395,7 +1238,6 @@ static int oasr_train_bwd_impl(oasr_ctx* c, const int64_t* tokens, const int32_t
   typename Engine<T>::Runner r{c, (hipStream_t)stream, B, S, text_len};
   r.train = true;
   r.cs_scratch = p.gemm_cs_scratch;
-  RC(lane_setup(c, r));
   RC(launch_dlogits_from_f32(dlogits, c->V, (long)B * S, c->Vp, p.logits, r.st));
   return train_backward<T>(c, r, p, tokens, B, S, ev);
 }

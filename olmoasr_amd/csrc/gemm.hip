@@ -735,344 +735,6 @@ __global__ __launch_bounds__(128 * NWN, (NWN == 2 && !SWAP) ? 3 : 2) void oasr_g
 }
 
 
-#define OASR_PP_BARRIER() asm volatile("s_barrier" ::: "memory")
-
-// ---- 256 x 128 x 64 "duo" kernel: TWO co-resident workgroups per CU --------------------------------------------------
-// Why: a CU's store path moves ~14-16 B/clk (MI355X_MICROARCH.md, "attention epilogue store tail": store-ISSUE bound), so the
-// 128 KiB of a 256 x 256 bf16 tile take >= 4.5 us to leave however idle HBM is -- 7.5 us measured with the launch/prologue, 14 us
-// with a residual read, 17 us with two outputs (profiles/r02_gemm_tile_cost_model.txt) -- against 24 us of K loop at K = 1024.
-// The ping-pong kernel owns the whole CU (128 KiB LDS, 8 x 256 VGPRs), so nothing runs under that tail.  Here a workgroup is
-// HALF a CU -- 4 waves (2 x 2, 128 x 64 outputs each: the ping-pong kernel's per-wave tile, fragment readers and LDS images),
-// 80 KiB of LDS, <= 256 VGPRs -- and two of them are resident: one's epilogue (and prologue) runs under the other's K loop, and
-// inside the loop the older workgroup's MFMA sections win the matrix pipe while the younger one reads and stages (VALU/MFMA
-// issue is arbitrated by priority, then age), so the two fall into the alternation the ping-pong kernel builds by hand.
-// LDS: the A image (256 x 64, 32 KiB) is double buffered; the B image (128 x 64, 16 KiB) is single: a wave reads ALL its B
-// fragments of a K-tile (64 columns x 64 k = 32 VGPRs) in the first read section, so the image is dead one barrier later and
-// tile t+1's B is staged into it under this tile's MFMAs.
-//   per K-tile:  S0 { ds_read B (8), A rows 0-63 (8); stage A(t+1) pieces 0-3 -> other A buffer; lgkmcnt(0); s_barrier;
-//                     16 MFMAs with the 4 B(t+1) pieces issued between them }
-//                S1 { ds_read A rows 64-127 (8); stage A(t+1) pieces 4-7; 16 MFMAs; vmcnt(0); s_barrier }
-// Hazards: A(t+1) lands in the buffer whose last readers (tile t-1, S1) are behind the closing barrier of t-1; B(t+1) is issued
-// after the S0 barrier, which every wave passes only with its B(t) reads retired; tile t+1 is read after its issuers' vmcnt(0)
-// and the closing barrier.  The vmcnt(0) is not a drain in the loop's critical path: the pieces it waits for were issued at
-// least one 16-MFMA section earlier, and the co-resident workgroup covers what is left.
-// Accumulation order per accumulator is that of the other direct-to-LDS kernels: results are bit-identical to theirs.
-template <bool TA, bool TB, bool CSUM>
-__global__ __launch_bounds__(256, 2) void oasr_gemm_duo_kernel(GemmArgs p) {
-  constexpr int NW = 4, FBN = 128;
-  constexpr int A_BYTES = FBM * 64 * 2, B_BYTES = FBN * 64 * 2;
-  constexpr int NIA = (A_BYTES / 1024) / NW, NIB = (B_BYTES / 1024) / NW;  // 8, 4 pieces per wave
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int tiles_m = (p.M + FBM - 1) / FBM, tiles_n = (p.N + FBN - 1) / FBN;
-  int tm, tn;
-  {  // groups of 8 tile rows walked rows-first: the 64 tiles an XCD runs at once are 8 A row panels x 8 column panels
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    int gm = p.raster_gm > 0 ? p.raster_gm : 8;
-    gm = gm < 1 ? 1 : (gm > 16 ? 16 : gm);
-    const int per_group = gm * tiles_n;
-    const int group = bid / per_group, in_group = bid - group * per_group;
-    const int first_m = group * gm;
-    const int gsz = min(gm, tiles_m - first_m);
-    tm = first_m + in_group % gsz;
-    tn = in_group / gsz;
-  }
-  const int m0 = tm * FBM, n0 = tn * FBN;
-  const int nt = p.K / BK;
-
-  unsigned offA[NIA], offB[NIB];
-  fast_offsets<TA, FBM, NIA, NW>(p.A, p.M, m0, lane, wave, offA);
-  fast_offsets<TB, FBN, NIB, NW>(p.B, p.N, n0, lane, wave, offB);
-  const bf16_t* baseA = TA ? p.A.ptr + m0 : p.A.ptr + (long)m0 * p.A.ld;
-  const bf16_t* baseB = TB ? p.B.ptr + n0 : p.B.ptr + (long)n0 * p.B.ld;
-  const long stepA = TA ? (long)BK * p.A.ld : BK, stepB = TB ? (long)BK * p.B.ld : BK;
-  char* const sB = smem + 2 * A_BYTES;
-
-#define OASR_DUO_STAGE_A(T, DST, J0, J1)                                                  \
-  do {                                                                                    \
-    const __amdgpu_buffer_rsrc_t r_ = make_rsrc(baseA + (T) * stepA);                     \
-    _Pragma("unroll") for (int j_ = (J0); j_ < (J1); ++j_) glds16(r_, (DST) + (j_ * NW + wave) * 1024, offA[j_]); \
-  } while (0)
-#define OASR_DUO_STAGE_B(T, J0, J1)                                                       \
-  do {                                                                                    \
-    const __amdgpu_buffer_rsrc_t r_ = make_rsrc(baseB + (T) * stepB);                     \
-    _Pragma("unroll") for (int j_ = (J0); j_ < (J1); ++j_) glds16(r_, sB + (j_ * NW + wave) * 1024, offB[j_]); \
-  } while (0)
-#define OASR_DUO_MFMA(MT, NT, KS) acc[MT][NT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[NT][KS], fa[(MT) & 1][KS], acc[MT][NT], 0, 0, 0)
-
-  f32x16_t acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  OASR_DUO_STAGE_A(0, smem, 0, NIA);
-  OASR_DUO_STAGE_B(0, 0, NIB);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  OASR_PP_BARRIER();
-
-  bf16x8_t fa[2][4], fb[2][4];
-  for (int t = 0; t < nt; ++t) {
-    const char* sA = smem + (t & 1) * A_BYTES;
-    char* nA = smem + ((t & 1) ^ 1) * A_BYTES;
-    const bool next = t + 1 < nt;
-    // ---- S0
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) fb[j][ks] = fast_frag<TB, FBN * 2>(sB, wn * 64 + j * 32, ks, lane);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i][ks] = fast_frag<TA, FBM * 2>(sA, wm * 128 + i * 32, ks, lane);
-    if (next) OASR_DUO_STAGE_A(t + 1, nA, 0, NIA / 2);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // B(t) is dead for this wave before the barrier
-    OASR_PP_BARRIER();
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-    asm volatile("" : "+v"(acc[0][0]), "+v"(acc[1][0]), "+v"(acc[0][1]), "+v"(acc[1][1]));
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      OASR_DUO_MFMA(0, 0, ks);
-      OASR_DUO_MFMA(1, 0, ks);
-      OASR_DUO_MFMA(0, 1, ks);
-      OASR_DUO_MFMA(1, 1, ks);
-      if (next && ks < 2) {  // B(t+1) -> the (dead) B image, two pieces after each of the first two k-steps
-        __builtin_amdgcn_sched_barrier(0);
-        OASR_DUO_STAGE_B(t + 1, 2 * ks, 2 * ks + 2);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    asm volatile("" : "+v"(acc[0][0]), "+v"(acc[1][0]), "+v"(acc[0][1]), "+v"(acc[1][1]));
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- S1
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i][ks] = fast_frag<TA, FBM * 2>(sA, wm * 128 + 64 + i * 32, ks, lane);
-    if (next) OASR_DUO_STAGE_A(t + 1, nA, NIA / 2, NIA);
-    __builtin_amdgcn_sched_barrier(0);  // (no explicit lgkmcnt here: hipcc's counted waits let the first MFMAs start under the later reads)
-    __builtin_amdgcn_s_setprio(1);
-    asm volatile("" : "+v"(acc[2][0]), "+v"(acc[3][0]), "+v"(acc[2][1]), "+v"(acc[3][1]));
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      OASR_DUO_MFMA(2, 0, ks);
-      OASR_DUO_MFMA(3, 0, ks);
-      OASR_DUO_MFMA(2, 1, ks);
-      OASR_DUO_MFMA(3, 1, ks);
-    }
-    asm volatile("" : "+v"(acc[2][0]), "+v"(acc[3][0]), "+v"(acc[2][1]), "+v"(acc[3][1]));
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile t+1 have landed
-    OASR_PP_BARRIER();
-  }
-#undef OASR_DUO_STAGE_A
-#undef OASR_DUO_STAGE_B
-#undef OASR_DUO_MFMA
-  // (the loop ended on a barrier: every LDS read is retired; the staging tiles alias the A buffers)
-  fast_epilogue<true, CSUM, true>(p, acc, smem + wave * 8192, (float*)(smem + wave * 8192 + 4096), m0, n0, wm, wn, lane);
-}
-
-
-// ---- 256 x 256 x 64 "quad" kernel: FOUR waves, 128 x 128 outputs each, operands staged through registers -------------------
-// The form the vendor library's best kernel for these shapes has (profiles/r02_gemm_vs_vendor.txt: 4 waves x 128x128, one wave
-// per SIMD): a wave's 128 x 128 block reads 2 x 128 x 64 fragment elements per K-tile instead of the ping-pong kernel's
-// (128 + 64) x 64 for half the outputs -- two thirds of the LDS fragment bytes per MFMA -- and one wave per SIMD issues half the
-// wave-instructions.  With a lone wave on a SIMD nothing else covers a stall, so the stream itself has to keep the matrix pipe
-// fed: a direct-to-LDS piece occupies the issue port for ~60 cycles (MI355X_MICROARCH.md), longer than the 32-cycle shadow of a
-// 32x32x16 MFMA, which is why the operands go global -> VGPR -> LDS here: a 16-byte global load and a ds_write_b128 each fit
-// inside one shadow.  Per K-tile and wave: 64 MFMAs, 32 ds_read_b128 (fragments of k-step ks+1 under the MFMAs of ks), 16 global
-// loads and 16 ds_write_b128 (under k-steps 2-3, into the other LDS buffer); ONE workgroup barrier per K-tile.  Every slot of the
-// stream is placed by hand (sched_barrier(0) fences, inline-asm fragment reads with counted waits); the loop body is branch-free
-// (the last iterations re-load the last tile into dead space).  Accumulators: 16 x 16 = 256 registers (AGPRs); LDS 2 x 64 KiB.
-// ABL (timing experiments only, results are garbage): bit 0 = no global loads / staging writes, bit 1 = no fragment reads,
-// bit 2 = no workgroup barrier, bit 3 = no MFMAs
-template <bool TA, bool TB, bool CSUM, int ABL = 0>
-__global__ __launch_bounds__(256, 1) void oasr_gemm_quad_kernel(GemmArgs p) {
-  static_assert(!TA && !TB, "quad kernel: k-contiguous operands (the NT forward layout)");
-  constexpr int IMG = 256 * 64 * 2;  // one operand image: 32 KiB; buffer b = [A image | B image] at b * 64 KiB
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
-  int tm, tn;
-  {
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    int gm = p.raster_gm > 0 ? p.raster_gm : 8;
-    gm = gm < 1 ? 1 : (gm > 16 ? 16 : gm);
-    const int per_group = gm * tiles_n;
-    const int group = bid / per_group, in_group = bid - group * per_group;
-    const int first_m = group * gm;
-    const int gsz = min(gm, tiles_m - first_m);
-    tm = first_m + in_group % gsz;
-    tn = in_group / gsz;
-  }
-  const int m0 = tm * 256, n0 = tn * 256;
-  const int nt = p.K / BK;
-  // Staging geometry (k-contiguous operands): piece i of this thread = row i*32 + (tid >> 3), 16-byte chunk tid & 7 of a 256 x 64
-  // image.  Global side: ONE per-lane byte offset per operand + a scalar offset per piece (rows past the operand's end are cut
-  // off by the buffer descriptor's range and read as zeros: they only reach outputs that are never stored).  LDS side: the XOR
-  // swizzle depends on (row >> 1) & 7, which the +32 rows of a piece leave alone: ONE per-lane address + 4 KiB immediates.
-  const int srow = tid >> 3, sc16 = tid & 7;
-  const unsigned voffA = (unsigned)(((long)srow * p.A.ld + sc16 * 8) * 2), voffB = (unsigned)(((long)srow * p.B.ld + sc16 * 8) * 2);
-  const unsigned pieceA = (unsigned)(32L * p.A.ld * 2), pieceB = (unsigned)(32L * p.B.ld * 2);  // bytes between pieces
-  const unsigned lw = (unsigned)(srow * 128 + ((sc16 ^ ((srow >> 1) & 7)) << 4));               // LDS offset of piece 0 in its image
-  const bf16_t* gA = p.A.ptr + (long)m0 * p.A.ld;
-  const bf16_t* gB = p.B.ptr + (long)n0 * p.B.ld;
-  const int rowsA = min(256, p.M - m0), rowsB = min(256, p.N - n0);
-  // descriptor of the operand tile at K-tile T: base advanced by T * 128 bytes, range = up to the end of the last valid row
-#define OASR_QUAD_RSRC(G, LD, ROWS, T) \
-  __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>((G) + (long)(T) * BK), 0, (int)((((long)(ROWS) - 1) * (LD) + (p.K - (T) * BK)) * 2), 0x00020000)
-  // fragment read addresses (buffer 0): lane holds row (l & 31) of a 32-row block, 16-byte chunk ks*2 + (l >> 5), XOR-swizzled by
-  // (row >> 1) & 7 -- the XOR makes the k-step a per-lane term, so one address per k-step; blocks are +4096 immediates
-  unsigned adrA[4], adrB[4];
-  {
-    const int h = lane >> 5, ra_ = wm * 128 + (lane & 31), rb_ = wn * 128 + (lane & 31);
-    const unsigned base = (unsigned)(size_t)smem;  // LDS byte offset of the dynamic segment (the low half of the generic address)
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      adrA[ks] = base + (unsigned)(ra_ * 128 + (((ks * 2 + h) ^ ((ra_ >> 1) & 7)) << 4));
-      adrB[ks] = base + (unsigned)(IMG + rb_ * 128 + (((ks * 2 + h) ^ ((rb_ >> 1) & 7)) << 4));
-    }
-  }
-
-  f32x16_t acc[2][4][2];  // [column half][mt][nt]: each half is the acc[4][2] block the shared epilogue takes
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.f;
-
-  // Register-staged operand pipeline, TWO K-tiles deep in registers and one in LDS: while tile t is multiplied out of LDS buffer
-  // t & 1, tile t+1 moves from staging set t & 1 ... into the other buffer, and each freed register is re-loaded with its piece
-  // of tile t+3 right behind the ds_write; the other set (tile t+2) stays in flight.  A load has two K-tiles (~2.5 us) to land:
-  // under full-chip load an HBM/MALL read takes 1.3-2.5 us (the one-tile-deep version of this loop ran at exactly its load
-  // latency: scripts/quad_probe.py ablations, profiles/r03_quad_ablation.txt).
-  // (The B operand -- weights, re-read by every row panel of an XCD and L2-resident -- keeps a one-tile flight: a second register
-  // set for it does not fit beside 64 fragment and 64 + 32 staging registers.)
-  u32x4_t xa[8], xb[8], ya[8];
-#define OASR_QUAD_LOAD_A(RA, T)                                                                                        \
-  do {                                                                                                                 \
-    const int t_ = (T) < nt ? (T) : nt - 1;                                                                            \
-    const __amdgpu_buffer_rsrc_t ra_ = OASR_QUAD_RSRC(gA, p.A.ld, rowsA, t_);                                          \
-    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) RA[i_] = __builtin_amdgcn_raw_buffer_load_b128(ra_, voffA, i_ * pieceA, 0); \
-  } while (0)
-#define OASR_QUAD_LOAD_B(RB, T)                                                                                        \
-  do {                                                                                                                 \
-    const int t_ = (T) < nt ? (T) : nt - 1;                                                                            \
-    const __amdgpu_buffer_rsrc_t rb_ = OASR_QUAD_RSRC(gB, p.B.ld, rowsB, t_);                                          \
-    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) RB[i_] = __builtin_amdgcn_raw_buffer_load_b128(rb_, voffB, i_ * pieceB, 0); \
-  } while (0)
-  OASR_QUAD_LOAD_A(xa, 0);
-  OASR_QUAD_LOAD_B(xb, 0);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    *(u32x4_t*)(smem + lw + i * 4096) = xa[i];
-    *(u32x4_t*)(smem + IMG + lw + i * 4096) = xb[i];
-  }
-  OASR_QUAD_LOAD_A(xa, 1);
-  OASR_QUAD_LOAD_B(xb, 1);
-  OASR_QUAD_LOAD_A(ya, 2);
-  __syncthreads();
-
-  // One MFMA and at most one LDS access + one global load per slot, in exactly this order (sched_barrier(0) on both sides).
-  // Fragment reads are inline asm so that hipcc neither moves them next to their consumers nor waits for them early: the
-  // wait is the counted s_waitcnt in front of the k-step that consumes them, and it names the destinations ("+v") so that no
-  // MFMA can be scheduled above it (cdna_hip_programming.md section 5.7, form (ii)).  The workgroup barrier of a K-tile sits in
-  // the MIDDLE of its last k-step, right behind the last staging write, and the first fragments of the next tile are read under
-  // the remaining 8 MFMAs: the top of a tile never waits for LDS either.
-  bf16x8_t fa[2][4], fb[2][4];
-#define OASR_QUAD_READ(DST, ADDR, BLK) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "i"((BLK) * 4096) : "memory")
-#define OASR_QUAD_WAIT(CNT, S)                                                                                                       \
-  asm volatile("s_waitcnt lgkmcnt(" #CNT ")"                                                                                         \
-               : "+v"(fa[S][0]), "+v"(fa[S][1]), "+v"(fa[S][2]), "+v"(fa[S][3]), "+v"(fb[S][0]), "+v"(fb[S][1]), "+v"(fb[S][2]), "+v"(fb[S][3]))
-#define OASR_QUAD_MFMA(C, MT, J) \
-  acc[(J) >> 1][MT][(J) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[C][J], fa[C][MT], acc[(J) >> 1][MT][(J) & 1], 0, 0, 0)
-#define OASR_QUAD_FENCE() __builtin_amdgcn_sched_barrier(0)
-  // one K-tile: multiply out of buffer (T & 1); RA holds A of tile T+1 and is re-loaded with tile T+3, xb holds B of tile T+1
-  // and is re-loaded with tile T+2
-#define OASR_QUAD_TILE(RA, RB, T)                                                                                                    \
-  do {                                                                                                                               \
-    const unsigned cur = (unsigned)((T) & 1) << 16, nxt = cur ^ 0x10000u;                                                            \
-    const int t3 = (T) + 3 < nt ? (T) + 3 : nt - 1, t2 = (T) + 2 < nt ? (T) + 2 : nt - 1;                                            \
-    const __amdgpu_buffer_rsrc_t rsa = OASR_QUAD_RSRC(gA, p.A.ld, rowsA, t3), rsb = OASR_QUAD_RSRC(gB, p.B.ld, rowsB, t2);           \
-    const unsigned wa = lw + nxt, wb = lw + IMG + nxt;                                                                               \
-    OASR_QUAD_WAIT(0, 0);                                                                                                            \
-    OASR_QUAD_FENCE();                                                                                                               \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                                               \
-      const int c = ks & 1, n = c ^ 1;                                                                                               \
-      const unsigned va = adrA[(ks + 1) & 3] + (ks < 3 ? cur : nxt), vb = adrB[(ks + 1) & 3] + (ks < 3 ? cur : nxt);                 \
-      _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                                                               \
-        const int mt = q >> 2, j = q & 3;                                                                                            \
-        if (!(ABL & 8)) OASR_QUAD_MFMA(c, mt, j);                                                                                    \
-        OASR_QUAD_FENCE();                                                                                                           \
-        if (!(ABL & 2) && ks < 3 && q < 8) {                                                                                         \
-          if ((q & 1) == 0) OASR_QUAD_READ(fa[n][q >> 1], va, q >> 1);                                                               \
-          else OASR_QUAD_READ(fb[n][q >> 1], vb, q >> 1);                                                                            \
-        }                                                                                                                            \
-        if (!(ABL & 1) && ks == 2 && q >= 8) {                                                                                       \
-          *(u32x4_t*)(smem + wa + (q - 8) * 4096) = RA[q - 8];                                                                       \
-          RA[q - 8] = __builtin_amdgcn_raw_buffer_load_b128(rsa, voffA, (q - 8) * pieceA, 0);                                        \
-        }                                                                                                                            \
-        if (!(ABL & 1) && ks == 3 && q < 8) {                                                                                        \
-          *(u32x4_t*)(smem + wb + q * 4096) = RB[q];                                                                                 \
-          RB[q] = __builtin_amdgcn_raw_buffer_load_b128(rsb, voffB, q * pieceB, 0);                                                  \
-        }                                                                                                                            \
-        if (ks == 3 && q == 7) {                                                                                                     \
-          OASR_QUAD_FENCE();                                                                                                         \
-          if (!(ABL & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                            \
-        }                                                                                                                            \
-        if (!(ABL & 2) && ks == 3 && q >= 8 && q < 12) {                                                                             \
-          OASR_QUAD_READ(fa[n][q - 8], va, q - 8);                                                                                   \
-          OASR_QUAD_READ(fb[n][q - 8], vb, q - 8);                                                                                   \
-        }                                                                                                                            \
-        OASR_QUAD_FENCE();                                                                                                           \
-      }                                                                                                                              \
-      if (ks == 0 || ks == 1) OASR_QUAD_WAIT(0, n);                                                                                  \
-      if (ks == 2) OASR_QUAD_WAIT(8, n);                                                                                             \
-      OASR_QUAD_FENCE();                                                                                                             \
-    }                                                                                                                                \
-  } while (0)
-  {
-    OASR_QUAD_READ(fa[0][0], adrA[0], 0);
-    OASR_QUAD_READ(fb[0][0], adrB[0], 0);
-    OASR_QUAD_READ(fa[0][1], adrA[0], 1);
-    OASR_QUAD_READ(fb[0][1], adrB[0], 1);
-    OASR_QUAD_READ(fa[0][2], adrA[0], 2);
-    OASR_QUAD_READ(fb[0][2], adrB[0], 2);
-    OASR_QUAD_READ(fa[0][3], adrA[0], 3);
-    OASR_QUAD_READ(fb[0][3], adrB[0], 3);
-  }
-  for (int t = 0; t < nt; t += 2) {
-    OASR_QUAD_TILE(xa, xb, t);
-    if (t + 1 < nt) OASR_QUAD_TILE(ya, xb, t + 1);
-  }
-  OASR_QUAD_WAIT(0, 0);  // the look-ahead reads of the last iteration land in registers the epilogue is about to reuse
-  __syncthreads();
-#undef OASR_QUAD_TILE
-#undef OASR_QUAD_LOAD_A
-#undef OASR_QUAD_LOAD_B
-#undef OASR_QUAD_RSRC
-#undef OASR_QUAD_READ
-#undef OASR_QUAD_WAIT
-#undef OASR_QUAD_MFMA
-#undef OASR_QUAD_FENCE
-  // epilogue: the wave's 128 x 128 block as two 128 x 64 halves through the shared row epilogue (staging tiles alias the A image)
-  fast_epilogue<true, CSUM, true>(p, acc[0], smem + wave * 8192, (float*)(smem + wave * 8192 + 4096), m0, n0 + wn * 64, wm, wn, lane);
-  fast_epilogue<true, CSUM, true>(p, acc[1], smem + wave * 8192, (float*)(smem + wave * 8192 + 4096), m0, n0 + wn * 64 + 64, wm, wn, lane);
-}
-
-
 // ---- 256 x 256 x 64 "ping-pong" kernel ---------------------------------------------------------------------------
 // 8 waves (2 along M x 4 along N, 128 x 64 outputs each), one workgroup per CU, 128 KiB of LDS = two K-tile buffers of
 // four 16 KiB half-tile images (A rows 0-127 / 128-255, B columns 0-127 / 128-255; each image is laid out exactly like
@@ -1094,6 +756,7 @@ __global__ __launch_bounds__(256, 1) void oasr_gemm_quad_kernel(GemmArgs p) {
 //        (two barrier events later even for the trailing wave group);
 //   WAR  an image is re-staged >= 2 phases after its last ds_read, or in the next phase when the reading phase
 //        retired its reads (lgkmcnt(0)) before its first barrier (B1 in phase 1 -> B restaged in phase 2).
+#define OASR_PP_BARRIER() asm volatile("s_barrier" ::: "memory")
 
 template <bool TA, bool TB, bool SWAP, bool CSUM, int VAR>
 __global__ __launch_bounds__(512, 2) void oasr_gemm_pp_kernel(GemmArgs p) {
@@ -1532,93 +1195,6 @@ int launch_fast_cfg(const GemmArgs& a, hipStream_t stream) {
   return OASR_OK;
 }
 
-template <bool TA, bool TB, bool CSUM = false>
-int launch_duo_cfg(const GemmArgs& a, hipStream_t stream) {
-  static bool attr = false;
-  const int lds = 2 * FBM * 64 * 2 + 128 * 64 * 2;  // two A images + one B image = 80 KiB: two workgroups per CU
-  if (!attr) {
-    OASR_CHECK_HIP(hipFuncSetAttribute((const void*)oasr_gemm_duo_kernel<TA, TB, CSUM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr = true;
-  }
-  const dim3 grid(cdiv(a.M, FBM) * cdiv(a.N, 128));
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (g_prof.on) {
-    const size_t idx = g_prof.recs.size();
-    while (g_prof.events.size() < 2 * (idx + 1)) {
-      hipEvent_t e;
-      OASR_CHECK_HIP(hipEventCreate(&e));
-      g_prof.events.push_back(e);
-    }
-    e0 = g_prof.events[2 * idx];
-    e1 = g_prof.events[2 * idx + 1];
-    auto tf = [](bool b) { return b ? "true" : "false"; };
-    static const std::string name = std::string("oasr_gemm_duo_kernel<") + tf(TA) + ", " + tf(TB) + ", " + tf(CSUM) + ">";
-    g_prof.recs.push_back({(TA ? 2 : 0) + (TB ? 1 : 0), 2.0 * (double)a.M * (double)a.N * (double)a.K, name.c_str()});
-    OASR_CHECK_HIP(hipEventRecord(e0, stream));
-  }
-  hipLaunchKernelGGL((oasr_gemm_duo_kernel<TA, TB, CSUM>), grid, dim3(256), lds, stream, a);
-  OASR_LAUNCH_CHECK();
-  if (e1) OASR_CHECK_HIP(hipEventRecord(e1, stream));
-  return OASR_OK;
-}
-
-template <int ABL>
-int launch_quad_abl(const GemmArgs& a, hipStream_t stream) {
-  static bool attr = false;
-  const int lds = 2 * 2 * 256 * 64 * 2;
-  if (!attr) {
-    OASR_CHECK_HIP(hipFuncSetAttribute((const void*)oasr_gemm_quad_kernel<false, false, false, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr = true;
-  }
-  hipLaunchKernelGGL((oasr_gemm_quad_kernel<false, false, false, ABL>), dim3(cdiv(a.M, 256) * cdiv(a.N, 256)), dim3(256), lds, stream, a);
-  OASR_LAUNCH_CHECK();
-  return OASR_OK;
-}
-template <bool TA, bool TB, bool CSUM = false>
-int launch_quad_cfg(const GemmArgs& a, hipStream_t stream) {
-  static const int env_abl = [] {
-    const char* e = getenv("OASR_QUAD_ABL");
-    return e ? atoi(e) : 0;
-  }();
-  if (env_abl && !CSUM) {
-    switch (env_abl) {
-      case 1: return launch_quad_abl<1>(a, stream);
-      case 2: return launch_quad_abl<2>(a, stream);
-      case 3: return launch_quad_abl<3>(a, stream);
-      case 4: return launch_quad_abl<4>(a, stream);
-      case 7: return launch_quad_abl<7>(a, stream);
-      case 8: return launch_quad_abl<8>(a, stream);
-      default: break;
-    }
-  }
-  static bool attr = false;
-  const int lds = 2 * 2 * 256 * 64 * 2;  // two K-tile buffers of an A and a B image: 128 KiB
-  if (!attr) {
-    OASR_CHECK_HIP(hipFuncSetAttribute((const void*)oasr_gemm_quad_kernel<TA, TB, CSUM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr = true;
-  }
-  const dim3 grid(cdiv(a.M, 256) * cdiv(a.N, 256));
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (g_prof.on) {
-    const size_t idx = g_prof.recs.size();
-    while (g_prof.events.size() < 2 * (idx + 1)) {
-      hipEvent_t e;
-      OASR_CHECK_HIP(hipEventCreate(&e));
-      g_prof.events.push_back(e);
-    }
-    e0 = g_prof.events[2 * idx];
-    e1 = g_prof.events[2 * idx + 1];
-    auto tf = [](bool b) { return b ? "true" : "false"; };
-    static const std::string name = std::string("oasr_gemm_quad_kernel<") + tf(TA) + ", " + tf(TB) + ", " + tf(CSUM) + ">";
-    g_prof.recs.push_back({(TA ? 2 : 0) + (TB ? 1 : 0), 2.0 * (double)a.M * (double)a.N * (double)a.K, name.c_str()});
-    OASR_CHECK_HIP(hipEventRecord(e0, stream));
-  }
-  hipLaunchKernelGGL((oasr_gemm_quad_kernel<TA, TB, CSUM>), grid, dim3(256), lds, stream, a);
-  OASR_LAUNCH_CHECK();
-  if (e1) OASR_CHECK_HIP(hipEventRecord(e1, stream));
-  return OASR_OK;
-}
-
 template <bool TA, bool TB, bool SWAP, bool CSUM, int DMA>
 int launch_pp_variant(const GemmArgs& a, hipStream_t stream) {
   static bool attr = false;
@@ -1743,33 +1319,6 @@ int launch_fast_t(const GemmArgs& a, hipStream_t stream) {
   }();
   const int geom = g_fast_geometry ? g_fast_geometry : env_geom;
   const bool big = geom == 2;  // (the 256x256 / 2-stage geometry lost to 256x128 on every measured shape incl. small split-K outputs: scripts/wgrad_sweep.py)
-  static const int env_duo_k = [] {
-    const char* e = getenv("OASR_GEMM_DUO_K");  // experiments: the duo kernel for every bf16-output GEMM with K <= this
-    return e ? atoi(e) : -1;
-  }();
-  static const int env_duo_n = [] {
-    const char* e = getenv("OASR_GEMM_DUO_N");  // ... and N <= this
-    return e ? atoi(e) : 0;
-  }();
-  const bool duo_rule = geom == 0 && !atomic_only && a.split_k == 1 && env_duo_k > 0 && a.K <= env_duo_k &&
-                        (env_duo_n <= 0 || a.N <= env_duo_n) && prefer_pingpong(a);
-  static const int env_quad = [] {
-    const char* e = getenv("OASR_GEMM_QUAD");  // experiments: 1 = the quad kernel for every NT bf16-output GEMM the ping-pong kernel would take
-    return e ? atoi(e) : 0;
-  }();
-  if ((geom == 6 || (geom == 0 && env_quad == 1 && prefer_pingpong(a))) && !atomic_only && a.split_k == 1 && !TA && !TB) {  // 256x256 "quad" kernel
-    const int rc = launch_quad_cfg<false, false>(a, stream);
-    return (rc || !a.colsum) ? rc : launch_colsum_accum(a.out, a.ldc, a.M, a.N, a.colsum, stream);
-  }
-  if ((geom == 5 || duo_rule) && !atomic_only && a.split_k == 1) {  // 256x128 "duo" kernel (two workgroups per CU)
-    if (a.colsum && !TA && TB) {
-      const int rc = launch_duo_cfg<false, true, true>(a, stream);
-      if (rc || !a.colsum_scratch) return rc;
-      return launch_colsum_accum(a.colsum_scratch, a.N, 2L * cdiv(a.M, 256), a.N, a.colsum, stream);
-    }
-    const int rc = launch_duo_cfg<TA, TB>(a, stream);
-    return (rc || !a.colsum) ? rc : launch_colsum_accum(a.out, a.ldc, a.M, a.N, a.colsum, stream);
-  }
   if (geom == 3 || (geom == 0 && !atomic_only && prefer_pingpong(a)) ||
       (geom == 0 && atomic_only && a.atomic_on_pp && (a.M % 256) == 0 && (a.N % 256) == 0)) {  // 256x256 ping-pong kernel
     if (atomic_only) return launch_pp_cfg<TA, TB, false>(a, stream);
@@ -1956,5 +1505,5 @@ int gemm_profile_collect(double ms[4], double flops[4], long count[4], char* by_
 
 void gemm_force_general(int on) {
   g_force_general = (on == 1);
-  g_fast_geometry = on >= 2 ? on - 1 : 0;  // 2 -> force 256x128, 3 -> force 256x256 (2-stage), 4 -> force 256x256 ping-pong, 6 -> force 256x128 duo, 7 -> force 256x256 quad (NT / NN)
+  g_fast_geometry = on >= 2 ? on - 1 : 0;  // 2 -> force 256x128, 3 -> force 256x256 (2-stage), 4 -> force 256x256 ping-pong
 }

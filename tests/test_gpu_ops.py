@@ -107,7 +107,7 @@ GEMM_SHAPES = [(256, 256, 128), (384, 128, 512), (296, 136, 200), (128, 1024, 64
                (3000, 1152, 384)]
 
 
-@pytest.fixture(params=[0, 1, 2, 3, 4, 6, 7], ids=["auto", "general", "fast256x128", "fast256x256", "pingpong256", "duo256x128", "quad256"])
+@pytest.fixture(params=[0, 1, 2, 3, 4], ids=["auto", "general", "fast256x128", "fast256x256", "pingpong256"])
 def gemm_path(request):
     """Run GEMM tests through both kernels: the direct-to-LDS fast path (where it applies) and the general one."""
     from olmoasr_amd import _native as N
@@ -195,86 +195,6 @@ def test_gemm_pingpong_persistent_launch_matches_plain(layout):
         # may round `pre` to the neighbouring bf16 value
         ulp = torch.maximum(pre.abs(), resid.float().abs()) * 2.0 ** -7
         assert bool(((outs[1][0].float() - ref).abs() <= ulp + 1e-2 * ref.abs() + 1e-3).all()), "persistent " + layout
-
-
-@pytest.mark.parametrize("layout", ["nt", "nt_gelu", "nt_bias_only"])
-def test_gemm_quad_kernel_is_bit_identical_to_pingpong(layout):
-    """The 4-wave / 128x128-per-wave register-staged kernel (hand-placed instruction stream, NT layout): per accumulator the k-steps
-    arrive in the ping-pong kernel's order and the epilogue is shared -> same bits.  Ragged M and N tiles, 24 K-tiles."""
-    from olmoasr_amd import _native as N
-    M, N_, K = 256 * 9 + 72, 1152, 1536
-    A = rnd(M, K, seed=1)
-    B = rnd(N_, K, seed=2, scale=0.05)
-    bias = torch.randn(N_, device=DEV)
-    resid = rnd(M, N_, seed=3)
-    outs = []
-    try:
-        for code in (4, 7):
-            N.lib().oasr_gemm_force_general(code)
-            o = torch.full((M, N_), float("nan"), device=DEV, dtype=BF)
-            if layout == "nt_gelu":
-                pre = torch.full((M, N_), float("nan"), device=DEV, dtype=BF)
-                ops().gemm(A, B, M, N_, K, bias=bias, act=2, out=o, out_pre=pre)
-                outs.append((o, pre))
-            elif layout == "nt_bias_only":
-                ops().gemm(A, B, M, N_, K, bias=bias, out=o)
-                outs.append((o,))
-            else:
-                ops().gemm(A, B, M, N_, K, bias=bias, resid=resid, out=o)
-                outs.append((o,))
-    finally:
-        N.lib().oasr_gemm_force_general(0)
-    for a, b in zip(outs[0], outs[1]):
-        assert torch.equal(a, b), layout
-    if layout == "nt":
-        pre = (A.float() @ B.float().t() + bias).bfloat16().float()
-        ref = pre + resid.float()
-        ulp = torch.maximum(pre.abs(), resid.float().abs()) * 2.0 ** -7
-        assert bool(((outs[1][0].float() - ref).abs() <= ulp + 1e-2 * ref.abs() + 1e-3).all()), "quad nt"
-
-
-@pytest.mark.parametrize("layout", ["nt", "nn", "nt_gelu", "nn_dgelu_colsum"])
-def test_gemm_duo_kernel_is_bit_identical_to_pingpong(layout):
-    """The two-workgroups-per-CU 256x128 kernel accumulates every output in the ping-pong kernel's order and shares its
-    epilogue: same bits, on a shape with ragged row panels and many K-tiles (the A double buffer and the recycled B image
-    wrap several times)."""
-    from olmoasr_amd import _native as N
-    M, N_, K = 256 * 9 + 72, 1152, 1536
-    A = rnd(M, K, seed=1)
-    nn = layout.startswith("nn")
-    B = rnd(K, N_, seed=2, scale=0.05) if nn else rnd(N_, K, seed=2, scale=0.05)
-    bias = torch.randn(N_, device=DEV)
-    resid = rnd(M, N_, seed=3)
-    u = rnd(M, N_, seed=4)
-    outs = []
-    try:
-        for code in (4, 6):
-            N.lib().oasr_gemm_force_general(code)
-            o = torch.full((M, N_), float("nan"), device=DEV, dtype=BF)
-            if layout == "nt_gelu":
-                pre = torch.full((M, N_), float("nan"), device=DEV, dtype=BF)
-                ops().gemm(A, B, M, N_, K, bias=bias, act=2, out=o, out_pre=pre)
-                outs.append((o, pre))
-            elif layout == "nn_dgelu_colsum":
-                cs = torch.zeros(N_, device=DEV)
-                ops().gemm(A, B, M, N_, K, tb=True, dgelu_u=u, out=o, colsum=cs)
-                outs.append((o, cs))
-            else:
-                ops().gemm(A, B, M, N_, K, tb=nn, bias=bias, resid=resid, out=o)
-                outs.append((o,))
-    finally:
-        N.lib().oasr_gemm_force_general(0)
-    for a, b in zip(outs[0], outs[1]):
-        if a.dtype == torch.float32:
-            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-3)  # column sums: partial-row order
-        else:
-            assert torch.equal(a, b), layout
-    if layout in ("nt", "nn"):
-        Bf = B.float() if nn else B.float().t()
-        pre = (A.float() @ Bf + bias).bfloat16().float()
-        ref = pre + resid.float()
-        ulp = torch.maximum(pre.abs(), resid.float().abs()) * 2.0 ** -7
-        assert bool(((outs[1][0].float() - ref).abs() <= ulp + 1e-2 * ref.abs() + 1e-3).all()), "duo " + layout
 
 
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
