@@ -303,15 +303,21 @@ def test_c5_small_dims_memorised_bf16_greedy_transcribe_is_exact():
     tl = torch.full((3,), L - 1, dtype=torch.int32)
     net = OLMoASR(_dims(dims), device=DEV, seed=3)  # bf16 production engine, training head
     args = (mel, ti.to(DEV), ty.to(DEV), tl.to(DEV))
-    loss = None
-    for step in range(1, 601):
+    loss, margin = None, 0.0
+    for step in range(1, 801):
         net.zero_grad()
-        loss, _ = net.loss_and_backward(*args, loss_scale=65536.0)
+        loss, logits = net.loss_and_backward(*args, loss_scale=65536.0, return_logits=step % 25 == 0)
         net.optim_step(step=step, lr=5e-4 * min(1.0, step / 20), inv_loss_scale=1.0 / 65536.0)
-        if step % 25 == 0 and float(loss) < 0.01:
-            break
-    print(f"memorised after {step} steps, loss {float(loss):.4f}")
-    assert float(loss) < 0.05
+        if step % 25 == 0 and step >= 100:
+            # "confident" = at EVERY supervised position the target's logit leads the runner-up by far more than the bf16-vs-fp32
+            # envelope (~0.1-0.25 at this size) -- including the first token, which only the audio can decide
+            top2 = logits[:, :L - 1].float().topk(2, -1)
+            right = bool((top2.indices[..., 0] == ty[:, :L - 1].to(DEV)).all())
+            margin = float((top2.values[..., 0] - top2.values[..., 1]).min()) if right else 0.0
+            if margin > 4.0:
+                break
+    print(f"memorised after {step} steps, loss {float(loss):.4f}, smallest top-2 margin {margin:.2f}")
+    assert margin > 4.0
     sd = {k: v.detach().cpu().float() for k, v in net.state_dict().items()}
     kw = dict(temperature=0.0, logprob_threshold=None, no_speech_threshold=None, without_timestamps=True, sample_len=80)
     got = net.transcribe(pcm, **kw)
