@@ -2,14 +2,18 @@
 // Reference: F.cross_entropy(logits.view(-1, V+1), text_y.view(-1), ignore_index=51864) / accumulation_steps
 // (scripts/training/train_timestamps.py:1444-1450) on logits that the reference produced in bf16 and then
 // .float()-ed (olmoasr/model.py:768-770); the gradient it back-propagates into the tied-logits matmul is bf16.
-// One 256-thread workgroup per token row: the 51865 bf16 logits (104 KB) are read ONCE into registers
-// (26 x 16 bytes per thread), softmax statistics in fp32, and (softmax - onehot) * g is written back in place
+// One 1024-thread workgroup per token row: the 51865 bf16 logits (104 KB) are read ONCE into registers
+// (7 x 16 bytes per thread), softmax statistics in fp32, and (softmax - onehot) * g is written back in place
 // as bf16 -> 2 * 2 * V bytes of HBM traffic per row, no fp32 logits tensor ever exists.
 #include "kernels.h"
 
 namespace {
 
-constexpr int CE_CHUNKS = 26;  // 26 * 256 threads * 8 = 53248 >= 51968
+// Workgroup width (scripts/ce_bench.py, [57344, 51968] bf16, every row valid, one MI355X): 256 threads x 26 chunks = 146 VGPRs, three rows
+// per CU: 2.66 ms; 512 x 13: 2.54 ms; 1024 x 7 (62 VGPRs, 32 waves per CU): 2.42 ms = 4.93 TB/s = 0.62 of 8 TB/s.  (Round 2: 3.34 ms, with a
+// per-element column test, a per-element onehot compare and the natural-base exponential in both passes.)
+constexpr int CE_THREADS = 1024;
+constexpr int CE_CHUNKS = 7;     // 7 * 1024 threads * 8 = 57344 >= 51968
 
 __device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -19,11 +23,23 @@ __device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) 
   __syncthreads();
   return is_max ? fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) : (red[0] + red[1]) + (red[2] + red[3]);
 }
+// the same over the 8 waves of a cross-entropy workgroup (fixed combination order: deterministic)
+__device__ __forceinline__ float block_reduce8(float v, float* red, bool is_max) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  v = is_max ? wave_max(v) : wave_sum(v);
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float r = red[0];
+#pragma unroll
+  for (int w = 1; w < CE_THREADS / 64; ++w) r = is_max ? fmaxf(r, red[w]) : r + red[w];
+  return r;
+}
 
-__global__ __launch_bounds__(256) void ce_kernel(bf16_t* __restrict__ logits, long ld, int V, const int64_t* __restrict__ targets,
+__global__ __launch_bounds__(CE_THREADS) void ce_kernel(bf16_t* __restrict__ logits, long ld, int V, const int64_t* __restrict__ targets,
                                                  long ignore, float gscale, const int32_t* __restrict__ n_valid_dev,
                                                  float* __restrict__ row_loss, int write_grad) {
-  __shared__ float red[4];
+  __shared__ float red[CE_THREADS / 64];
   const long row = blockIdx.x;
   bf16_t* lr = logits + row * ld;
   const long tgt = targets[row];
@@ -33,60 +49,73 @@ __global__ __launch_bounds__(256) void ce_kernel(bf16_t* __restrict__ logits, lo
   if (tgt == ignore || tgt < 0 || tgt >= V) {
     if (write_grad) {
       const u32x4_t z = {0u, 0u, 0u, 0u};
-      for (int ch = threadIdx.x; ch < nchunk; ch += 256) *(u32x4_t*)(lr + ch * 8) = z;
+      for (int ch = threadIdx.x; ch < nchunk; ch += CE_THREADS) *(u32x4_t*)(lr + ch * 8) = z;
     }
     if (threadIdx.x == 0) row_loss[row] = 0.f;
     return;
   }
+  // The row is VALU-heavy once it sits in registers (two exponentials per logit), so the per-element work is kept minimal: columns
+  // past V (the 128-padding of the tied head) are overwritten with -inf ONCE after the load -- they then drop out of the maximum,
+  // contribute exp(-inf) = 0 to the sum and get a zero gradient without any per-element test -- the exponent runs in the log2
+  // domain (one fma + v_exp_f32), and the "- onehot" of the target column is patched into the one chunk that holds it.
+  constexpr float L2E = 1.4426950408889634f;
   u32x4_t v[CE_CHUNKS];
   float mx = -3.0e38f;
 #pragma unroll
   for (int c = 0; c < CE_CHUNKS; ++c) {
-    const int ch = threadIdx.x + 256 * c;
+    const int ch = threadIdx.x + CE_THREADS * c;
     if (ch < nchunk) {
       v[c] = *(const u32x4_t*)(lr + ch * 8);
+      if (ch * 8 + 8 > V) {  // (only the last ~13 chunks of a row)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int col = ch * 8 + 2 * i;
-        if (col < V) mx = fmaxf(mx, bf_lo(v[c][i]));
-        if (col + 1 < V) mx = fmaxf(mx, bf_hi(v[c][i]));
+        for (int i = 0; i < 4; ++i) {
+          const int col = ch * 8 + 2 * i;
+          if (col >= V) v[c][i] = (v[c][i] & 0xffff0000u) | 0x0000ff80u;
+          if (col + 1 >= V) v[c][i] = (v[c][i] & 0x0000ffffu) | 0xff800000u;
+        }
       }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mx = fmaxf(mx, fmaxf(bf_lo(v[c][i]), bf_hi(v[c][i])));
     }
   }
-  mx = block_reduce(mx, red, true);
+  mx = block_reduce8(mx, red, true);
+  const float nm2 = -mx * L2E;
   float sum = 0.f;
 #pragma unroll
   for (int c = 0; c < CE_CHUNKS; ++c) {
-    const int ch = threadIdx.x + 256 * c;
+    const int ch = threadIdx.x + CE_THREADS * c;
     if (ch < nchunk) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int col = ch * 8 + 2 * i;
-        if (col < V) sum += __expf(bf_lo(v[c][i]) - mx);
-        if (col + 1 < V) sum += __expf(bf_hi(v[c][i]) - mx);
-      }
+      for (int i = 0; i < 4; ++i)
+        sum += __builtin_amdgcn_exp2f(fmaf(bf_lo(v[c][i]), L2E, nm2)) + __builtin_amdgcn_exp2f(fmaf(bf_hi(v[c][i]), L2E, nm2));
     }
   }
-  sum = block_reduce(sum, red, false);
+  sum = block_reduce8(sum, red, false);
   const float lse = mx + __logf(sum);
   if (threadIdx.x == 0) row_loss[row] = lse - bf2f(lr[tgt]);
   if (!write_grad) return;
   __syncthreads();  // lr[tgt] read above must precede the in-place overwrite
   const float g = gscale / (float)max(1, *n_valid_dev);
-  const float inv = 1.0f / sum;
+  const float sg = g / sum;  // softmax * g = exp2(..) * sg
+  const int tch = (int)(tgt >> 3), tpos = (int)(tgt & 7);
 #pragma unroll
   for (int c = 0; c < CE_CHUNKS; ++c) {
-    const int ch = threadIdx.x + 256 * c;
+    const int ch = threadIdx.x + CE_THREADS * c;
     if (ch < nchunk) {
-      u32x4_t o;
+      float e[8];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int col = ch * 8 + 2 * i;
-        float a = 0.f, b = 0.f;
-        if (col < V) a = (__expf(bf_lo(v[c][i]) - mx) * inv - (col == tgt ? 1.f : 0.f)) * g;
-        if (col + 1 < V) b = (__expf(bf_hi(v[c][i]) - mx) * inv - (col + 1 == tgt ? 1.f : 0.f)) * g;
-        o[i] = pack_bf2(a, b);
+        e[2 * i] = __builtin_amdgcn_exp2f(fmaf(bf_lo(v[c][i]), L2E, nm2)) * sg;
+        e[2 * i + 1] = __builtin_amdgcn_exp2f(fmaf(bf_hi(v[c][i]), L2E, nm2)) * sg;
       }
+      if (ch == tch) {  // (one thread of the row)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (i == tpos) e[i] -= g;
+      }
+      u32x4_t o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = pack_bf2(e[2 * i], e[2 * i + 1]);
       *(u32x4_t*)(lr + ch * 8) = o;
     }
   }
@@ -316,9 +345,9 @@ int launch_count_valid(const int64_t* targets, long rows, long ignore, int V, in
 int launch_cross_entropy(bf16_t* logits, long ld, int V, const int64_t* targets, long rows, long ignore, float gscale,
                          const int32_t* n_valid_dev, float* row_loss, int write_grad, hipStream_t s) {
   OASR_REQUIRE(logits && targets && n_valid_dev && row_loss, "cross_entropy: null pointer");
-  OASR_REQUIRE(ld % 8 == 0 && V <= ld && ld <= CE_CHUNKS * 256 * 8, "cross_entropy: ld=%ld V=%d unsupported", ld, V);
+  OASR_REQUIRE(ld % 8 == 0 && V <= ld && ld <= CE_CHUNKS * CE_THREADS * 8, "cross_entropy: ld=%ld V=%d unsupported", ld, V);
   if (rows <= 0) return OASR_OK;
-  hipLaunchKernelGGL(ce_kernel, dim3((unsigned)rows), dim3(256), 0, s, logits, ld, V, targets, ignore, gscale, n_valid_dev,
+  hipLaunchKernelGGL(ce_kernel, dim3((unsigned)rows), dim3(CE_THREADS), 0, s, logits, ld, V, targets, ignore, gscale, n_valid_dev,
                      row_loss, write_grad);
   OASR_LAUNCH_CHECK();
   return OASR_OK;
