@@ -30,11 +30,6 @@ if ROOT not in sys.path:
 
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16, MI355X_MICROARCH.md "Chip-level parameters"
 
-SUSTAINED_GEMM_TFLOPS = 1484.0  # measured: the best dense bf16 GEMM seen at the 1400 W package cap on these boxes -- hipBLASLt's 4-wave
-#                                 256x256x64 stream-K kernel, 1.83 GHz (profiles/r02_gemm_vs_vendor.txt)
-OWN_SUSTAINED_GEMM_TFLOPS = 1307.0  # this repo's layer GEMM alone at the same cap, 1.65 GHz (profiles/r02_gpu_power_under_gemm.txt)
-
-
 class PowerSampler:
     """Samples the amdgpu hwmon package power and shader clock of one GPU from a thread (sysfs reads, no subprocess) while a step runs."""
 
@@ -262,7 +257,7 @@ def main():
     ap.add_argument("--micro-batch", type=int, default=0,
                     help="clips per micro-batch (gradient accumulation over per-gpu-batch / micro-batch); 0 = the largest of "
                          "128/64/32/... whose saved activations fit in free HBM with 24 GiB to spare")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r02_hbm_traffic.json"),
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r03_hbm_traffic.json"),
                     help="per-symbol HBM bytes per launch from the rocprofv3 PMC passes (scripts/pmc_traffic.py)")
     ap.add_argument("--bucket-mb", type=float, default=128.0)
     ap.add_argument("--reducer", default="allreduce", choices=["allreduce", "direct"],
@@ -407,14 +402,10 @@ def main():
                                   "tflops": round(v["flops"] / v["ms"] / 1e9, 1)} for k, v in sorted(sym.items(), key=lambda kv: -kv[1]["ms"])},
                 "by_layout_tflops": {layouts[k]: round(fl[k] / ms[k] / 1e9, 1) for k in range(4) if cnt[k]},
                 "gemm_ms_per_step": round(sum(ms), 2)}
-        # The MI355X clocks to its 1400 W package budget: `frac` above is priced against the 2.4 GHz datasheet peak as
-        # the contract asks; this block says where the board actually was during the profiled step, and what a dense bf16 GEMM sustains
-        # when it alone holds the package at its cap: the vendor library's best kernel (the practical ceiling) and this repo's own.
-        roof["power_limited"] = {"sampled_during_profiled_step": power, "sustained_gemm_ceiling_tflops": SUSTAINED_GEMM_TFLOPS,
-                                 "ceiling_source": "profiles/r02_gemm_vs_vendor.txt (hipBLASLt MT256x256x64 stream-K via torch.matmul, N=K=4096, 6 s back to back: 1398-1400 W of 1400 W, sclk 1.83 GHz) -- NOT measured in this run",
-                                 "own_kernel_sustained_tflops": OWN_SUSTAINED_GEMM_TFLOPS,
-                                 "own_source": "profiles/r02_gpu_power_under_gemm.txt (this repo's ping-pong kernel, same shape: 1399-1400 W, sclk 1.65 GHz) -- NOT measured in this run",
-                                 "frac_of_sustained_ceiling": round(achieved / SUSTAINED_GEMM_TFLOPS, 4)}
+        # where the board actually was during the profiled step (live hwmon sample).  Reference points that were NOT measured in this
+        # run -- the package-cap ceilings of a dense bf16 GEMM on these boxes -- are in profiles/ (r02_gemm_vs_vendor.txt: vendor library
+        # 1484 TFLOP/s at 1400 W / 1.83 GHz, this repo's layer GEMM 1307 at 1.65 GHz) and are not replayed into this line.
+        roof["power_limited"] = {"sampled_during_profiled_step": power}
 
     out = None
     if rank == 0:
