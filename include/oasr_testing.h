@@ -19,6 +19,9 @@ int oasr_gemm_set_variant(int v);
 /* tests / A-B of the KV-cached step's LayerNorm placement: 1 = folded into the projections' operand loads for every B <= 32,
  * 0 = always separate kernels, -1 = default (folded up to 4 sequences).  Bit-identical (tests/test_gpu_decode_step.py). */
 int oasr_decode_set_ln_fold(int mode);
+/* tests / A-B: 1 (default) = the unmasked attention cases (encoder self-, cross-attention) run the 8-wave ping-pong kernels,
+ * 0 = the general (maskable) kernels run everything.  Same results up to accumulation order (tests/test_gpu_ops.py). */
+int oasr_attention_set_pingpong(int on);
 int oasr_gemm_set_stagger(int sleeps, int phases); /* experiments: first-wave phase stagger of the 256x256 kernel (0 = off) */
 int oasr_gemm_force_general(int on); /* tests: route every GEMM through the register-staged general kernel */
 int oasr_profile_gemm_collect(double* ms4, double* flops4, int64_t* count4, char* by_symbol /* "symbol\tlaunches\tms\tflops\n"... or NULL */, int cap);

@@ -67,6 +67,10 @@ extern "C" int oasr_gemm_set_stagger(int sleeps, int phases) {
   gemm_set_stagger(sleeps, phases);
   return OASR_OK;
 }
+extern "C" int oasr_attention_set_pingpong(int on) {
+  attention_set_pingpong(on);
+  return OASR_OK;
+}
 extern "C" int oasr_gemm_force_general(int on) {
   gemm_force_general(on);
   return OASR_OK;

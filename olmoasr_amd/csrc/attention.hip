@@ -465,6 +465,293 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Ping-pong kernels for the UNMASKED case (no causal mask, no per-sequence key length: encoder self-attention and
+// cross-attention, 98 % of the attention time of a training step).
+//
+// What the measurements on the kernels above say (scripts/attn_kernel_times.py under rocprofv3, in-kernel s_memtime stamps;
+// profiles/r03_attention_pingpong.txt):
+//  * they issue the way they are written -- fragment reads -> wait -> S/dP MFMAs -> softmax VALU -> second-stage MFMAs -- and with
+//    two waves per SIMD the matrix pipe idles through every LDS round trip and VALU block (MFMA-busy 0.33);
+//  * interleaving everything in ONE wave's stream (reads of step i+2, MFMAs of step i+1, VALU of step i) does not fix it: an MFMA
+//    whose operand comes from a ds_read issued even a full step earlier in the same wave still stalls (S/dP MFMAs alone 151 us,
+//    with dependent fragment reads 277 us, with the same reads and nothing depending on them 168 us);
+//  * v_pk_mul_f32 / v_pk_add_f32 beside MFMAs cost ~16 cycles each where two scalar ops cost ~0 (the compiler SLP-packs
+//    adjacent fp32 multiplies: this file is built with -fno-slp-vectorize).
+// So: 8 waves, two per SIMD, alternating roles between workgroup barriers -- one COMPUTEs (12 MFMAs with the softmax VALU in
+// their shadow, every operand already in registers, nothing inside the segment depends on anything else inside it) while its
+// partner LOADs (fragment reads for its next segment ending in lgkmcnt(0), DMA issue).  Waves 4-7 run one barrier behind
+// waves 0-3.  K/V tiles move global -> LDS by DMA (buffer_load ... lds: no staging registers, no commit stores) two tiles ahead
+// through a 4-stage ring; rows past the end read as zeros (buffer range check), which also makes the tail steps (the loop runs
+// in groups of four tiles) contribute nothing.  No masks, no branches in the loop.
+//   LOAD(j)   : operand fragments of step j+1, transposed fragments of step j-1; on even j the DMA of tile j/2+2 and the wait for
+//               this wave's pieces of tile j/2+1
+//   COMPUTE(j): first-stage MFMAs of step j+1, softmax VALU of step j, second-stage MFMAs of step j-1
+#define ATTN_FENCE() __builtin_amdgcn_sched_barrier(0)
+constexpr int PNS = 4;          // ring stages
+constexpr int PSTG = 2 * TILE;  // two 64-row tiles per stage
+
+// The DMA is issued from inline assembly on purpose: hipcc orders every later ds_read behind a compiler-visible LDS-DMA with
+// s_waitcnt vmcnt(0) (it cannot tell the ring stages apart), which would drain the tiles in flight at every step.  The loops
+// count their own pieces (s_waitcnt vmcnt(n) + s_barrier before a stage is read); in-order return makes any compiler-placed
+// vmcnt for its own loads merely conservative.  (m0 is reserved: the compiler-generated code of these kernels has no other user.)
+__device__ __forceinline__ void glds16_asm(const u32x4_t rs, unsigned lds_addr, unsigned voff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory");
+}
+struct PipeSrc1 {
+  u32x4_t rs;  // raw buffer descriptor over rows [0, rmax) of this (batch, head) slice, 64 columns
+  unsigned voff;
+  unsigned tile_bytes;
+};
+// Piece p (1 KiB = 8 rows) of a 64-row tile lands at LDS bytes [p * 1024, +1024) of the tile; lane l writes chunk c' = l & 7 of row
+// 8p + (l >> 3), which under tile_addr's swizzle holds source chunk c' ^ g(row).  Wave w of 8 moves piece w of each tile.
+__device__ __forceinline__ PipeSrc1 pipe_src1(const bf16_t* base, long ld, int rmax, int wave, int lane) {
+  PipeSrc1 t;
+  const unsigned long addr = (unsigned long)base;
+  t.rs[0] = (unsigned)addr;
+  t.rs[1] = (unsigned)(addr >> 32) & 0xffffu;  // stride 0: raw buffer
+  t.rs[2] = (unsigned)(((long)(rmax - 1) * ld + 64) * 2);
+  t.rs[3] = 0x00020000u;
+  t.tile_bytes = (unsigned)(64 * ld * 2);
+  const int row = wave * 8 + (lane >> 3);
+  const int x = (row >> 1) & 7;
+  const int c = (lane & 7) ^ x ^ ((x & 1) << 2);
+  t.voff = (unsigned)(row * ld * 2 + c * 16);  // the tile offset is added here too: the range check does not cover soffset
+  return t;
+}
+#define ATTN_BARRIER()                          \
+  do {                                          \
+    ATTN_FENCE();                               \
+    asm volatile("s_barrier" ::: "memory");     \
+    ATTN_FENCE();                               \
+  } while (0)
+
+__global__ __launch_bounds__(512, 1) void attn_bwd_dq_pp_kernel(AttnArgs a) {
+  __shared__ __attribute__((aligned(1024))) char smem[PNS * PSTG];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hh = lane >> 5;
+  const int grp = wave >> 2;
+  const unsigned smem_a = (unsigned)(size_t)smem;
+  const int nqb = (a.Tq + 255) >> 8;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = bid / nqb;
+  const int b = bh / a.H, h = bh - b * a.H;
+  const int q0 = (bid - bh * nqb) * 256;
+  const int myq = q0 + wave * 32 + (lane & 31);
+  const int myq_c = myq < a.Tq ? myq : a.Tq - 1;
+
+  const bf16_t* qp = a.q + (long)b * a.bsq + (long)myq_c * a.ldq + h * 64;
+  const bf16_t* dop = a.d_o + (long)b * a.bso + (long)myq_c * a.ldo + h * 64;
+  const bf16_t* op = a.o + (long)b * a.bso + (long)myq_c * a.ldo + h * 64;
+  const bf16_t* olop = a.o_lo ? a.o_lo + (long)b * a.bso + (long)myq_c * a.ldo + h * 64 : nullptr;
+  bf16x8_t qf[4], dof[4];
+  float dpart = 0.f;
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) {
+    qf[ds] = ld_frag_global(qp + ds * 16 + hh * 8);
+    const u32x4_t d4 = *(const u32x4_t*)(dop + ds * 16 + hh * 8);
+    dof[ds] = __builtin_bit_cast(bf16x8_t, d4);
+    const u32x4_t o4 = *(const u32x4_t*)(op + ds * 16 + hh * 8);
+    if (olop) {
+      const u32x4_t r4 = *(const u32x4_t*)(olop + ds * 16 + hh * 8);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        dpart += bf_lo(d4[i]) * (bf_lo(o4[i]) + bf_lo(r4[i])) + bf_hi(d4[i]) * (bf_hi(o4[i]) + bf_hi(r4[i]));
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dpart += bf_lo(d4[i]) * bf_lo(o4[i]) + bf_hi(d4[i]) * bf_hi(o4[i]);
+    }
+  }
+  const float delta = dpart + __shfl_xor(dpart, 32, 64);
+  const long stat_idx = ((long)b * a.H + h) * a.Tq + myq_c;
+  if (hh == 0 && myq < a.Tq) a.delta[stat_idx] = delta;
+  const float lse2 = a.lse[stat_idx] * LOG2E;
+  asm volatile("" ::"v"(lse2), "v"(delta), "v"(qf[3]), "v"(dof[3]));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the loop counts its own DMA pieces
+
+  const int ntiles = (a.Tk + 63) >> 6;
+  const int ngroups = (ntiles + PNS - 1) / PNS;
+  const PipeSrc1 ksrc = pipe_src1(a.k + (long)b * a.bsk + h * 64, a.ldk, a.Tk, wave, lane);
+  const PipeSrc1 vsrc = pipe_src1(a.v + (long)b * a.bsv + h * 64, a.ldv, a.Tk, wave, lane);
+  auto dma_tile = [&](int tile, int stage) {
+    const unsigned dst = smem_a + stage * PSTG + wave * 1024;
+    glds16_asm(ksrc.rs, dst, ksrc.voff + (unsigned)tile * ksrc.tile_bytes);
+    glds16_asm(vsrc.rs, dst + TILE, vsrc.voff + (unsigned)tile * vsrc.tile_bytes);
+  };
+
+  int ar[4], ac[2][2];
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) ar[ds] = tile_addr(lane & 31, ds * 2 + hh);
+  {
+    const int G = lane >> 4, i = lane & 15;
+    const int row = 4 * (G >> 1) + (i >> 2);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const int col = dt * 32 + (G & 1) * 16 + (i & 3) * 4;
+      ac[dt][0] = tile_addr(row, col >> 3) + (col & 7) * 2;
+      ac[dt][1] = tile_addr(row + 8, col >> 3) + (col & 7) * 2;
+    }
+  }
+  auto rd_rows = [&](int off, int ds) { return *(const bf16x8_t*)(smem + ar[ds] + off); };
+  auto rd_tr = [&](int off, int dt, int half) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(smem + ac[dt][half] + off));
+  };
+
+  bf16x8_t Ak[4], Av[4];
+  s16x4_t kc[2][2][2];  // [u][dt][half]
+  f32x16_t dqT[2], S[2], dP[2], ND;
+  u32x4_t w[2][2];  // [step parity][u]: bf16 dS^T, the B operand of the dQ MFMAs one segment later
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      dqT[i][r] = 0.f;
+      S[i][r] = 0.f;
+    }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) ND[r] = -delta;  // dP accumulators start at -delta (a lane's 16 rows all belong to its query)
+  dP[0] = ND;
+  dP[1] = ND;
+  const float c1 = SCALE * LOG2E, nl1 = -lse2;
+
+  // LOAD(j), j = 2t + kt, stage st = t & 3: K/V fragments of step j+1, transposed-K fragments of step j-1
+  auto load_seg = [&](int t, int st, int kt) {
+    if (kt == 0) dma_tile(t + 2, (st + 2) & 3);
+    const int a_st = kt ? ((st + 1) & 3) : st;                    // step j+1 lives in the next tile when kt == 1
+    const int c_st = kt ? st : ((st + 3) & 3);                    // step j-1 lives in the previous tile when kt == 0
+    const int a_off = a_st * PSTG + (kt ^ 1) * 32 * 128;
+    const int c_off = c_st * PSTG + (kt ^ 1) * 32 * 128;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) {
+      Ak[ds] = rd_rows(a_off, ds);
+      Av[ds] = rd_rows(a_off + TILE, ds);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        kc[u][dt][0] = rd_tr(c_off + u * 16 * 128, dt, 0);
+        kc[u][dt][1] = rd_tr(c_off + u * 16 * 128, dt, 1);
+      }
+    if (kt == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // this wave's pieces of tile t+1 have landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  // COMPUTE(j): S/dP MFMAs of step j+1, softmax VALU of step j, dQ MFMAs of step j-1 -- nothing here depends on anything else here
+  auto compute_seg = [&](int kt) {
+    const int n = kt ^ 1;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) {
+      if (ds == 0) {
+        f32x16_t z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+        S[n] = MFMA(Ak[0], qf[0], z);
+        dP[n] = MFMA(Av[0], dof[0], ND);
+      } else {
+        S[n] = MFMA(Ak[ds], qf[ds], S[n]);
+        dP[n] = MFMA(Av[ds], dof[ds], dP[n]);
+      }
+      if (ds < 2) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const s16x8_t kv8 = __builtin_shufflevector(kc[ds][dt][0], kc[ds][dt][1], 0, 1, 2, 3, 4, 5, 6, 7);
+          dqT[dt] = MFMA(__builtin_bit_cast(bf16x8_t, kv8), __builtin_bit_cast(bf16x8_t, w[n][ds]), dqT[dt]);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float p0 = __builtin_amdgcn_exp2f(fmaf(S[kt][2 * j], c1, nl1));
+      const float p1 = __builtin_amdgcn_exp2f(fmaf(S[kt][2 * j + 1], c1, nl1));
+      w[kt][j >> 2][j & 3] = pack_bf2(p0 * dP[kt][2 * j], p1 * dP[kt][2 * j + 1]);
+    }
+    // schedule request for this barrier-to-barrier region: 12 MFMA slots, the 56 VALU spread over them
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+    }
+  };
+
+  // prologue: tiles 0, 1 in flight; S/dP of step 0; LOAD(0) with nothing for the dQ MFMAs of "step -1" to add
+  dma_tile(0, 0);
+  dma_tile(1, 1);
+  asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  ATTN_BARRIER();
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) {
+    Ak[ds] = rd_rows(0, ds);
+    Av[ds] = rd_rows(TILE, ds);
+  }
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) {
+    S[0] = MFMA(Ak[ds], qf[ds], S[0]);
+    dP[0] = MFMA(Av[ds], dof[ds], dP[0]);
+  }
+  ATTN_FENCE();
+  load_seg(0, 0, 0);  // (its transposed-K reads hit stage 3, which nothing has written: overwritten with zeros below)
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    w[1][u] = u32x4_t{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      kc[u][dt][0] = s16x4_t{0, 0, 0, 0};
+      kc[u][dt][1] = s16x4_t{0, 0, 0, 0};
+    }
+  }
+  ATTN_BARRIER();
+  if (grp == 1) ATTN_BARRIER();  // the upper half trails by one barrier from here on
+
+  for (int g = 0; g < ngroups; ++g) {
+#pragma unroll
+    for (int st = 0; st < PNS; ++st) {
+      const int t = g * PNS + st;
+      compute_seg(0);
+      ATTN_BARRIER();
+      load_seg(t, st, 1);
+      ATTN_BARRIER();
+      compute_seg(1);
+      ATTN_BARRIER();
+      load_seg(t + 1, (st + 1) & 3, 0);
+      ATTN_BARRIER();
+    }
+  }
+  // the dQ MFMAs of the last step (its transposed-K fragments came with the last LOAD)
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const s16x8_t kv8 = __builtin_shufflevector(kc[u][dt][0], kc[u][dt][1], 0, 1, 2, 3, 4, 5, 6, 7);
+      dqT[dt] = MFMA(__builtin_bit_cast(bf16x8_t, kv8), __builtin_bit_cast(bf16x8_t, w[1][u]), dqT[dt]);
+    }
+  if (grp == 0) ATTN_BARRIER();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tail DMA pieces (zeros) must not land on the staging tiles below
+  __syncthreads();
+  float* wsum = (float*)(smem + 32768);  // [8 waves][64], behind the staging tiles
+  store_rows_bf16(smem + wave * 4096, dqT, SCALE, a.dq + (long)b * a.bsq + (long)(q0 + wave * 32) * a.ldq + h * 64, a.ldq,
+                  a.Tq - (q0 + wave * 32), lane, a.dq_colsum ? wsum + wave * 64 : nullptr);
+  if (a.dq_colsum) {  // two partial rows per workgroup, in the 128-query row numbering of the colsum scratch
+    __syncthreads();
+    if (tid < 128) {
+      const int half = tid >> 6, c = tid & 63;
+      const int nqb128 = (a.Tq + 127) >> 7;
+      const int blk128 = (bid - bh * nqb) * 2 + half;
+      if (blk128 < nqb128)
+        a.colsum_scratch[((long)(b * nqb128 + blk128) * a.H + h) * 64 + c] =
+            (wsum[half * 256 + c] + wsum[half * 256 + 64 + c]) + (wsum[half * 256 + 128 + c] + wsum[half * 256 + 192 + c]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // dK[k][:] = scale * sum_q dS[q][k] Q[q][:],  dV[k][:] = sum_q P[q][k] dO[q][:]
 template <bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
@@ -727,6 +1014,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
   }
 }
 
+int g_attn_pingpong = 1;  // tests / A-B (oasr_attention_set_pingpong): 0 routes the unmasked case through the general kernels
+
 int check_args(const AttnArgs& a, bool bwd) {
   OASR_REQUIRE(a.q && a.k && a.v && a.o, "attention: null pointer");
   OASR_REQUIRE(a.B > 0 && a.H > 0 && a.Tq > 0 && a.Tk > 0, "attention: bad shape");
@@ -738,6 +1027,8 @@ int check_args(const AttnArgs& a, bool bwd) {
 }
 
 }  // namespace
+
+void attention_set_pingpong(int on) { g_attn_pingpong = on; }
 
 int launch_attention_fwd(const AttnArgs& a, hipStream_t s) {
   int rc = check_args(a, false);
@@ -764,7 +1055,10 @@ int launch_attention_bwd(const AttnArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, gq, dim3(256), 0, s, a);
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, gk, dim3(256), 0, s, a);
   } else {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, gq, dim3(256), 0, s, a);
+    if (!a.kv_len && g_attn_pingpong)
+      hipLaunchKernelGGL(attn_bwd_dq_pp_kernel, dim3(cdiv(a.Tq, 256) * a.B * a.H), dim3(512), 0, s, a);
+    else
+      hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, gq, dim3(256), 0, s, a);
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, gk, dim3(256), 0, s, a);
   }
   OASR_LAUNCH_CHECK();

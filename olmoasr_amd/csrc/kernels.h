@@ -130,6 +130,7 @@ typedef AttnArgsT<bf16_t> AttnArgs;
 typedef AttnArgsT<float> AttnArgsF;
 int launch_attention_fwd(const AttnArgs& a, hipStream_t s);
 int launch_attention_bwd(const AttnArgs& a, hipStream_t s);
+void attention_set_pingpong(int on);  // testing hook: 0 = general kernels for the unmasked case too
 int launch_attention_fwd(const AttnArgsF& a, hipStream_t s);  // fp32 validation kernels (o_lo unused: O is fp32)
 int launch_attention_bwd(const AttnArgsF& a, hipStream_t s);
 

@@ -357,8 +357,25 @@ ATTN_CASES = [
 ]
 
 
+@pytest.fixture(params=[1, 0], ids=["pingpong", "general"])
+def attn_path(request):
+    """1 = default dispatch (8-wave ping-pong kernels for the unmasked cases), 0 = the general (maskable) kernels for everything."""
+    from olmoasr_amd import _native as N
+    N.lib().oasr_attention_set_pingpong(request.param)
+    yield request.param
+    N.lib().oasr_attention_set_pingpong(1)
+
+
+ATTN_CASES += [
+    dict(B=1, H=2, Tq=300, Tk=1000, causal=False, kv=False),    # ragged: 2 query blocks of 256 (one partial), 16 key tiles = 4 ring rounds
+    dict(B=2, H=1, Tq=257, Tk=65, causal=False, kv=False),      # one query row in the second block, one key in the second tile
+]
+
+
 @pytest.mark.parametrize("case", ATTN_CASES)
-def test_attention_fwd_bwd(case):
+def test_attention_fwd_bwd(case, attn_path):
+    if attn_path == 0 and (case["causal"] or case["kv"]):
+        pytest.skip("masked cases always run the general kernels")
     B, H, Tq, Tk = case["B"], case["H"], case["Tq"], case["Tk"]
     d = H * 64
     # fused-qkv style strided views, exactly as the engine lays them out
