@@ -921,6 +921,250 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Ping-pong dK/dV kernel for the unmasked case: 8 waves x 32 keys, Q / dO tiles (64 queries) + their lse / delta rows stream
+// through the ring.  The key operands are held as K' = -K/8 and V' = -V (exact in bf16) and the first-stage accumulators START at
+// lse[q] / delta[q] (read from LDS straight into the accumulator registers by the LOAD segment), so that
+//   S_acc = lse - scale * S      -> P = exp2(-log2e * S_acc)          (one multiply + one exponential per score)
+//   dP_acc = delta - dP          -> -dS = P * dP_acc                  (one multiply; the sign rides in dK's store scale)
+// with no per-row statistics in registers.
+constexpr int KSTAT = 2048;            // LDS: [4 stages x (lse[64] | delta[64])] then the 4 tile stages
+constexpr int KLDS = KSTAT + PNS * PSTG;
+
+__device__ __forceinline__ void glds4_asm(const u32x4_t rs, unsigned lds_addr, unsigned voff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory");
+}
+
+__global__ __launch_bounds__(512, 1) void attn_bwd_dkdv_pp_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hh = lane >> 5;
+  const int grp = wave >> 2;
+  const unsigned smem_a = (unsigned)(size_t)smem;
+  const int nkb = (a.Tk + 255) >> 8;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = bid / nkb;
+  const int b = bh / a.H, h = bh - b * a.H;
+  const int k0 = (bid - bh * nkb) * 256;
+  const int mykey = k0 + wave * 32 + (lane & 31);
+  const int mykey_c = mykey < a.Tk ? mykey : a.Tk - 1;
+
+  const bf16_t* kp = a.k + (long)b * a.bsk + (long)mykey_c * a.ldk + h * 64;
+  const bf16_t* vp = a.v + (long)b * a.bsv + (long)mykey_c * a.ldv + h * 64;
+  bf16x8_t kf[4], vf[4];
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) {
+    const u32x4_t k4 = *(const u32x4_t*)(kp + ds * 16 + hh * 8);
+    const u32x4_t v4 = *(const u32x4_t*)(vp + ds * 16 + hh * 8);
+    u32x4_t kn, vn;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      kn[i] = pack_bf2(bf_lo(k4[i]) * -0.125f, bf_hi(k4[i]) * -0.125f);  // exact: a power of two
+      vn[i] = v4[i] ^ 0x80008000u;
+    }
+    kf[ds] = __builtin_bit_cast(bf16x8_t, kn);
+    vf[ds] = __builtin_bit_cast(bf16x8_t, vn);
+  }
+  asm volatile("" ::"v"(kf[3]), "v"(vf[3]));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the loop counts its own DMA pieces
+
+  const int ntiles = (a.Tq + 63) >> 6;
+  const int ngroups = (ntiles + PNS - 1) / PNS;
+  const PipeSrc1 qsrc = pipe_src1(a.q + (long)b * a.bsq + h * 64, a.ldq, a.Tq, wave, lane);
+  const PipeSrc1 dosrc = pipe_src1(a.d_o + (long)b * a.bso + h * 64, a.ldo, a.Tq, wave, lane);
+  // lse / delta rows of a tile: 2 x 256 bytes; even waves bring lse, odd waves delta (four identical copies each: one DMA per
+  // wave keeps every wave's vmcnt arithmetic the same)
+  u32x4_t srs;
+  {
+    const unsigned long addr = (unsigned long)(((wave & 1) ? a.delta : a.lse) + ((long)b * a.H + h) * a.Tq);
+    srs[0] = (unsigned)addr;
+    srs[1] = (unsigned)(addr >> 32) & 0xffffu;
+    srs[2] = (unsigned)(a.Tq * 4);
+    srs[3] = 0x00020000u;
+  }
+  auto dma_tile = [&](int tile, int stage) {
+    const unsigned dst = smem_a + KSTAT + stage * PSTG + wave * 1024;
+    glds16_asm(qsrc.rs, dst, qsrc.voff + (unsigned)tile * qsrc.tile_bytes);
+    glds16_asm(dosrc.rs, dst + TILE, dosrc.voff + (unsigned)tile * dosrc.tile_bytes);
+    glds4_asm(srs, smem_a + stage * 512 + (wave & 1) * 256, (unsigned)(lane * 4 + tile * 256));
+  };
+
+  int ar[4], ac[2][2];
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) ar[ds] = KSTAT + tile_addr(lane & 31, ds * 2 + hh);
+  {
+    const int G = lane >> 4, i = lane & 15;
+    const int row = 4 * (G >> 1) + (i >> 2);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const int col = dt * 32 + (G & 1) * 16 + (i & 3) * 4;
+      ac[dt][0] = KSTAT + tile_addr(row, col >> 3) + (col & 7) * 2;
+      ac[dt][1] = KSTAT + tile_addr(row + 8, col >> 3) + (col & 7) * 2;
+    }
+  }
+  const int astat = hh * 16;  // byte offset of this lane's first row group in a 32-query statistics row
+  auto rd_rows = [&](int off, int ds) { return *(const bf16x8_t*)(smem + ar[ds] + off); };
+  auto rd_tr = [&](int off, int dt, int half) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(smem + ac[dt][half] + off));
+  };
+
+  bf16x8_t Aq[4], Ado[4];
+  s16x4_t cq[2][2][2], cdo[2][2][2];  // [u][dt][half]
+  f32x16_t dkT[2], dvT[2], S[2], dP[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      dkT[i][r] = 0.f;
+      dvT[i][r] = 0.f;
+    }
+
+  // LOAD(j), j = 2t + kt, stage st = t & 3: Q / dO fragments + accumulator seeds of step j+1, transposed fragments of step j.
+  // (The second stage runs in the SAME segment as its softmax here -- one pipeline stage less than the dQ kernel: a third stage
+  // would keep a second set of bf16 P / dS tiles alive, and 96 accumulator + key registers already leave no room for it.)
+  auto load_seg = [&](int t, int st, int kt) {
+    if (kt == 0) dma_tile(t + 3, (st + 3) & 3);
+    const int a_st = kt ? ((st + 1) & 3) : st;
+    const int a_off = a_st * PSTG + (kt ^ 1) * 32 * 128;
+    const int c_off = st * PSTG + kt * 32 * 128;
+    const int s_off = a_st * 512 + (kt ^ 1) * 128 + astat;
+    const int n = kt ^ 1;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) {
+      Aq[ds] = rd_rows(a_off, ds);
+      Ado[ds] = rd_rows(a_off + TILE, ds);
+    }
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const f32x4_t l4 = *(const f32x4_t*)(smem + s_off + g4 * 32);
+      const f32x4_t d4 = *(const f32x4_t*)(smem + s_off + 256 + g4 * 32);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        S[n][4 * g4 + i] = l4[i];
+        dP[n][4 * g4 + i] = d4[i];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          cq[u][dt][hf] = rd_tr(c_off + u * 16 * 128, dt, hf);
+          cdo[u][dt][hf] = rd_tr(c_off + TILE + u * 16 * 128, dt, hf);
+        }
+    if (kt == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // this wave's pieces of tile t+1 have landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  // COMPUTE(j): S / dP MFMAs of step j+1 (onto their seeds) with the softmax VALU of step j in their shadow, then the dV / dK
+  // MFMAs of step j (the u = 0 half of P / dS is packed first, so its four MFMAs cover the rest of the VALU)
+  auto compute_seg = [&](int kt) {
+    const int n = kt ^ 1;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) {
+      S[n] = MFMA(Aq[ds], kf[ds], S[n]);
+      dP[n] = MFMA(Ado[ds], vf[ds], dP[n]);
+    }
+    u32x4_t pf[2], dsf[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float p0 = __builtin_amdgcn_exp2f(S[kt][2 * j] * -LOG2E);
+      const float p1 = __builtin_amdgcn_exp2f(S[kt][2 * j + 1] * -LOG2E);
+      pf[j >> 2][j & 3] = pack_bf2(p0, p1);
+      dsf[j >> 2][j & 3] = pack_bf2(p0 * dP[kt][2 * j], p1 * dP[kt][2 * j + 1]);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const s16x8_t c1 = __builtin_shufflevector(cdo[u][dt][0], cdo[u][dt][1], 0, 1, 2, 3, 4, 5, 6, 7);
+        const s16x8_t c2 = __builtin_shufflevector(cq[u][dt][0], cq[u][dt][1], 0, 1, 2, 3, 4, 5, 6, 7);
+        dvT[dt] = MFMA(__builtin_bit_cast(bf16x8_t, c1), __builtin_bit_cast(bf16x8_t, pf[u]), dvT[dt]);
+        dkT[dt] = MFMA(__builtin_bit_cast(bf16x8_t, c2), __builtin_bit_cast(bf16x8_t, dsf[u]), dkT[dt]);
+      }
+    // 64 VALU: 6 beside each of the 8 first-stage MFMAs (all of u = 0 and half of u = 1), the rest beside the u = 0 second-stage MFMAs
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x402, 6, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x402, 4, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+  };
+
+  // prologue: tiles 0..2 in flight; seeds + S / dP of step 0; LOAD(0)
+  dma_tile(0, 0);
+  dma_tile(1, 1);
+  dma_tile(2, 2);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  ATTN_BARRIER();
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) {
+    Aq[ds] = rd_rows(0, ds);
+    Ado[ds] = rd_rows(TILE, ds);
+  }
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {
+    const f32x4_t l4 = *(const f32x4_t*)(smem + astat + g4 * 32);
+    const f32x4_t d4 = *(const f32x4_t*)(smem + astat + 256 + g4 * 32);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      S[0][4 * g4 + i] = l4[i];
+      dP[0][4 * g4 + i] = d4[i];
+    }
+  }
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) {
+    S[0] = MFMA(Aq[ds], kf[ds], S[0]);
+    dP[0] = MFMA(Ado[ds], vf[ds], dP[0]);
+  }
+  ATTN_FENCE();
+  load_seg(0, 0, 0);
+  ATTN_BARRIER();
+  if (grp == 1) ATTN_BARRIER();  // the upper half trails by one barrier from here on
+
+  for (int g = 0; g < ngroups; ++g) {
+#pragma unroll
+    for (int st = 0; st < PNS; ++st) {
+      const int t = g * PNS + st;
+      compute_seg(0);
+      ATTN_BARRIER();
+      load_seg(t, st, 1);
+      ATTN_BARRIER();
+      compute_seg(1);
+      ATTN_BARRIER();
+      load_seg(t + 1, (st + 1) & 3, 0);
+      ATTN_BARRIER();
+    }
+  }
+  if (grp == 0) ATTN_BARRIER();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tail DMA pieces (zeros) must not land on the staging tiles below
+  __syncthreads();
+  {
+    char* stg = smem + wave * 4096;
+    const int rows_valid = a.Tk - (k0 + wave * 32);
+    store_rows_bf16(stg, dkT, -SCALE, a.dk + (long)b * a.bsk + (long)(k0 + wave * 32) * a.ldk + h * 64, a.ldk, rows_valid, lane);
+    float* wsum = (float*)(smem + 32768);
+    store_rows_bf16(stg, dvT, 1.0f, a.dv + (long)b * a.bsv + (long)(k0 + wave * 32) * a.ldv + h * 64, a.ldv, rows_valid, lane,
+                    a.dv_colsum ? wsum + wave * 64 : nullptr);
+    if (a.dv_colsum) {  // two partial rows per workgroup, in the 128-key row numbering of the colsum scratch
+      __syncthreads();
+      if (tid < 128) {
+        const int half = tid >> 6, c = tid & 63;
+        const int nkb128 = (a.Tk + 127) >> 7;
+        const int blk128 = (bid - bh * nkb) * 2 + half;
+        const long dv_scratch_off = (long)a.B * ((a.Tq + 127) >> 7) * a.H * 64;
+        if (blk128 < nkb128)
+          a.colsum_scratch[dv_scratch_off + ((long)(b * nkb128 + blk128) * a.H + h) * 64 + c] =
+              (wsum[half * 256 + c] + wsum[half * 256 + 64 + c]) + (wsum[half * 256 + 128 + c] + wsum[half * 256 + 192 + c]);
+      }
+    }
+  }
+}
+
 
 // ------------------------------------------------------------------------------------------------------------
 // One query row per (batch, head): the KV-cached decode step (Tq == 1).  The 128-row flash tile above spends a whole
@@ -1059,7 +1303,16 @@ int launch_attention_bwd(const AttnArgs& a, hipStream_t s) {
       hipLaunchKernelGGL(attn_bwd_dq_pp_kernel, dim3(cdiv(a.Tq, 256) * a.B * a.H), dim3(512), 0, s, a);
     else
       hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, gq, dim3(256), 0, s, a);
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, gk, dim3(256), 0, s, a);
+    if (!a.kv_len && g_attn_pingpong) {
+      static bool attr_set = false;
+      if (!attr_set) {
+        OASR_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkdv_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, KLDS));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(attn_bwd_dkdv_pp_kernel, dim3(cdiv(a.Tk, 256) * a.B * a.H), dim3(512), KLDS, s, a);
+    } else {
+      hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, gk, dim3(256), 0, s, a);
+    }
   }
   OASR_LAUNCH_CHECK();
   // fused query / value bias gradients: reduce the per-workgroup partial rows (a few MB) into the fp32 gradients
