@@ -43,7 +43,12 @@ def test_autograd_backward_equals_the_fused_step(tiny_case, dtype):
     loss, logits = _ref_loss(net, c)
     (loss * 1024.0).backward()
     assert abs(float(loss.detach()) - float(loss_f)) < 1e-4 * abs(float(loss_f)) + 1e-5
-    tol = 2e-5 if dtype == "float32" else 1e-3  # (measured 3e-6 / 4e-7: the fp32 d(logits) rounds to the fused kernel's bf16 values)
+    # fp32: measured 3e-6.  bf16: the two paths meet at d(logits) -- torch's fp32 (softmax - onehot) * g rounded to bf16 by the bridge vs the
+    # fused kernel's exp2(..) * (g / sum) rounded to bf16.  The bf16-quantised logits put whole groups of equal probabilities exactly
+    # on bf16 rounding ties (e.g. 0.013275150 between 0.0132446 and 0.0133057), which the two formulas break differently for ~450 of
+    # 5.4 M elements; one such ulp re-rounds the activations of every layer below: 2e-3 median / 6e-3 worst per-tensor rel-L2 at tiny,
+    # the size of any other bf16 reordering (e.g. the two attention-backward kernel families, same test case: 6e-3).
+    tol = 2e-5 if dtype == "float32" else 2e-2
     worst = 0.0
     for n, p in net.named_parameters():
         assert p.grad is not None
