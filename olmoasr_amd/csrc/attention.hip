@@ -277,19 +277,21 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
         }
     }
     {
-      const f32x2_t c2 = {C, C}, nm2 = {-m_run, -m_run};
-      f32x2_t psum2 = {0.f, 0.f};
+      const float nm = -m_run;
+      float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-          const f32x2_t s2 = {sT[kt][r], sT[kt][r + 1]};
-          const f32x2_t p2 = pk_exp2(pk_fma(s2, c2, nm2));
-          sT[kt][r] = p2[0];
-          sT[kt][r + 1] = p2[1];
-          psum2 += p2;
+          const float p0 = __builtin_amdgcn_exp2f(fmaf(sT[kt][r], C, nm));
+          const float p1 = __builtin_amdgcn_exp2f(fmaf(sT[kt][r + 1], C, nm));
+          sT[kt][r] = p0;
+          sT[kt][r + 1] = p1;
+          ps0 += p0;
+          ps1 += p1;
         }
-      l_run2 += psum2;
+      l_run2[0] += ps0;
+      l_run2[1] += ps1;
     }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
