@@ -40,7 +40,14 @@ def sinusoids(length, channels, max_timescale=10000):
 
 
 class _ParamModule(nn.Module):
-    """Leaf holder: parameters are attached later as views of the flat arena."""
+    """Leaf holder: parameters are attached later as views of the flat arena.
+
+    The engine runs whole stacks (``model.encoder(mel)``, ``model.decoder(tokens, xa[, kv_cache])``, ``OLMoASR.forward`` /
+    ``loss_and_backward``): that is the hot path.  The per-module ``forward``s of the reference (``LayerNorm`` model.py:14-39,
+    ``Linear`` :42-101, ``Conv1d`` :104-196, ``MultiHeadAttention`` :266-345, ``ResidualAttentionBlock`` :485-528) exist below as
+    INFERENCE-ONLY compositions of the same native operators (bf16 MFMA GEMMs with fused bias / GELU / residual epilogues,
+    LayerNorm and flash-attention kernels) for code that walks the module tree -- probing one block, feature extraction, a
+    layer-wise comparison with a reference checkpoint.  They return tensors without a grad_fn; training goes through the engine."""
 
     def forward(self, *a, **k):  # pragma: no cover
         raise N.NativeError(f"{type(self).__name__}.forward: the native engine runs whole stacks -- call model.encoder(mel), "
@@ -52,6 +59,35 @@ class _ParamModule(nn.Module):
         if owner is None:
             raise N.NativeError(f"{type(self).__name__} is not attached to an OLMoASR model")
         return owner
+
+
+def _rows_bf16(x: Tensor):
+    """[..., d] activation -> contiguous bf16 [rows, d] on the device (the engine's activation format)."""
+    N.require_gpu(x, "x")
+    return x.detach().reshape(-1, x.shape[-1]).to(torch.bfloat16).contiguous()
+
+
+def _mask_to_native(mask: Optional[Tensor], B: int, Tq: int, Tk: int):
+    """The reference passes additive masks: the [n_ctx, n_ctx] causal triangle (eval, model.py:740) or, in training, causal +
+    key-padding as [B, n_ctx, n_ctx] (train_timestamps.py:314-315).  The kernels take (causal, kv_len[b]); anything that is not
+    exactly one of those two shapes of mask is refused rather than approximated."""
+    if mask is None:
+        return False, None
+    if Tq != Tk:
+        raise N.NativeError("MultiHeadAttention.forward: a mask needs self-attention (Tq == Tk)")
+    m = mask[..., :Tq, :Tk]
+    m = m if m.dim() == 3 else m.unsqueeze(0)
+    fin = torch.isfinite(m)
+    kv_len = fin[:, -1, :].sum(-1).to(torch.int32)  # the last query row sees every unpadded key
+    ar = torch.arange(Tk, device=m.device)
+    want = (ar[None, None, :] <= ar[None, :, None]) & (ar[None, None, :] < kv_len[:, None, None])
+    if not torch.equal(fin, want.expand_as(fin)) or bool((m[fin] != 0).any()):
+        raise N.NativeError("MultiHeadAttention.forward: only the causal mask, optionally with key padding (finite entries 0, masked "
+                            "entries -inf), maps onto the native attention kernels")
+    if kv_len.shape[0] == 1 and B > 1:
+        kv_len = kv_len.expand(B)
+    full = bool((kv_len == Tk).all())
+    return True, None if full else kv_len.contiguous()
 
 
 class _EngineKV:
@@ -152,11 +188,31 @@ class LayerNorm(_ParamModule):
         self.normalized_shape = (n_state,)
         self.eps = 1e-5
 
+    def forward(self, x: Tensor) -> Tensor:
+        """fp32 statistics on the bf16-rounded input, result in ``x.dtype`` (reference model.py:37-39: ``super().forward(x.float()).type(x.dtype)``)."""
+        from . import ops
+        y, _, _ = ops.layernorm_fwd(_rows_bf16(x), self.weight.detach(), self.bias.detach())
+        return y.view(x.shape).to(x.dtype)
+
 
 class Linear(_ParamModule):
     def __init__(self, in_features: int, out_features: int, bias: bool = True):
         super().__init__()
         self.in_features, self.out_features, self.has_bias = in_features, out_features, bias
+
+    def _apply(self, x: Tensor, act: int = 0, resid: Optional[Tensor] = None) -> Tensor:
+        """bf16 MFMA GEMM, fp32 accumulation, bias (+ GELU) (+ residual) in the epilogue -- what autocast(bfloat16) makes of
+        ``F.linear(x, self.weight.to(x.dtype), self.bias.to(x.dtype))`` (reference model.py:97-101)."""
+        from . import ops
+        a = _rows_bf16(x)
+        w = ops.cast_bf16(self.weight.detach())
+        out = torch.empty(a.shape[0], self.out_features, device=a.device, dtype=torch.bfloat16)
+        ops.gemm(a, w, a.shape[0], self.out_features, self.in_features, bias=self.bias.detach() if self.has_bias else None, act=act,
+                 resid=_rows_bf16(resid) if resid is not None else None, out=out)
+        return out.view(*x.shape[:-1], self.out_features)
+
+    def forward(self, x: Tensor) -> Tensor:
+        return self._apply(x).to(x.dtype)
 
 
 class Conv1d(_ParamModule):
@@ -164,6 +220,26 @@ class Conv1d(_ParamModule):
         super().__init__()
         self.in_channels, self.out_channels = in_channels, out_channels
         self.kernel_size, self.stride, self.padding = (kernel_size,), (stride,), (padding,)
+
+    def forward(self, x: Tensor) -> Tensor:
+        """[B, C_in, T] -> [B, C_out, T_out] (reference model.py:190-196): the windows are gathered by torch (index plumbing), the
+        products run on the native GEMM.  (The engine's own stem fuses window gathering, GELU and the positional embedding.)"""
+        from . import ops
+        N.require_gpu(x, "x")
+        B, Cin, T = x.shape
+        k, st, pd = self.kernel_size[0], self.stride[0], self.padding[0]
+        xp = torch.nn.functional.pad(x.detach().to(torch.bfloat16), (pd, pd))
+        win = xp.unfold(2, k, st)                                    # [B, C_in, T_out, k]
+        Tout = win.shape[2]
+        a = win.permute(0, 2, 1, 3).reshape(B * Tout, Cin * k).contiguous()
+        Kp = (Cin * k + 7) // 8 * 8                                   # operand rows are 16-byte multiples
+        if Kp != Cin * k:
+            a = torch.nn.functional.pad(a, (0, Kp - Cin * k))
+        w = torch.zeros(self.out_channels, Kp, device=x.device, dtype=torch.bfloat16)
+        w[:, :Cin * k] = self.weight.detach().reshape(self.out_channels, Cin * k).to(torch.bfloat16)
+        out = torch.empty(B * Tout, self.out_channels, device=x.device, dtype=torch.bfloat16)
+        ops.gemm(a, w, B * Tout, self.out_channels, Kp, bias=self.bias.detach(), out=out)
+        return out.view(B, Tout, self.out_channels).permute(0, 2, 1).to(x.dtype)
 
 
 class Embedding(_ParamModule):
@@ -181,6 +257,27 @@ class MultiHeadAttention(_ParamModule):
         self.value = Linear(n_state, n_state)
         self.out = Linear(n_state, n_state)
 
+    def forward(self, x: Tensor, xa: Optional[Tensor] = None, mask: Optional[Tensor] = None, kv_cache: Optional[dict] = None,
+                verbose: bool = False):
+        """(out, qk) of reference model.py:266-345, head_dim 64.  ``qk`` is always None: the flash kernels never form the score
+        matrix (its only consumer is word-level timestamp alignment, out of scope here).  ``kv_cache`` dicts belong to
+        ``TextDecoder.forward`` (the engine owns the cache); a per-module cache is refused."""
+        from . import ops
+        if kv_cache is not None:
+            raise N.NativeError("MultiHeadAttention.forward(kv_cache=...): the KV cache lives in the engine -- drive it through "
+                                "model.decoder(tokens, xa, kv_cache=cache) with cache, hooks = model.install_kv_cache_hooks()")
+        B, Tq, d = x.shape
+        src = x if xa is None else xa
+        Tk = src.shape[1]
+        H = self.n_head
+        assert d == H * 64, "the native attention kernels are built for head_dim 64"
+        causal, kv_len = _mask_to_native(mask, B, Tq, Tk)
+        q = self.query._apply(x).view(B, Tq, H, 64)
+        k = self.key._apply(src).view(B, Tk, H, 64)
+        v = self.value._apply(src).view(B, Tk, H, 64)
+        o, _ = ops.attention_fwd(q, k, v, kv_len, causal)
+        return self.out._apply(o).to(x.dtype), None
+
 
 class _Sequential(nn.Module):
     """Index-addressable container giving the reference's ``mlp.0`` / ``mlp.2`` state_dict keys."""
@@ -189,6 +286,13 @@ class _Sequential(nn.Module):
         super().__init__()
         for k, v in mods.items():
             self.add_module(k, v)
+
+    def __getitem__(self, i):
+        return getattr(self, str(i))
+
+    def forward(self, x: Tensor) -> Tensor:
+        """Linear -> GELU -> Linear (reference model.py:480-482), GELU fused into the first GEMM's epilogue."""
+        return self[2]._apply(self[0]._apply(x, act=1)).to(x.dtype)
 
 
 class ResidualAttentionBlock(_ParamModule):
@@ -200,6 +304,18 @@ class ResidualAttentionBlock(_ParamModule):
         self.cross_attn_ln = LayerNorm(n_state) if cross_attention else None
         self.mlp = _Sequential({"0": Linear(n_state, 4 * n_state), "2": Linear(4 * n_state, n_state)})
         self.mlp_ln = LayerNorm(n_state)
+
+    def forward(self, x: Tensor, xa: Optional[Tensor] = None, mask: Optional[Tensor] = None, kv_cache: Optional[dict] = None,
+                verbose: bool = False) -> Tensor:
+        """Pre-LN residual block (reference model.py:485-528): x + attn(ln(x)); x + cross_attn(ln(x), xa); x + mlp(ln(x)), with the
+        residual additions and the GELU in the GEMM epilogues, as in the engine."""
+        a, _ = self.attn(self.attn_ln(x), mask=mask, kv_cache=kv_cache)
+        x = (x.to(torch.bfloat16) + a.to(torch.bfloat16)).to(x.dtype)
+        if self.cross_attn is not None:
+            c, _ = self.cross_attn(self.cross_attn_ln(x), xa, kv_cache=kv_cache)
+            x = (x.to(torch.bfloat16) + c.to(torch.bfloat16)).to(x.dtype)
+        h = self.mlp[0]._apply(self.mlp_ln(x), act=1)
+        return self.mlp[2]._apply(h, resid=x).to(x.dtype)
 
 
 class AudioEncoder(_ParamModule):

@@ -1,0 +1,84 @@
+"""Per-module ``forward``s of the host-side mirror (olmoasr_amd/model.py: LayerNorm, Linear, Conv1d, MultiHeadAttention,
+ResidualAttentionBlock -- reference olmoasr/model.py:14-39, 42-101, 104-196, 266-345, 485-528) against the oracle's functional
+restatement of the same modules in fp32, on the tiny checkpoint layout.  Inference-only compositions of the native operators."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _net(tiny_case):
+    from olmoasr_amd.config.model_dims import ModelDimensions
+    from olmoasr_amd.model import OLMoASR
+    net = OLMoASR(ModelDimensions(**vars(tiny_case["dims"])), device=DEV, seed=0)
+    net.load_state_dict(tiny_case["sd"])
+    return net
+
+
+def _close(got, ref, tol, name):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    err = float((got - ref).abs().max())
+    scale = float(ref.abs().max())
+    assert err <= tol * scale + 1e-3, f"{name}: max abs err {err:.4g} vs scale {scale:.4g}"
+    return err / max(scale, 1e-9)
+
+
+def test_leaf_module_forwards_equal_the_oracle(tiny_case):
+    from oracle import model_oracle as mo
+    net, sd = _net(tiny_case), tiny_case["sd"]
+    cfg = mo._Cfg(False)
+    g = torch.Generator().manual_seed(1)
+    d = net.dims.n_audio_state
+    x = torch.randn(2, 50, d, generator=g)
+    blk = net.encoder.blocks[1]
+    y = blk.attn_ln(x.to(DEV))
+    assert y.dtype == torch.float32 and y.grad_fn is None
+    _close(y, mo.layer_norm(x, sd["encoder.blocks.1.attn_ln.weight"], sd["encoder.blocks.1.attn_ln.bias"]), 1e-2, "LayerNorm")
+    _close(blk.attn.query(x.to(DEV)), mo.linear(x, sd["encoder.blocks.1.attn.query.weight"], sd["encoder.blocks.1.attn.query.bias"], cfg), 1e-2, "Linear")
+    _close(blk.attn.key(x.to(DEV)), mo.linear(x, sd["encoder.blocks.1.attn.key.weight"], None, cfg), 1e-2, "Linear (no bias)")
+    _close(blk.mlp(x.to(DEV)), mo.linear(mo.gelu(mo.linear(x, sd["encoder.blocks.1.mlp.0.weight"], sd["encoder.blocks.1.mlp.0.bias"], cfg)),
+                                         sd["encoder.blocks.1.mlp.2.weight"], sd["encoder.blocks.1.mlp.2.bias"], cfg), 1.5e-2, "mlp Sequential")
+    mel = tiny_case["mel"][:, :, :200]
+    _close(net.encoder.conv1(mel.to(DEV)), mo.conv1d(mel, sd["encoder.conv1.weight"], sd["encoder.conv1.bias"], 1, cfg), 1e-2, "Conv1d k=3")
+    h = torch.randn(2, d, 200, generator=g)
+    _close(net.encoder.conv2(h.to(DEV)), mo.conv1d(h, sd["encoder.conv2.weight"], sd["encoder.conv2.bias"], 2, cfg), 1e-2, "Conv1d stride 2")
+
+
+@pytest.mark.parametrize("kind", ["encoder", "decoder-causal", "decoder-padding"])
+def test_attention_and_block_forwards_equal_the_oracle(tiny_case, kind):
+    from oracle import model_oracle as mo
+    from olmoasr_amd import _native as N
+    net, sd = _net(tiny_case), tiny_case["sd"]
+    cfg = mo._Cfg(False)
+    g = torch.Generator().manual_seed(2)
+    d, H = net.dims.n_text_state, net.dims.n_text_head
+    if kind == "encoder":
+        T, prefix, blk, cross, mask = 300, "encoder.blocks.0", net.encoder.blocks[0], False, None
+        xa = None
+    else:
+        T, prefix, blk, cross = 448, "decoder.blocks.2", net.decoder.blocks[2], True
+        xa = torch.randn(2, 1500, d, generator=g) * 0.5
+        mask = torch.full((T, T), -math.inf).triu_(1)
+        if kind == "decoder-padding":  # what TextDecoder.forward hands its blocks in training: column padding + causal (model.py:740-741)
+            mask = mo.build_padding_mask(torch.tensor([17, 201]), T) + mask
+    x = torch.randn(2, T, d, generator=g)
+    out, qk = blk.attn(x.to(DEV), mask=None if mask is None else mask.to(DEV))
+    assert qk is None and out.shape == x.shape
+    ref = mo.mha(sd, prefix + ".attn", x, None, mask, H, cfg)
+    _close(out, ref, 2e-2, "self-attention")
+    if cross:
+        oc, _ = blk.cross_attn(x.to(DEV), xa.to(DEV))
+        _close(oc, mo.mha(sd, prefix + ".cross_attn", x, xa, None, H, cfg), 2e-2, "cross-attention")
+    y = blk(x.to(DEV), None if xa is None else xa.to(DEV), mask=None if mask is None else mask.to(DEV))
+    ry = mo.block(sd, prefix, x, xa, mask, H, cfg, cross)
+    _close(y, ry, 2e-2, "ResidualAttentionBlock")
+    with pytest.raises(N.NativeError):
+        blk.attn(x.to(DEV), kv_cache={})
+    if mask is not None:
+        bad = mask.clone()
+        bad[..., 3, 1] = -math.inf  # a hole below the diagonal: not expressible as (causal, kv_len)
+        with pytest.raises(N.NativeError):
+            blk.attn(x.to(DEV), mask=bad.to(DEV))
