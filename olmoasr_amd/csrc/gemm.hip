@@ -431,20 +431,47 @@ __device__ __forceinline__ void store16(bf16_t* ptr, const u32x4_t& v, bool nt) 
 __device__ __forceinline__ u32x4_t load16(const bf16_t* ptr, bool nt) {
   return nt ? __builtin_nontemporal_load((const u32x4_t*)ptr) : *(const u32x4_t*)ptr;
 }
+// The runtime options of the epilogue, as a bit set.  The body below is written once over these flags; for the combinations the
+// training step actually launches (EPI_MODES) it is instantiated with the flags as compile-time constants, so that the ~12 wave-uniform
+// branches per 8-column chunk, the per-row bounds predicates and the dead arithmetic disappear from the instruction stream -- the
+// epilogue is instruction-bound (profiles/r03_gemm_tile_stamps.txt).  Anything else runs the generic instantiation (MODE < 0).
+enum : unsigned {
+  EPI_BIAS = 1, EPI_RESID = 2, EPI_U = 4, EPI_UDERIV = 8, EPI_PRE = 16, EPI_OUT = 32, EPI_GELU = 64, EPI_DERIV = 128, EPI_POS = 256,
+  EPI_SCALE = 512, EPI_NT_ST = 1024, EPI_NT_LD = 2048, EPI_PARTIAL = 4096
+};
+__device__ __forceinline__ unsigned epi_flags_of(const GemmArgs& p, bool partial) {
+  return (p.bias ? EPI_BIAS : 0) | (p.resid ? EPI_RESID : 0) | (p.dgelu_u ? EPI_U : 0) | (p.dgelu_deriv ? EPI_UDERIV : 0) |
+         (p.out_pre ? EPI_PRE : 0) | (p.out ? EPI_OUT : 0) | (p.act != 0 ? EPI_GELU : 0) | (p.act == 2 ? EPI_DERIV : 0) |
+         (p.pos ? EPI_POS : 0) | (p.alpha != 1.0f ? EPI_SCALE : 0) | ((p.epi_flags & 1) ? EPI_NT_ST : 0) |
+         ((p.epi_flags & 2) ? EPI_NT_LD : 0) | (partial ? EPI_PARTIAL : 0);
+}
+constexpr unsigned EPI_MODES[] = {
+    EPI_BIAS | EPI_OUT,                                   // Linear with bias (q|k|v, cross q / k|v)
+    EPI_BIAS | EPI_OUT | EPI_RESID,                       // attention / MLP output projection + residual
+    EPI_BIAS | EPI_OUT | EPI_PRE | EPI_GELU | EPI_DERIV,  // mlp.0 in training: GELU out, GELU' saved
+    EPI_BIAS | EPI_OUT | EPI_GELU,                        // mlp.0 in inference
+    EPI_OUT,                                              // dgrad
+    EPI_OUT | EPI_RESID,                                  // dgrad accumulating into an existing gradient
+    EPI_OUT | EPI_U | EPI_UDERIV,                         // dgrad through GELU (saved derivative)
+};
+constexpr int EPI_NMODES = (int)(sizeof(EPI_MODES) / sizeof(EPI_MODES[0]));
+
 // stg: this wave's staging tile, 8-row groups of 1 KiB placed GS bytes apart; bias_lds: 64 floats of wave-private LDS.
-template <bool CSUM, int GS = 1024, bool PF = true>
-__device__ __forceinline__ void fast_epilogue_rows(const GemmArgs& p, f32x16_t (&acc)[4][2], char* stg, float* bias_lds,
-                                                   int mrow0, int ncol0, int lane) {
+template <bool CSUM, int GS, bool PF, int MODE>
+__device__ __forceinline__ void fast_epilogue_rows_impl(const GemmArgs& p, f32x16_t (&acc)[4][2], char* stg, float* bias_lds,
+                                                        int mrow0, int ncol0, int lane, unsigned rt_flags) {
+  const unsigned F = MODE >= 0 ? EPI_MODES[MODE >= 0 ? MODE : 0] : rt_flags;  // compile-time constant when MODE >= 0
   const int h = lane >> 5, row = lane & 31;
-  const bool has_bias = p.bias != nullptr, has_side = p.dgelu_u != nullptr || p.resid != nullptr, has_u = p.dgelu_u != nullptr;
-  const bool has_pre = p.out_pre != nullptr, has_out = p.out != nullptr, gelu = p.act != 0, has_pos = p.pos != nullptr;
-  const bool save_deriv = p.act == 2, u_is_deriv = p.dgelu_deriv != 0;
-  const bool nt_st = (p.epi_flags & 1) != 0, nt_ld = (p.epi_flags & 2) != 0;
+  const bool has_bias = (F & EPI_BIAS) != 0, has_side = (F & (EPI_RESID | EPI_U)) != 0, has_u = (F & EPI_U) != 0;
+  const bool has_pre = (F & EPI_PRE) != 0, has_out = (F & EPI_OUT) != 0, gelu = (F & EPI_GELU) != 0, has_pos = (F & EPI_POS) != 0;
+  const bool save_deriv = (F & EPI_DERIV) != 0, u_is_deriv = (F & EPI_UDERIV) != 0;
+  const bool nt_st = (F & EPI_NT_ST) != 0, nt_ld = (F & EPI_NT_LD) != 0;
+  const bool partial = (F & EPI_PARTIAL) != 0;  // false: this wave's 128 x 64 block lies inside the matrix, no bounds predicates
   const bf16_t* side = has_u ? p.dgelu_u : p.resid;  // at most one of the two (fast_rows_ok)
   const long lds_ = has_u ? p.ldu : p.ldr;
   const int ch = lane & 7, nn = ncol0 + ch * 8;
-  const bool n_ok = nn < p.N;
-  if (has_bias) bias_lds[lane] = (ncol0 + lane < p.N) ? p.bias[ncol0 + lane] : 0.f;
+  const bool n_ok = !partial || nn < p.N;
+  if (has_bias) bias_lds[lane] = (!partial || ncol0 + lane < p.N) ? p.bias[ncol0 + lane] : 0.f;
   float cs[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) cs[e] = 0.f;
@@ -453,10 +480,25 @@ __device__ __forceinline__ void fast_epilogue_rows(const GemmArgs& p, f32x16_t (
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int mm = mrow0 + i * 8 + (lane >> 3);
-      if (n_ok && mm < p.M) sd[i] = load16(side + (long)mm * lds_ + nn, nt_ld);
+      if (n_ok && (!partial || mm < p.M)) sd[i] = load16(side + (long)mm * lds_ + nn, nt_ld);
     }
   }
   __builtin_amdgcn_wave_barrier();
+  // The epilogue is instruction-bound, not memory-bound (in-kernel cycle stamps, profiles/r03_gemm_tile_stamps.txt: 9.0 k cycles per
+  // tile with bias only, 17 k with a side input -- with every global load and store REMOVED), so the per-value work is kept minimal:
+  // the bias vectors of this wave's 64 columns are fetched once (not per 32-row block), alpha == 1 costs nothing, and values that
+  // are already bf16 (unpacked from the staged pre-activation, no GELU / positional term applied) are not rounded again.
+  const bool scale = (F & EPI_SCALE) != 0;
+  const bool exact = !(gelu || has_pos);  // pass B's x[] are bf16 values exactly as unpacked
+  // (hoisted only where 32 more registers are free: not beside side-input or GELU' temporaries, not in the generic instantiation)
+  constexpr bool HOIST = MODE >= 0 && (EPI_MODES[MODE >= 0 ? MODE : 0] & (EPI_RESID | EPI_U | EPI_DERIV)) == 0;
+  f32x4_t bv[2][4];
+  if (HOIST) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bv[nt][q] = has_bias ? *(const f32x4_t*)(bias_lds + nt * 32 + 8 * q + 4 * h) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
   // staging addresses: the swizzle XOR only touches bits 4-6, so every chunk address is (lane base) ^ (chunk << 4)
   unsigned wbase = (unsigned)(size_t)stg + (row >> 3) * GS + (row & 7) * 128 + h * 8 + ((row & 7) << 4);
   unsigned rbase = (unsigned)(size_t)stg + (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4);
@@ -470,12 +512,16 @@ __device__ __forceinline__ void fast_epilogue_rows(const GemmArgs& p, f32x16_t (
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float v[4];
+        const f32x4_t b4 = HOIST ? bv[nt][q] : has_bias ? *(const f32x4_t*)(bias_lds + nt * 32 + 8 * q + 4 * h) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (scale) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = acc[mt][nt][q * 4 + i] * p.alpha;
-        if (has_bias) {
-          const f32x4_t b4 = *(const f32x4_t*)(bias_lds + nt * 32 + 8 * q + 4 * h);
+          for (int i = 0; i < 4; ++i) v[i] = acc[mt][nt][q * 4 + i] * p.alpha + b4[i];
+        } else if (has_bias) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] += b4[i];
+          for (int i = 0; i < 4; ++i) v[i] = acc[mt][nt][q * 4 + i] + b4[i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = acc[mt][nt][q * 4 + i];
         }
         u32x2_t pk;
         pk[0] = pack_bf2(v[0], v[1]);
@@ -484,14 +530,14 @@ __device__ __forceinline__ void fast_epilogue_rows(const GemmArgs& p, f32x16_t (
       }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_sched_barrier(0);  // keep the blocks apart: hipcc otherwise hoists work across them and spills
-    // side inputs of the next 32-row block (its accumulators' predecessors are dead now)
     // (PF == false, register-capped kernels: this block's own side inputs, right after its accumulators died)
+    // side inputs of the next 32-row block (its accumulators' predecessors are dead now)
     u32x4_t sn[4];
     if (has_side && (mt < 3 || !PF)) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int mm = mrow0 + (mt + (PF ? 1 : 0)) * 32 + i * 8 + (lane >> 3);
-        if (n_ok && mm < p.M) sn[i] = load16(side + (long)mm * lds_ + nn, nt_ld);
+        if (n_ok && (!partial || mm < p.M)) sn[i] = load16(side + (long)mm * lds_ + nn, nt_ld);
       }
     }
     // pass B
@@ -499,7 +545,7 @@ __device__ __forceinline__ void fast_epilogue_rows(const GemmArgs& p, f32x16_t (
     for (int i = 0; i < 4; ++i) {
       const int r2 = i * 8 + (lane >> 3);
       const int mm = mrow0 + mt * 32 + r2;
-      const bool ok = n_ok && mm < p.M;
+      const bool ok = n_ok && (!partial || mm < p.M);
       const u32x4_t pre = *(lds_u32x4_ptr)(size_t)(rbase + i * GS);  // rows r2 = i*8 + (lane >> 3): (r2 & 7) == lane >> 3
       if (has_pre && !save_deriv && ok) store16(p.out_pre + (long)mm * p.ldc + nn, pre, nt_st);
       u32x4_t fin = pre;
@@ -538,20 +584,20 @@ __device__ __forceinline__ void fast_epilogue_rows(const GemmArgs& p, f32x16_t (
           if (has_u && u_is_deriv) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              x[2 * e] = bf_round(x[2 * e]) * bf_lo(sv[e]);
-              x[2 * e + 1] = bf_round(x[2 * e + 1]) * bf_hi(sv[e]);
+              x[2 * e] = (exact ? x[2 * e] : bf_round(x[2 * e])) * bf_lo(sv[e]);
+              x[2 * e + 1] = (exact ? x[2 * e + 1] : bf_round(x[2 * e + 1])) * bf_hi(sv[e]);
             }
           } else if (has_u) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              x[2 * e] = bf_round(x[2 * e]) * dgelu_f(bf_lo(sv[e]));
-              x[2 * e + 1] = bf_round(x[2 * e + 1]) * dgelu_f(bf_hi(sv[e]));
+              x[2 * e] = (exact ? x[2 * e] : bf_round(x[2 * e])) * dgelu_f(bf_lo(sv[e]));
+              x[2 * e + 1] = (exact ? x[2 * e + 1] : bf_round(x[2 * e + 1])) * dgelu_f(bf_hi(sv[e]));
             }
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              x[2 * e] = bf_round(x[2 * e]) + bf_lo(sv[e]);
-              x[2 * e + 1] = bf_round(x[2 * e + 1]) + bf_hi(sv[e]);
+              x[2 * e] = (exact ? x[2 * e] : bf_round(x[2 * e])) + bf_lo(sv[e]);
+              x[2 * e + 1] = (exact ? x[2 * e + 1] : bf_round(x[2 * e + 1])) + bf_hi(sv[e]);
             }
           }
         }
@@ -594,6 +640,28 @@ __device__ __forceinline__ void fast_epilogue_rows(const GemmArgs& p, f32x16_t (
       }
     }
   }
+}
+
+template <bool CSUM, int GS, bool PF, int MODE>
+__device__ __forceinline__ bool fast_epilogue_rows_try(const GemmArgs& p, f32x16_t (&acc)[4][2], char* stg, float* bias_lds, int mrow0,
+                                                       int ncol0, int lane, unsigned flags) {
+  if constexpr (MODE >= EPI_NMODES) {
+    return false;
+  } else {
+    if (flags == EPI_MODES[MODE]) {
+      fast_epilogue_rows_impl<CSUM, GS, PF, MODE>(p, acc, stg, bias_lds, mrow0, ncol0, lane, flags);
+      return true;
+    }
+    return fast_epilogue_rows_try<CSUM, GS, PF, MODE + 1>(p, acc, stg, bias_lds, mrow0, ncol0, lane, flags);
+  }
+}
+template <bool CSUM, int GS = 1024, bool PF = true>
+__device__ __forceinline__ void fast_epilogue_rows(const GemmArgs& p, f32x16_t (&acc)[4][2], char* stg, float* bias_lds,
+                                                   int mrow0, int ncol0, int lane) {
+  const bool partial = mrow0 + 128 > p.M || ncol0 + 64 > p.N;  // wave-uniform
+  const unsigned flags = epi_flags_of(p, partial);
+  if (!fast_epilogue_rows_try<CSUM, GS, PF, 0>(p, acc, stg, bias_lds, mrow0, ncol0, lane, flags))
+    fast_epilogue_rows_impl<CSUM, GS, PF, -1>(p, acc, stg, bias_lds, mrow0, ncol0, lane, flags);
 }
 
 // Epilogue shared by the direct-to-LDS kernels: each wave owns a 128 x 64 block of the output tile as acc[4][2]
