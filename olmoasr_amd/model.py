@@ -69,8 +69,8 @@ def _rows_bf16(x: Tensor):
 
 def _mask_to_native(mask: Optional[Tensor], B: int, Tq: int, Tk: int):
     """The reference passes additive masks: the [n_ctx, n_ctx] causal triangle (eval, model.py:740) or, in training, causal +
-    key-padding as [B, n_ctx, n_ctx] (train_timestamps.py:314-315).  The kernels take (causal, kv_len[b]); anything that is not
-    exactly one of those two shapes of mask is refused rather than approximated."""
+    key-padding as [B, n_ctx, n_ctx] (train_timestamps.py:314-315).  The kernels take (causal, kv_len[b]); a mask that is not a
+    combination of those two is refused rather than approximated."""
     if mask is None:
         return False, None
     if Tq != Tk:
@@ -80,14 +80,20 @@ def _mask_to_native(mask: Optional[Tensor], B: int, Tq: int, Tk: int):
     fin = torch.isfinite(m)
     kv_len = fin[:, -1, :].sum(-1).to(torch.int32)  # the last query row sees every unpadded key
     ar = torch.arange(Tk, device=m.device)
-    want = (ar[None, None, :] <= ar[None, :, None]) & (ar[None, None, :] < kv_len[:, None, None])
-    if not torch.equal(fin, want.expand_as(fin)) or bool((m[fin] != 0).any()):
-        raise N.NativeError("MultiHeadAttention.forward: only the causal mask, optionally with key padding (finite entries 0, masked "
-                            "entries -inf), maps onto the native attention kernels")
+    keys = ar[None, None, :] < kv_len[:, None, None]
+    if torch.equal(fin, keys.expand_as(fin)):
+        causal = False  # key padding only (or no masking at all)
+    elif torch.equal(fin, ((ar[None, None, :] <= ar[None, :, None]) & keys).expand_as(fin)):
+        causal = True
+    else:
+        causal = None
+    if causal is None or bool((m[fin] != 0).any()):
+        raise N.NativeError("MultiHeadAttention.forward: only key padding and / or the causal triangle (finite entries 0, masked entries "
+                            "-inf) map onto the native attention kernels")
     if kv_len.shape[0] == 1 and B > 1:
         kv_len = kv_len.expand(B)
     full = bool((kv_len == Tk).all())
-    return True, None if full else kv_len.contiguous()
+    return causal, None if full else kv_len.contiguous()
 
 
 class _EngineKV:

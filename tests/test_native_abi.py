@@ -126,3 +126,36 @@ def test_train_script_host_logic():
     assert sc.scale == 65536.0 and sc.growth_tracker == 0
     a = tt.parse_args(["--model_variant", "medium", "--betas", "(0.9, 0.98)", "--eff_batch_size", "2048"])
     assert a.model_variant == "medium" and a.eff_batch_size == 2048
+
+
+def test_module_forward_mask_mapping():
+    """MultiHeadAttention.forward takes the reference's additive masks (causal [T,T], model.py:740; causal + key padding [B,T,T],
+    train_timestamps.py:314-315 + model.py:741) and hands the kernels (causal, kv_len); anything else must be refused, not approximated."""
+    import math
+
+    import pytest
+    import torch
+    from olmoasr_amd import _native as N
+    from olmoasr_amd.model import _mask_to_native
+    T = 12
+    causal = torch.full((T, T), -math.inf).triu_(1)
+    assert _mask_to_native(None, 2, T, T) == (False, None)
+    c, kv = _mask_to_native(causal, 2, T, T)
+    assert c is True and kv is None
+    pad = torch.zeros(2, T, T)
+    pad[0, :, 5:] = -math.inf
+    pad[1, :, 9:] = -math.inf
+    c, kv = _mask_to_native(pad + causal, 2, T, T)
+    assert c is True and kv.tolist() == [5, 9] and kv.dtype == torch.int32
+    c, kv = _mask_to_native((pad + causal)[:, :7, :7], 2, 7, 7)  # a prefix of the context, as TextDecoder slices it
+    assert kv.tolist() == [5, 7]
+    hole = (pad + causal).clone()
+    hole[0, 4, 1] = -math.inf
+    c, kv = _mask_to_native(pad, 2, T, T)  # key padding without the triangle
+    assert c is False and kv.tolist() == [5, 9]
+    assert _mask_to_native(torch.zeros(T, T), 2, T, T) == (False, None)
+    for bad in (hole, causal + 1.0, causal.t()):  # a hole, a finite bias, an anti-causal triangle
+        with pytest.raises(N.NativeError):
+            _mask_to_native(bad, 2, T, T)
+    with pytest.raises(N.NativeError):
+        _mask_to_native(causal, 2, T, T + 1)
