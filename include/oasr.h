@@ -167,6 +167,8 @@ typedef struct oasr_attn_args {
   int B, H, Tq, Tk, causal; const void* d_o; float* delta; void *dq, *dk, *dv;
   float *dq_colsum, *dv_colsum; /* optional [H*64], accumulated: column sums of dq / dv = query / value bias gradients */
   float* colsum_scratch;        /* with either of them: B * (ceil(Tq/128) + ceil(Tk/128)) * H*64 floats of scratch */
+  int32_t* qtile_flags;         /* optional [B, H, ceil(Tq/64)] workspace (backward): 64-query tiles of d_o that are all zero -- the padded
+                                 * positions of a decoder batch -- are recorded by the dQ kernel and skipped by both; bit-identical */
 } oasr_attn_args;
 int oasr_attention_fwd(const oasr_attn_args*, void* stream);
 int oasr_attention_bwd(const oasr_attn_args*, void* stream);

@@ -40,7 +40,7 @@ class AttnArgs(C.Structure):
                 ("ldo", C.c_int64), ("bso", C.c_int64), ("lse", C.c_void_p), ("o_lo", C.c_void_p), ("kv_len", C.c_void_p), ("B", C.c_int),
                 ("H", C.c_int), ("Tq", C.c_int), ("Tk", C.c_int), ("causal", C.c_int), ("d_o", C.c_void_p),
                 ("delta", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p), ("dq_colsum", C.c_void_p),
-                ("dv_colsum", C.c_void_p), ("colsum_scratch", C.c_void_p)]
+                ("dv_colsum", C.c_void_p), ("colsum_scratch", C.c_void_p), ("qtile_flags", C.c_void_p)]
 
 
 def _declare(lib):

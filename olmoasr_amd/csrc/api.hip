@@ -124,6 +124,7 @@ static AttnArgs to_attn(const oasr_attn_args* a) {
   r.dq_colsum = a->dq_colsum;
   r.dv_colsum = a->dv_colsum;
   r.colsum_scratch = a->colsum_scratch;
+  r.qtile_flags = a->qtile_flags;
   return r;
 }
 extern "C" int oasr_attention_fwd(const oasr_attn_args* a, void* stream) {

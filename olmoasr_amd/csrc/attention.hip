@@ -99,6 +99,14 @@ __device__ __forceinline__ bf16x8_t pack_half(const f32x16_t& p, int u) {
 }
 __device__ __forceinline__ bf16x8_t ld_frag_global(const bf16_t* p) { return __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)p); }
 __device__ __forceinline__ int acc_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int t = __shfl_xor(v, o, 64);
+    v = t > v ? t : v;
+  }
+  return v;
+}
 
 // ---- row-coalesced output stores --------------------------------------------------------------------------------------
 // The kernels hold their results transposed, T[dt][r] = out[row = lane & 31][col = dt*32 + acc_row(r, lane >> 5)]: a lane owns
@@ -381,7 +389,27 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   kv_len = kv_len < a.Tk ? kv_len : a.Tk;
   int kv_end = kv_len;
   if (CAUSAL) kv_end = kv_end < q0 + 128 ? kv_end : q0 + 128;
-  const int ntiles = kv_end > 0 ? (kv_end + 63) >> 6 : 1;  // >= 1: a fully masked tile yields l = 0 -> O = 0
+  int ntiles = kv_end > 0 ? (kv_end + 63) >> 6 : 1;  // >= 1: a fully masked tile yields l = 0 -> O = 0
+  if (a.qtile_flags) {  // which 64-query tiles of d_o hold anything: recorded for the dK/dV kernel; a block of zeros has dQ = 0
+    __shared__ int nzs[4];
+    bool nz = false;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) {
+      const u32x4_t d4 = __builtin_bit_cast(u32x4_t, dof[ds]);
+      nz = nz || ((d4[0] | d4[1] | d4[2] | d4[3]) & 0x7fff7fffu) != 0u;
+    }
+    const bool wnz = __any(nz);
+    if (lane == 0) nzs[wave] = wnz ? 1 : 0;
+    __syncthreads();
+    const int t0nz = nzs[0] | nzs[1], t1nz = nzs[2] | nzs[3];
+    if (tid == 0) {
+      const int ntq = (a.Tq + 63) >> 6, tq = q0 >> 6;
+      int32_t* f = a.qtile_flags + ((long)b * a.H + h) * ntq;
+      if (tq < ntq) f[tq] = t0nz;
+      if (tq + 1 < ntq) f[tq + 1] = t1nz;
+    }
+    if (!(t0nz | t1nz)) ntiles = 0;
+  }
   const TileSrc ksrc = tile_src(a.k + (long)b * a.bsk + h * 64, a.ldk, a.Tk, tid);
   const TileSrc vsrc = tile_src(a.v + (long)b * a.bsv + h * 64, a.ldv, a.Tk, tid);
 
@@ -568,6 +596,25 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dq_pp_kernel(AttnArgs a) {
   const float lse2 = a.lse[stat_idx] * LOG2E;
   asm volatile("" ::"v"(lse2), "v"(delta), "v"(qf[3]), "v"(dof[3]));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the loop counts its own DMA pieces
+  bool blk_nz = true;
+  if (a.qtile_flags) {  // which 64-query tiles of d_o hold anything: recorded for the dK/dV kernel; a block of zeros has dQ = 0
+    int* nzs = (int*)smem;  // (the ring is not in use yet; a barrier below releases these bytes before the first DMA piece)
+    bool nz = false;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) {
+      const u32x4_t d4 = __builtin_bit_cast(u32x4_t, dof[ds]);
+      nz = nz || ((d4[0] | d4[1] | d4[2] | d4[3]) & 0x7fff7fffu) != 0u;
+    }
+    const bool wnz = __any(nz);
+    if (lane == 0) nzs[wave] = wnz ? 1 : 0;
+    __syncthreads();
+    if (tid < 4) {
+      const int ntq = (a.Tq + 63) >> 6, tq = (q0 >> 6) + tid;
+      if (tq < ntq) a.qtile_flags[((long)b * a.H + h) * ntq + tq] = nzs[2 * tid] | nzs[2 * tid + 1];
+    }
+    blk_nz = (nzs[0] | nzs[1] | nzs[2] | nzs[3] | nzs[4] | nzs[5] | nzs[6] | nzs[7]) != 0;
+    __syncthreads();
+  }
 
   const int ntiles = (a.Tk + 63) >> 6;
   const int ngroups = (ntiles + PNS - 1) / PNS;
@@ -683,6 +730,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dq_pp_kernel(AttnArgs a) {
     }
   };
 
+  if (blk_nz) {  // (workgroup-uniform)
   // prologue: tiles 0, 1 in flight; S/dP of step 0; LOAD(0) with nothing for the dQ MFMAs of "step -1" to add
   dma_tile(0, 0);
   dma_tile(1, 1);
@@ -736,6 +784,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dq_pp_kernel(AttnArgs a) {
     }
   if (grp == 0) ATTN_BARRIER();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tail DMA pieces (zeros) must not land on the staging tiles below
+  }
   __syncthreads();
   float* wsum = (float*)(smem + 32768);  // [8 waves][64], behind the staging tiles
   store_rows_bf16(smem + wave * 4096, dqT, SCALE, a.dq + (long)b * a.bsq + (long)(q0 + wave * 32) * a.ldq + h * 64, a.ldq,
@@ -755,6 +804,14 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dq_pp_kernel(AttnArgs a) {
 
 // ------------------------------------------------------------------------------------------------------------
 // dK[k][:] = scale * sum_q dS[q][k] Q[q][:],  dV[k][:] = sum_q P[q][k] dO[q][:]
+// index of the last 64-query tile whose d_o the dQ kernel found non-zero (-1: none); every wave computes it for itself
+__device__ __forceinline__ int last_nonzero_qtile(const int32_t* flags, int n, int lane) {
+  int last = -1;
+  for (int i = lane; i < n; i += 64)
+    if (flags[i] != 0) last = i;
+  return __builtin_amdgcn_readfirstlane(wave_max_i(last));
+}
+
 template <bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
   // stage s: Q tile, dO tile, then lse[64] | delta[64] floats
@@ -794,9 +851,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
   const float* lse_b = a.lse + ((long)b * a.H + h) * a.Tq;
   const float* delta_b = a.delta + ((long)b * a.H + h) * a.Tq;
 
-  const int nqt = (a.Tq + 63) >> 6;
+  int nqt = (a.Tq + 63) >> 6;
+  if (a.qtile_flags) nqt = last_nonzero_qtile(a.qtile_flags + ((long)b * a.H + h) * nqt, nqt, lane) + 1;  // d_o is zero past it
   const int t_begin = (CAUSAL && k0 < kv_len) ? (k0 >> 6) : 0;
-  const bool any = k0 < kv_len;  // otherwise every P is zero: fall through and write zeros
+  const bool any = k0 < kv_len && t_begin < nqt;  // otherwise every P (or every d_o row) is zero: fall through and write zeros
 
   u32x4_t rq[2], rd[2];
   float rstat = 0.f;
@@ -969,7 +1027,8 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkdv_pp_kernel(AttnArgs a) {
   asm volatile("" ::"v"(kf[3]), "v"(vf[3]));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the loop counts its own DMA pieces
 
-  const int ntiles = (a.Tq + 63) >> 6;
+  int ntiles = (a.Tq + 63) >> 6;
+  if (a.qtile_flags) ntiles = last_nonzero_qtile(a.qtile_flags + ((long)b * a.H + h) * ntiles, ntiles, lane) + 1;  // d_o is zero past it
   const int ngroups = (ntiles + PNS - 1) / PNS;
   const PipeSrc1 qsrc = pipe_src1(a.q + (long)b * a.bsq + h * 64, a.ldq, a.Tq, wave, lane);
   const PipeSrc1 dosrc = pipe_src1(a.d_o + (long)b * a.bso + h * 64, a.ldo, a.Tq, wave, lane);
@@ -1097,6 +1156,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkdv_pp_kernel(AttnArgs a) {
     __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
   };
 
+  if (ntiles > 0) {  // (workgroup-uniform)
   // prologue: tiles 0..2 in flight; seeds + S / dP of step 0; LOAD(0)
   dma_tile(0, 0);
   dma_tile(1, 1);
@@ -1144,6 +1204,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkdv_pp_kernel(AttnArgs a) {
   }
   if (grp == 0) ATTN_BARRIER();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tail DMA pieces (zeros) must not land on the staging tiles below
+  }
   __syncthreads();
   {
     char* stg = smem + wave * 4096;

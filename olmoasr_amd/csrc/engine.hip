@@ -180,6 +180,7 @@ struct Plan {
   // backward temporaries
   T *ga, *gb, *gc, *gln, *gqkv, *go, *gu, *gxa, *gkv, *gq, *gA2;
   float *delta, *tmp_w1p, *tmp_w2p, *cs_scratch, *gemm_cs_scratch;
+  int32_t* qtile_flags;  // attention backward of the decoder: which 64-position tiles of d_o are non-zero
 };
 
 static void plan_attn(Arena& A, AttnSave& s, long M, long Mkv, int d, int B, int H, long Tq, bool cross, bool train) {
@@ -264,6 +265,7 @@ static void make_plan(const oasr_ctx* c, Arena& A, Plan& p, int B, int S, bool t
     p.gA2 = A.template act<T>(Me * 3 * d);
     p.delta = A.f32((long)B * c->H * c->Te);
     p.cs_scratch = A.f32(attn_colsum_scratch_floats(B, c->H, c->Te, c->Te));  // (the largest of the three attention shapes)
+    p.qtile_flags = (int32_t*)A.f32((size_t)B * c->H * ((S + 63) / 64) + 16);
     p.gemm_cs_scratch = A.f32((size_t)2 * cdiv(Mmax, 256) * 4 * d + 64);
     p.tmp_w1p = A.f32((long)d * 256);
     p.tmp_w2p = A.f32((long)d * 3 * d);
@@ -567,6 +569,9 @@ struct Runner {
       a.dq_colsum = c->G(bp.cattn.qb);  // query / value bias gradients = column sums of dq / dv, fused into the store epilogues
       a.dv_colsum = c->G(bp.cattn.vb);
       a.colsum_scratch = p.cs_scratch;
+      // decoder positions the loss ignores have d_o == 0 exactly (three quarters of the 448 on the synthetic lengths): the kernels
+      // find those 64-position tiles themselves and skip them
+      a.qtile_flags = p.qtile_flags;
       RC(launch_attention_bwd(a, st));
       RC(wgrad(p.gq, d, M, d, plain_view(s.ca.ln, d), d, c->G(bp.cattn.qw), d));
       RC(wgrad(p.gkv, 2 * d, Mkv, 2 * d, plain_view(p.xa, d), d, c->G(bp.cattn.kw), d));
@@ -592,6 +597,7 @@ struct Runner {
     a.dq_colsum = c->G(bp.attn.qb);
     a.dv_colsum = c->G(bp.attn.vb);
     a.colsum_scratch = p.cs_scratch;
+    a.qtile_flags = causal ? p.qtile_flags : nullptr;  // (decoder blocks only: an encoder block's d_o has no zero rows)
     RC(launch_attention_bwd(a, st));
     RC(wgrad(p.gqkv, 3 * d, M, 3 * d, plain_view(s.sa.ln, d), d, c->G(bp.attn.qw), d));
     RC(dgrad(p.gqkv, M, 3 * d, c->template Wt<T>(bp.attn.qw), d, nullptr, nullptr, p.gln));

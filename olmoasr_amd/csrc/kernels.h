@@ -122,6 +122,10 @@ struct AttnArgsT {
   // query / value projection biases (key has none, olmoasr/model.py:259), fused into the backward kernels' store epilogues
   float *dq_colsum, *dv_colsum;
   float* colsum_scratch;     // required with either: fp32 [(B*ceil(Tq/128) + B*ceil(Tk/128)) * H*64] per-workgroup partial rows
+  // optional int32 [B, H, ceil(Tq/64)] workspace: the dQ kernel records which 64-query tiles of d_o hold any non-zero value, the
+  // dK/dV kernel stops at the last such tile (decoder side of a padded batch: the loss ignores the padded positions, their d_o rows
+  // are exactly zero and contribute exactly nothing -- three quarters of the 448 positions on average).  Results are bit-identical.
+  int32_t* qtile_flags;
 };
 static inline size_t attn_colsum_scratch_floats(int B, int H, int Tq, int Tk) {
   return (size_t)B * ((size_t)(Tq + 127) / 128 + (size_t)(Tk + 127) / 128) * H * 64;

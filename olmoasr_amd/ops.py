@@ -87,7 +87,8 @@ def attention_fwd(q, k, v, kv_len=None, causal=False, want_o_lo=False):
     return (o, lse, o_lo) if want_o_lo else (o, lse)
 
 
-def attention_bwd(q, k, v, o, lse, d_o, kv_len=None, causal=False, o_lo=None, dq_colsum=None, dv_colsum=None):
+def attention_bwd(q, k, v, o, lse, d_o, kv_len=None, causal=False, o_lo=None, dq_colsum=None, dv_colsum=None, qtile_flags=None):
+    """qtile_flags: optional int32 [B, H, ceil(Tq/64)] workspace -- all-zero 64-query tiles of d_o are recorded and skipped (bit-identical)."""
     B, Tq, H, _ = q.shape
     # gradients use the operands' own (possibly fused-qkv) strides
     dq, dk, dv = (torch.empty_strided(t.shape, t.stride(), device=t.device, dtype=t.dtype) for t in (q, k, v))
@@ -98,6 +99,7 @@ def attention_bwd(q, k, v, o, lse, d_o, kv_len=None, causal=False, o_lo=None, dq
     a.dq, a.dk, a.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
     a.dq_colsum = dq_colsum.data_ptr() if dq_colsum is not None else None
     a.dv_colsum = dv_colsum.data_ptr() if dv_colsum is not None else None
+    a.qtile_flags = qtile_flags.data_ptr() if qtile_flags is not None else None
     scratch = None
     if dq_colsum is not None or dv_colsum is not None:
         Tk = k.shape[1]

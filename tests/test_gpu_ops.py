@@ -413,6 +413,41 @@ def test_attention_fwd_bwd(case, attn_path):
     close(dq2, qr.grad, rtol=3e-2, atol=1e-2 * float(qr.grad.abs().max()) + 1e-3, name="dq (bf16-O delta)")
 
 
+@pytest.mark.parametrize("kind", ["decoder-self", "cross", "cross-ragged", "all-zero", "dense"])
+def test_attention_bwd_skips_zero_gradient_tiles_exactly(kind, attn_path):
+    """d_o rows of decoder positions the loss ignores are exactly zero; with the qtile_flags workspace the dQ kernel records the
+    all-zero 64-query tiles, a block of them leaves dQ = 0 without touching K / V, and the dK/dV kernel stops at the last non-zero
+    tile.  Must be bit-identical to the run without the workspace (it only removes additions of zero)."""
+    B, H = 3, 2
+    d = H * 64
+    lens = {"decoder-self": [7, 130, 300], "cross": [20, 64, 201], "cross-ragged": [1, 448, 65], "all-zero": [0, 0, 0], "dense": [448, 448, 448]}[kind]
+    causal = kind == "decoder-self"
+    Tq, Tk = 448, (448 if causal else 1500)
+    if causal:
+        qkv = rnd(B, Tq, 3 * d, seed=41)
+        q, k, v = (qkv[:, :, i * d:(i + 1) * d].unflatten(2, (H, 64)) for i in range(3))
+        kv_len = torch.tensor([max(n, 1) for n in lens], dtype=torch.int32, device=DEV)
+    else:
+        qb, kvb = rnd(B, Tq, d, seed=42), rnd(B, Tk, 2 * d, seed=43)
+        q = qb.unflatten(2, (H, 64))
+        k, v = (kvb[:, :, i * d:(i + 1) * d].unflatten(2, (H, 64)) for i in range(2))
+        kv_len = None
+    o, lse, o_lo = ops().attention_fwd(q, k, v, kv_len, causal, want_o_lo=True)
+    d_o = rnd(B, Tq, d, seed=44, scale=0.5)
+    for b, n in enumerate(lens):
+        d_o[b, n:] = 0
+    ref = ops().attention_bwd(q, k, v, o, lse, d_o, kv_len, causal, o_lo=o_lo)
+    flags = torch.full((B, H, (Tq + 63) // 64), -7, dtype=torch.int32, device=DEV)
+    cs, cv = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    got = ops().attention_bwd(q, k, v, o, lse, d_o, kv_len, causal, o_lo=o_lo, dq_colsum=cs, dv_colsum=cv, qtile_flags=flags)
+    for name, a_, b_ in zip(("dq", "dk", "dv"), got, ref):
+        assert torch.equal(a_, b_), (name, float((a_.float() - b_.float()).abs().max()))
+    want = torch.tensor([[[1 if t * 64 < n else 0 for t in range((Tq + 63) // 64)] for _ in range(H)] for n in lens], dtype=torch.int32)
+    assert torch.equal(flags.cpu(), want), (flags.cpu(), want)
+    close(cs, ref[0].float().sum((0, 1)).reshape(d), rtol=1e-4, atol=1e-3 * float(ref[0].float().abs().max()) + 1e-4, name="dq column sums")
+    close(cv, ref[2].float().sum((0, 1)).reshape(d), rtol=1e-4, atol=1e-3 * float(ref[2].float().abs().max()) + 1e-4, name="dv column sums")
+
+
 def test_attention_bwd_delta_precision():
     """When mean(V) dominates V's variation (LayerNorm'ed encoder output + value bias -- the cross-attention case), dP and
     delta = rowsum(dO*O) nearly cancel; taking delta from the bf16-rounded O then costs several % of dQ/dK.  The
