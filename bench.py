@@ -109,6 +109,21 @@ def train_flops_per_sample(d, L, T=1500, S=448, V=51865, F=3000, n_mels=80):
     return 3 * (conv + L * enc_layer + L * dec_layer + logits)
 
 
+def executed_flops_per_sample(d, L, span_rows_mean, T=1500, S=448, V=51865, F=3000, n_mels=80):
+    """FLOPs the supervised-span step actually executes per sample: the forward over all S positions, the decoder's backward (2 x
+    forward) over `span_rows_mean` = mean_b ceil64(span_b) token rows.  Attention backward of the decoder: the query side shrinks
+    to the span (self-attention: keys too)."""
+    conv = 2 * F * n_mels * 3 * d + 2 * T * d * 3 * d
+    enc_layer = 24 * T * d * d + 4 * T * T * d
+
+    def dec(Sq, cross_kv=True):
+        return (8 * Sq * d * d + 4 * Sq * Sq * d) + (4 * Sq * d * d + (4 * T * d * d if cross_kv else 0) + 4 * Sq * T * d) + 16 * Sq * d * d
+    fwd = conv + L * enc_layer + L * dec(S) + 2 * S * d * V
+    R = span_rows_mean
+    bwd = 2 * (conv + L * enc_layer + L * dec(R) + 2 * R * d * V)
+    return fwd + bwd
+
+
 def synth_batch(indices, device):
     """SURVEY.md section 8(d)'s generator, sample by sample on the host (olmoasr_amd/synth.py: seed 1234 + sample index, bit-equal
     to oracle.model_oracle.synthetic_sample, tests/test_synth_cpu.py): int16 PCM ~ round(clip(N(0, 0.1)) * 32767) with a zeroed
@@ -247,6 +262,66 @@ def hbm_kernel_rooflines(net, dims, mb, dev):
     return out
 
 
+def self_launch(n, argv, module="torch.distributed.run", extra_env=None):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: re-run this file as N ranks on this node and relay rank 0's stdout.
+    Fails with a plain message -- not an assert -- when the node has fewer devices."""
+    import socket
+    import subprocess
+    n_dev = n if os.environ.get("OASR_BENCH_STUB") == "1" else torch.cuda.device_count()
+    if n_dev < n:
+        print(f"bench.py: --gpus {n} needs {n} devices on this node, {n_dev} visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:  # a free loopback port for the rendezvous
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", module, "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if extra_env:
+        env.update(extra_env)
+    return subprocess.call(cmd, env=env)
+
+
+def stub_main(args):
+    """OASR_BENCH_STUB=1: everything bench.py does AROUND the step -- rank environment, process group, warm-up, barrier-bracketed
+    timing of exactly K steps, max over ranks, one JSON line from rank 0 -- with a stand-in step (a gloo all-reduce), so the
+    multi-rank launch path is covered on a machine without GPUs.  Never a measurement."""
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    buf = torch.ones(1024)
+
+    def one_step():
+        if world > 1:
+            dist.all_reduce(buf)
+            buf.div_(world)
+        time.sleep(0.002)
+    for _ in range(args.warmup):
+        one_step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": round(world * args.steps / elapsed, 3), "unit": "steps/sec", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 3),
+                          "data": "stub (OASR_BENCH_STUB=1: launch-path rehearsal on CPU, not a measurement)",
+                          "buf_ok": bool(float(buf[0]) == 1.0)}), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -265,9 +340,20 @@ def main():
     ap.add_argument("--trim-padding", action="store_true",
                     help="opt-in, NOT the reference's computation shape: run the decoder over ceil16(max text_len) of each "
                          "micro-batch instead of the padded 448 positions (same loss and gradients; see DESIGN.md)")
+    ap.add_argument("--full-backward", action="store_true",
+                    help="A/B: run the decoder's backward over all 448 padded positions (the plain step) instead of the supervised "
+                         "span (oasr_train_fwd_bwd_span: same loss and gradients, the forward covers 448 positions either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher: start one rank per GPU ourselves (torch.distributed.run, loopback rendezvous)
+    # and let rank 0's JSON line through -- the shape of the driver's N = 1 command works for every N.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus, sys.argv[1:])
+
+    if os.environ.get("OASR_BENCH_STUB") == "1":  # tests/test_ddp_cpu.py: the launch / rendezvous / rank-0-prints plumbing on CPU (gloo)
+        return stub_main(args)
 
     from olmoasr_amd import _native as N
     from olmoasr_amd import ddp, ops
@@ -277,7 +363,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    n_dev = torch.cuda.device_count()
+    if local_rank >= n_dev:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} needs {args.gpus} devices on this node, {n_dev} visible (rank {rank})")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # OASR_BENCH_FORCE_DDP=1: take the multi-GPU code path (RCCL group, broadcast, event-driven bucket all-reduce, barriers) with
@@ -322,6 +412,13 @@ def main():
     ctx = [None] * accum
     if args.trim_padding:
         ctx = [min(448, (int(tl[i * mb:(i + 1) * mb].max()) + 15) // 16 * 16) for i in range(accum)]
+    # supervised span per sample, on the HOST like the loader has it (train_timestamps.py:238-343 builds the sequences there):
+    # one past the last position whose target is not the ignore index, >= text_len
+    spans = None
+    if not args.full_backward and not args.trim_padding:
+        sp = OLMoASR.supervised_span(ty, tl)
+        spans = [sp[i * mb:(i + 1) * mb].contiguous() for i in range(accum)]
+        span_rows_mean = float(((sp + 63) // 64 * 64).float().mean())
 
     def one_step():
         state["step"] += 1
@@ -332,7 +429,7 @@ def main():
             last = i == accum - 1
             net.loss_and_backward(mel, ti[sl], ty[sl], tl[sl], loss_scale=loss_scale, accumulation_steps=accum, loss_out=loss_buf,
                                   accumulate_loss=i > 0, segment_events=reducer.segment_events() if (reducer and last) else None,
-                                  text_ctx=ctx[i])
+                                  text_ctx=ctx[i], span=spans[i] if spans else None)
         div = 1.0
         if reducer:
             reducer.reduce()
@@ -411,8 +508,9 @@ def main():
     if rank == 0:
         ms_per_step = 1000.0 * elapsed / args.steps
         value = world * B * 30.0 * args.steps / elapsed
-        fl_sample = sum(train_flops_per_sample(dims.n_audio_state, dims.n_audio_layer, S=(c or 448)) for c in ctx) / len(ctx)  # executed flops
-        step_tflops = B * fl_sample / (elapsed / args.steps) / 1e12
+        fl_sample = sum(train_flops_per_sample(dims.n_audio_state, dims.n_audio_layer, S=(c or 448)) for c in ctx) / len(ctx)
+        step_tflops = B * fl_sample / (elapsed / args.steps) / 1e12  # ALGORITHMIC flops (3 x forward over the padded context) per second
+        fl_exec = executed_flops_per_sample(dims.n_audio_state, dims.n_audio_layer, span_rows_mean) if spans else fl_sample
         out = {
             "metric": "audio-seconds/sec/node (train step)", "value": round(value, 1), "unit": "audio-seconds/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
@@ -423,9 +521,15 @@ def main():
                        "global_batch": world * B, "micro_batch": mb, "parallelism": f"dp{world}" + (f" ({args.reducer} gradient exchange, {args.bucket_mb:g} MiB buckets)" if world > 1 else ""),
                        "optimizer": "AdamW fused (unscale+clip+step), loss scale 65536",
                        "decoder_positions": ("trimmed to ceil16(max text_len) per micro-batch: %s (opt-in, not the reference shape)" % ctx)
-                       if args.trim_padding else "448 (padded, as the reference)"},
+                       if args.trim_padding else ("448 forward (padded, as the reference); backward over the supervised span: mean "
+                                                  f"{span_rows_mean:.1f} of 448 token rows per clip (exact: the rows left out are zeros)" if spans
+                                                  else "448 (padded, as the reference), forward and backward")},
             "step_model_tflops_per_gpu": round(step_tflops, 1),
             "step_frac_of_mfma_peak": round(step_tflops / PEAK_BF16_TFLOPS, 4),
+            # the roofline fraction above prices the reference's ALGORITHMIC work (3 x forward over 448 padded positions); the
+            # span step executes less: rows whose gradient is exactly zero are not multiplied
+            "executed_over_algorithmic_flops": round(fl_exec / fl_sample, 4),
+            "step_executed_tflops_per_gpu": round(B * fl_exec / (elapsed / args.steps) / 1e12, 1),
             "final_loss": round(final_loss, 4), "found_inf": found_inf,
         }
         if roof:
@@ -472,4 +576,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -32,6 +32,9 @@ typedef struct oasr_dims {
 } oasr_dims;
 
 const char* oasr_last_error(void);
+/* ABI version: 100 * major + minor.  Structs passed by pointer (oasr_attn_args, oasr_gemm_args) only grow at the end and only with a
+ * major bump; olmoasr_amd/_native.py refuses to drive a library whose version differs from OASR_ABI_VERSION. */
+#define OASR_ABI_VERSION 200
 int oasr_version(void);
 
 /* ---- log-mel front end: whisper.audio.log_mel_spectrogram as called at train_timestamps.py:196,214 and
@@ -121,6 +124,18 @@ int oasr_train_fwd_bwd_s(oasr_ctx*, const float* mel, const int64_t* tokens, con
                          int S, float loss_scale, float inv_accum, float* loss_out, int accumulate_loss, float* logits_out,
                          void** seg_events, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same micro-step with the decoder's BACKWARD limited to the supervised span -- exact, and the forward still covers all
+ * n_text_ctx positions like the reference's (train_timestamps.py:318-329 pads every sample to 448; :1444 then ignores the padding).
+ * span_host: HOST int32 [B] (the data loader builds the token sequences on the host, train_timestamps.py:238-343):
+ * every target of sample b at a position >= span_host[b] is ignore_index, and span_host[b] >= text_len[b].  Gradient rows past the
+ * span are exactly zero in the reference's computation, so the decoder's token rows are stored in 64-position chunks with the
+ * chunks that can carry gradient first and the decoder's backward GEMMs / LayerNorms / attention run over those rows only
+ * (olmoasr_amd/csrc/engine.hip).  Loss and gradients equal oasr_train_fwd_bwd's up to fp32 summation order.  Falls back to the
+ * plain step when n_text_ctx is not a multiple of 64 or B > 512. */
+int oasr_train_fwd_bwd_span(oasr_ctx*, const float* mel, const int64_t* tokens, const int64_t* targets, const int32_t* text_len,
+                            const int32_t* span_host, int B, float loss_scale, float inv_accum, float* loss_out, int accumulate_loss,
+                            void** seg_events, void* workspace, size_t workspace_bytes, void* stream);
+
 /* The same micro-step cut at the logits, for torch.autograd: OLMoASR.forward in training mode (olmoasr/model.py:856-887) followed by
  * the CALLER's loss and .backward() (train_timestamps.py:1440-1454 unchanged).  train_fwd: fp32 logits [B, S, rows], every saved
  * activation stays in the workspace.  train_bwd: dlogits = d(loss)/d(logits), fp32, same shape -> parameter gradients ACCUMULATED into
@@ -169,7 +184,15 @@ typedef struct oasr_attn_args {
   float* colsum_scratch;        /* with either of them: B * (ceil(Tq/128) + ceil(Tk/128)) * H*64 floats of scratch */
   int32_t* qtile_flags;         /* optional [B, H, ceil(Tq/64)] workspace (backward): 64-query tiles of d_o that are all zero -- the padded
                                  * positions of a decoder batch -- are recorded by the dQ kernel and skipped by both; bit-identical */
+  /* ABI 200: chunked token rows (the decoder of oasr_train_fwd_bwd_span).  q_rows / k_rows: optional int32 [B][OASR_ROWTAB]: first
+   * token row -- relative to the base pointers, batch strides unused -- of every 64-position chunk of sample b (q_rows: q, o, o_lo,
+   * d_o, dq; k_rows: k, v, dk, dv); q_span: optional int32 [B], multiples of 64 (backward): d_o is zero at query positions >=
+   * q_span[b]; those rows are not read and their dq (self-attention: dk / dv too) not written. */
+  const int32_t *q_rows, *k_rows, *q_span;
 } oasr_attn_args;
+#define OASR_ROWTAB 16
+/* sizeof(oasr_attn_args) as the library was built: a binding compares it with its own before the first call */
+size_t oasr_sizeof_attn_args(void);
 int oasr_attention_fwd(const oasr_attn_args*, void* stream);
 int oasr_attention_bwd(const oasr_attn_args*, void* stream);
 int oasr_cross_entropy(void* logits_bf16, int64_t ld, int V, const int64_t* targets, int64_t rows, int64_t ignore, float gscale,

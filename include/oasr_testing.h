@@ -27,6 +27,11 @@ int oasr_gemm_force_general(int on); /* tests: route every GEMM through the regi
 int oasr_profile_gemm_collect(double* ms4, double* flops4, int64_t* count4, char* by_symbol /* "symbol\tlaunches\tms\tflops\n"... or NULL */, int cap);
 int oasr_probe_lds_oob(const void* src_u16 /*[512]*/, void* dst_u16 /*[512]*/, void* stream);
 int oasr_probe_tr16(const void* src_bf16 /*[16][64]*/, void* dst_bf16 /*[64 lanes][4]*/, void* stream);
+/* tests: the tables oasr_train_fwd_bwd_span builds for one micro-batch -- span_host: HOST int32 [B]; rows_out: device int32
+ * [B][OASR_ROWTAB] chunk-row table; span_out: device int32 [B] spans rounded up to 64; targets_rows_out: device int64 [B*S] targets in
+ * row order (active rows only); active_rows_out: HOST int64, the number of leading rows the decoder's backward runs over. */
+int oasr_test_span_tables(const int32_t* span_host, int B, int S, const int64_t* targets, int32_t* rows_out, int32_t* span_out,
+                          int64_t* targets_rows_out, int64_t* active_rows_out, void* stream);
 
 #ifdef __cplusplus
 }

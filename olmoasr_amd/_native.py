@@ -40,7 +40,12 @@ class AttnArgs(C.Structure):
                 ("ldo", C.c_int64), ("bso", C.c_int64), ("lse", C.c_void_p), ("o_lo", C.c_void_p), ("kv_len", C.c_void_p), ("B", C.c_int),
                 ("H", C.c_int), ("Tq", C.c_int), ("Tk", C.c_int), ("causal", C.c_int), ("d_o", C.c_void_p),
                 ("delta", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p), ("dq_colsum", C.c_void_p),
-                ("dv_colsum", C.c_void_p), ("colsum_scratch", C.c_void_p), ("qtile_flags", C.c_void_p)]
+                ("dv_colsum", C.c_void_p), ("colsum_scratch", C.c_void_p), ("qtile_flags", C.c_void_p),
+                ("q_rows", C.c_void_p), ("k_rows", C.c_void_p), ("q_span", C.c_void_p)]
+
+
+ABI_VERSION = 200  # include/oasr.h: OASR_ABI_VERSION
+ROWTAB = 16        # include/oasr.h: OASR_ROWTAB (entries per sample of a chunk-row table)
 
 
 def _declare(lib):
@@ -76,6 +81,9 @@ def _declare(lib):
         "oasr_forward": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, sz, vp]),
         "oasr_train_fwd_bwd": (i32, [vp, vp, vp, vp, vp, i32, f32, f32, vp, i32, vp, vp, vp, sz, vp]),
         "oasr_train_fwd_bwd_s": (i32, [vp, vp, vp, vp, vp, i32, i32, f32, f32, vp, i32, vp, vp, vp, sz, vp]),
+        "oasr_train_fwd_bwd_span": (i32, [vp, vp, vp, vp, vp, vp, i32, f32, f32, vp, i32, vp, vp, sz, vp]),
+        "oasr_sizeof_attn_args": (sz, []),
+        "oasr_test_span_tables": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp]),
         "oasr_train_fwd": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, sz, vp]),
         "oasr_train_bwd": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, sz, vp]),
         "oasr_zero_grad": (i32, [vp, vp]),
@@ -123,6 +131,12 @@ def lib():
         except OSError as e:  # pragma: no cover
             raise NativeError(f"cannot load {LIB_PATH}: {e}") from e
         EXPORTS = _declare(_lib)
+        # a library of another ABI generation reads structs of a different size through the same pointers: refuse it up front
+        ver = _lib.oasr_version()
+        if ver != ABI_VERSION or _lib.oasr_sizeof_attn_args() != C.sizeof(AttnArgs):
+            bad, _lib = _lib, None
+            raise NativeError(f"{LIB_PATH}: ABI version {ver} / oasr_attn_args of {bad.oasr_sizeof_attn_args()} bytes, this binding "
+                              f"is written for version {ABI_VERSION} / {C.sizeof(AttnArgs)} bytes -- rebuild (__graft_entry__.build())")
     return _lib
 
 

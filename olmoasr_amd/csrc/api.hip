@@ -16,7 +16,8 @@ void oasr_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* oasr_last_error(void) { return g_err; }
-extern "C" int oasr_version(void) { return 100; }
+extern "C" int oasr_version(void) { return OASR_ABI_VERSION; }
+extern "C" size_t oasr_sizeof_attn_args(void) { return sizeof(oasr_attn_args); }
 
 static OperandView to_view(const oasr_operand& o) {
   return OperandView{(const bf16_t*)o.ptr, (long)o.ld, o.rpb, (long)o.bstride, o.lead, o.kvalid, o.trail_from};
@@ -125,6 +126,9 @@ static AttnArgs to_attn(const oasr_attn_args* a) {
   r.dv_colsum = a->dv_colsum;
   r.colsum_scratch = a->colsum_scratch;
   r.qtile_flags = a->qtile_flags;
+  r.q_rows = a->q_rows;
+  r.k_rows = a->k_rows;
+  r.q_span = a->q_span;
   return r;
 }
 extern "C" int oasr_attention_fwd(const oasr_attn_args* a, void* stream) {
@@ -134,6 +138,15 @@ extern "C" int oasr_attention_fwd(const oasr_attn_args* a, void* stream) {
 extern "C" int oasr_attention_bwd(const oasr_attn_args* a, void* stream) {
   OASR_REQUIRE(a, "oasr_attention_bwd: null args");
   return launch_attention_bwd(to_attn(a), (hipStream_t)stream);
+}
+
+extern "C" int oasr_test_span_tables(const int32_t* span_host, int B, int S, const int64_t* targets, int32_t* rows_out, int32_t* span_out,
+                                     int64_t* targets_rows_out, int64_t* active_rows_out, void* stream) {
+  OASR_REQUIRE(active_rows_out, "oasr_test_span_tables: null");
+  long act = 0;
+  const int rc = launch_build_span_tables(span_host, B, S, targets, 51864, rows_out, span_out, targets_rows_out, &act, (hipStream_t)stream);
+  *active_rows_out = act;
+  return rc;
 }
 
 extern "C" int oasr_cross_entropy(void* logits, int64_t ld, int V, const int64_t* targets, int64_t rows, int64_t ignore, float gscale,

@@ -165,6 +165,10 @@ __device__ __forceinline__ void store_rows_bf16(char* stg, const f32x16_t (&T)[2
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
+// Chunked token rows (AttnArgs.q_rows / k_rows, kernels.h): first row of the 64-position chunk that holds position t of sample b.
+// Wave-uniform when t is (scalar load); entries past the last chunk hold a row far outside every tensor.
+__device__ __forceinline__ int chunk_row(const int32_t* rows, int b, int t) { return rows[b * OASR_ROWTAB + (t >> 6)] + (t & 63); }
+
 // Softmax arithmetic on pairs: gfx950's v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 process two fp32 values per lane per
 // issue slot.  With head_dim 64 these kernels are VALU-issue bound (16 MFMAs against ~145 scalar VALU per 64-key tile and
 // wave in the forward), so halving the fma / add / mul counts is what moves them; the exponential stays one v_exp_f32 each.
@@ -181,7 +185,9 @@ __device__ __forceinline__ f32x2_t pk_exp2(f32x2_t a) {
 constexpr float RESCALE_THR = 8.0f;
 
 // ------------------------------------------------------------------------------------------------------------
-template <bool CAUSAL>
+// ROWS: the query side (and, when a.k_rows is set, the key side) lives in chunked token rows (kernels.h) -- the decoder of a
+// span-limited training step.  ROWS == false is the plain strided layout and compiles to exactly the code it always was.
+template <bool CAUSAL, bool ROWS>
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE];  // stage s: K at 2s*TILE, V at (2s+1)*TILE
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
@@ -194,8 +200,9 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
   const int q0 = (bid - bh * nqb) * 128;
   const int myq = q0 + wave * 32 + (lane & 31);
   const int myq_c = myq < a.Tq ? myq : a.Tq - 1;
+  const bool krows = ROWS && a.k_rows != nullptr;  // (block-uniform)
 
-  const bf16_t* qp = a.q + (long)b * a.bsq + (long)myq_c * a.ldq + h * 64;
+  const bf16_t* qp = ROWS ? a.q + (long)chunk_row(a.q_rows, b, myq_c) * a.ldq + h * 64 : a.q + (long)b * a.bsq + (long)myq_c * a.ldq + h * 64;
   bf16x8_t qf[4];
 #pragma unroll
   for (int ds = 0; ds < 4; ++ds) qf[ds] = ld_frag_global(qp + ds * 16 + hh * 8);
@@ -206,8 +213,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
   if (CAUSAL) kv_end = kv_end < q0 + 128 ? kv_end : q0 + 128;
   const int ntiles = kv_end > 0 ? (kv_end + 63) >> 6 : 1;  // >= 1: a fully masked tile yields l = 0 -> O = 0
 
-  const TileSrc ksrc = tile_src(a.k + (long)b * a.bsk + h * 64, a.ldk, a.Tk, tid);
-  const TileSrc vsrc = tile_src(a.v + (long)b * a.bsv + h * 64, a.ldv, a.Tk, tid);
+  const TileSrc ksrc = krows ? tile_src(a.k + h * 64, a.ldk, a.B * a.Tk, tid) : tile_src(a.k + (long)b * a.bsk + h * 64, a.ldk, a.Tk, tid);
+  const TileSrc vsrc = krows ? tile_src(a.v + h * 64, a.ldv, a.B * a.Tk, tid) : tile_src(a.v + (long)b * a.bsv + h * 64, a.ldv, a.Tk, tid);
+  // first row of key tile t (64 keys = one chunk)
+  auto krow0 = [&](int t) { return krows ? __builtin_amdgcn_readfirstlane(a.k_rows[b * OASR_ROWTAB + t]) : t * 64; };
 
   f32x16_t oT[2];
 #pragma unroll
@@ -221,8 +230,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
   // the compiler's wait-count state at the loop header, and hipcc then re-waits vmcnt(3..0) in front of the first MFMAs
   // of EVERY iteration -- i.e. for the K/V prefetch it has just issued -- serialising the load latency into the loop.
   u32x4_t rk[2], rv[2];
-  tile_issue(ksrc, 0, rk);
-  tile_issue(vsrc, 0, rv);
+  tile_issue(ksrc, krow0(0), rk);
+  tile_issue(vsrc, krow0(0), rv);
   tile_commit(smem, tid, rk);
   tile_commit(smem + TILE, tid, rv);
   __syncthreads();
@@ -232,8 +241,9 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
     const char* vb = kb + TILE;
     const bool more = t + 1 < ntiles;
     if (more) {
-      tile_issue(ksrc, (t + 1) * 64, rk);
-      tile_issue(vsrc, (t + 1) * 64, rv);
+      const int r0 = krow0(t + 1);
+      tile_issue(ksrc, r0, rk);
+      tile_issue(vsrc, r0, rv);
     }
     f32x16_t sT[2];
 #pragma unroll
@@ -324,7 +334,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
     // (the loop ended on a barrier: the K/V stages are free; 4 KiB of staging per wave)
     char* stg = smem + wave * 4096;
     const int rows_valid = a.Tq - (q0 + wave * 32);  // may be <= 0 or > 32
-    const long row0 = (long)b * a.bso + (long)(q0 + wave * 32) * a.ldo + h * 64;
+    // (a wave's 32 rows lie inside one chunk; past Tq the table entry is a sentinel and rows_valid <= 0 keeps it unused)
+    const long row0 = ROWS ? (long)chunk_row(a.q_rows, b, q0 + wave * 32) * a.ldo + h * 64 : (long)b * a.bso + (long)(q0 + wave * 32) * a.ldo + h * 64;
     store_rows_bf16(stg, oT, inv, a.o + row0, a.ldo, rows_valid, lane);
     // rounding residual of O for the backward's delta term (bf16 O alone loses it when mean(V) dominates V's variation;
     // O + residual is fp32-grade at 4 bytes per element instead of 2 + 4)
@@ -344,7 +355,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
 
 // ------------------------------------------------------------------------------------------------------------
 // dQ[q][:] = scale * sum_k dS[q][k] K[k][:],  dS = P o (dP - delta),  P = exp(scale*S - lse),  dP = dO V^T
-template <bool CAUSAL>
+template <bool CAUSAL, bool ROWS>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
@@ -356,18 +367,29 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   const int b = bh / a.H, h = bh - b * a.H;
   const int q0 = (bid - bh * nqb) * 128;
   const int myq = q0 + wave * 32 + (lane & 31);
-  const int myq_c = myq < a.Tq ? myq : a.Tq - 1;
+  const bool krows = ROWS && a.k_rows != nullptr;  // (block-uniform)
+  // span-limited backward: query positions >= q_span[b] hold no gradient -- their d_o / o rows are not read, dq is not written
+  const int q_lim = (ROWS && a.q_span) ? min(a.q_span[b], a.Tq) : a.Tq;
+  if (ROWS && q0 >= q_lim) {  // (block-uniform) nothing to do, but the partial bias-gradient row of this block must read as zeros
+    if (a.dq_colsum && tid < 64) a.colsum_scratch[((long)(b * nqb + (bid - bh * nqb)) * a.H + h) * 64 + tid] = 0.f;
+    return;
+  }
+  const bool w_act = !ROWS || q0 + wave * 32 < q_lim;        // (wave-uniform; spans are multiples of 64)
+  const int myq_c = !w_act ? q0 + (lane & 31) : (myq < a.Tq ? myq : a.Tq - 1);  // an inactive wave re-reads rows of the block's first chunk
 
-  const bf16_t* qp = a.q + (long)b * a.bsq + (long)myq_c * a.ldq + h * 64;
-  const bf16_t* dop = a.d_o + (long)b * a.bso + (long)myq_c * a.ldo + h * 64;
-  const bf16_t* op = a.o + (long)b * a.bso + (long)myq_c * a.ldo + h * 64;
-  const bf16_t* olop = a.o_lo ? a.o_lo + (long)b * a.bso + (long)myq_c * a.ldo + h * 64 : nullptr;
+  const long qrow = ROWS ? (long)chunk_row(a.q_rows, b, myq_c) : 0;
+  const bf16_t* qp = ROWS ? a.q + qrow * a.ldq + h * 64 : a.q + (long)b * a.bsq + (long)myq_c * a.ldq + h * 64;
+  const long orow_off = ROWS ? qrow * a.ldo + h * 64 : (long)b * a.bso + (long)myq_c * a.ldo + h * 64;
+  const bf16_t* dop = a.d_o + orow_off;
+  const bf16_t* op = a.o + orow_off;
+  const bf16_t* olop = a.o_lo ? a.o_lo + orow_off : nullptr;
   bf16x8_t qf[4], dof[4];
   float dpart = 0.f;
 #pragma unroll
   for (int ds = 0; ds < 4; ++ds) {
     qf[ds] = ld_frag_global(qp + ds * 16 + hh * 8);
-    const u32x4_t d4 = *(const u32x4_t*)(dop + ds * 16 + hh * 8);
+    u32x4_t d4 = *(const u32x4_t*)(dop + ds * 16 + hh * 8);
+    if (ROWS && !w_act) d4 = u32x4_t{0u, 0u, 0u, 0u};
     dof[ds] = __builtin_bit_cast(bf16x8_t, d4);
     const u32x4_t o4 = *(const u32x4_t*)(op + ds * 16 + hh * 8);
     if (olop) {  // O = bf16 O + bf16 rounding residual (an fp32-grade O in 4 bytes per element, like the forward wrote it)
@@ -382,7 +404,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   }
   const float delta = dpart + __shfl_xor(dpart, 32, 64);
   const long stat_idx = ((long)b * a.H + h) * a.Tq + myq_c;
-  if (hh == 0 && myq < a.Tq) a.delta[stat_idx] = delta;
+  if (hh == 0 && myq < a.Tq && w_act) a.delta[stat_idx] = delta;
   const float lse2 = a.lse[stat_idx] * LOG2E;
 
   int kv_len = a.kv_len ? a.kv_len[b] : a.Tk;
@@ -410,8 +432,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     }
     if (!(t0nz | t1nz)) ntiles = 0;
   }
-  const TileSrc ksrc = tile_src(a.k + (long)b * a.bsk + h * 64, a.ldk, a.Tk, tid);
-  const TileSrc vsrc = tile_src(a.v + (long)b * a.bsv + h * 64, a.ldv, a.Tk, tid);
+  const TileSrc ksrc = krows ? tile_src(a.k + h * 64, a.ldk, a.B * a.Tk, tid) : tile_src(a.k + (long)b * a.bsk + h * 64, a.ldk, a.Tk, tid);
+  const TileSrc vsrc = krows ? tile_src(a.v + h * 64, a.ldv, a.B * a.Tk, tid) : tile_src(a.v + (long)b * a.bsv + h * 64, a.ldv, a.Tk, tid);
+  auto krow0 = [&](int t) { return krows ? __builtin_amdgcn_readfirstlane(a.k_rows[b * OASR_ROWTAB + t]) : t * 64; };
 
   f32x16_t dqT[2];
 #pragma unroll
@@ -423,8 +446,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   // the compiler's wait-count state at the loop header, and hipcc then re-waits vmcnt(3..0) in front of the first MFMAs
   // of EVERY iteration -- i.e. for the K/V prefetch it has just issued -- serialising the load latency into the loop.
   u32x4_t rk[2], rv[2];
-  tile_issue(ksrc, 0, rk);
-  tile_issue(vsrc, 0, rv);
+  tile_issue(ksrc, krow0(0), rk);
+  tile_issue(vsrc, krow0(0), rv);
   tile_commit(smem, tid, rk);
   tile_commit(smem + TILE, tid, rv);
   __syncthreads();
@@ -433,8 +456,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     const char* vb = kb + TILE;
     const bool more = t + 1 < ntiles;
     if (more) {
-      tile_issue(ksrc, (t + 1) * 64, rk);
-      tile_issue(vsrc, (t + 1) * 64, rv);
+      const int r0 = krow0(t + 1);
+      tile_issue(ksrc, r0, rk);
+      tile_issue(vsrc, r0, rv);
     }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
@@ -484,8 +508,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   }
   // (the loop ended on a barrier: the K/V stages are free for the per-wave staging tiles)
   float* wsum = (float*)(smem + 16384);  // [4 waves][64], behind the staging tiles
-  store_rows_bf16(smem + wave * 4096, dqT, SCALE, a.dq + (long)b * a.bsq + (long)(q0 + wave * 32) * a.ldq + h * 64, a.ldq,
-                  a.Tq - (q0 + wave * 32), lane, a.dq_colsum ? wsum + wave * 64 : nullptr);
+  {
+    const long drow0 = ROWS ? (long)chunk_row(a.q_rows, b, q0 + wave * 32) * a.ldq + h * 64 : (long)b * a.bsq + (long)(q0 + wave * 32) * a.ldq + h * 64;
+    store_rows_bf16(smem + wave * 4096, dqT, SCALE, a.dq + drow0, a.ldq, w_act ? a.Tq - (q0 + wave * 32) : 0, lane,
+                    a.dq_colsum ? wsum + wave * 64 : nullptr);
+  }
   if (a.dq_colsum) {  // one partial row per workgroup: colsum_scratch[(b, query block)][h*64 + c], reduced by the launcher
     __syncthreads();
     if (tid < 64)
@@ -555,6 +582,8 @@ __device__ __forceinline__ PipeSrc1 pipe_src1(const bf16_t* base, long ld, int r
     ATTN_FENCE();                               \
   } while (0)
 
+// ROWS: the query side lives in chunked token rows and is limited to q_span (kernels.h): the cross-attention of a span-limited step
+template <bool ROWS>
 __global__ __launch_bounds__(512, 1) void attn_bwd_dq_pp_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(1024))) char smem[PNS * PSTG];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hh = lane >> 5;
@@ -566,18 +595,30 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dq_pp_kernel(AttnArgs a) {
   const int b = bh / a.H, h = bh - b * a.H;
   const int q0 = (bid - bh * nqb) * 256;
   const int myq = q0 + wave * 32 + (lane & 31);
-  const int myq_c = myq < a.Tq ? myq : a.Tq - 1;
+  const int q_lim = (ROWS && a.q_span) ? min(a.q_span[b], a.Tq) : a.Tq;
+  if (ROWS && q0 >= q_lim) {  // (block-uniform) no gradient in this block: only its two partial bias-gradient rows must read as zeros
+    if (a.dq_colsum && tid < 128) {
+      const int nqb128 = (a.Tq + 127) >> 7, blk128 = (bid - bh * nqb) * 2 + (tid >> 6);
+      if (blk128 < nqb128) a.colsum_scratch[((long)(b * nqb128 + blk128) * a.H + h) * 64 + (tid & 63)] = 0.f;
+    }
+    return;
+  }
+  const bool w_act = !ROWS || q0 + wave * 32 < q_lim;  // (wave-uniform)
+  const int myq_c = !w_act ? q0 + (lane & 31) : (myq < a.Tq ? myq : a.Tq - 1);  // an inactive wave re-reads rows of the first chunk
 
-  const bf16_t* qp = a.q + (long)b * a.bsq + (long)myq_c * a.ldq + h * 64;
-  const bf16_t* dop = a.d_o + (long)b * a.bso + (long)myq_c * a.ldo + h * 64;
-  const bf16_t* op = a.o + (long)b * a.bso + (long)myq_c * a.ldo + h * 64;
-  const bf16_t* olop = a.o_lo ? a.o_lo + (long)b * a.bso + (long)myq_c * a.ldo + h * 64 : nullptr;
+  const long qrow = ROWS ? (long)chunk_row(a.q_rows, b, myq_c) : 0;
+  const bf16_t* qp = ROWS ? a.q + qrow * a.ldq + h * 64 : a.q + (long)b * a.bsq + (long)myq_c * a.ldq + h * 64;
+  const long orow_off = ROWS ? qrow * a.ldo + h * 64 : (long)b * a.bso + (long)myq_c * a.ldo + h * 64;
+  const bf16_t* dop = a.d_o + orow_off;
+  const bf16_t* op = a.o + orow_off;
+  const bf16_t* olop = a.o_lo ? a.o_lo + orow_off : nullptr;
   bf16x8_t qf[4], dof[4];
   float dpart = 0.f;
 #pragma unroll
   for (int ds = 0; ds < 4; ++ds) {
     qf[ds] = ld_frag_global(qp + ds * 16 + hh * 8);
-    const u32x4_t d4 = *(const u32x4_t*)(dop + ds * 16 + hh * 8);
+    u32x4_t d4 = *(const u32x4_t*)(dop + ds * 16 + hh * 8);
+    if (ROWS && !w_act) d4 = u32x4_t{0u, 0u, 0u, 0u};
     dof[ds] = __builtin_bit_cast(bf16x8_t, d4);
     const u32x4_t o4 = *(const u32x4_t*)(op + ds * 16 + hh * 8);
     if (olop) {
@@ -592,7 +633,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dq_pp_kernel(AttnArgs a) {
   }
   const float delta = dpart + __shfl_xor(dpart, 32, 64);
   const long stat_idx = ((long)b * a.H + h) * a.Tq + myq_c;
-  if (hh == 0 && myq < a.Tq) a.delta[stat_idx] = delta;
+  if (hh == 0 && myq < a.Tq && w_act) a.delta[stat_idx] = delta;
   const float lse2 = a.lse[stat_idx] * LOG2E;
   asm volatile("" ::"v"(lse2), "v"(delta), "v"(qf[3]), "v"(dof[3]));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the loop counts its own DMA pieces
@@ -787,8 +828,11 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dq_pp_kernel(AttnArgs a) {
   }
   __syncthreads();
   float* wsum = (float*)(smem + 32768);  // [8 waves][64], behind the staging tiles
-  store_rows_bf16(smem + wave * 4096, dqT, SCALE, a.dq + (long)b * a.bsq + (long)(q0 + wave * 32) * a.ldq + h * 64, a.ldq,
-                  a.Tq - (q0 + wave * 32), lane, a.dq_colsum ? wsum + wave * 64 : nullptr);
+  {
+    const long drow0 = ROWS ? (long)chunk_row(a.q_rows, b, q0 + wave * 32) * a.ldq + h * 64 : (long)b * a.bsq + (long)(q0 + wave * 32) * a.ldq + h * 64;
+    store_rows_bf16(smem + wave * 4096, dqT, SCALE, a.dq + drow0, a.ldq, w_act ? a.Tq - (q0 + wave * 32) : 0, lane,
+                    a.dq_colsum ? wsum + wave * 64 : nullptr);
+  }
   if (a.dq_colsum) {  // two partial rows per workgroup, in the 128-query row numbering of the colsum scratch
     __syncthreads();
     if (tid < 128) {
@@ -812,7 +856,7 @@ __device__ __forceinline__ int last_nonzero_qtile(const int32_t* flags, int n, i
   return __builtin_amdgcn_readfirstlane(wave_max_i(last));
 }
 
-template <bool CAUSAL>
+template <bool CAUSAL, bool ROWS>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
   // stage s: Q tile, dO tile, then lse[64] | delta[64] floats
   constexpr int STAGE = 2 * TILE + 512;
@@ -824,13 +868,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
   const int b = bh / a.H, h = bh - b * a.H;
   const int k0 = (bid - bh * nkb) * 128;
   const int mykey = k0 + wave * 32 + (lane & 31);
-  const int mykey_c = mykey < a.Tk ? mykey : a.Tk - 1;
+  const bool krows = ROWS && a.k_rows != nullptr;  // (block-uniform) chunked key rows: decoder self-attention
+  // span-limited backward: query positions >= q_span[b] hold no gradient (their d_o rows are never read); with chunked key rows the
+  // same positions are keys no supervised query sees -- their dk / dv rows lie outside the active rows and are not written
+  const int q_lim = (ROWS && a.q_span) ? min(a.q_span[b], a.Tq) : a.Tq;
+  const long dv_scratch_off0 = (long)a.B * ((a.Tq + 127) >> 7) * a.H * 64;
+  if (krows && a.q_span && k0 >= q_lim) {
+    if (a.dv_colsum && tid < 64) a.colsum_scratch[dv_scratch_off0 + ((long)(b * nkb + (bid - bh * nkb)) * a.H + h) * 64 + tid] = 0.f;
+    return;
+  }
+  const bool w_store = !(krows && a.q_span) || k0 + wave * 32 < q_lim;  // (wave-uniform)
+  const int mykey_c = !w_store ? k0 + (lane & 31) : (mykey < a.Tk ? mykey : a.Tk - 1);
 
   int kv_len = a.kv_len ? a.kv_len[b] : a.Tk;
   kv_len = kv_len < a.Tk ? kv_len : a.Tk;
 
-  const bf16_t* kp = a.k + (long)b * a.bsk + (long)mykey_c * a.ldk + h * 64;
-  const bf16_t* vp = a.v + (long)b * a.bsv + (long)mykey_c * a.ldv + h * 64;
+  const bf16_t* kp = krows ? a.k + (long)chunk_row(a.k_rows, b, mykey_c) * a.ldk + h * 64 : a.k + (long)b * a.bsk + (long)mykey_c * a.ldk + h * 64;
+  const bf16_t* vp = krows ? a.v + (long)chunk_row(a.k_rows, b, mykey_c) * a.ldv + h * 64 : a.v + (long)b * a.bsv + (long)mykey_c * a.ldv + h * 64;
   bf16x8_t kf[4], vf[4];
 #pragma unroll
   for (int ds = 0; ds < 4; ++ds) {
@@ -846,21 +900,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
       dvT[i][r] = 0.f;
     }
 
-  const TileSrc qsrc = tile_src(a.q + (long)b * a.bsq + h * 64, a.ldq, a.Tq, tid);
-  const TileSrc dosrc = tile_src(a.d_o + (long)b * a.bso + h * 64, a.ldo, a.Tq, tid);
+  const TileSrc qsrc = ROWS ? tile_src(a.q + h * 64, a.ldq, a.B * a.Tq, tid) : tile_src(a.q + (long)b * a.bsq + h * 64, a.ldq, a.Tq, tid);
+  const TileSrc dosrc = ROWS ? tile_src(a.d_o + h * 64, a.ldo, a.B * a.Tq, tid) : tile_src(a.d_o + (long)b * a.bso + h * 64, a.ldo, a.Tq, tid);
   const float* lse_b = a.lse + ((long)b * a.H + h) * a.Tq;
   const float* delta_b = a.delta + ((long)b * a.H + h) * a.Tq;
 
   int nqt = (a.Tq + 63) >> 6;
   if (a.qtile_flags) nqt = last_nonzero_qtile(a.qtile_flags + ((long)b * a.H + h) * nqt, nqt, lane) + 1;  // d_o is zero past it
+  if (ROWS && (q_lim >> 6) < nqt) nqt = q_lim >> 6;
   const int t_begin = (CAUSAL && k0 < kv_len) ? (k0 >> 6) : 0;
   const bool any = k0 < kv_len && t_begin < nqt;  // otherwise every P (or every d_o row) is zero: fall through and write zeros
 
   u32x4_t rq[2], rd[2];
   float rstat = 0.f;
   auto issue = [&](int t) {
-    tile_issue(qsrc, t * 64, rq);
-    tile_issue(dosrc, t * 64, rd);
+    const int qr0 = ROWS ? __builtin_amdgcn_readfirstlane(a.q_rows[b * OASR_ROWTAB + t]) : t * 64;
+    tile_issue(qsrc, qr0, rq);
+    tile_issue(dosrc, qr0, rd);
     if (tid < 128) {
       int qi = t * 64 + (tid & 63);
       qi = qi < a.Tq ? qi : a.Tq - 1;
@@ -873,12 +929,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
     if (tid < 128) ((float*)(st + 2 * TILE))[tid] = rstat;
   };
   // dv partial rows live behind the dq ones: [B * ceil(Tq/128)][H*64] then [B * ceil(Tk/128)][H*64]
-  const long dv_scratch_off = (long)a.B * ((a.Tq + 127) >> 7) * a.H * 64;
+  const long dv_scratch_off = dv_scratch_off0;
   if (!any) {  // every key of this block is padding: dK = dV = 0 (uniform early exit, before any load is issued)
     if (a.dv_colsum && tid < 64) a.colsum_scratch[dv_scratch_off + ((long)(b * nkb + (bid - bh * nkb)) * a.H + h) * 64 + tid] = 0.f;
-    if (mykey < a.Tk) {
-      bf16_t* dkp0 = a.dk + (long)b * a.bsk + (long)mykey * a.ldk + h * 64;
-      bf16_t* dvp0 = a.dv + (long)b * a.bsv + (long)mykey * a.ldv + h * 64;
+    if (mykey < a.Tk && w_store) {
+      bf16_t* dkp0 = krows ? a.dk + (long)chunk_row(a.k_rows, b, mykey) * a.ldk + h * 64 : a.dk + (long)b * a.bsk + (long)mykey * a.ldk + h * 64;
+      bf16_t* dvp0 = krows ? a.dv + (long)chunk_row(a.k_rows, b, mykey) * a.ldv + h * 64 : a.dv + (long)b * a.bsv + (long)mykey * a.ldv + h * 64;
       const u32x4_t z = {0u, 0u, 0u, 0u};
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -967,11 +1023,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
   }
   {
     char* stg = smem + wave * 4096;  // the loop ended on a barrier: both stages are free
-    const int rows_valid = a.Tk - (k0 + wave * 32);
-    store_rows_bf16(stg, dkT, SCALE, a.dk + (long)b * a.bsk + (long)(k0 + wave * 32) * a.ldk + h * 64, a.ldk, rows_valid, lane);
+    const int rows_valid = w_store ? a.Tk - (k0 + wave * 32) : 0;
+    const long krow0 = krows ? (long)chunk_row(a.k_rows, b, k0 + wave * 32) : 0;
+    store_rows_bf16(stg, dkT, SCALE, krows ? a.dk + krow0 * a.ldk + h * 64 : a.dk + (long)b * a.bsk + (long)(k0 + wave * 32) * a.ldk + h * 64,
+                    a.ldk, rows_valid, lane);
     float* wsum = (float*)(smem + 16384);
-    store_rows_bf16(stg, dvT, 1.0f, a.dv + (long)b * a.bsv + (long)(k0 + wave * 32) * a.ldv + h * 64, a.ldv, rows_valid, lane,
-                    a.dv_colsum ? wsum + wave * 64 : nullptr);
+    store_rows_bf16(stg, dvT, 1.0f, krows ? a.dv + krow0 * a.ldv + h * 64 : a.dv + (long)b * a.bsv + (long)(k0 + wave * 32) * a.ldv + h * 64,
+                    a.ldv, rows_valid, lane, a.dv_colsum ? wsum + wave * 64 : nullptr);
     if (a.dv_colsum) {
       __syncthreads();
       if (tid < 64)
@@ -995,6 +1053,8 @@ __device__ __forceinline__ void glds4_asm(const u32x4_t rs, unsigned lds_addr, u
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory");
 }
 
+// ROWS: the query side (q, d_o) lives in chunked token rows and is limited to q_span (kernels.h)
+template <bool ROWS>
 __global__ __launch_bounds__(512, 1) void attn_bwd_dkdv_pp_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hh = lane >> 5;
@@ -1029,9 +1089,23 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkdv_pp_kernel(AttnArgs a) {
 
   int ntiles = (a.Tq + 63) >> 6;
   if (a.qtile_flags) ntiles = last_nonzero_qtile(a.qtile_flags + ((long)b * a.H + h) * ntiles, ntiles, lane) + 1;  // d_o is zero past it
+  if (ROWS && a.q_span) ntiles = min(ntiles, min(a.q_span[b], a.Tq) >> 6);  // d_o rows past the span are not even written
   const int ngroups = (ntiles + PNS - 1) / PNS;
-  const PipeSrc1 qsrc = pipe_src1(a.q + (long)b * a.bsq + h * 64, a.ldq, a.Tq, wave, lane);
-  const PipeSrc1 dosrc = pipe_src1(a.d_o + (long)b * a.bso + h * 64, a.ldo, a.Tq, wave, lane);
+  const PipeSrc1 qsrc = ROWS ? pipe_src1(a.q + h * 64, a.ldq, a.B * a.Tq, wave, lane) : pipe_src1(a.q + (long)b * a.bsq + h * 64, a.ldq, a.Tq, wave, lane);
+  const PipeSrc1 dosrc = ROWS ? pipe_src1(a.d_o + h * 64, a.ldo, a.B * a.Tq, wave, lane) : pipe_src1(a.d_o + (long)b * a.bso + h * 64, a.ldo, a.Tq, wave, lane);
+  // ROWS: the first token row of every 64-query tile, tiles at or past ntiles mapped far outside the tensors (the DMA then writes
+  // zeros, exactly what the plain layout gets from its range check for the tail steps of the last group of four)
+  int qrow[8];
+  if (ROWS) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qrow[i] = i < ntiles ? __builtin_amdgcn_readfirstlane(a.q_rows[b * OASR_ROWTAB + i]) : 0x3fffffff;
+  }
+  auto qrow_of = [&](int tile) {  // (scalar select chain: `tile` is wave-uniform, no register indexing)
+    int r = 0x3fffffff;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r = tile == i ? qrow[i] : r;
+    return r;
+  };
   // lse / delta rows of a tile: 2 x 256 bytes; even waves bring lse, odd waves delta (four identical copies each: one DMA per
   // wave keeps every wave's vmcnt arithmetic the same)
   u32x4_t srs;
@@ -1044,9 +1118,19 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkdv_pp_kernel(AttnArgs a) {
   }
   auto dma_tile = [&](int tile, int stage) {
     const unsigned dst = smem_a + KSTAT + stage * PSTG + wave * 1024;
-    glds16_asm(qsrc.rs, dst, qsrc.voff + (unsigned)tile * qsrc.tile_bytes);
-    glds16_asm(dosrc.rs, dst + TILE, dosrc.voff + (unsigned)tile * dosrc.tile_bytes);
-    glds4_asm(srs, smem_a + stage * 512 + (wave & 1) * 256, (unsigned)(lane * 4 + tile * 256));
+    if (ROWS) {
+      // a sentinel row times the row pitch wraps in 32 bits: clamp the byte offset to "past the end" instead
+      const int r0 = qrow_of(tile);
+      const unsigned qo = r0 == 0x3fffffff ? 0x7fffff00u : (unsigned)r0 * (unsigned)(a.ldq * 2);
+      const unsigned oo = r0 == 0x3fffffff ? 0x7fffff00u : (unsigned)r0 * (unsigned)(a.ldo * 2);
+      glds16_asm(qsrc.rs, dst, r0 == 0x3fffffff ? qo : qsrc.voff + qo);
+      glds16_asm(dosrc.rs, dst + TILE, r0 == 0x3fffffff ? oo : dosrc.voff + oo);
+      glds4_asm(srs, smem_a + stage * 512 + (wave & 1) * 256, r0 == 0x3fffffff ? 0x7fffff00u : (unsigned)(lane * 4 + tile * 256));
+    } else {
+      glds16_asm(qsrc.rs, dst, qsrc.voff + (unsigned)tile * qsrc.tile_bytes);
+      glds16_asm(dosrc.rs, dst + TILE, dosrc.voff + (unsigned)tile * dosrc.tile_bytes);
+      glds4_asm(srs, smem_a + stage * 512 + (wave & 1) * 256, (unsigned)(lane * 4 + tile * 256));
+    }
   };
 
   int ar[4], ac[2][2];
@@ -1330,6 +1414,10 @@ int check_args(const AttnArgs& a, bool bwd) {
   OASR_REQUIRE(!a.causal || a.Tq == a.Tk, "attention: causal needs Tq == Tk");
   if (bwd) OASR_REQUIRE(a.d_o && a.lse && a.delta && a.dq && a.dk && a.dv, "attention_bwd: null pointer");
   if (bwd) OASR_REQUIRE((!a.dq_colsum && !a.dv_colsum) || a.colsum_scratch, "attention_bwd: fused bias gradients need colsum_scratch");
+  OASR_REQUIRE(!a.k_rows || a.q_rows, "attention: k_rows needs q_rows");
+  OASR_REQUIRE(!a.q_span || a.q_rows, "attention: q_span needs q_rows");
+  OASR_REQUIRE(!a.q_rows || ((a.Tq % 64) == 0 && a.Tq <= 64 * OASR_ROWTAB), "attention: chunked query rows need Tq %% 64 == 0 and Tq <= %d", 64 * OASR_ROWTAB);
+  OASR_REQUIRE(!a.k_rows || ((a.Tk % 64) == 0 && a.Tk <= 64 * OASR_ROWTAB), "attention: chunked key rows need Tk %% 64 == 0 and Tk <= %d", 64 * OASR_ROWTAB);
   return OASR_OK;
 }
 
@@ -1337,19 +1425,38 @@ int check_args(const AttnArgs& a, bool bwd) {
 
 void attention_set_pingpong(int on) { g_attn_pingpong = on; }
 
+// hipFuncSetAttribute is per device: remember it per device id (one host thread drives a context, include/oasr.h)
+static int ensure_dkdv_pp_lds(const void* fn) {
+  static bool done[2][64] = {};
+  int dev = 0;
+  OASR_CHECK_HIP(hipGetDevice(&dev));
+  const int which = fn == (const void*)attn_bwd_dkdv_pp_kernel<true> ? 1 : 0;
+  if (dev < 0 || dev >= 64 || !done[which][dev]) {
+    OASR_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, KLDS));
+    if (dev >= 0 && dev < 64) done[which][dev] = true;
+  }
+  return OASR_OK;
+}
+
 int launch_attention_fwd(const AttnArgs& a, hipStream_t s) {
   int rc = check_args(a, false);
   if (rc) return rc;
-  if (a.Tq == 1 && a.Tk <= 1536 && !a.o_lo) {  // decode step (causality is implied: every cached key is visible)
+  if (a.Tq == 1 && a.Tk <= 1536 && !a.o_lo && !a.q_rows) {  // decode step (causality is implied: every cached key is visible)
     hipLaunchKernelGGL(attn_decode_kernel, dim3(a.B * a.H), dim3(256), 0, s, a);
     OASR_LAUNCH_CHECK();
     return OASR_OK;
   }
   dim3 grid(cdiv(a.Tq, 128) * a.B * a.H);
-  if (a.causal)
-    hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, s, a);
-  else
-    hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, s, a);
+  if (a.q_rows) {
+    if (a.causal)
+      hipLaunchKernelGGL((attn_fwd_kernel<true, true>), grid, dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((attn_fwd_kernel<false, true>), grid, dim3(256), 0, s, a);
+  } else if (a.causal) {
+    hipLaunchKernelGGL((attn_fwd_kernel<true, false>), grid, dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((attn_fwd_kernel<false, false>), grid, dim3(256), 0, s, a);
+  }
   OASR_LAUNCH_CHECK();
   return OASR_OK;
 }
@@ -1358,23 +1465,32 @@ int launch_attention_bwd(const AttnArgs& a, hipStream_t s) {
   int rc = check_args(a, true);
   if (rc) return rc;
   dim3 gq(cdiv(a.Tq, 128) * a.B * a.H), gk(cdiv(a.Tk, 128) * a.B * a.H);
+  const bool rows = a.q_rows != nullptr;
   if (a.causal) {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, gq, dim3(256), 0, s, a);
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, gk, dim3(256), 0, s, a);
-  } else {
-    if (!a.kv_len && g_attn_pingpong)
-      hipLaunchKernelGGL(attn_bwd_dq_pp_kernel, dim3(cdiv(a.Tq, 256) * a.B * a.H), dim3(512), 0, s, a);
-    else
-      hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, gq, dim3(256), 0, s, a);
-    if (!a.kv_len && g_attn_pingpong) {
-      static bool attr_set = false;
-      if (!attr_set) {
-        OASR_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkdv_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, KLDS));
-        attr_set = true;
-      }
-      hipLaunchKernelGGL(attn_bwd_dkdv_pp_kernel, dim3(cdiv(a.Tk, 256) * a.B * a.H), dim3(512), KLDS, s, a);
+    if (rows) {
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<true, true>), gq, dim3(256), 0, s, a);
+      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<true, true>), gk, dim3(256), 0, s, a);
     } else {
-      hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, gk, dim3(256), 0, s, a);
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<true, false>), gq, dim3(256), 0, s, a);
+      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<true, false>), gk, dim3(256), 0, s, a);
+    }
+  } else {
+    // the ping-pong kernels take the unmasked case; with chunked rows only the cross-attention form (plain key side, <= 8 query tiles)
+    const bool pp = !a.kv_len && g_attn_pingpong && (!rows || (!a.k_rows && a.Tq <= 512));
+    if (pp) {
+      if (rows) hipLaunchKernelGGL(attn_bwd_dq_pp_kernel<true>, dim3(cdiv(a.Tq, 256) * a.B * a.H), dim3(512), 0, s, a);
+      else hipLaunchKernelGGL(attn_bwd_dq_pp_kernel<false>, dim3(cdiv(a.Tq, 256) * a.B * a.H), dim3(512), 0, s, a);
+      const void* fn = rows ? (const void*)attn_bwd_dkdv_pp_kernel<true> : (const void*)attn_bwd_dkdv_pp_kernel<false>;
+      rc = ensure_dkdv_pp_lds(fn);
+      if (rc) return rc;
+      if (rows) hipLaunchKernelGGL(attn_bwd_dkdv_pp_kernel<true>, dim3(cdiv(a.Tk, 256) * a.B * a.H), dim3(512), KLDS, s, a);
+      else hipLaunchKernelGGL(attn_bwd_dkdv_pp_kernel<false>, dim3(cdiv(a.Tk, 256) * a.B * a.H), dim3(512), KLDS, s, a);
+    } else if (rows) {
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<false, true>), gq, dim3(256), 0, s, a);
+      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<false, true>), gk, dim3(256), 0, s, a);
+    } else {
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<false, false>), gq, dim3(256), 0, s, a);
+      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<false, false>), gk, dim3(256), 0, s, a);
     }
   }
   OASR_LAUNCH_CHECK();

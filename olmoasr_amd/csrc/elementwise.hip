@@ -87,14 +87,15 @@ __global__ __launch_bounds__(256) void mel_tm_kernel(const float* __restrict__ m
 
 __global__ __launch_bounds__(256) void embedding_fwd_kernel(const int64_t* __restrict__ tok, const float* __restrict__ E,
                                                             const float* __restrict__ pos, bf16_t* __restrict__ x, int S, int d,
-                                                            long rows, long n_embed) {
+                                                            long rows, long n_embed, const int32_t* __restrict__ rowtab) {
   const int cpr = d >> 3;  // 8-element chunks per row
   const long total = rows * cpr;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long r = i / cpr;
-    const int ch = (int)(i - r * cpr);
-    const long t = tok[r];
-    const int s = (int)(r % S);
+    const long lr = i / cpr;  // logical row (b, s)
+    const int ch = (int)(i - lr * cpr);
+    const long t = tok[lr];
+    const int s = (int)(lr % S);
+    const long r = rowtab ? (long)rowtab[(lr / S) * OASR_ROWTAB + (s >> 6)] + (s & 63) : lr;  // row of x
     // ids outside the table (nn.Embedding would raise; e.g. the pad id fed to the pad-row-less inference model) read as
     // a zero row instead of out-of-bounds memory
     const bool ok = t >= 0 && t < n_embed;
@@ -114,15 +115,17 @@ __global__ __launch_bounds__(256) void embedding_fwd_kernel(const int64_t* __res
 // dE[tok[b,s]] += dx[b,s,:] with fp32 atomics (tokens repeat across the batch)
 __global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* __restrict__ tok, const bf16_t* __restrict__ dx,
                                                             float* __restrict__ dE, float* __restrict__ dpos, int B, int S, int d,
-                                                            long pad_id, long n_embed) {
+                                                            long pad_id, long n_embed, const int32_t* __restrict__ rowtab,
+                                                            const int32_t* __restrict__ span) {
   const int s = blockIdx.x;
   for (int c = threadIdx.x; c < d; c += 256) {
     float acc = 0.f;
     for (int b = 0; b < B; ++b) {
-      const long r = (long)b * S + s;
+      if (span && s >= span[b]) continue;  // no gradient at this position (and its dx row was never written)
+      const long r = rowtab ? (long)rowtab[b * OASR_ROWTAB + (s >> 6)] + (s & 63) : (long)b * S + s;
       const float g = bf2f(dx[r * d + c]);
       acc += g;
-      const long t = tok[r];
+      const long t = tok[(long)b * S + s];
       if (t != pad_id && t >= 0 && t < n_embed) unsafeAtomicAdd(dE + t * d + c, g);  // ids outside the table: no scatter (fwd read zeros)
     }
     dpos[(long)s * d + c] += acc;
@@ -271,17 +274,84 @@ int launch_mel_to_time_major(const float* mel, bf16_t* out, int B, int n_mels, i
   return OASR_OK;
 }
 int launch_embedding_fwd(const int64_t* tok, const float* E, const float* pos, bf16_t* x, int B, int S, int d, long n_embed,
-                         hipStream_t s) {
+                         hipStream_t s, const int32_t* rows_tab) {
   OASR_REQUIRE(tok && E && pos && x && d % 8 == 0, "embedding_fwd: bad args");
+  OASR_REQUIRE(!rows_tab || (S % 64 == 0 && S <= 64 * OASR_ROWTAB), "embedding_fwd: chunk rows need S %% 64 == 0");
   const long rows = (long)B * S;
-  hipLaunchKernelGGL(embedding_fwd_kernel, dim3(grid_for(rows * (d / 8))), dim3(256), 0, s, tok, E, pos, x, S, d, rows, n_embed);
+  hipLaunchKernelGGL(embedding_fwd_kernel, dim3(grid_for(rows * (d / 8))), dim3(256), 0, s, tok, E, pos, x, S, d, rows, n_embed, rows_tab);
   OASR_LAUNCH_CHECK();
   return OASR_OK;
 }
 int launch_embedding_bwd(const int64_t* tok, const bf16_t* dx, float* dE, float* dpos, int B, int S, int d, long pad_id, long n_embed,
-                         hipStream_t s) {
+                         hipStream_t s, const int32_t* rows_tab, const int32_t* span) {
   OASR_REQUIRE(tok && dx && dE && dpos, "embedding_bwd: bad args");
-  hipLaunchKernelGGL(embedding_bwd_kernel, dim3(S), dim3(256), 0, s, tok, dx, dE, dpos, B, S, d, pad_id, n_embed);
+  OASR_REQUIRE(!rows_tab || (S % 64 == 0 && S <= 64 * OASR_ROWTAB), "embedding_bwd: chunk rows need S %% 64 == 0");
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3(S), dim3(256), 0, s, tok, dx, dE, dpos, B, S, d, pad_id, n_embed, rows_tab, span);
+  OASR_LAUNCH_CHECK();
+  return OASR_OK;
+}
+
+// ---- supervised-span tables (engine.hip) ------------------------------------------------------------------------------------
+namespace {
+struct SpanArg {
+  uint16_t span[512];
+};
+// one workgroup.  Chunk (b, c) = positions [64c, 64c + 64) of sample b; active iff 64c < span[b].  Row order: active chunks first,
+// position-block-major (c outer, b inner), then the inactive ones in the same order.
+__global__ __launch_bounds__(1024) void build_span_tables_kernel(SpanArg sp, int B, int S, const int64_t* __restrict__ targets, long ignore,
+                                                                 int32_t* __restrict__ rows, int32_t* __restrict__ span_dev,
+                                                                 int64_t* __restrict__ targets_phys) {
+  __shared__ int cnt_act[OASR_ROWTAB + 1];  // active chunks in position blocks < c
+  __shared__ int rows_s[512 * OASR_ROWTAB];
+  const int nch = S >> 6, tid = threadIdx.x;
+  if (tid <= OASR_ROWTAB) cnt_act[tid] = 0;
+  __syncthreads();
+  if (tid < nch) {  // active samples of position block tid
+    int n = 0;
+    for (int b = 0; b < B; ++b) n += (64 * tid < (int)sp.span[b]) ? 1 : 0;
+    for (int c = tid + 1; c <= nch; ++c) atomicAdd(&cnt_act[c], n);
+  }
+  __syncthreads();
+  const int total_act = cnt_act[nch];
+  for (int i = tid; i < B * OASR_ROWTAB; i += 1024) {
+    const int b = i / OASR_ROWTAB, c = i - b * OASR_ROWTAB;
+    int row = 0x3fffffff;  // past every tensor: out of range for the buffer descriptors
+    if (c < nch) {
+      const bool act = 64 * c < (int)sp.span[b];
+      // rank of (b, c) among the chunks of its kind: blocks before c, then samples before b inside block c
+      int before = 0;
+      for (int bb = 0; bb < b; ++bb) before += ((64 * c < (int)sp.span[bb]) == act) ? 1 : 0;
+      const int blk_before = act ? cnt_act[c] : c * B - cnt_act[c];
+      row = 64 * ((act ? 0 : total_act) + blk_before + before);
+    }
+    rows[i] = row;
+    rows_s[i] = row;
+  }
+  for (int b = tid; b < B; b += 1024) span_dev[b] = ((int)sp.span[b] + 63) & ~63;
+  __syncthreads();
+  // targets in row order for the active rows (every target of an inactive chunk is `ignore` by the caller's contract)
+  for (long i = tid; i < (long)B * S; i += 1024) {
+    const int b = (int)(i / S), s = (int)(i - (long)b * S);
+    if (s < (((int)sp.span[b] + 63) & ~63)) targets_phys[(long)rows_s[b * OASR_ROWTAB + (s >> 6)] + (s & 63)] = targets[i];
+  }
+  (void)ignore;
+}
+}  // namespace
+int launch_build_span_tables(const int32_t* span_host, int B, int S, const int64_t* targets, long ignore, int32_t* rows, int32_t* span_dev,
+                             int64_t* targets_phys, long* active_rows, hipStream_t s) {
+  OASR_REQUIRE(span_host && targets && rows && span_dev && targets_phys && active_rows, "build_span_tables: null pointer");
+  OASR_REQUIRE(B > 0 && B <= 512 && S > 0 && S % 64 == 0 && S <= 64 * OASR_ROWTAB, "build_span_tables: need B <= 512, S %% 64 == 0, S <= %d (B=%d S=%d)",
+               64 * OASR_ROWTAB, B, S);
+  SpanArg sp;
+  long act = 0;
+  for (int b = 0; b < B; ++b) {
+    OASR_REQUIRE(span_host[b] >= 0 && span_host[b] <= S, "build_span_tables: span[%d] = %d outside [0, %d]", b, span_host[b], S);
+    sp.span[b] = (uint16_t)span_host[b];
+    act += (span_host[b] + 63) / 64 * 64;
+  }
+  for (int b = B; b < 512; ++b) sp.span[b] = 0;
+  *active_rows = act;
+  hipLaunchKernelGGL(build_span_tables_kernel, dim3(1), dim3(1024), 0, s, sp, B, S, targets, ignore, rows, span_dev, targets_phys);
   OASR_LAUNCH_CHECK();
   return OASR_OK;
 }

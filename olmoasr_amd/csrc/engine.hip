@@ -181,6 +181,9 @@ struct Plan {
   T *ga, *gb, *gc, *gln, *gqkv, *go, *gu, *gxa, *gkv, *gq, *gA2;
   float *delta, *tmp_w1p, *tmp_w2p, *cs_scratch, *gemm_cs_scratch;
   int32_t* qtile_flags;  // attention backward of the decoder: which 64-position tiles of d_o are non-zero
+  // supervised-span step (oasr_train_fwd_bwd_span): chunk-row table of the decoder's token rows, spans, targets in row order
+  int32_t *rows, *span_dev;
+  int64_t* targets_phys;
 };
 
 static void plan_attn(Arena& A, AttnSave& s, long M, long Mkv, int d, int B, int H, long Tq, bool cross, bool train) {
@@ -250,7 +253,12 @@ static void make_plan(const oasr_ctx* c, Arena& A, Plan& p, int B, int S, bool t
   p.logits = A.template act<T>(Md * c->Vp);
   p.row_loss = A.f32(Md);
   p.n_valid = (int32_t*)A.raw(256);
+  p.rows = p.span_dev = nullptr;
+  p.targets_phys = nullptr;
   if (train) {
+    p.rows = (int32_t*)A.raw((size_t)B * OASR_ROWTAB * 4);
+    p.span_dev = (int32_t*)A.raw((size_t)B * 4);
+    p.targets_phys = (int64_t*)A.raw((size_t)Md * 8);
     const long Mmax = Me > Md ? Me : Md;
     p.ga = A.template act<T>(Mmax * d);
     p.gb = A.template act<T>(Mmax * d);
@@ -283,6 +291,11 @@ struct Runner {
   const int32_t* text_len;
   bool train = false;  // the training forward saves GELU'(u) in place of u (GemmArgs.act == 2)
   float* cs_scratch = nullptr;  // partial rows of fused bias-gradient column sums (GemmArgs.colsum_scratch)
+  // Supervised-span step: the decoder's token rows are CHUNKED (64 positions per chunk, kernels.h: AttnArgs.q_rows) with every
+  // chunk that can carry gradient first, so the whole decoder backward runs on the first `dec_rows_bwd` rows as plain matrices.
+  const int32_t* dec_rows = nullptr;  // chunk-row table [B][OASR_ROWTAB] (device) or null = plain [B, S] rows
+  const int32_t* dec_span = nullptr;  // [B] spans rounded up to 64 (device); backward only
+  long dec_rows_bwd = 0;              // active decoder rows (0 = all B*S)
 
   int linear(const T* x, long M, int K, const T* W, int N, const float* bias, int act, const T* resid, T* out,
              T* out_pre) {
@@ -400,6 +413,10 @@ struct Runner {
     a.Tq = (int)Tq;
     a.Tk = (int)Tk;
     a.causal = causal ? 1 : 0;
+    if (dec_rows && (causal || cross)) {  // a decoder attention of a span-limited step: chunked query rows (+ key rows for self-attention)
+      a.q_rows = dec_rows;
+      a.k_rows = cross ? nullptr : dec_rows;
+    }
     return OASR_OK;
   }
 
@@ -509,7 +526,7 @@ struct Runner {
   int decoder_fwd(Plan& p, const int64_t* tokens, bool last_only = false) {
     const int d = c->d;
     const long Md = (long)B * S;
-    RC(launch_embedding_fwd(tokens, c->P(c->tok_emb), c->P(c->dec_pos), p.dx0, B, S, d, c->V, st));
+    RC(launch_embedding_fwd(tokens, c->P(c->tok_emb), c->P(c->dec_pos), p.dx0, B, S, d, c->V, st, dec_rows));
     const T* x = p.dx0;
     for (int i = 0; i < c->L_dec; ++i) {
       RC(block_fwd(c->dec[i], p.dec[i], x, Md, S, p.xa, true));
@@ -570,8 +587,10 @@ struct Runner {
       a.dv_colsum = c->G(bp.cattn.vb);
       a.colsum_scratch = p.cs_scratch;
       // decoder positions the loss ignores have d_o == 0 exactly (three quarters of the 448 on the synthetic lengths): the kernels
-      // find those 64-position tiles themselves and skip them
-      a.qtile_flags = p.qtile_flags;
+      // find those 64-position tiles themselves and skip them (span-limited step: the span says where they are, and the rows past
+      // it are not even written)
+      a.qtile_flags = dec_span ? nullptr : p.qtile_flags;
+      a.q_span = dec_span;
       RC(launch_attention_bwd(a, st));
       RC(wgrad(p.gq, d, M, d, plain_view(s.ca.ln, d), d, c->G(bp.cattn.qw), d));
       RC(wgrad(p.gkv, 2 * d, Mkv, 2 * d, plain_view(p.xa, d), d, c->G(bp.cattn.kw), d));
@@ -597,7 +616,8 @@ struct Runner {
     a.dq_colsum = c->G(bp.attn.qb);
     a.dv_colsum = c->G(bp.attn.vb);
     a.colsum_scratch = p.cs_scratch;
-    a.qtile_flags = causal ? p.qtile_flags : nullptr;  // (decoder blocks only: an encoder block's d_o has no zero rows)
+    a.qtile_flags = (causal && !dec_span) ? p.qtile_flags : nullptr;  // (decoder blocks only: an encoder block's d_o has no zero rows)
+    a.q_span = causal ? dec_span : nullptr;
     RC(launch_attention_bwd(a, st));
     RC(wgrad(p.gqkv, 3 * d, M, 3 * d, plain_view(s.sa.ln, d), d, c->G(bp.attn.qw), d));
     RC(dgrad(p.gqkv, M, 3 * d, c->template Wt<T>(bp.attn.qw), d, nullptr, nullptr, p.gln));
@@ -1075,7 +1095,9 @@ extern "C" int oasr_train_fwd_bwd(oasr_ctx* c, const float* mel, const int64_t* 
 template <typename T>
 static int train_backward(oasr_ctx* c, typename Engine<T>::Runner& r, typename Engine<T>::Plan& p, const int64_t* tokens, int B, int S, void** ev) {
   const int d = c->d;
-  const long Md = (long)B * S, Me = (long)B * c->Te, M1 = (long)B * c->T1;
+  // Md: the decoder's token rows the backward runs over -- all B*S, or (supervised-span step) the leading rows that hold every
+  // position able to carry gradient; the rows behind them are never read or written by the backward
+  const long Md = r.dec_rows_bwd ? r.dec_rows_bwd : (long)B * S, Me = (long)B * c->Te, M1 = (long)B * c->T1;
   hipStream_t st = r.st;
   // ---------------- backward: decoder ----------------
   int seg = 0;
@@ -1109,7 +1131,7 @@ static int train_backward(oasr_ctx* c, typename Engine<T>::Runner& r, typename E
     dx = dx_in;
     RC(r.record(ev, seg++));
   }
-  RC(launch_embedding_bwd(tokens, dx, c->G(c->tok_emb), c->G(c->dec_pos), B, S, d, PAD_ID, c->V, st));
+  RC(launch_embedding_bwd(tokens, dx, c->G(c->tok_emb), c->G(c->dec_pos), B, S, d, PAD_ID, c->V, st, r.dec_rows, r.dec_span));
   RC(r.record(ev, seg++));  // decoder.positional_embedding
   RC(r.record(ev, seg++));  // token embedding (arena tail)
 
@@ -1215,6 +1237,62 @@ static int oasr_train_fwd_bwd_s_impl(oasr_ctx* c, const float* mel, const int64_
   RC(launch_cross_entropy(p.logits, c->Vp, c->V, targets, Md, PAD_ID, loss_scale * inv_accum, p.n_valid, p.row_loss, 1, st));
   RC(launch_loss_reduce(p.row_loss, Md, p.n_valid, inv_accum, loss_out, accumulate_loss, st));
   return train_backward<T>(c, r, p, tokens, B, S, ev);
+}
+
+// ---- the supervised-span micro-step ---------------------------------------------------------------------------------------------
+// Same forward (all n_text_ctx positions, as the reference pads them: train_timestamps.py:318-329), same loss, same gradients; what
+// changes is WHERE the decoder's token rows live and how much of the backward is executed.  span_host[b] (host memory, known to the
+// data loader: train_timestamps.py:238-343 builds the token sequences on the host) bounds the positions of sample b that can carry
+// gradient: every target at or past it is ignore_index (train_timestamps.py:1444) and it is >= text_len[b], the first masked key
+// column (:314-315).  Rows of every decoder-side gradient past the span are exactly zero in the reference's computation -- the loss
+// ignores them, no supervised query attends to them -- so:
+//   * the decoder's activations are laid out in 64-position CHUNKS, every chunk with a position < span first (kernels.h:
+//     AttnArgs.q_rows; only the embedding, the attention kernels and the target gather know about the permutation -- LayerNorm, the
+//     GEMMs and their epilogues are row-wise and see plain matrices);
+//   * the backward of the decoder (dgrad / wgrad GEMMs, LayerNorm, attention, cross-entropy gradient, embedding scatter) runs on the
+//     leading R = sum_b ceil64(span[b]) rows only -- on the synthetic lengths 1/3 of the 448 * B.
+// The results differ from oasr_train_fwd_bwd's only by fp32 summation order (weight gradients sum over fewer, re-ordered token rows).
+template <typename T>
+static int oasr_train_fwd_bwd_span_impl(oasr_ctx* c, const float* mel, const int64_t* tokens, const int64_t* targets, const int32_t* text_len,
+                                       const int32_t* span_host, int B, float loss_scale, float inv_accum, float* loss_out,
+                                       int accumulate_loss, void** ev, void* workspace, size_t workspace_bytes, void* stream) {
+  const int S = c->S_max;
+  const long Md = (long)B * S;
+  Arena A(workspace, workspace_bytes);
+  typename Engine<T>::Plan p;
+  Engine<T>::make_plan(c, A, p, B, S, true);
+  typename Engine<T>::Runner r{c, (hipStream_t)stream, B, S, text_len};
+  r.train = true;
+  r.cs_scratch = p.gemm_cs_scratch;
+  hipStream_t st = r.st;
+  long R = 0;
+  RC(launch_build_span_tables(span_host, B, S, targets, PAD_ID, p.rows, p.span_dev, p.targets_phys, &R, st));
+  OASR_REQUIRE(R > 0, "oasr_train_fwd_bwd_span: no position of the micro-batch carries gradient (every span is 0)");
+  r.dec_rows = p.rows;
+  r.dec_span = p.span_dev;
+  r.dec_rows_bwd = R;
+  // ---------------- forward (every position) ----------------
+  RC(r.encoder_fwd(p, mel));
+  RC(r.decoder_fwd(p, tokens));
+  // loss over the active rows (the other rows' targets are ignore_index: they add nothing to the sum and nothing to the count)
+  RC(launch_count_valid(targets, Md, PAD_ID, c->V, p.n_valid, st));
+  RC(launch_cross_entropy(p.logits, c->Vp, c->V, p.targets_phys, R, PAD_ID, loss_scale * inv_accum, p.n_valid, p.row_loss, 1, st));
+  RC(launch_loss_reduce(p.row_loss, R, p.n_valid, inv_accum, loss_out, accumulate_loss, st));
+  return train_backward<T>(c, r, p, tokens, B, S, ev);
+}
+extern "C" int oasr_train_fwd_bwd_span(oasr_ctx* c, const float* mel, const int64_t* tokens, const int64_t* targets, const int32_t* text_len,
+                                       const int32_t* span_host, int B, float loss_scale, float inv_accum, float* loss_out,
+                                       int accumulate_loss, void** ev, void* workspace, size_t workspace_bytes, void* stream) {
+  RC(check_bound(c, true));
+  OASR_REQUIRE(mel && tokens && targets && text_len && span_host && loss_out && workspace && B > 0, "oasr_train_fwd_bwd_span: bad args");
+  OASR_REQUIRE(workspace_bytes >= oasr_workspace_bytes(c, B, c->S_max, OASR_MODE_TRAIN), "oasr_train_fwd_bwd_span: workspace too small");
+  if ((c->S_max % 64) != 0 || c->S_max > 64 * OASR_ROWTAB || B > 512)  // no chunking for this shape: the plain step (same results)
+    return oasr_train_fwd_bwd_s(c, mel, tokens, targets, text_len, B, c->S_max, loss_scale, inv_accum, loss_out, accumulate_loss, nullptr, ev,
+                                workspace, workspace_bytes, stream);
+  return c->f32 ? oasr_train_fwd_bwd_span_impl<float>(c, mel, tokens, targets, text_len, span_host, B, loss_scale, inv_accum, loss_out,
+                                                      accumulate_loss, ev, workspace, workspace_bytes, stream)
+                : oasr_train_fwd_bwd_span_impl<bf16_t>(c, mel, tokens, targets, text_len, span_host, B, loss_scale, inv_accum, loss_out,
+                                                       accumulate_loss, ev, workspace, workspace_bytes, stream);
 }
 
 // ---- the same micro-step cut at the logits, for torch.autograd (OLMoASR.forward in training mode, olmoasr/model.py:856-887 followed

@@ -124,6 +124,11 @@ __device__ __forceinline__ int visible_keys(const AttnArgsF& a, int b, int i) { 
   return max(n, 0);
 }
 
+// element offset of token row t of sample b: chunk-row table (kernels.h) or batch stride
+__device__ __forceinline__ long tok_off(const int32_t* rows, int b, int t, long ld, long bs) {
+  return rows ? ((long)rows[b * OASR_ROWTAB + (t >> 6)] + (t & 63)) * ld : (long)b * bs + (long)t * ld;
+}
+
 __device__ __forceinline__ float dot64(const float* __restrict__ row, const float* __restrict__ vec_lds) {
   float s = 0.f;
 #pragma unroll 16
@@ -134,14 +139,14 @@ __device__ __forceinline__ float dot64(const float* __restrict__ row, const floa
 __global__ __launch_bounds__(64) void attn_fwd_f32_kernel(AttnArgsF a) {
   __shared__ float qs[64], ps[MAX_T];
   const int i = blockIdx.x, h = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
-  qs[lane] = a.q[(long)b * a.bsq + (long)i * a.ldq + h * 64 + lane];
+  qs[lane] = a.q[tok_off(a.q_rows, b, i, a.ldq, a.bsq) + h * 64 + lane];
   __syncthreads();
   const int nk = visible_keys(a, b, i);
-  const float* K = a.k + (long)b * a.bsk + h * 64;
-  const float* V = a.v + (long)b * a.bsv + h * 64;
+  const float* K = a.k + h * 64;
+  const float* V = a.v + h * 64;
   float mx = -INFINITY;
   for (int j = lane; j < nk; j += 64) {
-    const float s = ATT_SCALE * dot64(K + (long)j * a.ldk, qs);
+    const float s = ATT_SCALE * dot64(K + tok_off(a.k_rows, b, j, a.ldk, a.bsk), qs);
     ps[j] = s;
     mx = fmaxf(mx, s);
   }
@@ -156,8 +161,8 @@ __global__ __launch_bounds__(64) void attn_fwd_f32_kernel(AttnArgsF a) {
   __syncthreads();
   float o = 0.f;
 #pragma unroll 8
-  for (int j = 0; j < nk; ++j) o = fmaf(ps[j], V[(long)j * a.ldv + lane], o);
-  a.o[(long)b * a.bso + (long)i * a.ldo + h * 64 + lane] = nk ? o / sum : 0.f;
+  for (int j = 0; j < nk; ++j) o = fmaf(ps[j], V[tok_off(a.k_rows, b, j, a.ldv, a.bsv) + lane], o);
+  a.o[tok_off(a.q_rows, b, i, a.ldo, a.bso) + h * 64 + lane] = nk ? o / sum : 0.f;
   if (lane == 0) a.lse[((long)b * a.H + h) * a.Tq + i] = nk ? mx + logf(sum) : -INFINITY;
 }
 
@@ -165,8 +170,9 @@ __global__ __launch_bounds__(64) void attn_fwd_f32_kernel(AttnArgsF a) {
 __global__ __launch_bounds__(64) void attn_bwd_q_f32_kernel(AttnArgsF a) {
   __shared__ float qs[64], dos[64], ds[MAX_T];
   const int i = blockIdx.x, h = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
-  const long orow = (long)b * a.bso + (long)i * a.ldo + h * 64 + lane;
-  qs[lane] = a.q[(long)b * a.bsq + (long)i * a.ldq + h * 64 + lane];
+  if (a.q_span && i >= a.q_span[b]) return;  // no gradient at this query position: d_o row not read, dq row not written
+  const long orow = tok_off(a.q_rows, b, i, a.ldo, a.bso) + h * 64 + lane;
+  qs[lane] = a.q[tok_off(a.q_rows, b, i, a.ldq, a.bsq) + h * 64 + lane];
   const float dov = a.d_o[orow];
   dos[lane] = dov;
   const float delta = wave_sum(dov * a.o[orow]);
@@ -175,19 +181,19 @@ __global__ __launch_bounds__(64) void attn_bwd_q_f32_kernel(AttnArgsF a) {
   if (lane == 0) a.delta[sidx] = delta;
   const int nk = visible_keys(a, b, i);
   const float lse = a.lse[sidx];
-  const float* K = a.k + (long)b * a.bsk + h * 64;
-  const float* V = a.v + (long)b * a.bsv + h * 64;
+  const float* K = a.k + h * 64;
+  const float* V = a.v + h * 64;
   for (int j = lane; j < nk; j += 64) {
-    const float s = ATT_SCALE * dot64(K + (long)j * a.ldk, qs);
+    const float s = ATT_SCALE * dot64(K + tok_off(a.k_rows, b, j, a.ldk, a.bsk), qs);
     const float pj = expf(s - lse);
-    const float dp = dot64(V + (long)j * a.ldv, dos);
+    const float dp = dot64(V + tok_off(a.k_rows, b, j, a.ldv, a.bsv), dos);
     ds[j] = pj * (dp - delta);
   }
   __syncthreads();
   float dq = 0.f;
 #pragma unroll 8
-  for (int j = 0; j < nk; ++j) dq = fmaf(ds[j], K[(long)j * a.ldk + lane], dq);
-  a.dq[(long)b * a.bsq + (long)i * a.ldq + h * 64 + lane] = ATT_SCALE * dq;
+  for (int j = 0; j < nk; ++j) dq = fmaf(ds[j], K[tok_off(a.k_rows, b, j, a.ldk, a.bsk) + lane], dq);
+  a.dq[tok_off(a.q_rows, b, i, a.ldq, a.bsq) + h * 64 + lane] = ATT_SCALE * dq;
   if (a.dq_colsum) atomicAdd(a.dq_colsum + h * 64 + lane, ATT_SCALE * dq);
 }
 
@@ -195,20 +201,22 @@ __global__ __launch_bounds__(64) void attn_bwd_q_f32_kernel(AttnArgsF a) {
 __global__ __launch_bounds__(64) void attn_bwd_kv_f32_kernel(AttnArgsF a) {
   __shared__ float ks[64], vs[64], ps[MAX_T], ds[MAX_T];
   const int j = blockIdx.x, h = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
-  ks[lane] = a.k[(long)b * a.bsk + (long)j * a.ldk + h * 64 + lane];
-  vs[lane] = a.v[(long)b * a.bsv + (long)j * a.ldv + h * 64 + lane];
+  const int q_end = a.q_span ? min(a.q_span[b], a.Tq) : a.Tq;  // queries past it carry no gradient (their d_o rows are not read)
+  if (a.k_rows && a.q_span && j >= q_end) return;  // chunked self-attention: this key's dk / dv rows are outside the active span
+  ks[lane] = a.k[tok_off(a.k_rows, b, j, a.ldk, a.bsk) + h * 64 + lane];
+  vs[lane] = a.v[tok_off(a.k_rows, b, j, a.ldv, a.bsv) + h * 64 + lane];
   __syncthreads();
   const bool key_ok = !a.kv_len || j < a.kv_len[b];
   const int i0 = a.causal ? j : 0;  // queries i >= i0 see key j
-  const float* Q = a.q + (long)b * a.bsq + h * 64;
-  const float* dO = a.d_o + (long)b * a.bso + h * 64;
+  const float* Q = a.q + h * 64;
+  const float* dO = a.d_o + h * 64;
   const long sbase = ((long)b * a.H + h) * a.Tq;
   if (key_ok) {
-    for (int i = i0 + lane; i < a.Tq; i += 64) {
-      const float s = ATT_SCALE * dot64(Q + (long)i * a.ldq, ks);
+    for (int i = i0 + lane; i < q_end; i += 64) {
+      const float s = ATT_SCALE * dot64(Q + tok_off(a.q_rows, b, i, a.ldq, a.bsq), ks);
       const float lse = a.lse[sbase + i];
       const float pi = expf(s - lse);  // lse = -inf cannot happen for a row that sees key j
-      const float dp = dot64(dO + (long)i * a.ldo, vs);
+      const float dp = dot64(dO + tok_off(a.q_rows, b, i, a.ldo, a.bso), vs);
       ps[i] = pi;
       ds[i] = pi * (dp - a.delta[sbase + i]);
     }
@@ -217,13 +225,13 @@ __global__ __launch_bounds__(64) void attn_bwd_kv_f32_kernel(AttnArgsF a) {
   float dk = 0.f, dv = 0.f;
   if (key_ok) {
 #pragma unroll 4
-    for (int i = i0; i < a.Tq; ++i) {
-      dv = fmaf(ps[i], dO[(long)i * a.ldo + lane], dv);
-      dk = fmaf(ds[i], Q[(long)i * a.ldq + lane], dk);
+    for (int i = i0; i < q_end; ++i) {
+      dv = fmaf(ps[i], dO[tok_off(a.q_rows, b, i, a.ldo, a.bso) + lane], dv);
+      dk = fmaf(ds[i], Q[tok_off(a.q_rows, b, i, a.ldq, a.bsq) + lane], dk);
     }
   }
-  a.dk[(long)b * a.bsk + (long)j * a.ldk + h * 64 + lane] = ATT_SCALE * dk;
-  a.dv[(long)b * a.bsv + (long)j * a.ldv + h * 64 + lane] = dv;
+  a.dk[tok_off(a.k_rows, b, j, a.ldk, a.bsk) + h * 64 + lane] = ATT_SCALE * dk;
+  a.dv[tok_off(a.k_rows, b, j, a.ldv, a.bsv) + h * 64 + lane] = dv;
   if (a.dv_colsum) atomicAdd(a.dv_colsum + h * 64 + lane, dv);
 }
 
@@ -341,26 +349,30 @@ __global__ __launch_bounds__(256) void mel_tm_f32_kernel(const float* __restrict
 }
 __global__ __launch_bounds__(256) void embedding_fwd_f32_kernel(const int64_t* __restrict__ tok, const float* __restrict__ E,
                                                                const float* __restrict__ pos, float* __restrict__ x, int S, int d,
-                                                               long total, long n_embed) {
+                                                               long total, long n_embed, const int32_t* __restrict__ rowtab) {
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long r = i / d;
+    const long r = i / d;  // logical row (b, s)
     const int c = (int)(i - r * d);
     const long t = tok[r];
     const float e = (t >= 0 && t < n_embed) ? E[t * d + c] : 0.f;
-    x[i] = e + pos[(r % S) * d + c];
+    const int s = (int)(r % S);
+    const long xr = rowtab ? (long)rowtab[(r / S) * OASR_ROWTAB + (s >> 6)] + (s & 63) : r;
+    x[xr * d + c] = e + pos[(long)s * d + c];
   }
 }
 __global__ __launch_bounds__(256) void embedding_bwd_f32_kernel(const int64_t* __restrict__ tok, const float* __restrict__ dx,
                                                                float* __restrict__ dE, float* __restrict__ dpos, int B, int S, int d,
-                                                               long pad_id, long n_embed) {
+                                                               long pad_id, long n_embed, const int32_t* __restrict__ rowtab,
+                                                               const int32_t* __restrict__ span) {
   const int s = blockIdx.x;
   for (int c = threadIdx.x; c < d; c += 256) {
     float acc = 0.f;
     for (int b = 0; b < B; ++b) {
-      const long r = (long)b * S + s;
+      if (span && s >= span[b]) continue;
+      const long r = rowtab ? (long)rowtab[b * OASR_ROWTAB + (s >> 6)] + (s & 63) : (long)b * S + s;
       const float g = dx[r * d + c];
       acc += g;
-      const long t = tok[r];
+      const long t = tok[(long)b * S + s];
       if (t != pad_id && t >= 0 && t < n_embed) atomicAdd(dE + t * d + c, g);
     }
     dpos[(long)s * d + c] += acc;
@@ -512,17 +524,18 @@ int launch_mel_to_time_major(const float* mel, float* out, int B, int n_mels, in
   OASR_LAUNCH_CHECK();
   return OASR_OK;
 }
-int launch_embedding_fwd(const int64_t* tok, const float* E, const float* pos, float* x, int B, int S, int d, long n_embed, hipStream_t s) {
+int launch_embedding_fwd(const int64_t* tok, const float* E, const float* pos, float* x, int B, int S, int d, long n_embed, hipStream_t s,
+                         const int32_t* rows_tab) {
   OASR_REQUIRE(tok && E && pos && x, "embedding_fwd(f32): bad args");
   const long total = (long)B * S * d;
-  hipLaunchKernelGGL(embedding_fwd_f32_kernel, dim3(grid_for(total)), dim3(256), 0, s, tok, E, pos, x, S, d, total, n_embed);
+  hipLaunchKernelGGL(embedding_fwd_f32_kernel, dim3(grid_for(total)), dim3(256), 0, s, tok, E, pos, x, S, d, total, n_embed, rows_tab);
   OASR_LAUNCH_CHECK();
   return OASR_OK;
 }
 int launch_embedding_bwd(const int64_t* tok, const float* dx, float* dE, float* dpos, int B, int S, int d, long pad_id, long n_embed,
-                         hipStream_t s) {
+                         hipStream_t s, const int32_t* rows_tab, const int32_t* span) {
   OASR_REQUIRE(tok && dx && dE && dpos, "embedding_bwd(f32): bad args");
-  hipLaunchKernelGGL(embedding_bwd_f32_kernel, dim3(S), dim3(256), 0, s, tok, dx, dE, dpos, B, S, d, pad_id, n_embed);
+  hipLaunchKernelGGL(embedding_bwd_f32_kernel, dim3(S), dim3(256), 0, s, tok, dx, dE, dpos, B, S, d, pad_id, n_embed, rows_tab, span);
   OASR_LAUNCH_CHECK();
   return OASR_OK;
 }

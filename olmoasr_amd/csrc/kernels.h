@@ -126,7 +126,18 @@ struct AttnArgsT {
   // dK/dV kernel stops at the last such tile (decoder side of a padded batch: the loss ignores the padded positions, their d_o rows
   // are exactly zero and contribute exactly nothing -- three quarters of the 448 positions on average).  Results are bit-identical.
   int32_t* qtile_flags;
+  // ---- chunked token rows (the decoder side of a span-limited training step, engine.hip "supervised span") -----------------
+  // q_rows / k_rows: optional int32 [B][OASR_ROWTAB]: entry c = first token row (relative to the tensor base pointers, batch
+  // strides unused) of the 64-position chunk c of sample b; q_rows addresses q / o / o_lo / d_o / dq, k_rows k / v / dk / dv.
+  // lse / delta / qtile_flags keep their logical [B, H, Tq] indexing.  Needs Tq (Tk) % 64 == 0 and <= 64 * OASR_ROWTAB.
+  const int32_t *q_rows, *k_rows;
+  // q_span: optional int32 [B], multiples of 64 (backward only): d_o of sample b is zero at every query position >= q_span[b];
+  // those rows of d_o / o are not read, dq (and, for self-attention, dk / dv: their keys see no supervised query) not written.
+  const int32_t* q_span;
 };
+#ifndef OASR_ROWTAB
+#define OASR_ROWTAB 16  // (also defined by include/oasr.h)
+#endif
 static inline size_t attn_colsum_scratch_floats(int B, int H, int Tq, int Tk) {
   return (size_t)B * ((size_t)(Tq + 127) / 128 + (size_t)(Tk + 127) / 128) * H * 64;
 }
@@ -152,12 +163,19 @@ int launch_unpack_conv_grad(const float* g, float* dw, int co, int ci, int ldk, 
 int launch_pack_embedding(const float* e, bf16_t* dst, int rows, int rows_pad, int d, hipStream_t s);
 // mel f32 [B][80][T] -> bf16 time-major [B][T][80]
 int launch_mel_to_time_major(const float* mel, bf16_t* out, int B, int n_mels, int T, hipStream_t s);
-// x[b,s,:] = bf16(E[tok[b,s]] + pos[s])
+// x[b,s,:] = bf16(E[tok[b,s]] + pos[s]);  rows (optional): chunk-row table [B][OASR_ROWTAB] -- x row of (b, s) =
+// rows[b][s >> 6] + (s & 63) instead of b*S + s
 int launch_embedding_fwd(const int64_t* tok, const float* E, const float* pos, bf16_t* x, int B, int S, int d, long n_embed,
-                         hipStream_t s);
-// dE[tok] += dx (skipping pad_id), dpos[s] += sum_b dx
+                         hipStream_t s, const int32_t* rows = nullptr);
+// dE[tok] += dx (skipping pad_id), dpos[s] += sum_b dx;  span (optional, with rows): positions s >= span[b] hold no gradient and are skipped
 int launch_embedding_bwd(const int64_t* tok, const bf16_t* dx, float* dE, float* dpos, int B, int S, int d, long pad_id, long n_embed,
-                         hipStream_t s);
+                         hipStream_t s, const int32_t* rows = nullptr, const int32_t* span = nullptr);
+// Supervised-span tables of one decoder micro-batch (engine.hip): span_host[b] (host, <= S) -> on the device
+//   rows [B][OASR_ROWTAB]: the chunk-row table -- the active chunks (64*c < span[b]) of all samples first, position-block-major,
+//                          then the inactive ones; span_dev [B] = span rounded up to 64; targets_phys [B*S]: targets in row order
+// Returns the number of active token rows through *active_rows (host).  S % 64 == 0, S <= 64 * OASR_ROWTAB, B <= 512.
+int launch_build_span_tables(const int32_t* span_host, int B, int S, const int64_t* targets, long ignore, int32_t* rows, int32_t* span_dev,
+                             int64_t* targets_phys, long* active_rows, hipStream_t s);
 // out[n] += sum_m x[m, n]   (x bf16 [M, ld], columns [0, ncols))
 int launch_colsum_accum(const bf16_t* x, long ld, long M, int ncols, float* out, hipStream_t s);
 // conv2 input-gradient fold + conv1 GELU backward: dpre1[b,t,c] = gelu'(u1) * sum of the dA windows covering t
@@ -168,9 +186,10 @@ int launch_axpy_f32(const float* src, float* dst, long n, float a, hipStream_t s
 // fp32 validation overloads (fp32ref.hip): same contracts with fp32 activations
 int launch_pack_conv_weight(const float* w, float* dst, int co, int ci, int ldk, hipStream_t s);
 int launch_mel_to_time_major(const float* mel, float* out, int B, int n_mels, int T, hipStream_t s);
-int launch_embedding_fwd(const int64_t* tok, const float* E, const float* pos, float* x, int B, int S, int d, long n_embed, hipStream_t s);
+int launch_embedding_fwd(const int64_t* tok, const float* E, const float* pos, float* x, int B, int S, int d, long n_embed, hipStream_t s,
+                         const int32_t* rows = nullptr);
 int launch_embedding_bwd(const int64_t* tok, const float* dx, float* dE, float* dpos, int B, int S, int d, long pad_id, long n_embed,
-                         hipStream_t s);
+                         hipStream_t s, const int32_t* rows = nullptr, const int32_t* span = nullptr);
 int launch_colsum_accum(const float* x, long ld, long M, int ncols, float* out, hipStream_t s);
 int launch_conv2_col2im_dgelu(const float* dA, const float* u1, float* dpre1, int B, int T1, int d, hipStream_t s);
 int launch_dgelu_mul(const bf16_t* dy, const bf16_t* u, bf16_t* out, long n, hipStream_t s);

@@ -760,9 +760,15 @@ class OLMoASR(nn.Module):
 
     def loss_and_backward(self, mel: Tensor, tokens: Tensor, targets: Tensor, text_len: Tensor, *, loss_scale: float = 1.0,
                           accumulation_steps: int = 1, loss_out: Optional[Tensor] = None, accumulate_loss: bool = False,
-                          return_logits: bool = False, segment_events=None, text_ctx: Optional[int] = None):
+                          return_logits: bool = False, segment_events=None, text_ctx: Optional[int] = None, span=None):
         """forward + F.cross_entropy(ignore_index=51864)/accumulation_steps + backward of (loss * loss_scale)
         (train_timestamps.py:1440-1454).  Gradients accumulate into ``flat_grads``.  Returns (loss tensor [1], logits|None).
+
+        ``span``: limit the decoder's BACKWARD to the positions that can carry gradient (``oasr_train_fwd_bwd_span``; the forward
+        still covers all 448 positions, loss and gradients are those of the plain step up to fp32 summation order).  ``True``:
+        derive it here from ``targets`` / ``text_len`` (one small device->host copy); a HOST int sequence / CPU tensor [B]: the
+        caller's own bound (the data loader knows the token counts: every target at or past ``span[b]`` must be the ignore
+        index and ``span[b] >= text_len[b]``); ``None`` / ``False``: the plain step.  Not combinable with ``return_logits`` / ``text_ctx``.
 
         ``text_ctx`` (opt-in, not in the reference): run the decoder over the first ``text_ctx`` positions only.  With
         ``text_ctx >= max(text_len)`` the loss and gradients equal the full-context ones (the rest is padding the
@@ -790,11 +796,32 @@ class OLMoASR(nn.Module):
             if not all(handles):
                 raise N.NativeError("segment_events must be recorded-once torch.cuda.Event objects (null HIP event handle)")
             ev = (C.c_void_p * len(segment_events))(*handles)
+        if span is not None and span is not False:
+            if return_logits or text_ctx is not None:
+                raise ValueError("span= cannot be combined with return_logits / text_ctx")
+            span_h = self.supervised_span(targets, text_len) if span is True else torch.as_tensor(span, dtype=torch.int32, device="cpu")
+            span_h = span_h.to(torch.int32).contiguous()
+            assert span_h.numel() == B and not span_h.is_cuda
+            with torch.cuda.device(mel.device):
+                N.check(N.lib().oasr_train_fwd_bwd_span(self._ctx, N.ptr(mel), N.ptr(tokens), N.ptr(targets), N.ptr(text_len),
+                                                        C.c_void_p(span_h.data_ptr()), B, float(loss_scale), 1.0 / accumulation_steps,
+                                                        N.ptr(loss_out), int(accumulate_loss), ev, N.ptr(ws), ws.numel(), N.stream_ptr()),
+                        "oasr_train_fwd_bwd_span")
+            return loss_out, None
         with torch.cuda.device(mel.device):
             N.check(N.lib().oasr_train_fwd_bwd_s(self._ctx, N.ptr(mel), N.ptr(tokens), N.ptr(targets), N.ptr(text_len), B, S,
                                                  float(loss_scale), 1.0 / accumulation_steps, N.ptr(loss_out), int(accumulate_loss),
                                                  N.ptr(logits), ev, N.ptr(ws), ws.numel(), N.stream_ptr()), "oasr_train_fwd_bwd")
         return loss_out, logits
+
+    @staticmethod
+    def supervised_span(targets: Tensor, text_len: Tensor, ignore_index: int = 51864) -> Tensor:
+        """HOST int32 [B]: per sample, one past the last decoder position that can carry gradient = max(text_len, index of the last
+        target != ignore_index + 1) -- what ``loss_and_backward(span=...)`` / ``oasr_train_fwd_bwd_span`` take."""
+        S = targets.shape[1]
+        pos = torch.arange(1, S + 1, device=targets.device, dtype=torch.int32)
+        last = ((targets != ignore_index).to(torch.int32) * pos).amax(dim=1)
+        return torch.maximum(last, text_len.to(torch.int32).clamp(max=S)).cpu()
 
     def init_optimizer_state(self):
         if getattr(self, "_opt_state", None) is None:

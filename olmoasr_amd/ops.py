@@ -109,6 +109,91 @@ def attention_bwd(q, k, v, o, lse, d_o, kv_len=None, causal=False, o_lo=None, dq
     return dq, dk, dv
 
 
+# ---- chunked token rows (include/oasr.h: oasr_attn_args.q_rows / k_rows / q_span) -----------------------------------------------------
+def chunk_rows_table(order, B, n_chunks):
+    """Chunk-row table int32 [B, ROWTAB] (CPU) for a given placement: ``order`` lists the (b, chunk) pairs in the order their 64 rows
+    appear in memory.  Entries past ``n_chunks`` hold the out-of-range sentinel the kernels expect."""
+    tab = torch.full((B, N.ROWTAB), 0x3FFFFFFF, dtype=torch.int32)
+    for i, (b, c) in enumerate(order):
+        tab[b, c] = 64 * i
+    assert int((tab[:, :n_chunks] == 0x3FFFFFFF).sum()) == 0, "every (b, chunk) needs a place"
+    return tab
+
+
+def to_chunked(x, tab):
+    """x [B, T, ...] -> [B*T, ...] with the 64-position chunk c of sample b at rows tab[b, c] .. +63 (test helper)."""
+    B, T = x.shape[:2]
+    out = torch.empty((B * T,) + tuple(x.shape[2:]), device=x.device, dtype=x.dtype)
+    for b in range(B):
+        for c in range(T // 64):
+            r = int(tab[b, c])
+            out[r:r + 64] = x[b, 64 * c:64 * c + 64]
+    return out
+
+
+def from_chunked(xc, tab, B, T):
+    out = torch.empty((B, T) + tuple(xc.shape[1:]), device=xc.device, dtype=xc.dtype)
+    for b in range(B):
+        for c in range(T // 64):
+            r = int(tab[b, c])
+            out[b, 64 * c:64 * c + 64] = xc[r:r + 64]
+    return out
+
+
+def _attn_args_rows(qc, kc, vc, oc, lse, B, H, Tq, Tk, q_rows, k_rows, kv_len, causal):
+    """qc / oc: chunked [B*Tq, H, 64] views (any token stride); kc / vc: chunked [B*Tk, H, 64] when k_rows is given, else plain [B, Tk, H, 64]."""
+    a = N.AttnArgs()
+    a.q, a.k, a.v, a.o = qc.data_ptr(), kc.data_ptr(), vc.data_ptr(), oc.data_ptr()
+    a.ldq, a.ldo = qc.stride(0), oc.stride(0)
+    if k_rows is not None:
+        a.ldk, a.ldv = kc.stride(0), vc.stride(0)
+        a.k_rows = k_rows.data_ptr()
+    else:
+        a.ldk, a.ldv, a.bsk, a.bsv = kc.stride(1), vc.stride(1), kc.stride(0), vc.stride(0)
+    a.lse = lse.data_ptr()
+    a.kv_len = kv_len.data_ptr() if kv_len is not None else None
+    a.B, a.H, a.Tq, a.Tk, a.causal = B, H, Tq, Tk, int(causal)
+    a.q_rows = q_rows.data_ptr()
+    return a
+
+
+def attention_fwd_rows(qc, kc, vc, B, H, Tq, Tk, q_rows, k_rows=None, kv_len=None, causal=False, want_o_lo=False):
+    """attention_fwd on chunked token rows: returns oc [B*Tq, H*64] (chunked like qc), lse [B, H, Tq] (logical)(, o_lo)."""
+    oc = torch.empty(B * Tq, H * 64, device=qc.device, dtype=BF)
+    lse = torch.empty(B, H, Tq, device=qc.device, dtype=torch.float32)
+    a = _attn_args_rows(qc, kc, vc, oc.view(B * Tq, H, 64), lse, B, H, Tq, Tk, q_rows, k_rows, kv_len, causal)
+    o_lo = torch.empty_like(oc) if want_o_lo else None
+    a.o_lo = o_lo.data_ptr() if want_o_lo else None
+    N.check(N.lib().oasr_attention_fwd(C.byref(a), N.stream_ptr()), "attention_fwd(rows)")
+    return (oc, lse, o_lo) if want_o_lo else (oc, lse)
+
+
+def attention_bwd_rows(qc, kc, vc, oc, lse, doc, B, H, Tq, Tk, q_rows, k_rows=None, q_span=None, kv_len=None, causal=False, o_lo=None,
+                       dq_colsum=None, dv_colsum=None, fill=None):
+    """attention_bwd on chunked token rows.  Gradients are allocated with the operands' strides and pre-filled with ``fill`` (e.g. NaN)
+    so that a test can see which rows the kernels left untouched."""
+    def like(t):
+        g = torch.empty_strided(t.shape, t.stride(), device=t.device, dtype=t.dtype)
+        if fill is not None:
+            g.fill_(fill)
+        return g
+    dq, dk, dv = like(qc), like(kc), like(vc)
+    delta = torch.zeros(B, H, Tq, device=qc.device, dtype=torch.float32)
+    a = _attn_args_rows(qc, kc, vc, oc.view(B * Tq, H, 64), lse, B, H, Tq, Tk, q_rows, k_rows, kv_len, causal)
+    a.d_o, a.delta = doc.data_ptr(), delta.data_ptr()
+    a.o_lo = o_lo.data_ptr() if o_lo is not None else None
+    a.dq, a.dk, a.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    a.q_span = q_span.data_ptr() if q_span is not None else None
+    a.dq_colsum = dq_colsum.data_ptr() if dq_colsum is not None else None
+    a.dv_colsum = dv_colsum.data_ptr() if dv_colsum is not None else None
+    scratch = None
+    if dq_colsum is not None or dv_colsum is not None:
+        scratch = torch.empty(B * ((Tq + 127) // 128 + (Tk + 127) // 128) * H * 64, device=qc.device, dtype=torch.float32)
+        a.colsum_scratch = scratch.data_ptr()
+    N.check(N.lib().oasr_attention_bwd(C.byref(a), N.stream_ptr()), "attention_bwd(rows)")
+    return dq, dk, dv
+
+
 def cross_entropy_(logits, V, targets, ignore, gscale=1.0, write_grad=True):
     """In place on bf16 logits [rows, ld]: returns (mean loss over non-ignored rows, row_loss); logits become the gradient."""
     rows, ld = logits.shape

@@ -354,3 +354,31 @@ def test_ddp_wrapper_world2_mean_allreduce_and_no_sync():
     for p in procs:
         p.join(30)
     assert all(r[1] == "ok" for r in res), res
+
+
+def test_bench_self_launches_ranks_without_torchrun():
+    """`python bench.py --gpus N` is the shape of the driver's N = 1 command: for N > 1 outside a launcher bench.py starts the ranks
+    itself (torch.distributed.run, loopback rendezvous) and rank 0 prints the single JSON line.  Covered here on CPU with the stub step
+    (OASR_BENCH_STUB=1: gloo all-reduce, same barrier / max-over-ranks / rank-0-prints plumbing); without devices the real path must
+    fail with a plain message, not an assert."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OASR_BENCH_STUB="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-profile",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout  # exactly one JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["buf_ok"] is True
+    # the real path on a machine with fewer devices than ranks: a message and a non-zero exit code
+    import torch
+    if torch.cuda.device_count() < 2:
+        env.pop("OASR_BENCH_STUB")
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, capture_output=True,
+                           text=True, timeout=300)
+        assert r.returncode != 0 and "needs 2 devices" in r.stderr and "AssertionError" not in r.stderr, r.stderr[-2000:]

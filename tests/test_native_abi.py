@@ -33,7 +33,12 @@ def test_library_exports_every_declared_symbol(native):
     for n in sorted(names):
         assert hasattr(lib, n), f"{n} declared in include/oasr.h but not exported"
     assert set(native.EXPORTS) <= names | {"oasr_last_error"}
-    assert lib.oasr_version() == 100
+    # ABI generation: the header's constant, the library's answer and the binding's expectation agree (and so do the struct sizes the
+    # binding passes by pointer) -- a stale library is refused by _native.lib() itself
+    hdr_ver = int(re.search(r"#define\s+OASR_ABI_VERSION\s+(\d+)", product).group(1))
+    assert lib.oasr_version() == hdr_ver == native.ABI_VERSION
+    assert lib.oasr_sizeof_attn_args() == ctypes.sizeof(native.AttnArgs)
+    assert int(re.search(r"#define\s+OASR_ROWTAB\s+(\d+)", product).group(1)) == native.ROWTAB
 
 
 def test_param_table_matches_reference_state_dict(native):
