@@ -26,6 +26,7 @@ same cache, its rows re-gathered in place between steps (``kv_cache_reorder`` = 
 inf_model.py:422-453 hooks); ``use_kv_cache=False`` re-runs the decoder on the whole prefix each step (the pattern of
 notebooks/ow_decoding.py:42-72).
 """
+import zlib
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence, Union
 
@@ -140,8 +141,31 @@ def _timestamp_rules(logits: torch.Tensor, tokens: torch.Tensor, sample_begin: i
 
 
 @torch.no_grad()
-def decode(model, mel: torch.Tensor, options: Optional[DecodingOptions] = None, **kwargs):
-    """``mel``: [80, 3000] or [n, 80, 3000] windows (or already-encoded audio features).  Returns DecodingResult / list."""
+def compression_ratio(text: str) -> float:
+    """whisper.utils.compression_ratio: utf-8 bytes over their zlib-compressed size -- high for repetitive text (the "too repetitive"
+    test of olmoasr/transcribe.py:213-217)."""
+    b = text.encode("utf-8")
+    return len(b) / len(zlib.compress(b))
+
+
+def resolve_tokenizer(model, tokenizer=None, language: str = "en", task: str = "transcribe"):
+    """The tokenizer PLUG: openai-whisper is not vendored by the reference (requirements.txt:21) and is absent offline, so text is
+    optional here.  ``tokenizer``: any object with ``decode(list[int]) -> str`` (and ``encode(str) -> list[int]`` for
+    ``initial_prompt``), e.g. ``whisper.tokenizer.get_tokenizer(...)``; ``None``: whisper's own when the package is importable (the
+    reference's environment, olmoasr/transcribe.py:167-172), else no text -- token-level results only."""
+    if tokenizer is not None:
+        return tokenizer
+    try:
+        from whisper.tokenizer import get_tokenizer  # noqa: PLC0415 -- optional dependency of the reference's environment
+    except Exception:
+        return None
+    return get_tokenizer(getattr(model, "is_multilingual", False), num_languages=getattr(model, "num_languages", 0), language=language, task=task)
+
+
+def decode(model, mel: torch.Tensor, options: Optional[DecodingOptions] = None, *, tokenizer=None, **kwargs):
+    """``mel``: [80, 3000] or [n, 80, 3000] windows (or already-encoded audio features).  Returns DecodingResult / list.
+    With a ``tokenizer`` (see ``resolve_tokenizer``) the results carry ``text`` and ``compression_ratio`` exactly as
+    whisper.decoding.DecodingTask.run fills them: text = tokenizer.decode(tokens without timestamps).strip()."""
     if options is None:
         options = DecodingOptions(**kwargs)
     elif kwargs:
@@ -308,8 +332,12 @@ def decode(model, mel: torch.Tensor, options: Optional[DecodingOptions] = None, 
             body = seq[sample_begin:]
             cands.append((body[:body.index(EOT)], lp))
         best, lp = rank(cands)
-        results.append(DecodingResult(audio_features=xa[a], tokens=best, avg_logprob=lp / (len(best) + 1), no_speech_prob=no_speech[a],
-                                      temperature=options.temperature))
+        res = DecodingResult(audio_features=xa[a], tokens=best, avg_logprob=lp / (len(best) + 1), no_speech_prob=no_speech[a],
+                             temperature=options.temperature)
+        if tokenizer is not None:  # (whisper's Tokenizer.decode drops the timestamp tokens itself; any other plug gets them dropped here)
+            res.text = tokenizer.decode([t for t in best if t < TIMESTAMP_BEGIN]).strip()
+            res.compression_ratio = compression_ratio(res.text)
+        results.append(res)
     return results[0] if single else results
 
 

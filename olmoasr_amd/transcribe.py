@@ -1,8 +1,13 @@
 """Long-form transcription driver on the native engine: ``OLMoASR.transcribe`` (reference olmoasr/transcribe.py:47-523).
 
-Same signature, defaults and control flow as the reference at TOKEN level (no tokenizer offline, so ``text`` is None and
-the text-based tests -- ``compression_ratio_threshold``, ``word_timestamps``, ``hallucination_silence_threshold``,
-``initial_prompt`` -- are accepted and ignored with a warning):
+Same signature, defaults and control flow as the reference.  Text is a PLUG (``tokenizer=``, ``decoding.resolve_tokenizer``): the
+reference takes its tokenizer from the un-vendored openai-whisper package (:167-172), which is absent offline.  With a tokenizer
+(whisper's own is picked up automatically where the package is installed) every text-dependent step of the reference runs:
+``text`` of each segment and of the result, the ``compression_ratio_threshold`` fallback (:213-217: "too repetitive" -> next
+temperature), the "instantaneous or no text" rule on the decoded string (:494-499), ``initial_prompt`` (:258-264), ``verbose``
+printing (:488-492).  Without one the same loop runs at TOKEN level: ``text`` is None, the compression-ratio test is skipped and a
+segment counts as empty when it holds no token below eot.  ``word_timestamps`` / ``hallucination_silence_threshold`` need the
+cross-attention weights (never formed by the flash kernels) and are refused with a warning either way:
 
   * whole-file log-mel once with ``padding=N_SAMPLES`` (:148), ``content_frames = n_frames - 3000`` (:149)
   * ``clip_timestamps`` -> seek clips (:177-186); window = ``mel[:, seek : seek + segment_size]`` with
@@ -27,7 +32,16 @@ import numpy as np
 import torch
 
 from .audio import FRAMES_PER_SECOND, HOP_LENGTH, N_FRAMES, N_SAMPLES, SAMPLE_RATE, log_mel_spectrogram, pad_or_trim
-from .decoding import EOT, TIMESTAMP_BEGIN, DecodingOptions, DecodingResult, decode
+from .decoding import EOT, TIMESTAMP_BEGIN, DecodingOptions, DecodingResult, decode, resolve_tokenizer
+
+
+def format_timestamp(seconds: float) -> str:
+    """whisper.utils.format_timestamp with its defaults (mm:ss.mmm, hours only when needed) -- the verbose line of :488-492."""
+    ms = round(seconds * 1000.0)
+    h, ms = divmod(ms, 3_600_000)
+    m, ms = divmod(ms, 60_000)
+    sec, ms = divmod(ms, 1000)
+    return (f"{h:02d}:" if h > 0 else "") + f"{m:02d}:{sec:02d}.{ms:03d}"
 
 
 @torch.no_grad()
@@ -37,12 +51,13 @@ def transcribe(model, audio, *, verbose: Optional[bool] = None,
                no_speech_threshold: Optional[float] = 0.6, condition_on_previous_text: bool = True,
                initial_prompt: Optional[str] = None, carry_initial_prompt: bool = False, word_timestamps: bool = False,
                prepend_punctuations: str = "", append_punctuations: str = "", clip_timestamps: Union[str, Sequence[float]] = "0",
-               hallucination_silence_threshold: Optional[float] = None, batch_windows: int = 16, **decode_options):
+               hallucination_silence_threshold: Optional[float] = None, batch_windows: int = 16, tokenizer=None, **decode_options):
     if isinstance(audio, str):
         from .audio import load_audio
         audio = load_audio(audio)
-    if word_timestamps or initial_prompt is not None or hallucination_silence_threshold is not None:
-        warnings.warn("word_timestamps / initial_prompt / hallucination_silence_threshold need the tokenizer's text and are ignored")
+    if word_timestamps or hallucination_silence_threshold is not None:
+        warnings.warn("word_timestamps / hallucination_silence_threshold need the cross-attention weights, which the flash kernels never "
+                      "form (olmoasr/model.py:331-340 returns qk only on the non-SDPA path): ignored")
     if not torch.is_tensor(audio):
         audio = torch.from_numpy(np.ascontiguousarray(audio))
     mel = log_mel_spectrogram(audio, model.dims.n_mels, padding=N_SAMPLES, device=model.device)  # [80, content + 3000]
@@ -58,6 +73,12 @@ def transcribe(model, audio, *, verbose: Optional[bool] = None,
         seek_points.append(content_frames)
     seek_clips = list(zip(seek_points[::2], seek_points[1::2]))
     temperatures = [temperature] if isinstance(temperature, (int, float)) else list(temperature)
+    tokenizer = resolve_tokenizer(model, tokenizer, decode_options["language"], decode_options.get("task", "transcribe"))  # (:167-172)
+    if tokenizer is None and initial_prompt is not None:
+        warnings.warn("initial_prompt needs a tokenizer (tokenizer=...): ignored")
+    initial_prompt_tokens: List[int] = []
+    if tokenizer is not None and initial_prompt is not None:  # (:258-264; the prompt conditioning itself is commented out in the reference)
+        initial_prompt_tokens = list(tokenizer.encode(" " + initial_prompt.strip()))
     input_stride = N_FRAMES // model.dims.n_audio_ctx          # mel frames per output token: 2
     time_precision = input_stride * HOP_LENGTH / SAMPLE_RATE   # 0.02 s
 
@@ -72,11 +93,15 @@ def transcribe(model, audio, *, verbose: Optional[bool] = None,
                 kwargs.pop("patience", None)
             else:
                 kwargs.pop("best_of", None)     # and the greedy/beam pass without best_of (:205-207)
-            out = decode(model, segments[todo], DecodingOptions(**kwargs, temperature=t))
+            out = decode(model, segments[todo], DecodingOptions(**kwargs, temperature=t), tokenizer=tokenizer)
             still = []
             for j, r in zip(todo, out):
                 results[j] = r
-                needs_fallback = logprob_threshold is not None and r.avg_logprob < logprob_threshold
+                needs_fallback = False
+                if tokenizer is not None and compression_ratio_threshold is not None and r.compression_ratio > compression_ratio_threshold:
+                    needs_fallback = True       # too repetitive (:213-217)
+                if logprob_threshold is not None and r.avg_logprob < logprob_threshold:
+                    needs_fallback = True       # average log probability is too low (:218-222)
                 if (no_speech_threshold is not None and r.no_speech_prob > no_speech_threshold and logprob_threshold is not None
                         and r.avg_logprob < logprob_threshold):
                     needs_fallback = False      # a quiet window is accepted as it is (:223-229)
@@ -91,7 +116,7 @@ def transcribe(model, audio, *, verbose: Optional[bool] = None,
         segment_size = min(N_FRAMES, content_frames - seek, clip_end - seek)
         return pad_or_trim(mel[:, seek:seek + segment_size], N_FRAMES), segment_size
 
-    all_tokens: List[int] = []
+    all_tokens: List[int] = list(initial_prompt_tokens)
     all_segments: List[dict] = []
     independent = bool(decode_options.get("without_timestamps", False))
     clip_idx = 0
@@ -133,7 +158,8 @@ def transcribe(model, audio, *, verbose: Optional[bool] = None,
         current_segments: List[dict] = []
 
         def new_segment(*, start: float, end: float, toks: List[int]):
-            return {"seek": seek, "start": start, "end": end, "text": None, "tokens": list(toks), "temperature": result.temperature,
+            text = tokenizer.decode([t for t in toks if t < EOT]) if tokenizer is not None else None  # (:266-279)
+            return {"seek": seek, "start": start, "end": end, "text": text, "tokens": list(toks), "temperature": result.temperature,
                     "avg_logprob": result.avg_logprob, "compression_ratio": result.compression_ratio,
                     "no_speech_prob": result.no_speech_prob}
 
@@ -162,11 +188,20 @@ def transcribe(model, audio, *, verbose: Optional[bool] = None,
             current_segments.append(new_segment(start=time_offset, end=time_offset + duration, toks=tokens))
             seek += segment_size
 
-        # zero-length segments and segments without a text token keep their slot but lose their tokens (:494-499)
+        if verbose and tokenizer is not None:  # (:488-492)
+            for seg in current_segments:
+                print(f"[{format_timestamp(seg['start'])} --> {format_timestamp(seg['end'])}] {seg['text']}")
+        # instantaneous segments and segments without text keep their slot but lose their tokens (:494-499).  "Without text": the
+        # decoded string is blank; at token level (no tokenizer) no token below eot
         for seg in current_segments:
-            if seg["start"] == seg["end"] or not any(t < EOT for t in seg["tokens"]):
+            empty = seg["text"].strip() == "" if tokenizer is not None else not any(t < EOT for t in seg["tokens"])
+            if seg["start"] == seg["end"] or empty:
                 seg["tokens"] = []
+                if tokenizer is not None:
+                    seg["text"] = ""
         all_segments.extend({"id": i, **seg} for i, seg in enumerate(current_segments, start=len(all_segments)))
         all_tokens.extend(t for seg in current_segments for t in seg["tokens"])
 
-    return {"text": None, "tokens": all_tokens, "segments": all_segments, "language": decode_options["language"]}
+    out_tokens = all_tokens[len(initial_prompt_tokens):]
+    return {"text": tokenizer.decode(out_tokens) if tokenizer is not None else None, "tokens": out_tokens, "segments": all_segments,
+            "language": decode_options["language"]}

@@ -60,6 +60,17 @@ class Result:
     no_speech_prob: float = float("nan")
     temperature: float = 0.0
     sum_logprob: float = float("nan")
+    # whisper.decoding.DecodingTask.run: text = tokenizer.decode(tokens).strip() (timestamps dropped), compression_ratio = gzip ratio
+    # of it.  Filled only when a tokenizer is supplied (the package is un-vendored: there is none offline).
+    text: str = ""
+    compression_ratio: float = float("nan")
+
+
+def compression_ratio(text: str) -> float:
+    """whisper.utils.compression_ratio (published algorithm of the un-vendored dependency): len(utf-8 bytes) / len(zlib of them)."""
+    import zlib
+    b = text.encode("utf-8")
+    return len(b) / len(zlib.compress(b))
 
 
 def suppress_list(opt: Options) -> List[int]:
@@ -211,10 +222,14 @@ def decode(sd, dims, mel: torch.Tensor, opt: Options) -> List[Result]:
 
 
 def transcribe(sd, dims, mel_padded: torch.Tensor, *, temperature=(0.0, 0.2, 0.4, 0.6, 0.8, 1.0), logprob_threshold: Optional[float] = -1.0,
-               no_speech_threshold: Optional[float] = 0.6, clip_timestamps: Sequence[float] = (0.0,), **decode_kw) -> dict:
-    """olmoasr/transcribe.py:147-517 at token level.  ``mel_padded`` = log_mel_spectrogram(audio, padding=N_SAMPLES)
-    [80, content_frames + 3000] (:148).  compression_ratio_threshold / word_timestamps / hallucination_silence_threshold need
-    text and are outside; prompt conditioning is commented out in the reference (:297-302)."""
+               no_speech_threshold: Optional[float] = 0.6, clip_timestamps: Sequence[float] = (0.0,), tokenizer=None,
+               compression_ratio_threshold: Optional[float] = 2.4, initial_prompt: Optional[str] = None, **decode_kw) -> dict:
+    """olmoasr/transcribe.py:147-517.  ``mel_padded`` = log_mel_spectrogram(audio, padding=N_SAMPLES) [80, content_frames + 3000]
+    (:148).  With ``tokenizer`` (decode / encode; the reference's comes from the un-vendored whisper package, :167-172) the text steps
+    run too: the compression-ratio fallback (:213-217, on the ``compression_ratio`` the decode result carries), segment / result text
+    (:266-279, :519-523), the empty-text rule (:494-499), initial_prompt (:258-264).  Without one: token level, the compression test
+    skipped.  word_timestamps / hallucination_silence_threshold are outside; prompt conditioning is commented out in the reference
+    (:297-302)."""
     content_frames = mel_padded.shape[-1] - N_FRAMES
     seek_points = [round(ts * FRAMES_PER_SECOND) for ts in clip_timestamps] or [0]
     if len(seek_points) % 2 == 1:
@@ -233,7 +248,11 @@ def transcribe(sd, dims, mel_padded: torch.Tensor, *, temperature=(0.0, 0.2, 0.4
             else:
                 kw.pop("best_of", None)
             res = decode(sd, dims, segment[None], Options(temperature=t, **kw))[0]
-            needs_fallback = logprob_threshold is not None and res.avg_logprob < logprob_threshold
+            needs_fallback = False
+            if tokenizer is not None and compression_ratio_threshold is not None and res.compression_ratio > compression_ratio_threshold:
+                needs_fallback = True  # too repetitive (:213-217)
+            if logprob_threshold is not None and res.avg_logprob < logprob_threshold:
+                needs_fallback = True  # (:218-222)
             if (no_speech_threshold is not None and res.no_speech_prob > no_speech_threshold and logprob_threshold is not None
                     and res.avg_logprob < logprob_threshold):
                 needs_fallback = False
@@ -242,6 +261,8 @@ def transcribe(sd, dims, mel_padded: torch.Tensor, *, temperature=(0.0, 0.2, 0.4
         return res
 
     all_tokens, all_segments, seeks = [], [], []
+    prompt_tokens = list(tokenizer.encode(" " + initial_prompt.strip())) if (tokenizer is not None and initial_prompt is not None) else []
+    all_tokens.extend(prompt_tokens)  # (:258-264)
     clip_idx, seek = 0, seek_clips[0][0]
     while clip_idx < len(seek_clips):
         clip_start, clip_end = seek_clips[clip_idx]
@@ -270,8 +291,12 @@ def transcribe(sd, dims, mel_padded: torch.Tensor, *, temperature=(0.0, 0.2, 0.4
         current = []
 
         def new_segment(start, end, toks):
-            return {"seek": seek, "start": start, "end": end, "tokens": list(toks), "temperature": result.temperature,
-                    "avg_logprob": result.avg_logprob, "no_speech_prob": result.no_speech_prob}
+            seg = {"seek": seek, "start": start, "end": end, "tokens": list(toks), "temperature": result.temperature,
+                   "avg_logprob": result.avg_logprob, "no_speech_prob": result.no_speech_prob}
+            if tokenizer is not None:  # (:266-279)
+                seg["text"] = tokenizer.decode([t for t in toks if t < EOT])
+                seg["compression_ratio"] = result.compression_ratio
+            return seg
         is_ts = [t >= TIMESTAMP_BEGIN for t in tokens]
         single_timestamp_ending = is_ts[-2:] == [False, True]
         consecutive = [i + 1 for i in range(len(tokens) - 1) if is_ts[i] and is_ts[i + 1]]
@@ -296,10 +321,16 @@ def transcribe(sd, dims, mel_padded: torch.Tensor, *, temperature=(0.0, 0.2, 0.4
                 duration = (stamps[-1] - TIMESTAMP_BEGIN) * time_precision
             current.append(new_segment(time_offset, time_offset + duration, tokens))
             seek += segment_size
-        for s in current:  # "instantaneous or does not contain text" (:494-499); text == tokens below eot here
-            if s["start"] == s["end"] or not any(t < EOT for t in s["tokens"]):
+        for s in current:  # "instantaneous or does not contain text" (:494-499); without a tokenizer text == tokens below eot
+            empty = s["text"].strip() == "" if tokenizer is not None else not any(t < EOT for t in s["tokens"])
+            if s["start"] == s["end"] or empty:
                 s["tokens"] = []
+                if tokenizer is not None:
+                    s["text"] = ""
         base_id = len(all_segments)  # ids continue across windows (:501-508); evaluated before the list grows
         all_segments.extend({"id": base_id + i, **s} for i, s in enumerate(current))
         all_tokens.extend(t for s in current for t in s["tokens"])
-    return {"tokens": all_tokens, "segments": all_segments, "seeks": seeks}
+    out = {"tokens": all_tokens[len(prompt_tokens):], "segments": all_segments, "seeks": seeks}
+    if tokenizer is not None:
+        out["text"] = tokenizer.decode(all_tokens[len(prompt_tokens):])  # (:519-523)
+    return out

@@ -1,6 +1,7 @@
 """Writes tests/golden/transcribe_ref.json: outputs of the UNMODIFIED reference ``olmoasr/transcribe.py`` (run through
 oracle/ref_transcribe_harness.py in the build container) on (a) the 40 scripted-decode cases of
-``ref_transcribe_harness.scripted_cases()`` and (b) a real tiny model with the timestamp bonus, 41 s of the seeded generator's
+``ref_transcribe_harness.scripted_cases()`` (token level) and the 24 of ``scripted_cr_cases()`` (with a tokenizer: texts,
+compression-ratio fallback, initial_prompt) and (b) a real tiny model with the timestamp bonus, 41 s of the seeded generator's
 audio.  ``python -m oracle.gen_transcribe_golden``.  TEST INFRASTRUCTURE ONLY; the fixture travels to the GPU box, the reference
 does not."""
 import json
@@ -32,10 +33,13 @@ def model_case():
 
 def main():
     torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
-    out = {"scripted": [], "model": None}
+    out = {"scripted": [], "scripted_cr": [], "model": None}
     for c in H.scripted_cases():
         ref = H.run_reference(H.scripted_decode(c["seed"]), H.index_mel(c["content_frames"]), **dict(c["kw"]))
         out["scripted"].append(H.comparable(ref))
+    for c in H.scripted_cr_cases():  # with a tokenizer: compression-ratio fallback, segment / result text, initial_prompt
+        ref = H.run_reference(H.scripted_decode_cr(c["seed"]), H.index_mel(c["content_frames"]), **dict(c["kw"]))
+        out["scripted_cr"].append(H.comparable(ref, text=True))
     sd, dims, mel_padded, bias, kw = model_case()
     out["model"] = H.comparable(H.run_reference(H.model_decode(sd, dims, bias), mel_padded, **kw))
     with open(OUT, "w") as f:

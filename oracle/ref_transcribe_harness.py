@@ -74,6 +74,47 @@ def scripted_decode(seed: int) -> Callable:
     return decode
 
 
+class Tok:
+    """Stand-in for whisper.tokenizer.Tokenizer on both sides of the comparison: a token spells itself."""
+    eot, timestamp_begin = do.EOT, do.TIMESTAMP_BEGIN
+
+    def encode(self, s):
+        return [int(x) for x in s.split()]
+
+    def decode(self, ids):
+        return " ".join(str(int(i)) for i in ids)
+
+
+def scripted_decode_cr(seed: int) -> Callable:
+    """Like ``scripted_decode`` but with TEXT: the result carries text / compression_ratio the way whisper.decoding.DecodingTask.run
+    fills them (tokenizer.decode of the tokens without timestamps, stripped; gzip ratio of that) and the grammar has repetitive
+    outputs (ratio 3-6) that cool down as the temperature rises, blank segments (a token that decodes to nothing does not exist for
+    this stand-in tokenizer, so "blank" = no token below eot) and confident-but-repetitive windows where ONLY the compression ratio
+    triggers the fallback."""
+    base = scripted_decode(seed)
+
+    def decode(segment: torch.Tensor, temperature: float, kw: dict) -> do.Result:
+        seek = int(segment[0, 0].item()) - 1
+        size = int((segment[0] > 0).sum().item())
+        rng = random.Random(hash((770001, seed, seek, size, round(temperature * 10))) & 0xFFFFFFFF)  # (ints only: str hashes are salted per process)
+        r = base(segment, temperature, kw)
+        mode = rng.choice(["plain", "plain", "loop", "loop_confident", "loop_forever"])
+        toks = list(r.tokens)
+        lp = r.avg_logprob
+        if mode != "plain" and (mode == "loop_forever" or temperature < rng.choice([0.2, 0.4, 0.6])):
+            # a repetition loop: the same 1-3 tokens over and over inside one closed pair (or bare text without timestamps)
+            unit = [rng.randrange(100, 200) for _ in range(rng.randrange(1, 4))]
+            body = unit * rng.randrange(12, 40)
+            t0 = rng.randrange(0, 200)
+            toks = body if kw.get("without_timestamps") else [do.TIMESTAMP_BEGIN + t0] + body + [do.TIMESTAMP_BEGIN + t0 + rng.randrange(1, 600)]
+            if mode == "loop_confident":
+                lp = -0.1  # the log-probability test alone would accept it
+        text = Tok().decode([t for t in toks if t < do.TIMESTAMP_BEGIN]).strip()
+        return do.Result(tokens=toks, avg_logprob=lp, no_speech_prob=r.no_speech_prob, temperature=temperature,
+                         sum_logprob=lp * (len(toks) + 1), text=text, compression_ratio=do.compression_ratio(text))
+    return decode
+
+
 def model_decode(sd, dims, logit_bias: Optional[torch.Tensor] = None) -> Callable:
     def decode(segment: torch.Tensor, temperature: float, kw: dict) -> do.Result:
         kw = {k: v for k, v in kw.items() if k in do.Options.__dataclass_fields__}
@@ -89,7 +130,8 @@ def run_oracle(decode: Callable, mel_padded: torch.Tensor, **kw) -> dict:
         fields = {k: getattr(opt, k) for k in opt.__dataclass_fields__ if k not in ("temperature", "logit_bias")}
         passed = {k: v for k, v in fields.items() if k in shim.kw}  # only what transcribe() forwarded
         return [decode(seg[0], opt.temperature, passed)]
-    tkw = {k: kw.pop(k) for k in list(kw) if k in ("temperature", "logprob_threshold", "no_speech_threshold", "clip_timestamps")}
+    tkw = {k: kw.pop(k) for k in list(kw) if k in ("temperature", "logprob_threshold", "no_speech_threshold", "clip_timestamps", "tokenizer",
+                                                   "compression_ratio_threshold", "initial_prompt")}
     shim.kw = dict(kw)
     do.decode = shim
     try:
@@ -103,15 +145,6 @@ def run_reference(decode: Callable, mel_padded: torch.Tensor, **kw) -> dict:
     from . import ref_import
     rt = ref_import.load_transcribe()
 
-    class Tok:
-        eot, timestamp_begin = do.EOT, do.TIMESTAMP_BEGIN
-
-        def encode(self, s):
-            return [int(x) for x in s.split()]
-
-        def decode(self, ids):
-            return " ".join(str(int(i)) for i in ids)
-
     class Opt(types.SimpleNamespace):
         pass
 
@@ -120,8 +153,9 @@ def run_reference(decode: Callable, mel_padded: torch.Tensor, **kw) -> dict:
         t = d.pop("temperature")
         d.pop("language", None), d.pop("fp16", None)
         r = decode(segment, t, d)
+        cr = r.compression_ratio if r.compression_ratio == r.compression_ratio else 1.0  # (NaN: a token-level script)
         return types.SimpleNamespace(tokens=list(r.tokens), avg_logprob=r.avg_logprob, no_speech_prob=r.no_speech_prob,
-                                     temperature=r.temperature, compression_ratio=1.0)
+                                     temperature=r.temperature, compression_ratio=cr, text=r.text)
 
     model = types.SimpleNamespace(dims=types.SimpleNamespace(n_mels=80, n_audio_ctx=1500, n_text_ctx=448), device=torch.device("cpu"),
                                   is_multilingual=False, num_languages=0, decode=ref_decode)
@@ -131,16 +165,21 @@ def run_reference(decode: Callable, mel_padded: torch.Tensor, **kw) -> dict:
     rt.DecodingOptions = Opt
     if "clip_timestamps" in kw:
         kw["clip_timestamps"] = list(kw["clip_timestamps"])
-    out = rt.transcribe(model, mel_padded, verbose=None, compression_ratio_threshold=None, **kw)
+    kw.pop("tokenizer", None)  # (the reference builds its own through get_tokenizer, patched above)
+    kw.setdefault("compression_ratio_threshold", None)
+    out = rt.transcribe(model, mel_padded, verbose=None, **kw)
     toks = [t for s in out["segments"] for t in s["tokens"]]
     return {"segments": out["segments"], "tokens": toks, "text": out["text"]}
 
 
-def comparable(out: dict) -> dict:
-    """The fields both sides define, JSON-ready."""
-    keys = ("id", "seek", "start", "end", "tokens", "temperature", "avg_logprob", "no_speech_prob")
-    return {"tokens": [int(t) for t in out["tokens"]],
-            "segments": [{k: ([int(t) for t in s[k]] if k == "tokens" else s[k]) for k in keys} for s in out["segments"]]}
+def comparable(out: dict, text: bool = False) -> dict:
+    """The fields both sides define, JSON-ready.  ``text``: also the text-level fields (runs with a tokenizer)."""
+    keys = ("id", "seek", "start", "end", "tokens", "temperature", "avg_logprob", "no_speech_prob") + (("text", "compression_ratio") if text else ())
+    res = {"tokens": [int(t) for t in out["tokens"]],
+           "segments": [{k: ([int(t) for t in s[k]] if k == "tokens" else s[k]) for k in keys} for s in out["segments"]]}
+    if text:
+        res["text"] = out["text"]
+    return res
 
 
 def scripted_cases() -> List[dict]:
@@ -158,5 +197,24 @@ def scripted_cases() -> List[dict]:
             kw["beam_size"], kw["best_of"] = 5, 5
         if rng.random() < 0.3:
             kw["without_timestamps"] = True
+        cases.append(dict(seed=seed, content_frames=content, kw=kw))
+    return cases
+
+
+def scripted_cr_cases() -> List[dict]:
+    """Cases of the fixture's "scripted_cr" list: the same loop WITH a tokenizer -- compression-ratio fallback, texts, initial_prompt."""
+    cases = []
+    for seed in range(24):
+        rng = random.Random(5000 + seed)
+        kw: dict = dict(temperature=rng.choice([(0.0, 0.2, 0.4, 0.6, 0.8, 1.0), (0.0, 0.2, 0.4, 0.6, 0.8, 1.0), (0.0, 0.4), 0.0]),
+                        logprob_threshold=rng.choice([-1.0, -1.0, None]), no_speech_threshold=rng.choice([0.6, None]),
+                        compression_ratio_threshold=rng.choice([2.4, 2.4, 2.4, 1.2, None]))
+        content = rng.choice([2999, 3001, 9000, 12345])
+        if rng.random() < 0.25:
+            kw["without_timestamps"] = True
+        if rng.random() < 0.3:
+            kw["initial_prompt"] = " ".join(str(rng.randrange(0, 50000)) for _ in range(rng.randrange(1, 6)))
+        if rng.random() < 0.25:
+            kw["beam_size"], kw["best_of"] = 5, 5
         cases.append(dict(seed=seed, content_frames=content, kw=kw))
     return cases

@@ -53,7 +53,8 @@ IGNORED_FLAGS = ("eval_dir", "eval_batch_size", "pin_memory", "persistent_worker
 NATIVE_FLAGS = dict(  # additions of this implementation
     synthetic=True, n_synthetic=4096, timestamps=False, seed=0, bucket_cap_mb=128.0, reducer="allreduce", resume=False,
     force_dist=False,  # run the RCCL group / bucketed exchange / sharded step even at world_size 1 (single-GPU rehearsal of the N > 1 path)
-    zero_stage=0)  # zero_stage 1: AdamW moments sharded over the ranks (olmoasr_amd/zero.py; the reference's FSDP script's role)
+    zero_stage=0,  # zero_stage 1: AdamW moments sharded over the ranks (olmoasr_amd/zero.py; the reference's FSDP script's role)
+    span_backward=True)  # decoder backward over the supervised span only (oasr_train_fwd_bwd_span; same loss / gradients, forward over all 448)
 
 
 class Args(dict):
@@ -335,13 +336,21 @@ def main(argv=None):
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
     rank = int(os.environ.get("RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
     force_dist = bool(args.force_dist) and world_size == 1
     own_group = (world_size > 1 or force_dist) and not dist.is_initialized()
+    if own_group and not force_dist:
+        # world_size > 1: every rank must name the SAME rendezvous, so it has to come from the launcher (torchrun exports both).  A
+        # per-process default would make each rank wait on a different port until the RCCL timeout instead of failing here.
+        missing = [k for k in ("MASTER_ADDR", "MASTER_PORT") if k not in os.environ]
+        if missing:
+            raise SystemExit(f"train_timestamps.py: WORLD_SIZE={world_size} but {' and '.join(missing)} not set -- launch with "
+                             f"torchrun (train_timestamps.py:2227-2230 reads the same environment), or export them for every rank")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     if own_group:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 400))
+        if force_dist:  # the single-rank rehearsal needs no launcher: loopback rendezvous on a port of its own
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 400))
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world_size)  # RCCL over xGMI
 
     betas = tuple(args.betas)
@@ -408,9 +417,11 @@ def main(argv=None):
                 cursor, epoch = 0, epoch + 1
             mel = ops.log_mel(pcm)
             last = i == accum - 1
+            # (a logging step wants the logits back: it takes the plain step; every other step limits the decoder's backward to the span)
             _, logits = net.loss_and_backward(mel, ti, ty, tl, loss_scale=scaler.scale, accumulation_steps=accum, loss_out=loss_buf,
                                               accumulate_loss=i > 0, return_logits=log_now,
-                                              segment_events=reducer.segment_events() if (reducer and last) else None)
+                                              segment_events=reducer.segment_events() if (reducer and last) else None,
+                                              span=True if (args.span_backward and not log_now) else None)
             if log_now:
                 p_, t_ = gen_pred(logits, ty)
                 preds += p_

@@ -69,6 +69,11 @@ def test_span_tables(B, S, seed):
                 assert r >= ref_act and bool((tp[r:r + 64] == -7).all())  # not touched
 
 
+def _cs_close(a, b):
+    """fused bias-gradient column sums: the per-workgroup partial rows are identical, their fp32 atomic reduction order is not"""
+    return bool(((a - b).abs() <= 1e-5 * b.abs() + 1e-5 * float(b.abs().max())).all())
+
+
 def _placement(B, n_chunks, seed):
     """A scrambled chunk placement (any placement is legal for the kernels)."""
     from olmoasr_amd import ops
@@ -129,7 +134,7 @@ def test_attention_on_chunked_rows_is_bit_identical(kind, attn_path):
     else:
         assert torch.equal(ops.from_chunked(dqc.reshape(B * Tq, d), tab, B, Tq), dq.reshape(B, Tq, d))
         assert torch.equal(dkc, dk) and torch.equal(dvc, dv)
-    assert torch.equal(cs[2], cs[0]) and torch.equal(cs[3], cs[1])
+    assert _cs_close(cs[2], cs[0]) and _cs_close(cs[3], cs[1])
 
     # ---- backward with a span: d_o is zero past it in the plain run; on chunked rows those rows hold NaN and must not be read,
     # and the gradient rows past the span must not be written
@@ -158,7 +163,7 @@ def test_attention_on_chunked_rows_is_bit_identical(kind, attn_path):
             assert float(r2[~keep_q].abs().max()) == 0.0
     else:
         assert torch.equal(dkc, dk) and torch.equal(dvc, dv)
-    assert torch.equal(cs[2], cs[0]) and torch.equal(cs[3], cs[1])
+    assert _cs_close(cs[2], cs[0]) and _cs_close(cs[3], cs[1])
 
 
 def _grads_by_tensor(net):

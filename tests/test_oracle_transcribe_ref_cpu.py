@@ -5,6 +5,10 @@
   closing timestamp / no timestamps / empty output, the instantaneous-or-empty rule, segment ids) and on a real tiny model
   with the timestamp bonus -- via the committed fixture tests/golden/transcribe_ref.json (oracle/gen_transcribe_golden.py)
   everywhere, and LIVE against /root/reference when it is mounted (build container).
+* the same with a TOKENIZER (a stand-in whose tokens spell themselves, supplied to both sides): 24 scripted cases whose decode
+  results carry text / compression_ratio like whisper.decoding fills them -- the compression-ratio fallback (:213-217, in half of
+  the cases the only thing that changes the outcome), segment and result text, the blank-text rule (:494-499), initial_prompt
+  (:258-264) -- oracle and product against the reference's own file (fixture + live).
 * the PRODUCT's host-side seek loop (olmoasr_amd/transcribe.py) on the same scripted cases against the same fixture: its
   decode call is replaced by the scripted one, so this is pure host logic (no GPU, no native library)."""
 import json
@@ -25,14 +29,16 @@ def golden(golden_dir):
         return json.load(f)
 
 
-def _eq(got, want, what):
+def _eq(got, want, what, text=False):
     assert got["tokens"] == want["tokens"], what
     assert len(got["segments"]) == len(want["segments"]), what
     for a, b in zip(got["segments"], want["segments"]):
-        for k in ("id", "seek", "tokens", "temperature"):
+        for k in ("id", "seek", "tokens", "temperature") + (("text",) if text else ()):
             assert a[k] == b[k], (what, k, a, b)
-        for k in ("start", "end", "avg_logprob", "no_speech_prob"):
+        for k in ("start", "end", "avg_logprob", "no_speech_prob") + (("compression_ratio",) if text else ()):
             assert abs(a[k] - b[k]) < 1e-9, (what, k, a, b)
+    if text:
+        assert got["text"] == want["text"], what
 
 
 def test_oracle_transcribe_equals_reference_fixture_scripted(golden):
@@ -57,6 +63,22 @@ def test_oracle_transcribe_equals_reference_fixture_scripted(golden):
     assert fallback >= 5 and seek_driven >= 5 and cleared >= 5 and skipped >= 3 and clipped >= 5, (fallback, seek_driven, cleared, skipped, clipped)
 
 
+def test_oracle_transcribe_with_tokenizer_equals_reference_fixture(golden):
+    """Text level: compression-ratio fallback, texts, initial_prompt (a21's text half)."""
+    cases = H.scripted_cr_cases()
+    assert len(cases) == len(golden["scripted_cr"]) == 24
+    cr_decides = prompts = fallback = 0
+    for c, want in zip(cases, golden["scripted_cr"]):
+        dec, mel = H.scripted_decode_cr(c["seed"]), H.index_mel(c["content_frames"])
+        got = H.comparable(H.run_oracle(dec, mel, tokenizer=H.Tok(), **dict(c["kw"])), text=True)
+        _eq(got, want, f"scripted_cr case {c['seed']} {c['kw']}", text=True)
+        no_cr = H.comparable(H.run_oracle(dec, mel, tokenizer=H.Tok(), **{**c["kw"], "compression_ratio_threshold": None}), text=True)
+        cr_decides += no_cr != got
+        prompts += "initial_prompt" in c["kw"]
+        fallback += any(s["temperature"] > 0 for s in got["segments"])
+    assert cr_decides >= 8 and prompts >= 3 and fallback >= 8, (cr_decides, prompts, fallback)
+
+
 def test_oracle_transcribe_equals_reference_fixture_real_model(golden):
     from oracle.gen_transcribe_golden import model_case
     torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
@@ -72,6 +94,10 @@ def test_oracle_transcribe_equals_reference_live():
                                                                                no_speech_threshold=0.5, clip_timestamps=[3.0, 200.0, 210.5]))]:
         dec, mel = H.scripted_decode(c["seed"]), H.index_mel(c["content_frames"])
         _eq(H.comparable(H.run_oracle(dec, mel, **dict(c["kw"]))), H.comparable(H.run_reference(dec, mel, **dict(c["kw"]))), f"live {c}")
+    for c in H.scripted_cr_cases():
+        dec, mel = H.scripted_decode_cr(c["seed"]), H.index_mel(c["content_frames"])
+        _eq(H.comparable(H.run_oracle(dec, mel, tokenizer=H.Tok(), **dict(c["kw"])), text=True),
+            H.comparable(H.run_reference(dec, mel, **dict(c["kw"])), text=True), f"live, with tokenizer {c}", text=True)
 
 
 def test_product_seek_loop_equals_reference_fixture(golden, monkeypatch):
@@ -81,20 +107,54 @@ def test_product_seek_loop_equals_reference_fixture(golden, monkeypatch):
     model = types.SimpleNamespace(dims=types.SimpleNamespace(n_mels=80, n_audio_ctx=1500, n_text_ctx=448), device="cpu")
     for c, want in zip(H.scripted_cases(), golden["scripted"]):
         dec = H.scripted_decode(c["seed"])
-
-        def fake_decode(_model, segments, options, dec=dec):
-            kw = {k: getattr(options, k) for k in ("beam_size", "best_of", "without_timestamps", "patience")}
-            out = []
-            for seg in segments:
-                r = dec(seg, options.temperature, kw)
-                out.append(T.DecodingResult(audio_features=None, tokens=list(r.tokens), avg_logprob=r.avg_logprob,
-                                            no_speech_prob=r.no_speech_prob, temperature=r.temperature))
-            return out
-        monkeypatch.setattr(T, "decode", fake_decode)
+        monkeypatch.setattr(T, "decode", _fake_decode(T, dec))
         monkeypatch.setattr(T, "log_mel_spectrogram", lambda audio, n_mels=80, padding=0, device=None: audio)
+        monkeypatch.setattr(T, "resolve_tokenizer", lambda model, tokenizer=None, *a, **k: tokenizer)  # (no whisper package lookup)
         kw = dict(c["kw"])
         if "clip_timestamps" in kw:
             kw["clip_timestamps"] = ",".join(str(x) for x in kw["clip_timestamps"])
         for bw in (1, 5):
             out = T.transcribe(model, H.index_mel(c["content_frames"]), compression_ratio_threshold=None, batch_windows=bw, **kw)
+            assert out["text"] is None and all(s["text"] is None for s in out["segments"])  # token level: no tokenizer, no text
             _eq(H.comparable(out), want, f"product loop, case {c['seed']}, batch_windows {bw}")
+
+
+def _fake_decode(T, dec):
+    def fake_decode(_model, segments, options, tokenizer=None):
+        kw = {k: getattr(options, k) for k in ("beam_size", "best_of", "without_timestamps", "patience")}
+        out = []
+        for seg in segments:
+            r = dec(seg, options.temperature, kw)
+            out.append(T.DecodingResult(audio_features=None, tokens=list(r.tokens), avg_logprob=r.avg_logprob, no_speech_prob=r.no_speech_prob,
+                                        temperature=r.temperature, text=r.text, compression_ratio=r.compression_ratio))
+        return out
+    return fake_decode
+
+
+def test_product_seek_loop_with_tokenizer_equals_reference_fixture(golden, monkeypatch):
+    """olmoasr_amd/transcribe.py with the tokenizer PLUG: compression-ratio fallback, texts, the blank-text rule and initial_prompt
+    against what the reference's own transcribe() produced on the same decode results (fixture "scripted_cr")."""
+    from olmoasr_amd import transcribe as T
+    model = types.SimpleNamespace(dims=types.SimpleNamespace(n_mels=80, n_audio_ctx=1500, n_text_ctx=448), device="cpu")
+    monkeypatch.setattr(T, "log_mel_spectrogram", lambda audio, n_mels=80, padding=0, device=None: audio)
+    for c, want in zip(H.scripted_cr_cases(), golden["scripted_cr"]):
+        monkeypatch.setattr(T, "decode", _fake_decode(T, H.scripted_decode_cr(c["seed"])))
+        for bw in (1, 4):
+            out = T.transcribe(model, H.index_mel(c["content_frames"]), batch_windows=bw, tokenizer=H.Tok(), **dict(c["kw"]))
+            _eq(H.comparable(out, text=True), want, f"product loop with tokenizer, case {c['seed']}, batch_windows {bw}", text=True)
+
+
+def test_decode_fills_text_and_compression_ratio_like_whisper():
+    """olmoasr_amd.decoding: compression_ratio == the oracle's restatement of whisper.utils.compression_ratio; resolve_tokenizer
+    returns the plug, or None when whisper is not installed."""
+    from olmoasr_amd import decoding as D
+    for text in ("", "a", "hello hello hello hello hello hello hello hello hello hello", "The quick brown fox."):
+        if text:
+            assert D.compression_ratio(text) == do.compression_ratio(text)
+    assert D.compression_ratio("ab " * 200) > 2.4 > D.compression_ratio("The quick brown fox jumps over the lazy dog.")
+    tok = H.Tok()
+    assert D.resolve_tokenizer(None, tok) is tok
+    try:
+        import whisper  # noqa: F401
+    except Exception:
+        assert D.resolve_tokenizer(types.SimpleNamespace(is_multilingual=False, num_languages=0)) is None

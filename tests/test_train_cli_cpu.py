@@ -54,6 +54,19 @@ def test_precision_and_unknown_flags(tt):
         tt.parse_args(["--no_such_flag=1"])
 
 
+def test_multi_rank_without_a_rendezvous_fails_at_once(tt, monkeypatch):
+    """WORLD_SIZE > 1 with no MASTER_ADDR / MASTER_PORT (srun, mp.spawn without the exports): a per-process default port would leave
+    every rank waiting on a different rendezvous until the RCCL timeout -- the script must stop with a message instead."""
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    monkeypatch.delenv("MASTER_ADDR", raising=False)
+    monkeypatch.delenv("MASTER_PORT", raising=False)
+    with pytest.raises(SystemExit) as e:
+        tt.main(["--model_variant=tiny", "--train_steps=1"])
+    assert "MASTER_ADDR and MASTER_PORT not set" in str(e.value)
+
+
 def test_checkpoint_pieces_load_on_the_reference_side(tt, tmp_path):
     """What the reference's load_ckpt does with a checkpoint (train_timestamps.py:1031-1056), piece by piece, on OUR file:
     OLMoASR(dims=ckpt['dims']) with the UNMODIFIED reference model class, model.load_state_dict, AdamW.load_state_dict,
