@@ -343,6 +343,9 @@ def main():
     ap.add_argument("--full-backward", action="store_true",
                     help="A/B: run the decoder's backward over all 448 padded positions (the plain step) instead of the supervised "
                          "span (oasr_train_fwd_bwd_span: same loss and gradients, the forward covers 448 positions either way)")
+    ap.add_argument("--span-forward", action="store_true",
+                    help="opt-in, NOT the reference's computation shape: the decoder's FORWARD leaves the positions past the supervised "
+                         "span out as well (their logits are computed by the reference and read by nothing; same loss and gradients)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
@@ -429,7 +432,7 @@ def main():
             last = i == accum - 1
             net.loss_and_backward(mel, ti[sl], ty[sl], tl[sl], loss_scale=loss_scale, accumulation_steps=accum, loss_out=loss_buf,
                                   accumulate_loss=i > 0, segment_events=reducer.segment_events() if (reducer and last) else None,
-                                  text_ctx=ctx[i], span=spans[i] if spans else None)
+                                  text_ctx=ctx[i], span=spans[i] if spans else None, span_forward=bool(spans) and args.span_forward)
         div = 1.0
         if reducer:
             reducer.reduce()
@@ -521,8 +524,9 @@ def main():
                        "global_batch": world * B, "micro_batch": mb, "parallelism": f"dp{world}" + (f" ({args.reducer} gradient exchange, {args.bucket_mb:g} MiB buckets)" if world > 1 else ""),
                        "optimizer": "AdamW fused (unscale+clip+step), loss scale 65536",
                        "decoder_positions": ("trimmed to ceil16(max text_len) per micro-batch: %s (opt-in, not the reference shape)" % ctx)
-                       if args.trim_padding else ("448 forward (padded, as the reference); backward over the supervised span: mean "
-                                                  f"{span_rows_mean:.1f} of 448 token rows per clip (exact: the rows left out are zeros)" if spans
+                       if args.trim_padding else (("forward AND backward over the supervised span (opt-in --span-forward, not the reference shape): mean "
+                                                   if args.span_forward else "448 forward (padded, as the reference); backward over the supervised span: mean ")
+                                                  + f"{span_rows_mean:.1f} of 448 token rows per clip (exact: the rows left out are zeros)" if spans
                                                   else "448 (padded, as the reference), forward and backward")},
             "step_model_tflops_per_gpu": round(step_tflops, 1),
             "step_frac_of_mfma_peak": round(step_tflops / PEAK_BF16_TFLOPS, 4),

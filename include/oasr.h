@@ -132,9 +132,12 @@ int oasr_train_fwd_bwd_s(oasr_ctx*, const float* mel, const int64_t* tokens, con
  * chunks that can carry gradient first and the decoder's backward GEMMs / LayerNorms / attention run over those rows only
  * (olmoasr_amd/csrc/engine.hip).  Loss and gradients equal oasr_train_fwd_bwd's up to fp32 summation order.  Falls back to the
  * plain step when n_text_ctx is not a multiple of 64 or B > 512. */
+#define OASR_SPAN_FORWARD_ALL 0    /* the reference's shape: the decoder's forward covers all n_text_ctx positions */
+#define OASR_SPAN_FORWARD_ACTIVE 1 /* opt-in: the forward leaves the positions past the span out too -- their logits exist in the reference
+                                    * (model.py:768-770 over the padded context) but nothing reads them: loss and gradients unchanged */
 int oasr_train_fwd_bwd_span(oasr_ctx*, const float* mel, const int64_t* tokens, const int64_t* targets, const int32_t* text_len,
-                            const int32_t* span_host, int B, float loss_scale, float inv_accum, float* loss_out, int accumulate_loss,
-                            void** seg_events, void* workspace, size_t workspace_bytes, void* stream);
+                            const int32_t* span_host, int forward_rows, int B, float loss_scale, float inv_accum, float* loss_out,
+                            int accumulate_loss, void** seg_events, void* workspace, size_t workspace_bytes, void* stream);
 
 /* The same micro-step cut at the logits, for torch.autograd: OLMoASR.forward in training mode (olmoasr/model.py:856-887) followed by
  * the CALLER's loss and .backward() (train_timestamps.py:1440-1454 unchanged).  train_fwd: fp32 logits [B, S, rows], every saved

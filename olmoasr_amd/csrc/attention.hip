@@ -201,6 +201,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
   const int myq = q0 + wave * 32 + (lane & 31);
   const int myq_c = myq < a.Tq ? myq : a.Tq - 1;
   const bool krows = ROWS && a.k_rows != nullptr;  // (block-uniform)
+  // span-limited FORWARD (opt-in of the span step): query positions >= q_span[b] are not computed at all -- no output row written
+  const int q_lim = (ROWS && a.q_span) ? min(a.q_span[b], a.Tq) : a.Tq;
+  if (ROWS && q0 >= q_lim) return;  // (block-uniform, before any barrier)
+  const bool w_act = !ROWS || q0 + wave * 32 < q_lim;  // (wave-uniform) an inactive wave computes on whatever its rows hold and stores nothing
 
   const bf16_t* qp = ROWS ? a.q + (long)chunk_row(a.q_rows, b, myq_c) * a.ldq + h * 64 : a.q + (long)b * a.bsq + (long)myq_c * a.ldq + h * 64;
   bf16x8_t qf[4];
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
   {
     // (the loop ended on a barrier: the K/V stages are free; 4 KiB of staging per wave)
     char* stg = smem + wave * 4096;
-    const int rows_valid = a.Tq - (q0 + wave * 32);  // may be <= 0 or > 32
+    const int rows_valid = w_act ? a.Tq - (q0 + wave * 32) : 0;  // may be <= 0 or > 32
     // (a wave's 32 rows lie inside one chunk; past Tq the table entry is a sentinel and rows_valid <= 0 keeps it unused)
     const long row0 = ROWS ? (long)chunk_row(a.q_rows, b, q0 + wave * 32) * a.ldo + h * 64 : (long)b * a.bso + (long)(q0 + wave * 32) * a.ldo + h * 64;
     store_rows_bf16(stg, oT, inv, a.o + row0, a.ldo, rows_valid, lane);
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
         }
       store_rows_bf16(stg, oT, 1.0f, a.o_lo + row0, a.ldo, rows_valid, lane);
     }
-    if (myq < a.Tq && hh == 0 && a.lse) a.lse[((long)b * a.H + h) * a.Tq + myq] = (m_run + __builtin_amdgcn_logf(l_tot)) * LN2;
+    if (myq < a.Tq && hh == 0 && a.lse && w_act) a.lse[((long)b * a.H + h) * a.Tq + myq] = (m_run + __builtin_amdgcn_logf(l_tot)) * LN2;
   }
 }
 
@@ -1425,19 +1429,6 @@ int check_args(const AttnArgs& a, bool bwd) {
 
 void attention_set_pingpong(int on) { g_attn_pingpong = on; }
 
-// hipFuncSetAttribute is per device: remember it per device id (one host thread drives a context, include/oasr.h)
-static int ensure_dkdv_pp_lds(const void* fn) {
-  static bool done[2][64] = {};
-  int dev = 0;
-  OASR_CHECK_HIP(hipGetDevice(&dev));
-  const int which = fn == (const void*)attn_bwd_dkdv_pp_kernel<true> ? 1 : 0;
-  if (dev < 0 || dev >= 64 || !done[which][dev]) {
-    OASR_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, KLDS));
-    if (dev >= 0 && dev < 64) done[which][dev] = true;
-  }
-  return OASR_OK;
-}
-
 int launch_attention_fwd(const AttnArgs& a, hipStream_t s) {
   int rc = check_args(a, false);
   if (rc) return rc;
@@ -1480,8 +1471,9 @@ int launch_attention_bwd(const AttnArgs& a, hipStream_t s) {
     if (pp) {
       if (rows) hipLaunchKernelGGL(attn_bwd_dq_pp_kernel<true>, dim3(cdiv(a.Tq, 256) * a.B * a.H), dim3(512), 0, s, a);
       else hipLaunchKernelGGL(attn_bwd_dq_pp_kernel<false>, dim3(cdiv(a.Tq, 256) * a.B * a.H), dim3(512), 0, s, a);
-      const void* fn = rows ? (const void*)attn_bwd_dkdv_pp_kernel<true> : (const void*)attn_bwd_dkdv_pp_kernel<false>;
-      rc = ensure_dkdv_pp_lds(fn);
+      static LdsAttrOnce attr_rows, attr_plain;
+      rc = rows ? ensure_dynamic_lds(attr_rows, (const void*)attn_bwd_dkdv_pp_kernel<true>, KLDS)
+                : ensure_dynamic_lds(attr_plain, (const void*)attn_bwd_dkdv_pp_kernel<false>, KLDS);
       if (rc) return rc;
       if (rows) hipLaunchKernelGGL(attn_bwd_dkdv_pp_kernel<true>, dim3(cdiv(a.Tk, 256) * a.B * a.H), dim3(512), KLDS, s, a);
       else hipLaunchKernelGGL(attn_bwd_dkdv_pp_kernel<false>, dim3(cdiv(a.Tk, 256) * a.B * a.H), dim3(512), KLDS, s, a);

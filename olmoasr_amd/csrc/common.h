@@ -41,6 +41,22 @@ void oasr_set_error(const char* fmt, ...);
 
 #define OASR_LAUNCH_CHECK() OASR_CHECK_HIP(hipGetLastError())
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel: a process that touches a second GPU must set
+// it there too.  One of these per launch site (a function-local static); setting it again is harmless, so two host threads racing on
+// a slot only repeat the call.
+struct LdsAttrOnce {
+  bool done[64] = {};
+};
+static inline int ensure_dynamic_lds(LdsAttrOnce& st, const void* fn, int bytes) {
+  int dev = 0;
+  OASR_CHECK_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !st.done[dev]) {
+    OASR_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    if (dev >= 0 && dev < 64) st.done[dev] = true;
+  }
+  return OASR_OK;
+}
+
 // ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved) -------------------------------------------
 __host__ __device__ __forceinline__ float bf2f(bf16_t h) {
   union { uint32_t u; float f; } c;

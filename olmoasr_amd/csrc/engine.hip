@@ -296,6 +296,9 @@ struct Runner {
   const int32_t* dec_rows = nullptr;  // chunk-row table [B][OASR_ROWTAB] (device) or null = plain [B, S] rows
   const int32_t* dec_span = nullptr;  // [B] spans rounded up to 64 (device); backward only
   long dec_rows_bwd = 0;              // active decoder rows (0 = all B*S)
+  // opt-in (OASR_SPAN_FORWARD_ACTIVE): the decoder's FORWARD covers the active rows only as well.  The rows left out are the padded
+  // positions whose logits the reference computes and nothing ever reads (no supervised query attends to them, the loss ignores them).
+  long dec_rows_fwd = 0;
 
   int linear(const T* x, long M, int K, const T* W, int N, const float* bias, int act, const T* resid, T* out,
              T* out_pre) {
@@ -416,6 +419,7 @@ struct Runner {
     if (dec_rows && (causal || cross)) {  // a decoder attention of a span-limited step: chunked query rows (+ key rows for self-attention)
       a.q_rows = dec_rows;
       a.k_rows = cross ? nullptr : dec_rows;
+      if (dec_rows_fwd) a.q_span = dec_span;  // (the backward sets it itself)
     }
     return OASR_OK;
   }
@@ -525,7 +529,7 @@ struct Runner {
 
   int decoder_fwd(Plan& p, const int64_t* tokens, bool last_only = false) {
     const int d = c->d;
-    const long Md = (long)B * S;
+    const long Md = dec_rows_fwd ? dec_rows_fwd : (long)B * S;  // token rows the row-wise kernels run over
     RC(launch_embedding_fwd(tokens, c->P(c->tok_emb), c->P(c->dec_pos), p.dx0, B, S, d, c->V, st, dec_rows));
     const T* x = p.dx0;
     for (int i = 0; i < c->L_dec; ++i) {
@@ -1254,7 +1258,7 @@ static int oasr_train_fwd_bwd_s_impl(oasr_ctx* c, const float* mel, const int64_
 // The results differ from oasr_train_fwd_bwd's only by fp32 summation order (weight gradients sum over fewer, re-ordered token rows).
 template <typename T>
 static int oasr_train_fwd_bwd_span_impl(oasr_ctx* c, const float* mel, const int64_t* tokens, const int64_t* targets, const int32_t* text_len,
-                                       const int32_t* span_host, int B, float loss_scale, float inv_accum, float* loss_out,
+                                       const int32_t* span_host, int forward_rows, int B, float loss_scale, float inv_accum, float* loss_out,
                                        int accumulate_loss, void** ev, void* workspace, size_t workspace_bytes, void* stream) {
   const int S = c->S_max;
   const long Md = (long)B * S;
@@ -1271,7 +1275,8 @@ static int oasr_train_fwd_bwd_span_impl(oasr_ctx* c, const float* mel, const int
   r.dec_rows = p.rows;
   r.dec_span = p.span_dev;
   r.dec_rows_bwd = R;
-  // ---------------- forward (every position) ----------------
+  r.dec_rows_fwd = forward_rows == OASR_SPAN_FORWARD_ACTIVE ? R : 0;
+  // ---------------- forward (every position, unless the caller opted out of the padded ones) ----------------
   RC(r.encoder_fwd(p, mel));
   RC(r.decoder_fwd(p, tokens));
   // loss over the active rows (the other rows' targets are ignore_index: they add nothing to the sum and nothing to the count)
@@ -1281,18 +1286,19 @@ static int oasr_train_fwd_bwd_span_impl(oasr_ctx* c, const float* mel, const int
   return train_backward<T>(c, r, p, tokens, B, S, ev);
 }
 extern "C" int oasr_train_fwd_bwd_span(oasr_ctx* c, const float* mel, const int64_t* tokens, const int64_t* targets, const int32_t* text_len,
-                                       const int32_t* span_host, int B, float loss_scale, float inv_accum, float* loss_out,
+                                       const int32_t* span_host, int forward_rows, int B, float loss_scale, float inv_accum, float* loss_out,
                                        int accumulate_loss, void** ev, void* workspace, size_t workspace_bytes, void* stream) {
   RC(check_bound(c, true));
   OASR_REQUIRE(mel && tokens && targets && text_len && span_host && loss_out && workspace && B > 0, "oasr_train_fwd_bwd_span: bad args");
+  OASR_REQUIRE(forward_rows == OASR_SPAN_FORWARD_ALL || forward_rows == OASR_SPAN_FORWARD_ACTIVE, "oasr_train_fwd_bwd_span: forward_rows");
   OASR_REQUIRE(workspace_bytes >= oasr_workspace_bytes(c, B, c->S_max, OASR_MODE_TRAIN), "oasr_train_fwd_bwd_span: workspace too small");
   if ((c->S_max % 64) != 0 || c->S_max > 64 * OASR_ROWTAB || B > 512)  // no chunking for this shape: the plain step (same results)
     return oasr_train_fwd_bwd_s(c, mel, tokens, targets, text_len, B, c->S_max, loss_scale, inv_accum, loss_out, accumulate_loss, nullptr, ev,
                                 workspace, workspace_bytes, stream);
-  return c->f32 ? oasr_train_fwd_bwd_span_impl<float>(c, mel, tokens, targets, text_len, span_host, B, loss_scale, inv_accum, loss_out,
-                                                      accumulate_loss, ev, workspace, workspace_bytes, stream)
-                : oasr_train_fwd_bwd_span_impl<bf16_t>(c, mel, tokens, targets, text_len, span_host, B, loss_scale, inv_accum, loss_out,
-                                                       accumulate_loss, ev, workspace, workspace_bytes, stream);
+  return c->f32 ? oasr_train_fwd_bwd_span_impl<float>(c, mel, tokens, targets, text_len, span_host, forward_rows, B, loss_scale, inv_accum,
+                                                      loss_out, accumulate_loss, ev, workspace, workspace_bytes, stream)
+                : oasr_train_fwd_bwd_span_impl<bf16_t>(c, mel, tokens, targets, text_len, span_host, forward_rows, B, loss_scale, inv_accum,
+                                                       loss_out, accumulate_loss, ev, workspace, workspace_bytes, stream);
 }
 
 // ---- the same micro-step cut at the logits, for torch.autograd (OLMoASR.forward in training mode, olmoasr/model.py:856-887 followed

@@ -139,6 +139,7 @@ __device__ __forceinline__ float dot64(const float* __restrict__ row, const floa
 __global__ __launch_bounds__(64) void attn_fwd_f32_kernel(AttnArgsF a) {
   __shared__ float qs[64], ps[MAX_T];
   const int i = blockIdx.x, h = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
+  if (a.q_span && i >= a.q_span[b]) return;  // span-limited forward: this query row is not computed
   qs[lane] = a.q[tok_off(a.q_rows, b, i, a.ldq, a.bsq) + h * 64 + lane];
   __syncthreads();
   const int nk = visible_keys(a, b, i);

@@ -1231,13 +1231,9 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
 
 template <bool TA, bool TB, int FBN, int NWN, int NSTAGE, bool SWAP, bool CSUM = false>
 int launch_fast_cfg(const GemmArgs& a, hipStream_t stream) {
-  static bool attr = false;
+  static LdsAttrOnce attr;
   const int lds = NSTAGE * (FBM * 64 * 2 + FBN * 64 * 2);
-  if (!attr) {
-    OASR_CHECK_HIP(hipFuncSetAttribute((const void*)oasr_gemm_fast_kernel<TA, TB, FBN, NWN, NSTAGE, SWAP, CSUM>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr = true;
-  }
+  { const int rc_ = ensure_dynamic_lds(attr, (const void*)oasr_gemm_fast_kernel<TA, TB, FBN, NWN, NSTAGE, SWAP, CSUM>, lds); if (rc_) return rc_; }
   const int tiles = cdiv(a.M, FBM) * cdiv(a.N, FBN);
   dim3 grid(tiles, a.split_k);
   if (!SWAP && (a.split_k & 7) == 0) grid = dim3(tiles * a.split_k, 1);  // split index tied to the XCD (see kernel)
@@ -1265,13 +1261,9 @@ int launch_fast_cfg(const GemmArgs& a, hipStream_t stream) {
 
 template <bool TA, bool TB, bool SWAP, bool CSUM, int DMA>
 int launch_pp_variant(const GemmArgs& a, hipStream_t stream) {
-  static bool attr = false;
+  static LdsAttrOnce attr;
   const int lds = 2 * 4 * 128 * 64 * 2 + 8 * 256;  // two K-tile buffers + the epilogue's per-wave bias rows
-  if (!attr) {
-    OASR_CHECK_HIP(hipFuncSetAttribute((const void*)oasr_gemm_pp_kernel<TA, TB, SWAP, CSUM, DMA>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr = true;
-  }
+  { const int rc_ = ensure_dynamic_lds(attr, (const void*)oasr_gemm_pp_kernel<TA, TB, SWAP, CSUM, DMA>, lds); if (rc_) return rc_; }
   const int tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
   dim3 grid(tiles, a.split_k);
   if (!SWAP && (a.split_k & 7) == 0) grid = dim3(tiles * a.split_k, 1);
@@ -1420,12 +1412,9 @@ int launch_fast_t(const GemmArgs& a, hipStream_t stream) {
 
 template <bool TA, bool TB>
 int launch_t(const GemmArgs& a, hipStream_t stream) {
-  static bool attr = false;
+  static LdsAttrOnce attr;
   const int lds = 4 * TILE_BYTES;
-  if (!attr) {
-    OASR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_kernel<TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr = true;
-  }
+  { const int rc_ = ensure_dynamic_lds(attr, (const void*)gemm_kernel<TA, TB>, lds); if (rc_) return rc_; }
   const int tiles = cdiv(a.M, BM) * cdiv(a.N, BN);
   dim3 grid(tiles, a.split_k);
   hipEvent_t e0 = nullptr, e1 = nullptr;

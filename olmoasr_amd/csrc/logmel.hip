@@ -604,19 +604,13 @@ extern "C" int oasr_log_mel(const void* pcm, int pcm_dtype, int B, int n_samples
   if (!use_mfma_dft) {
     const size_t xlds = sizeof(float) * XLDS_FLOATS;
     const dim3 xgrid((unsigned)(cdiv(n_frames, XT) * B));
-    static bool attr16 = false, attr32 = false;
+    static LdsAttrOnce attr16, attr32;
     if (pcm_dtype == 1) {
-      if (!attr16) {
-        OASR_CHECK_HIP(hipFuncSetAttribute((const void*)logmel_fft<int16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)xlds));
-        attr16 = true;
-      }
+      { const int rc_ = ensure_dynamic_lds(attr16, (const void*)logmel_fft<int16_t>, (int)xlds); if (rc_) return rc_; }
       hipLaunchKernelGGL(logmel_fft<int16_t>, xgrid, dim3(256), xlds, stream, (const int16_t*)pcm, n_samples, n_frames, t->fft_tab,
                          t->mel_words, t->mel_span, mel, clipmax);
     } else {
-      if (!attr32) {
-        OASR_CHECK_HIP(hipFuncSetAttribute((const void*)logmel_fft<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)xlds));
-        attr32 = true;
-      }
+      { const int rc_ = ensure_dynamic_lds(attr32, (const void*)logmel_fft<float>, (int)xlds); if (rc_) return rc_; }
       hipLaunchKernelGGL(logmel_fft<float>, xgrid, dim3(256), xlds, stream, (const float*)pcm, n_samples, n_frames, t->fft_tab, t->mel_words,
                          t->mel_span, mel, clipmax);
     }
@@ -630,19 +624,13 @@ extern "C" int oasr_log_mel(const void* pcm, int pcm_dtype, int B, int n_samples
   const size_t lds = sizeof(float) * (((REG0 + 3) & ~3) + KS * SLAB_LD);
   dim3 grid(cdiv(n_frames, FT), B);
   if (pcm_dtype == 1) {
-    static bool attr = false;
-    if (!attr) {
-      OASR_CHECK_HIP(hipFuncSetAttribute((const void*)logmel_main<int16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr = true;
-    }
+    static LdsAttrOnce attr;
+    { const int rc_ = ensure_dynamic_lds(attr, (const void*)logmel_main<int16_t>, (int)lds); if (rc_) return rc_; }
     hipLaunchKernelGGL(logmel_main<int16_t>, grid, dim3(256), lds, stream, (const int16_t*)pcm, n_samples, n_frames,
                        t->basis, t->melfilt, mel, clipmax);
   } else {
-    static bool attr = false;
-    if (!attr) {
-      OASR_CHECK_HIP(hipFuncSetAttribute((const void*)logmel_main<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr = true;
-    }
+    static LdsAttrOnce attr;
+    { const int rc_ = ensure_dynamic_lds(attr, (const void*)logmel_main<float>, (int)lds); if (rc_) return rc_; }
     hipLaunchKernelGGL(logmel_main<float>, grid, dim3(256), lds, stream, (const float*)pcm, n_samples, n_frames, t->basis,
                        t->melfilt, mel, clipmax);
   }

@@ -760,7 +760,8 @@ class OLMoASR(nn.Module):
 
     def loss_and_backward(self, mel: Tensor, tokens: Tensor, targets: Tensor, text_len: Tensor, *, loss_scale: float = 1.0,
                           accumulation_steps: int = 1, loss_out: Optional[Tensor] = None, accumulate_loss: bool = False,
-                          return_logits: bool = False, segment_events=None, text_ctx: Optional[int] = None, span=None):
+                          return_logits: bool = False, segment_events=None, text_ctx: Optional[int] = None, span=None,
+                          span_forward: bool = False):
         """forward + F.cross_entropy(ignore_index=51864)/accumulation_steps + backward of (loss * loss_scale)
         (train_timestamps.py:1440-1454).  Gradients accumulate into ``flat_grads``.  Returns (loss tensor [1], logits|None).
 
@@ -769,6 +770,8 @@ class OLMoASR(nn.Module):
         derive it here from ``targets`` / ``text_len`` (one small device->host copy); a HOST int sequence / CPU tensor [B]: the
         caller's own bound (the data loader knows the token counts: every target at or past ``span[b]`` must be the ignore
         index and ``span[b] >= text_len[b]``); ``None`` / ``False``: the plain step.  Not combinable with ``return_logits`` / ``text_ctx``.
+        ``span_forward=True`` (opt-in, with ``span``): the decoder's forward leaves the positions past the span out as well -- the
+        reference computes their logits (it pads every sample to 448) and nothing reads them; loss and gradients are unchanged.
 
         ``text_ctx`` (opt-in, not in the reference): run the decoder over the first ``text_ctx`` positions only.  With
         ``text_ctx >= max(text_len)`` the loss and gradients equal the full-context ones (the rest is padding the
@@ -804,7 +807,8 @@ class OLMoASR(nn.Module):
             assert span_h.numel() == B and not span_h.is_cuda
             with torch.cuda.device(mel.device):
                 N.check(N.lib().oasr_train_fwd_bwd_span(self._ctx, N.ptr(mel), N.ptr(tokens), N.ptr(targets), N.ptr(text_len),
-                                                        C.c_void_p(span_h.data_ptr()), B, float(loss_scale), 1.0 / accumulation_steps,
+                                                        C.c_void_p(span_h.data_ptr()), int(bool(span_forward)), B, float(loss_scale),
+                                                        1.0 / accumulation_steps,
                                                         N.ptr(loss_out), int(accumulate_loss), ev, N.ptr(ws), ws.numel(), N.stream_ptr()),
                         "oasr_train_fwd_bwd_span")
             return loss_out, None

@@ -51,7 +51,7 @@ def _batch_vs_singles(variant, B, dtype, tol_loss, tol_total, tol_tensor, span_m
         assert torch.isfinite(ref_flat).all() and float(ref_flat.abs().max()) > 0
         for mode in span_modes:
             net.zero_grad()
-            loss, _ = net.loss_and_backward(mel, ti, ty, tl, loss_scale=SC, span=(True if mode == "span" else None))
+            loss, _ = net.loss_and_backward(mel, ti, ty, tl, loss_scale=SC, span=(True if mode != "plain" else None), span_forward=mode == "span-forward")
             torch.cuda.synchronize()
             total = _rel(net.flat_grads, ref_flat)
             worst = max((_rel(p.grad, ref[n]), n) for n, p in net.named_parameters())
@@ -67,12 +67,12 @@ def _batch_vs_singles(variant, B, dtype, tol_loss, tol_total, tol_tensor, span_m
 
 def test_medium_b128_step_equals_sum_of_single_clip_steps_bf16():
     # (gradients: fp32 atomics in another order + bf16 activations whose GEMM tiles are scheduled differently at M = 192,000 than at 1,500)
-    _batch_vs_singles("medium", 128, "bfloat16", tol_loss=2e-5, tol_total=2e-3, tol_tensor=2e-3, span_modes=("plain", "span"))
+    _batch_vs_singles("medium", 128, "bfloat16", tol_loss=2e-5, tol_total=2e-3, tol_tensor=2e-3, span_modes=("plain", "span", "span-forward"))
 
 
 def test_medium_batch_step_equals_sum_of_single_clip_steps_fp32():
     # the fp32 validation engine keeps 2x the bytes per activation and runs on plain VALU kernels: B = 8 keeps the test in seconds
-    _batch_vs_singles("medium", 8, "float32", tol_loss=1e-6, tol_total=1e-5, tol_tensor=1e-4, span_modes=("plain", "span"))
+    _batch_vs_singles("medium", 8, "float32", tol_loss=1e-6, tol_total=1e-5, tol_tensor=1e-4, span_modes=("plain", "span", "span-forward"))
 
 
 def _ref_attention_bh(q, k, v, causal, kv_len_b):

@@ -189,16 +189,16 @@ def test_span_step_equals_plain_step(variant, B, dtype):
     torch.cuda.synchronize()
     g0 = _grads_by_tensor(net)
     f0 = net.flat_grads.clone()
-    for mode in ("derived", "host", "loose"):
+    for mode in ("derived", "host", "loose", "forward"):
         net.zero_grad()
-        if mode == "derived":
+        if mode in ("derived", "forward"):  # "forward": the opt-in that also leaves the padded positions out of the decoder's forward
             span = True
         else:
             span = net.supervised_span(ty, tl)
             assert span.tolist() == tl.cpu().tolist()  # the synthetic targets are supervised exactly up to text_len
             if mode == "loose":  # any upper bound is legal: more rows than needed, same result
                 span = (span + torch.tensor([0, 70, 500, 1, 64, 129, 13, 5, 300][:B], dtype=torch.int32)).clamp(max=448)
-        loss1, lg = net.loss_and_backward(mel, ti, ty, tl, loss_scale=1024.0, span=span)
+        loss1, lg = net.loss_and_backward(mel, ti, ty, tl, loss_scale=1024.0, span=span, span_forward=mode == "forward")
         torch.cuda.synchronize()
         assert lg is None
         tol_l, tol_g, tol_t = (1e-6, 2e-4, 2e-3) if dtype == "bfloat16" else (1e-6, 1e-5, 1e-4)
