@@ -255,6 +255,22 @@ def hbm_kernel_rooflines(net, dims, mb, dev):
     tgt = torch.randint(0, 50000, (rows_d,), device=dev)
     line("ce_kernel", timed(lambda: ops.cross_entropy_(lg, V, tgt, PAD_ID)), rows_d * 4 * Vp, f"[{rows_d}, {Vp}] bf16 logits -> dlogits in place")
     del lg
+    # KV-cached greedy decode step (an HBM-bound sub-path): one new token for ONE sequence streams every decoder weight
+    # once (bf16: 14 d^2 per layer + the tied logits matrix), the cross-attention K/V of every layer and the self-attention cache so far
+    L_dec, S_pos = dims.n_text_layer, 32
+    xa = torch.randn(1, dims.n_audio_ctx, d, device=dev).to(BF)
+    state = net.kv_cache_begin(xa)
+    tok = torch.tensor([50257], device=dev)
+    for _ in range(S_pos):  # fill positions 0 .. S_pos-1, then time steps at a fixed position (rewinding the cursor: same work each time)
+        net.kv_cache_step(state, tok)
+
+    def dstep():
+        state["pos"] = S_pos
+        net.kv_cache_step(state, tok)
+    dbytes = 2 * (L_dec * 14 * d * d + V * d) + 2 * L_dec * (dims.n_audio_ctx * 2 * d + S_pos * 2 * d) + 4 * V
+    line("decode_step(B=1)", timed(dstep, reps=20), dbytes,
+         f"one KV-cached decoder step of this model at position {S_pos}: bf16 decoder weights + tied logits matrix once, cross K/V [{dims.n_audio_ctx}, {2 * d}] x {L_dec} layers, self K/V so far; ~{8 * L_dec + 2} dependent launches (latency-bound, profiles/r02_decode_step.txt)")
+    del state, xa
     n = net.flat_params.numel()
     # (step count irrelevant for the timing; gradients are whatever the last step left, state is restored by nobody: run last)
     line("grad_stats+adamw_kernel", timed(lambda: net.optim_step(step=1, lr=0.0), reps=3), n * (28 + 2 + 4),
@@ -395,8 +411,12 @@ def main():
     else:  # no-recompute training keeps ~1.9 GiB of activations per medium clip: 128 clips = 240 GiB of the 288
         free = torch.cuda.mem_get_info(dev)[0]
         mb = 1
+        # head-room beside the saved activations: 24 GiB for the transient tensors of a step; with more than one rank RCCL's channel /
+        # proxy buffers (a few hundred MiB per peer over 7 xGMI links) and its staging for the bucketed exchange come out of the same
+        # HBM -- 8 GiB more, so a short box drops to micro-batch 64 instead of failing inside the first collective
+        margin = (24 << 30) + ((8 << 30) if world > 1 else 0)
         for cand in (128, 64, 32, 16, 8, 4, 2):
-            if cand <= B and B % cand == 0 and N.lib().oasr_workspace_bytes(net._ctx, cand, dims.n_text_ctx, 1) + (24 << 30) <= free:
+            if cand <= B and B % cand == 0 and N.lib().oasr_workspace_bytes(net._ctx, cand, dims.n_text_ctx, 1) + margin <= free:
                 mb = cand
                 break
         if ddp_path:  # same choice on every rank

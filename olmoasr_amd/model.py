@@ -700,9 +700,14 @@ class OLMoASR(nn.Module):
             return
         n_self, n_cross = 3 * B * self.dims.n_text_ctx * d, B * self.dims.n_audio_ctx * 2 * d
         esz = 4 if self._act_dtype == torch.float32 else 2
+        if bool((idx == torch.arange(B, device=idx.device)).all()):
+            return  # every beam continues itself: nothing moves
         flat = state["cache"][: (n_self + n_cross) * L * esz].view(self._act_dtype).view(L, n_self + n_cross)
-        rows = flat[:, :n_self].view(L, B, self.dims.n_text_ctx, 3 * d)[:, :, :pos]
-        rows.copy_(rows.index_select(1, idx))  # (index_select materialises the gathered rows before the copy back)
+        # layer by layer, and only the cached k | v columns (the q third of a row is the step's scratch slot): the gathered copy that
+        # index_select materialises before the write-back is B * pos * 2d elements at a time, not L times that plus the q slots
+        for layer in range(L):
+            rows = flat[layer, :n_self].view(B, self.dims.n_text_ctx, 3 * d)[:, :pos, d:]
+            rows.copy_(rows.index_select(0, idx))
 
     def kv_cache_check(self, state) -> None:
         """Synchronises the stream (oasr_decode_check); call once per decoded window, before reading the tokens back."""

@@ -66,13 +66,14 @@ def _batch_vs_singles(variant, B, dtype, tol_loss, tol_total, tol_tensor, span_m
 
 
 def test_medium_b128_step_equals_sum_of_single_clip_steps_bf16():
-    # (gradients: fp32 atomics in another order + bf16 activations whose GEMM tiles are scheduled differently at M = 192,000 than at 1,500)
-    _batch_vs_singles("medium", 128, "bfloat16", tol_loss=2e-5, tol_total=2e-3, tol_tensor=2e-3, span_modes=("plain", "span", "span-forward"))
+    # Measured (profiles/r04_span_step.txt): loss equal to the last printed digit, gradients rel-L2 1.3-1.8e-6, worst tensor 7e-6 -- only the
+    # order of the fp32 atomic accumulation differs; every per-row result is bit-identical whatever the batch.  Bounds 50x above that.
+    _batch_vs_singles("medium", 128, "bfloat16", tol_loss=2e-6, tol_total=1e-4, tol_tensor=4e-4, span_modes=("plain", "span", "span-forward"))
 
 
 def test_medium_batch_step_equals_sum_of_single_clip_steps_fp32():
     # the fp32 validation engine keeps 2x the bytes per activation and runs on plain VALU kernels: B = 8 keeps the test in seconds
-    _batch_vs_singles("medium", 8, "float32", tol_loss=1e-6, tol_total=1e-5, tol_tensor=1e-4, span_modes=("plain", "span", "span-forward"))
+    _batch_vs_singles("medium", 8, "float32", tol_loss=1e-6, tol_total=1e-5, tol_tensor=1e-4, span_modes=("plain", "span", "span-forward"))  # measured 1.6e-6 / 3.2e-6
 
 
 def _ref_attention_bh(q, k, v, causal, kv_len_b):

@@ -201,7 +201,7 @@ def test_span_step_equals_plain_step(variant, B, dtype):
         loss1, lg = net.loss_and_backward(mel, ti, ty, tl, loss_scale=1024.0, span=span, span_forward=mode == "forward")
         torch.cuda.synchronize()
         assert lg is None
-        tol_l, tol_g, tol_t = (1e-6, 2e-4, 2e-3) if dtype == "bfloat16" else (1e-6, 1e-5, 1e-4)
+        tol_l, tol_g, tol_t = (1e-6, 1e-5, 1e-4)  # measured: loss equal to 7 digits, gradients 1e-7 (total) / 1e-6 (worst tensor), both engines
         assert abs(float(loss1) - float(loss0)) <= tol_l * abs(float(loss0)), (mode, float(loss1), float(loss0))
         worst = max((_rel(p.grad, g0[n]), n) for n, p in net.named_parameters())
         total = _rel(net.flat_grads, f0)
