@@ -215,6 +215,20 @@ int oasr_pick_tokens(const float* logits, int64_t ld, int V, int64_t rows, const
 int oasr_pick_tokens_ts(const float* logits, int64_t ld, int V, int64_t rows, const float* mask, const float* mask2,
                         const int64_t* history, int64_t history_ld, int n_history, int timestamp_begin, int eot, int no_timestamps,
                         int max_initial_index, int64_t* tok, float* logprob, void* stream);
+/* Beam search and sampling on the SAME filtered distribution (suppress masks; with n_history >= 0 also ApplyTimestampRules from the
+ * device-resident history, as above; n_history < 0: masks only -- the without_timestamps mode).
+ * topk: tok / logprob [rows, K] = the K (<= 16) largest log_softmax values and their tokens, descending, ties to the lower id --
+ *       whisper.decoding.BeamSearchDecoder.update's logprobs.topk(beam_size + 1) (the reference's long-form eval is beam 5,
+ *       scripts/eval/eval.py:2077-2084).
+ * sample: one draw per row from softmax(filtered logits / temperature) by inverse CDF on uniforms[row] in [0, 1) (the caller's
+ *       generator), logprob = the draw's log_softmax at temperature 1 -- GreedyDecoder.update at temperature > 0 (the fallback
+ *       temperatures of olmoasr/transcribe.py:193-233). */
+int oasr_topk_tokens(const float* logits, int64_t ld, int V, int64_t rows, const float* mask, const float* mask2, const int64_t* history,
+                     int64_t history_ld, int n_history, int timestamp_begin, int eot, int no_timestamps, int max_initial_index, int K,
+                     int64_t* tok, float* logprob, void* stream);
+int oasr_sample_tokens(const float* logits, int64_t ld, int V, int64_t rows, const float* mask, const float* mask2, const int64_t* history,
+                       int64_t history_ld, int n_history, int timestamp_begin, int eot, int no_timestamps, int max_initial_index,
+                       float temperature, const float* uniforms, int64_t* tok, float* logprob, void* stream);
 /* Measurement / test hooks (GEMM launch timing for bench.py, kernel-path forcing, hardware probes) are declared in
  * include/oasr_testing.h: they are exported by the same library but are not part of the product surface. */
 

@@ -99,6 +99,8 @@ def _declare(lib):
         "oasr_cast_f32_bf16": (i32, [vp, vp, i64, vp]),
         "oasr_pick_tokens": (i32, [vp, i64, i32, i64, vp, vp, vp, vp, vp]),
         "oasr_pick_tokens_ts": (i32, [vp, i64, i32, i64, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp, vp, vp]),
+        "oasr_topk_tokens": (i32, [vp, i64, i32, i64, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
+        "oasr_sample_tokens": (i32, [vp, i64, i32, i64, vp, vp, vp, i64, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp]),
         "oasr_probe_tr16": (i32, [vp, vp, vp]),
         "oasr_probe_lds_oob": (i32, [vp, vp, vp]),
         "oasr_profile_gemm": (i32, [i32]),

@@ -172,6 +172,19 @@ extern "C" int oasr_pick_tokens_ts(const float* logits, int64_t ld, int V, int64
                                max_initial_index, tok, logprob, (hipStream_t)stream);
 }
 
+extern "C" int oasr_topk_tokens(const float* logits, int64_t ld, int V, int64_t rows, const float* mask, const float* mask2,
+                                const int64_t* history, int64_t history_ld, int n_history, int timestamp_begin, int eot, int no_timestamps,
+                                int max_initial_index, int K, int64_t* tok, float* logprob, void* stream) {
+  return launch_topk_tokens_ts(logits, ld, V, rows, mask, mask2, history, history_ld, n_history, timestamp_begin, eot, no_timestamps,
+                               max_initial_index, K, tok, logprob, (hipStream_t)stream);
+}
+extern "C" int oasr_sample_tokens(const float* logits, int64_t ld, int V, int64_t rows, const float* mask, const float* mask2,
+                                  const int64_t* history, int64_t history_ld, int n_history, int timestamp_begin, int eot, int no_timestamps,
+                                  int max_initial_index, float temperature, const float* uniforms, int64_t* tok, float* logprob, void* stream) {
+  return launch_sample_tokens_ts(logits, ld, V, rows, mask, mask2, history, history_ld, n_history, timestamp_begin, eot, no_timestamps,
+                                 max_initial_index, temperature, uniforms, tok, logprob, (hipStream_t)stream);
+}
+
 extern "C" int oasr_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream) {
   return launch_cast_f32_bf16(src, (bf16_t*)dst, n, (hipStream_t)stream);
 }

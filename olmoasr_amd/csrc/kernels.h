@@ -219,6 +219,16 @@ int launch_pick_tokens_ts(const float* logits, long ld, int V, long rows, const 
                           long hist_ld, int n_hist, int ts_begin, int eot, int no_ts, int max_initial_index, int64_t* tok, float* logprob,
                           hipStream_t s);
 
+// the K best (log_softmax, token) pairs per row over the same filtered distribution (n_hist < 0: masks only, no timestamp rules):
+// tok / logprob [rows][K] -- BeamSearchDecoder.update's topk(beam_size + 1)
+int launch_topk_tokens_ts(const float* logits, long ld, int V, long rows, const float* mask, const float* mask2, const int64_t* hist,
+                          long hist_ld, int n_hist, int ts_begin, int eot, int no_ts, int max_initial_index, int K, int64_t* tok,
+                          float* logprob, hipStream_t s);
+// one draw per row from softmax(filtered logits / temperature) by inverse CDF on u[row] in [0, 1); logprob at temperature 1
+int launch_sample_tokens_ts(const float* logits, long ld, int V, long rows, const float* mask, const float* mask2, const int64_t* hist,
+                            long hist_ld, int n_hist, int ts_begin, int eot, int no_ts, int max_initial_index, float temperature,
+                            const float* u, int64_t* tok, float* logprob, hipStream_t s);
+
 // ---- optimizer (flat fp32 arenas) ---------------------------------------------------------------------------
 // stats[0] = sum g^2 (of the *scaled* grads), stats[1] = found_inf flag (nonzero if any non-finite)
 int launch_grad_stats(const float* g, long n, double* partial /*[1024]*/, float* stats /*[2]*/, hipStream_t s);

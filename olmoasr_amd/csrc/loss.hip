@@ -324,7 +324,246 @@ __global__ __launch_bounds__(256) void pick_ts_kernel(const float* __restrict__ 
   }
 }
 
+// ---- beam search / sampling on the same filtered distribution ---------------------------------------------------------------------
+// whisper.decoding: BeamSearchDecoder.update takes, per beam, the beam_size + 1 best log-probabilities of log_softmax(filtered logits);
+// GreedyDecoder.update at temperature > 0 draws from Categorical(filtered logits / T) and scores the draw with the UN-tempered
+// log_softmax.  "Filtered" = SuppressBlank / SuppressTokens (the additive masks) and, in timestamp mode, ApplyTimestampRules -- the
+// predicate of pick_ts_kernel, restated once here as a struct so the two new kernels cannot drift apart (n_hist < 0: no timestamp rules).
+struct TsRules {
+  bool on, last_was_ts, pen_was_ts, first;
+  int ts_begin, eot, no_ts, ts_lo, ts_hi;
+  __device__ __forceinline__ bool dead(int c) const {
+    if (!on) return false;
+    const bool is_ts = c >= ts_begin;
+    bool d = c == no_ts;
+    if (last_was_ts) d = d || (pen_was_ts ? is_ts : c < eot);
+    if (is_ts) d = d || c < ts_lo || c > ts_hi;
+    else d = d || first;
+    return d;
+  }
+};
+// (all 256 threads call it; sh_last: 4 ints of LDS)
+__device__ __forceinline__ TsRules ts_rules(const int64_t* h, int n_hist, int ts_begin, int eot, int no_ts, int max_initial_index, int* sh_last) {
+  TsRules r;
+  r.on = n_hist >= 0;
+  r.ts_begin = ts_begin;
+  r.eot = eot;
+  r.no_ts = no_ts;
+  r.last_was_ts = r.pen_was_ts = r.first = false;
+  r.ts_lo = -1;
+  r.ts_hi = 0x7fffffff;
+  if (!r.on) return r;
+  int last_pos = -1;
+  for (int t = threadIdx.x; t < n_hist; t += 256)
+    if (h[t] >= ts_begin) last_pos = t;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) last_pos = max(last_pos, __shfl_xor(last_pos, o, 64));
+  if ((threadIdx.x & 63) == 0) sh_last[threadIdx.x >> 6] = last_pos;
+  __syncthreads();
+  last_pos = max(max(sh_last[0], sh_last[1]), max(sh_last[2], sh_last[3]));
+  r.last_was_ts = n_hist >= 1 && h[n_hist - 1] >= ts_begin;
+  r.pen_was_ts = n_hist < 2 || h[n_hist - 2] >= ts_begin;
+  if (last_pos >= 0) r.ts_lo = (int)h[last_pos] + ((r.last_was_ts && !r.pen_was_ts) ? 0 : 1);
+  r.first = n_hist == 0;
+  if (r.first && max_initial_index >= 0) r.ts_hi = ts_begin + max_initial_index;
+  return r;
+}
+// Filtered value of column c (-inf when masked)
+__device__ __forceinline__ float filt(const float* lr, const float* mask, const float* mask2, const TsRules& R, int c) {
+  float x = lr[c];
+  if (mask) x += mask[c];
+  if (mask2) x += mask2[c];
+  return (R.dead(c) || !(x > -INFINITY)) ? -INFINITY : x;
+}
+// pass 1 of both kernels: (max, sum-exp, argmax) of the text and the timestamp part -> M = row maximum, lse = log sum exp(x - M) over the
+// survivors, text_off = whether the "timestamp mass beats every text token" rule removes the text part.  Returns false for an empty row.
+struct RowStat {
+  float M, lse;
+  bool text_off, any;
+};
+__device__ __forceinline__ RowStat row_stat(const float* lr, int V, const float* mask, const float* mask2, const TsRules& R, PickPart* sh) {
+  PickPart text{-INFINITY, 0.f, 0x7fffffff}, stamp{-INFINITY, 0.f, 0x7fffffff};
+  for (int c = threadIdx.x; c < V; c += 256) {
+    const float x = filt(lr, mask, mask2, R, c);
+    if (!(x > -INFINITY)) continue;
+    PickPart& p = (R.on && c >= R.ts_begin) ? stamp : text;
+    if (x > p.m) {
+      p.s = p.s * __expf(p.m - x) + 1.f;
+      p.m = x;
+      p.i = c;
+    } else {
+      p.s += __expf(x - p.m);
+    }
+  }
+  text = pick_block_reduce(text, sh);
+  stamp = pick_block_reduce(stamp, sh);
+  RowStat st;
+  st.M = fmaxf(text.m, stamp.m);
+  st.any = st.M > -INFINITY;
+  st.text_off = false;
+  st.lse = 0.f;
+  if (st.any) {
+    const float a = text.m > -INFINITY ? text.s * __expf(text.m - st.M) : 0.f;
+    const float b = stamp.m > -INFINITY ? stamp.s * __expf(stamp.m - st.M) : 0.f;
+    st.lse = __logf(a + b);
+    st.text_off = stamp.m > -INFINITY && (text.m == -INFINITY || (__logf(b) - st.lse) > ((text.m - st.M) - st.lse));
+    if (st.text_off) {
+      st.M = stamp.m;
+      st.lse = __logf(stamp.s);
+    }
+  }
+  return st;
+}
+
+// K <= 16 best (log_softmax value, token) pairs of each row, descending, ties to the lower token id.  K + 1 passes over the row (it
+// stays in L2): pass j finds the best survivor strictly after pick j-1 in (value desc, id asc) order.
+__global__ __launch_bounds__(256) void topk_ts_kernel(const float* __restrict__ logits, long ld, int V, const float* __restrict__ mask,
+                                                     const float* __restrict__ mask2, const int64_t* __restrict__ hist, long hist_ld,
+                                                     int n_hist, int ts_begin, int eot, int no_ts, int max_initial_index, int K,
+                                                     int64_t* __restrict__ tok, float* __restrict__ logprob) {
+  __shared__ PickPart sh[4];
+  __shared__ int sh_last[4];
+  __shared__ float bv[4];
+  __shared__ int bi[4];
+  const float* lr = logits + (long)blockIdx.x * ld;
+  const TsRules R = ts_rules(hist ? hist + (long)blockIdx.x * hist_ld : nullptr, n_hist, ts_begin, eot, no_ts, max_initial_index, sh_last);
+  const RowStat st = row_stat(lr, V, mask, mask2, R, sh);
+  float prev_v = INFINITY;
+  int prev_i = -1;
+  for (int j = 0; j < K; ++j) {
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+    if (st.any) {
+      for (int c = threadIdx.x; c < V; c += 256) {
+        if (st.text_off && c < R.ts_begin) continue;
+        const float x = filt(lr, mask, mask2, R, c);
+        if (!(x > -INFINITY)) continue;
+        if (!(x < prev_v || (x == prev_v && c > prev_i))) continue;  // not after the previous pick
+        if (x > best) {  // (ascending c within a thread: the first of equal values wins)
+          best = x;
+          besti = c;
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(besti, o, 64);
+      if (ov > best || (ov == best && oi < besti)) {
+        best = ov;
+        besti = oi;
+      }
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+      bv[threadIdx.x >> 6] = best;
+      bi[threadIdx.x >> 6] = besti;
+    }
+    __syncthreads();
+    best = bv[0];
+    besti = bi[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+      if (bv[w] > best || (bv[w] == best && bi[w] < besti)) {
+        best = bv[w];
+        besti = bi[w];
+      }
+    if (threadIdx.x == 0) {
+      const bool ok = best > -INFINITY;
+      tok[(long)blockIdx.x * K + j] = ok ? besti : 0;
+      logprob[(long)blockIdx.x * K + j] = ok ? (best - st.M) - st.lse : -INFINITY;
+    }
+    prev_v = best;
+    prev_i = besti;
+  }
+}
+
+// One draw per row from softmax(filtered logits / temperature) by inverse CDF on the caller's uniform u[row] in [0, 1): every thread
+// owns a contiguous range of columns, the block scans the range masses, the owner of u * total walks its range.  logprob = the draw's
+// log_softmax at temperature 1 (what GreedyDecoder.update accumulates).
+__global__ __launch_bounds__(256) void sample_ts_kernel(const float* __restrict__ logits, long ld, int V, const float* __restrict__ mask,
+                                                       const float* __restrict__ mask2, const int64_t* __restrict__ hist, long hist_ld,
+                                                       int n_hist, int ts_begin, int eot, int no_ts, int max_initial_index, float inv_temp,
+                                                       const float* __restrict__ u, int64_t* __restrict__ tok, float* __restrict__ logprob) {
+  __shared__ PickPart sh[4];
+  __shared__ int sh_last[4];
+  __shared__ float part[256];
+  __shared__ int pick_sh;
+  const float* lr = logits + (long)blockIdx.x * ld;
+  const TsRules R = ts_rules(hist ? hist + (long)blockIdx.x * hist_ld : nullptr, n_hist, ts_begin, eot, no_ts, max_initial_index, sh_last);
+  const RowStat st = row_stat(lr, V, mask, mask2, R, sh);
+  const int per = (V + 255) / 256, c0 = threadIdx.x * per, c1 = min(V, c0 + per);
+  float mass = 0.f;
+  if (st.any)
+    for (int c = c0; c < c1; ++c) {
+      if (st.text_off && c < R.ts_begin) continue;
+      const float x = filt(lr, mask, mask2, R, c);
+      if (x > -INFINITY) mass += __expf((x - st.M) * inv_temp);
+    }
+  part[threadIdx.x] = mass;
+  if (threadIdx.x == 0) pick_sh = -1;
+  __syncthreads();
+  if (threadIdx.x == 0 && st.any) {  // (256 additions: not worth a parallel scan)
+    float total = 0.f;
+    for (int t = 0; t < 256; ++t) total += part[t];
+    const float target = u[blockIdx.x] * total;
+    float acc = 0.f;
+    int owner = -1, last_nz = -1;
+    for (int t = 0; t < 256; ++t) {
+      if (part[t] > 0.f) last_nz = t;
+      if (owner < 0 && part[t] > 0.f && target < acc + part[t]) owner = t;
+      if (owner < 0) acc += part[t];
+    }
+    if (owner < 0) {  // rounding pushed the target past the end: the last range with any mass
+      owner = last_nz;
+      acc = total - part[last_nz];
+    }
+    // walk the owner's range
+    const int a0 = owner * per, a1 = min(V, a0 + per);
+    int pick = -1, last = -1;
+    float run = acc;
+    for (int c = a0; c < a1 && pick < 0; ++c) {
+      if (st.text_off && c < R.ts_begin) continue;
+      const float x = filt(lr, mask, mask2, R, c);
+      if (!(x > -INFINITY)) continue;
+      last = c;
+      run += __expf((x - st.M) * inv_temp);
+      if (target < run) pick = c;
+    }
+    pick_sh = pick >= 0 ? pick : last;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int pick = pick_sh;
+    tok[blockIdx.x] = pick >= 0 ? pick : 0;
+    if (logprob) logprob[blockIdx.x] = pick >= 0 ? (filt(lr, mask, mask2, R, pick) - st.M) - st.lse : -INFINITY;
+  }
+}
+
 }  // namespace
+
+int launch_topk_tokens_ts(const float* logits, long ld, int V, long rows, const float* mask, const float* mask2, const int64_t* hist,
+                          long hist_ld, int n_hist, int ts_begin, int eot, int no_ts, int max_initial_index, int K, int64_t* tok,
+                          float* logprob, hipStream_t s) {
+  OASR_REQUIRE(logits && tok && logprob && V > 0 && ld >= V && K >= 1 && K <= 16 && K <= V, "topk_tokens_ts: bad args (K=%d)", K);
+  OASR_REQUIRE(n_hist < 0 || ((n_hist == 0 || (hist && hist_ld >= n_hist)) && 0 <= eot && eot < ts_begin && ts_begin < V), "topk_tokens_ts: bad history / token ids");
+  if (rows <= 0) return OASR_OK;
+  hipLaunchKernelGGL(topk_ts_kernel, dim3((unsigned)rows), dim3(256), 0, s, logits, ld, V, mask, mask2, hist, hist_ld, n_hist, ts_begin, eot,
+                     no_ts, max_initial_index, K, tok, logprob);
+  OASR_LAUNCH_CHECK();
+  return OASR_OK;
+}
+int launch_sample_tokens_ts(const float* logits, long ld, int V, long rows, const float* mask, const float* mask2, const int64_t* hist,
+                            long hist_ld, int n_hist, int ts_begin, int eot, int no_ts, int max_initial_index, float temperature,
+                            const float* u, int64_t* tok, float* logprob, hipStream_t s) {
+  OASR_REQUIRE(logits && tok && u && V > 0 && ld >= V && temperature > 0.f, "sample_tokens_ts: bad args");
+  OASR_REQUIRE(n_hist < 0 || ((n_hist == 0 || (hist && hist_ld >= n_hist)) && 0 <= eot && eot < ts_begin && ts_begin < V), "sample_tokens_ts: bad history / token ids");
+  if (rows <= 0) return OASR_OK;
+  hipLaunchKernelGGL(sample_ts_kernel, dim3((unsigned)rows), dim3(256), 0, s, logits, ld, V, mask, mask2, hist, hist_ld, n_hist, ts_begin, eot,
+                     no_ts, max_initial_index, 1.0f / temperature, u, tok, logprob);
+  OASR_LAUNCH_CHECK();
+  return OASR_OK;
+}
 
 int launch_pick_tokens(const float* logits, long ld, int V, long rows, const float* mask, const float* mask2, int64_t* tok, float* logprob,
                        hipStream_t s) {

@@ -245,15 +245,12 @@ def decode(model, mel: torch.Tensor, options: Optional[DecodingOptions] = None, 
             nxt, cur = ops.pick_tokens_ts(lg.float().contiguous(), tokens[:, sample_begin:], tokens.shape[1] - sample_begin,
                                           timestamp_begin=TIMESTAMP_BEGIN, eot=EOT, no_timestamps=NO_TIMESTAMPS,
                                           max_initial_index=max_init_idx, mask=base_mask, mask2=fm)
-        else:
-            lg = lg.float() + base_mask
-            if fm is not None:
-                lg = lg + fm
-            if not options.without_timestamps:
-                _timestamp_rules(lg, tokens, sample_begin, max_init_idx)
+        # beam search and sampling select on the device too (round 4): one kernel applies the masks and -- in timestamp mode -- the
+        # rules from the device-resident history, then returns the beam_size + 1 best log-probabilities / draws by inverse CDF
+        sel = dict(history=tokens[:, sample_begin:], n_history=None if options.without_timestamps else tokens.shape[1] - sample_begin,
+                   timestamp_begin=TIMESTAMP_BEGIN, eot=EOT, no_timestamps=NO_TIMESTAMPS, max_initial_index=max_init_idx, mask=base_mask, mask2=fm)
         if beam:  # BeamSearchDecoder.update
-            logprobs = torch.log_softmax(lg, dim=-1)
-            top_lp, top_tok = logprobs.topk(beam + 1, dim=-1)
+            top_lp, top_tok = ops.topk_tokens(lg.float().contiguous(), beam + 1, **sel)
             top_lp, top_tok = top_lp.cpu(), top_tok.cpu()
             prev_sum, tok_cpu = sum_logprobs.cpu(), tokens.cpu()
             next_tokens, new_sum, sources = [], [], []
@@ -287,12 +284,8 @@ def decode(model, mel: torch.Tensor, options: Optional[DecodingOptions] = None, 
                 model.kv_cache_reorder(state, sources)
             completed = all(len(f) >= max_candidates for f in finished)
         else:  # GreedyDecoder.update
-            if not simple:
-                if options.temperature == 0:
-                    nxt = lg.argmax(-1)
-                else:
-                    nxt = torch.multinomial(torch.softmax(lg / options.temperature, dim=-1), 1, generator=gen)[:, 0]
-                cur = torch.log_softmax(lg, dim=-1).gather(1, nxt[:, None])[:, 0]
+            if not simple:  # temperature > 0: Categorical(logits / T) by inverse CDF on uniforms of this decode's generator
+                nxt, cur = ops.sample_tokens(lg.float().contiguous(), options.temperature, torch.rand(lg.shape[0], device=dev, generator=gen), **sel)
             alive = tokens[:, -1] != EOT
             sum_logprobs = sum_logprobs + cur * alive
             nxt = torch.where(alive, nxt, torch.full_like(nxt, EOT))

@@ -261,3 +261,44 @@ def pick_tokens_ts(logits, history, n_history, *, timestamp_begin, eot, no_times
                                         -1 if max_initial_index is None else int(max_initial_index), N.ptr(tok), N.ptr(lp), N.stream_ptr()),
             "oasr_pick_tokens_ts")
     return tok, lp
+
+
+def _ts_args(logits, history, n_history, mask, mask2):
+    N.require_gpu(logits, "logits")
+    assert logits.dtype == torch.float32 and logits.dim() == 2 and logits.stride(1) == 1
+    rows, V = logits.shape
+    if n_history is not None and n_history > 0:
+        assert (history.dtype == torch.int64 and history.dim() == 2 and history.shape[0] == rows and history.stride(1) == 1
+                and history.shape[1] >= n_history and history.device == logits.device)
+    for m in (mask, mask2):
+        assert m is None or (m.dtype == torch.float32 and m.numel() == V and m.is_contiguous())
+    nh = -1 if n_history is None else int(n_history)
+    return rows, V, (N.ptr(history) if nh > 0 else None), (history.stride(0) if nh > 0 else 0), nh
+
+
+def topk_tokens(logits, k, *, history=None, n_history=None, timestamp_begin=50363, eot=50256, no_timestamps=50362, max_initial_index=None,
+                mask=None, mask2=None):
+    """The k best (log_softmax value, token) pairs per row of the filtered distribution (suppress masks; ``n_history`` not None: whisper's
+    ApplyTimestampRules from ``history``, as ``pick_tokens_ts``) -- BeamSearchDecoder.update's ``logprobs.topk(beam_size + 1)`` in one
+    kernel.  Returns (logprob f32 [rows, k] descending, ids int64 [rows, k])."""
+    rows, V, hp, hld, nh = _ts_args(logits, history, n_history, mask, mask2)
+    tok = torch.empty(rows, k, device=logits.device, dtype=torch.int64)
+    lp = torch.empty(rows, k, device=logits.device, dtype=torch.float32)
+    N.check(N.lib().oasr_topk_tokens(N.ptr(logits), logits.stride(0), V, rows, N.ptr(mask), N.ptr(mask2), hp, hld, nh, int(timestamp_begin),
+                                     int(eot), int(no_timestamps), -1 if max_initial_index is None else int(max_initial_index), int(k),
+                                     N.ptr(tok), N.ptr(lp), N.stream_ptr()), "oasr_topk_tokens")
+    return lp, tok
+
+
+def sample_tokens(logits, temperature, uniforms, *, history=None, n_history=None, timestamp_begin=50363, eot=50256, no_timestamps=50362,
+                  max_initial_index=None, mask=None, mask2=None):
+    """One draw per row from softmax(filtered logits / temperature) by inverse CDF on ``uniforms`` (f32 [rows] in [0, 1)); returns
+    (ids int64 [rows], log_softmax of the draw at temperature 1) -- GreedyDecoder.update at temperature > 0."""
+    rows, V, hp, hld, nh = _ts_args(logits, history, n_history, mask, mask2)
+    assert uniforms.dtype == torch.float32 and uniforms.numel() == rows and uniforms.device == logits.device
+    tok = torch.empty(rows, device=logits.device, dtype=torch.int64)
+    lp = torch.empty(rows, device=logits.device, dtype=torch.float32)
+    N.check(N.lib().oasr_sample_tokens(N.ptr(logits), logits.stride(0), V, rows, N.ptr(mask), N.ptr(mask2), hp, hld, nh, int(timestamp_begin),
+                                       int(eot), int(no_timestamps), -1 if max_initial_index is None else int(max_initial_index),
+                                       float(temperature), N.ptr(uniforms), N.ptr(tok), N.ptr(lp), N.stream_ptr()), "oasr_sample_tokens")
+    return tok, lp

@@ -364,3 +364,89 @@ def test_pick_tokens_ts_kernel_equals_the_rules_then_argmax(length):
                                              no_timestamps=dec.NO_TIMESTAMPS, max_initial_index=max_init, mask=base, mask2=fm)
                 assert torch.equal(tok, want_tok), (length, rows_v, max_init, (tok != want_tok).nonzero().flatten().tolist())
                 assert float((lp - want_lp).abs().max()) < 2e-4
+
+
+@pytest.mark.parametrize("length", [None, 0, 1, 2, 5, 40])
+def test_topk_and_sample_kernels_equal_the_rules_then_torch(length):
+    """oasr_topk_tokens / oasr_sample_tokens (round 4: beam search and temperature sampling select on the device like greedy does)
+    against the tensor form of the filters (suppress masks; ``length`` not None: whisper's ApplyTimestampRules on a random history,
+    pinned to transformers' processor on the CPU) followed by torch: log_softmax().topk(k) -- same ids, same values -- and the
+    inverse CDF of softmax(filtered / T) in float64 at the same uniforms -- same draws, scored with the T = 1 log_softmax
+    (whisper.decoding BeamSearchDecoder.update / GreedyDecoder.update).  ``length`` None = the without_timestamps mode (no rules)."""
+    from olmoasr_amd import decoding as dec
+    from olmoasr_amd import ops
+    from test_decoding_rules_cpu import _random_history
+    g = torch.Generator().manual_seed(140 + (length or 0))
+    for rows_v in (51864, 51865):
+        n, sample_begin = 24, 1
+        tokens = _random_history(g, n, length or 0, sample_begin).to(DEV)
+        logits = (torch.randn(n, rows_v, generator=g) * 3.0).to(DEV)
+        logits[: n // 2, dec.TIMESTAMP_BEGIN:] += 6.0  # half the rows: enough timestamp mass to force a timestamp (when the rules are on)
+        logits[3, 1000] = logits[3, 2000] = float(logits[3].max()) + 1.0  # a tie at the top: the lower id comes first
+        base = torch.zeros(rows_v, device=DEV)
+        base[dec.suppress_list(dec.DecodingOptions())] = -float("inf")
+        first = torch.zeros(rows_v, device=DEV)
+        first[[dec.BLANK, dec.EOT]] = -float("inf")
+        for max_init in (None, 50):
+            for fm in (None, first):
+                ref = logits + base + (fm if fm is not None else 0.0)
+                if length is not None:
+                    dec._timestamp_rules(ref, tokens, sample_begin, max_init)
+                sel = dict(history=tokens[:, sample_begin:], n_history=length, timestamp_begin=dec.TIMESTAMP_BEGIN, eot=dec.EOT,
+                           no_timestamps=dec.NO_TIMESTAMPS, max_initial_index=max_init, mask=base, mask2=fm)
+                lsm = torch.log_softmax(ref.double(), -1)
+                for k in (1, 6):
+                    want_lp, want_tok = lsm.topk(k, -1)
+                    lp, tok = ops.topk_tokens(logits, k, **sel)
+                    # (torch.topk does not define the order of equal values: compare values, and ids wherever the value is unique)
+                    assert float((lp.double() - want_lp).abs().max()) < 2e-4, (length, rows_v, k)
+                    uniq = torch.ones_like(tok, dtype=torch.bool)
+                    if k > 1:
+                        uniq[:, 1:] &= want_lp[:, 1:] != want_lp[:, :-1]
+                        uniq[:, :-1] &= want_lp[:, 1:] != want_lp[:, :-1]
+                    assert torch.equal(tok[uniq], want_tok[uniq]), (length, rows_v, k)
+                    assert bool((lsm.gather(1, tok) - lp.double()).abs().max() < 2e-4)  # every returned id carries its own log-probability
+                if length is None or max_init is None:
+                    lp2, tok2 = ops.topk_tokens(logits, 2, **sel)
+                    if not (length is not None and 3 < n // 2):  # (row 3 is a forced-timestamp row when the rules are on)
+                        assert tok2[3].tolist() == [1000, 2000]
+                for T in (0.4, 1.0):
+                    u = torch.rand(n, generator=g).to(DEV)
+                    u[0], u[1] = 0.0, 0.999999
+                    tok, lp = ops.sample_tokens(logits, T, u, **sel)
+                    p = torch.softmax(ref.double() / T, -1)
+                    cdf = p.cumsum(-1)
+                    want = torch.searchsorted(cdf, (u.double() * cdf[:, -1])[:, None]).clamp(max=rows_v - 1)[:, 0]
+                    # a draw within float32 rounding of a CDF step may land on either side: accept the neighbouring SURVIVOR there
+                    near = ((cdf.gather(1, want[:, None])[:, 0] - u.double() * cdf[:, -1]).abs() < 1e-5) | \
+                           ((cdf.gather(1, tok[:, None])[:, 0] - p.gather(1, tok[:, None])[:, 0] - u.double() * cdf[:, -1]).abs() < 1e-5)
+                    assert bool(((tok == want) | near).all()), (length, rows_v, T, (tok != want).nonzero().flatten().tolist())
+                    assert bool((p.gather(1, tok[:, None]) > 0).all())  # never a masked token
+                    assert float((lp.double() - lsm.gather(1, tok[:, None])[:, 0]).abs().max()) < 2e-4
+
+
+def test_sampling_frequencies_follow_the_tempered_distribution():
+    """20,000 rows of the same small distribution (everything but 6 tokens masked), independent uniforms: empirical frequencies of
+    oasr_sample_tokens within 4 sigma of softmax(logits / T)."""
+    from olmoasr_amd import ops
+    V, n, T = 51864, 20000, 0.7
+    keep = torch.tensor([5, 300, 301, 20000, 50256, 51000])
+    vals = torch.tensor([1.0, 0.0, -1.0, 2.0, 0.5, -0.5])
+    mask = torch.full((V,), -float("inf"))
+    mask[keep] = 0.0
+    row = torch.zeros(V)
+    row[keep] = vals
+    logits = row.to(DEV)[None].expand(n, V).contiguous()
+    u = torch.rand(n, generator=torch.Generator().manual_seed(3)).to(DEV)
+    tok, lp = ops.sample_tokens(logits, T, u, mask=mask.to(DEV))
+    p = torch.softmax(vals.double() / T, -1)
+    for j, t in enumerate(keep.tolist()):
+        f = float((tok == t).float().mean())
+        sigma = float((p[j] * (1 - p[j]) / n).sqrt())
+        assert abs(f - float(p[j])) < 4 * sigma + 1e-4, (t, f, float(p[j]))
+    assert int(torch.isin(tok.cpu(), keep).sum()) == n
+    want_lp = torch.log_softmax(vals.double(), -1)
+    for j, t in enumerate(keep.tolist()):
+        sel = tok == t
+        if bool(sel.any()):
+            assert float((lp[sel].double() - want_lp[j]).abs().max()) < 1e-5
