@@ -247,7 +247,10 @@ def hbm_kernel_rooflines(net, dims, mb, dev):
          f"[{rows}, {d}]: dy, x, dres in, dx out (+ stats)")
     del x, y, dy
     pcm = torch.zeros(mb, 480000, dtype=torch.int16, device=dev).random_(-3000, 3000)
-    line("logmel_main+finalize", timed(lambda: ops.log_mel(pcm)), mb * 1.92e6, f"{mb} clips: int16 PCM in + fp32 [80,3000] out")
+    line("logmel_fft (floor fused into the encoder's transpose)", timed(lambda: ops.log_mel(pcm, finalize=False)), mb * 1.92e6,
+         f"{mb} clips: int16 PCM in + fp32 [80,3000] log10 mel power + per-clip maximum out (what the timed step runs)")
+    line("logmel_fft+finalize (whisper.audio.log_mel_spectrogram's own output)", timed(lambda: ops.log_mel(pcm)), mb * 1.92e6,
+         f"{mb} clips: the same + the in-place floor / scale pass (3.84 MB per clip actually move)")
     del pcm
     Vp, V = (dims.n_vocab + 1 + 127) // 128 * 128, dims.n_vocab + 1
     rows_d = mb * dims.n_text_ctx
@@ -448,11 +451,14 @@ def main():
         net.zero_grad()
         for i in range(accum):
             sl = slice(i * mb, (i + 1) * mb)
-            mel = ops.log_mel(pcm[sl])
+            # (span step: whisper's floor-at-max-minus-8 / (x + 4) / 4 lines ride in the encoder's time-major transpose instead of a
+            # second pass over the log-mel tensor)
+            mel, clip_max = ops.log_mel(pcm[sl], finalize=False) if spans else (ops.log_mel(pcm[sl]), None)
             last = i == accum - 1
             net.loss_and_backward(mel, ti[sl], ty[sl], tl[sl], loss_scale=loss_scale, accumulation_steps=accum, loss_out=loss_buf,
                                   accumulate_loss=i > 0, segment_events=reducer.segment_events() if (reducer and last) else None,
-                                  text_ctx=ctx[i], span=spans[i] if spans else None, span_forward=bool(spans) and args.span_forward)
+                                  text_ctx=ctx[i], span=spans[i] if spans else None, span_forward=bool(spans) and args.span_forward,
+                                  mel_clip_max=clip_max)
         div = 1.0
         if reducer:
             reducer.reduce()

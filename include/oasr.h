@@ -43,6 +43,10 @@ int oasr_version(void);
  *      (max - 8) is per clip.  workspace: oasr_log_mel_workspace_bytes(B) bytes. */
 size_t oasr_log_mel_workspace_bytes(int B);
 int oasr_log_mel(const void* pcm, int pcm_dtype, int B, int n_samples, float* mel, void* workspace, void* stream);
+/* The same front end without its last pass over the tensor: mel_raw = log10(max(mel power, 1e-10)), clip_max f32 [B] = each clip's maximum
+ * of it.  whisper.audio's last two lines -- max(x, x.max() - 8), (x + 4) / 4 -- are then applied by the consumer while it reads the
+ * tensor anyway (oasr_train_fwd_bwd_span's mel_clip_max): half the HBM traffic of this front end, bit-identical encoder input. */
+int oasr_log_mel_raw(const void* pcm, int pcm_dtype, int B, int n_samples, float* mel_raw, float* clip_max, void* workspace, void* stream);
 /* HOST helper: the slaney 80 x 201 filterbank (whisper assets/mel_filters.npz) into a host buffer. */
 int oasr_mel_filterbank(float* out_host);
 
@@ -135,9 +139,10 @@ int oasr_train_fwd_bwd_s(oasr_ctx*, const float* mel, const int64_t* tokens, con
 #define OASR_SPAN_FORWARD_ALL 0    /* the reference's shape: the decoder's forward covers all n_text_ctx positions */
 #define OASR_SPAN_FORWARD_ACTIVE 1 /* opt-in: the forward leaves the positions past the span out too -- their logits exist in the reference
                                     * (model.py:768-770 over the padded context) but nothing reads them: loss and gradients unchanged */
+/* mel_clip_max: NULL (mel is finished log-mel, as everywhere else), or device f32 [B] with mel = oasr_log_mel_raw's output. */
 int oasr_train_fwd_bwd_span(oasr_ctx*, const float* mel, const int64_t* tokens, const int64_t* targets, const int32_t* text_len,
-                            const int32_t* span_host, int forward_rows, int B, float loss_scale, float inv_accum, float* loss_out,
-                            int accumulate_loss, void** seg_events, void* workspace, size_t workspace_bytes, void* stream);
+                            const int32_t* span_host, int forward_rows, const float* mel_clip_max, int B, float loss_scale, float inv_accum,
+                            float* loss_out, int accumulate_loss, void** seg_events, void* workspace, size_t workspace_bytes, void* stream);
 
 /* The same micro-step cut at the logits, for torch.autograd: OLMoASR.forward in training mode (olmoasr/model.py:856-887) followed by
  * the CALLER's loss and .backward() (train_timestamps.py:1440-1454 unchanged).  train_fwd: fp32 logits [B, S, rows], every saved

@@ -81,7 +81,8 @@ def _declare(lib):
         "oasr_forward": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, sz, vp]),
         "oasr_train_fwd_bwd": (i32, [vp, vp, vp, vp, vp, i32, f32, f32, vp, i32, vp, vp, vp, sz, vp]),
         "oasr_train_fwd_bwd_s": (i32, [vp, vp, vp, vp, vp, i32, i32, f32, f32, vp, i32, vp, vp, vp, sz, vp]),
-        "oasr_train_fwd_bwd_span": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, vp, i32, vp, vp, sz, vp]),
+        "oasr_train_fwd_bwd_span": (i32, [vp, vp, vp, vp, vp, vp, i32, vp, i32, f32, f32, vp, i32, vp, vp, sz, vp]),
+        "oasr_log_mel_raw": (i32, [vp, i32, i32, i32, vp, vp, vp, vp]),
         "oasr_sizeof_attn_args": (sz, []),
         "oasr_test_span_tables": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp]),
         "oasr_train_fwd": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, sz, vp]),

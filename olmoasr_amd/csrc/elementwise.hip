@@ -69,13 +69,19 @@ __global__ __launch_bounds__(256) void pack_embedding_kernel(const float* __rest
 }
 
 // mel [B][C][T] f32 -> out [B][T][C] bf16 through a 32(t) x C LDS tile so both sides stay coalesced
-__global__ __launch_bounds__(256) void mel_tm_kernel(const float* __restrict__ mel, bf16_t* __restrict__ out, int C, int T) {
+// clip_max (optional, [B]): `mel` is the UN-finalized log10 mel power (oasr_log_mel_raw) and whisper's last two lines are applied here,
+// on the way through: max(x, clip_max[b] - 8), then (x + 4) / 4 -- the same fp32 operations logmel_finalize performs
+__global__ __launch_bounds__(256) void mel_tm_kernel(const float* __restrict__ mel, bf16_t* __restrict__ out, int C, int T,
+                                                     const float* __restrict__ clip_max) {
   __shared__ float tile[128][33];
   const int b = blockIdx.y, t0 = blockIdx.x * 32;
   const float* src = mel + (long)b * C * T;
+  const float floor_v = clip_max ? clip_max[b] - 8.0f : 0.f;
   for (int i = threadIdx.x; i < C * 32; i += 256) {
     const int c = i >> 5, tt = i & 31;
-    tile[c][tt] = (t0 + tt < T) ? src[(long)c * T + t0 + tt] : 0.f;
+    float v = (t0 + tt < T) ? src[(long)c * T + t0 + tt] : 0.f;
+    if (clip_max) v = (fmaxf(v, floor_v) + 4.0f) * 0.25f;
+    tile[c][tt] = v;
   }
   __syncthreads();
   bf16_t* dst = out + ((long)b * T + t0) * C;
@@ -267,9 +273,9 @@ int launch_pack_embedding(const float* e, bf16_t* dst, int rows, int rows_pad, i
   OASR_LAUNCH_CHECK();
   return OASR_OK;
 }
-int launch_mel_to_time_major(const float* mel, bf16_t* out, int B, int n_mels, int T, hipStream_t s) {
+int launch_mel_to_time_major(const float* mel, bf16_t* out, int B, int n_mels, int T, hipStream_t s, const float* clip_max) {
   OASR_REQUIRE(mel && out && n_mels <= 128, "mel_to_time_major: bad args");
-  hipLaunchKernelGGL(mel_tm_kernel, dim3(cdiv(T, 32), B), dim3(256), 0, s, mel, out, n_mels, T);
+  hipLaunchKernelGGL(mel_tm_kernel, dim3(cdiv(T, 32), B), dim3(256), 0, s, mel, out, n_mels, T, clip_max);
   OASR_LAUNCH_CHECK();
   return OASR_OK;
 }

@@ -299,6 +299,7 @@ struct Runner {
   // opt-in (OASR_SPAN_FORWARD_ACTIVE): the decoder's FORWARD covers the active rows only as well.  The rows left out are the padded
   // positions whose logits the reference computes and nothing ever reads (no supervised query attends to them, the loss ignores them).
   long dec_rows_fwd = 0;
+  const float* mel_clip_max = nullptr;  // [B] or null: `mel` is oasr_log_mel_raw's output, finalized in the time-major transpose
 
   int linear(const T* x, long M, int K, const T* W, int N, const float* bias, int act, const T* resid, T* out,
              T* out_pre) {
@@ -461,7 +462,7 @@ struct Runner {
   int encoder_fwd(Plan& p, const float* mel) {
     const int d = c->d;
     const long M1 = (long)B * c->T1, Me = (long)B * c->Te;
-    RC(launch_mel_to_time_major(mel, p.mel_tm, B, c->dims.n_mels, c->T1, st));
+    RC(launch_mel_to_time_major(mel, p.mel_tm, B, c->dims.n_mels, c->T1, st, mel_clip_max));
     // Both convolutions run on the direct-to-LDS kernels: the im2col matrix is the input itself read as a PLAIN matrix of
     // overlapping rows (row stride = conv stride * C) that starts one time row before the buffer.  That view is exact
     // except at sample boundaries -- window (b, 0) sees the previous sample's last row (or the zeroed guard row) where
@@ -1258,8 +1259,9 @@ static int oasr_train_fwd_bwd_s_impl(oasr_ctx* c, const float* mel, const int64_
 // The results differ from oasr_train_fwd_bwd's only by fp32 summation order (weight gradients sum over fewer, re-ordered token rows).
 template <typename T>
 static int oasr_train_fwd_bwd_span_impl(oasr_ctx* c, const float* mel, const int64_t* tokens, const int64_t* targets, const int32_t* text_len,
-                                       const int32_t* span_host, int forward_rows, int B, float loss_scale, float inv_accum, float* loss_out,
-                                       int accumulate_loss, void** ev, void* workspace, size_t workspace_bytes, void* stream) {
+                                       const int32_t* span_host, int forward_rows, const float* mel_clip_max, int B, float loss_scale,
+                                       float inv_accum, float* loss_out, int accumulate_loss, void** ev, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
   const int S = c->S_max;
   const long Md = (long)B * S;
   Arena A(workspace, workspace_bytes);
@@ -1276,6 +1278,7 @@ static int oasr_train_fwd_bwd_span_impl(oasr_ctx* c, const float* mel, const int
   r.dec_span = p.span_dev;
   r.dec_rows_bwd = R;
   r.dec_rows_fwd = forward_rows == OASR_SPAN_FORWARD_ACTIVE ? R : 0;
+  r.mel_clip_max = mel_clip_max;
   // ---------------- forward (every position, unless the caller opted out of the padded ones) ----------------
   RC(r.encoder_fwd(p, mel));
   RC(r.decoder_fwd(p, tokens));
@@ -1286,19 +1289,20 @@ static int oasr_train_fwd_bwd_span_impl(oasr_ctx* c, const float* mel, const int
   return train_backward<T>(c, r, p, tokens, B, S, ev);
 }
 extern "C" int oasr_train_fwd_bwd_span(oasr_ctx* c, const float* mel, const int64_t* tokens, const int64_t* targets, const int32_t* text_len,
-                                       const int32_t* span_host, int forward_rows, int B, float loss_scale, float inv_accum, float* loss_out,
-                                       int accumulate_loss, void** ev, void* workspace, size_t workspace_bytes, void* stream) {
+                                       const int32_t* span_host, int forward_rows, const float* mel_clip_max, int B, float loss_scale,
+                                       float inv_accum, float* loss_out, int accumulate_loss, void** ev, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
   RC(check_bound(c, true));
   OASR_REQUIRE(mel && tokens && targets && text_len && span_host && loss_out && workspace && B > 0, "oasr_train_fwd_bwd_span: bad args");
   OASR_REQUIRE(forward_rows == OASR_SPAN_FORWARD_ALL || forward_rows == OASR_SPAN_FORWARD_ACTIVE, "oasr_train_fwd_bwd_span: forward_rows");
   OASR_REQUIRE(workspace_bytes >= oasr_workspace_bytes(c, B, c->S_max, OASR_MODE_TRAIN), "oasr_train_fwd_bwd_span: workspace too small");
-  if ((c->S_max % 64) != 0 || c->S_max > 64 * OASR_ROWTAB || B > 512)  // no chunking for this shape: the plain step (same results)
+  if (((c->S_max % 64) != 0 || c->S_max > 64 * OASR_ROWTAB || B > 512) && !mel_clip_max)  // no chunking for this shape: the plain step (same results)
     return oasr_train_fwd_bwd_s(c, mel, tokens, targets, text_len, B, c->S_max, loss_scale, inv_accum, loss_out, accumulate_loss, nullptr, ev,
                                 workspace, workspace_bytes, stream);
-  return c->f32 ? oasr_train_fwd_bwd_span_impl<float>(c, mel, tokens, targets, text_len, span_host, forward_rows, B, loss_scale, inv_accum,
-                                                      loss_out, accumulate_loss, ev, workspace, workspace_bytes, stream)
-                : oasr_train_fwd_bwd_span_impl<bf16_t>(c, mel, tokens, targets, text_len, span_host, forward_rows, B, loss_scale, inv_accum,
-                                                       loss_out, accumulate_loss, ev, workspace, workspace_bytes, stream);
+  return c->f32 ? oasr_train_fwd_bwd_span_impl<float>(c, mel, tokens, targets, text_len, span_host, forward_rows, mel_clip_max, B, loss_scale,
+                                                      inv_accum, loss_out, accumulate_loss, ev, workspace, workspace_bytes, stream)
+                : oasr_train_fwd_bwd_span_impl<bf16_t>(c, mel, tokens, targets, text_len, span_host, forward_rows, mel_clip_max, B, loss_scale,
+                                                       inv_accum, loss_out, accumulate_loss, ev, workspace, workspace_bytes, stream);
 }
 
 // ---- the same micro-step cut at the logits, for torch.autograd (OLMoASR.forward in training mode, olmoasr/model.py:856-887 followed

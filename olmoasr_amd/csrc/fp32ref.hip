@@ -339,13 +339,16 @@ __global__ __launch_bounds__(256) void pack_conv_f32_kernel(const float* __restr
     dst[i] = v;
   }
 }
-__global__ __launch_bounds__(256) void mel_tm_f32_kernel(const float* __restrict__ mel, float* __restrict__ out, int C, int T, long total) {
+__global__ __launch_bounds__(256) void mel_tm_f32_kernel(const float* __restrict__ mel, float* __restrict__ out, int C, int T, long total,
+                                                        const float* __restrict__ clip_max) {
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {  // i over [B][T][C]
     const int c = (int)(i % C);
     const long bt = i / C;
     const int t = (int)(bt % T);
     const long b = bt / T;
-    out[i] = mel[(b * C + c) * T + t];
+    float v = mel[(b * C + c) * T + t];
+    if (clip_max) v = (fmaxf(v, clip_max[b] - 8.0f) + 4.0f) * 0.25f;  // un-finalized log-mel (kernels.h)
+    out[i] = v;
   }
 }
 __global__ __launch_bounds__(256) void embedding_fwd_f32_kernel(const int64_t* __restrict__ tok, const float* __restrict__ E,
@@ -518,10 +521,10 @@ int launch_pack_conv_weight(const float* w, float* dst, int co, int ci, int ldk,
   OASR_LAUNCH_CHECK();
   return OASR_OK;
 }
-int launch_mel_to_time_major(const float* mel, float* out, int B, int n_mels, int T, hipStream_t s) {
+int launch_mel_to_time_major(const float* mel, float* out, int B, int n_mels, int T, hipStream_t s, const float* clip_max) {
   OASR_REQUIRE(mel && out, "mel_to_time_major(f32): bad args");
   const long total = (long)B * T * n_mels;
-  hipLaunchKernelGGL(mel_tm_f32_kernel, dim3(grid_for(total)), dim3(256), 0, s, mel, out, n_mels, T, total);
+  hipLaunchKernelGGL(mel_tm_f32_kernel, dim3(grid_for(total)), dim3(256), 0, s, mel, out, n_mels, T, total, clip_max);
   OASR_LAUNCH_CHECK();
   return OASR_OK;
 }

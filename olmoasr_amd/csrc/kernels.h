@@ -162,7 +162,8 @@ int launch_unpack_conv_grad(const float* g, float* dw, int co, int ci, int ldk, 
 // token embedding rows f32 [rows][d] -> bf16 [rows_pad][d], rows >= rows zero
 int launch_pack_embedding(const float* e, bf16_t* dst, int rows, int rows_pad, int d, hipStream_t s);
 // mel f32 [B][80][T] -> bf16 time-major [B][T][80]
-int launch_mel_to_time_major(const float* mel, bf16_t* out, int B, int n_mels, int T, hipStream_t s);
+// clip_max (optional [B]): mel is the un-finalized log10 mel power of oasr_log_mel_raw; max(x, clip_max[b] - 8), (x + 4) / 4 on the fly
+int launch_mel_to_time_major(const float* mel, bf16_t* out, int B, int n_mels, int T, hipStream_t s, const float* clip_max = nullptr);
 // x[b,s,:] = bf16(E[tok[b,s]] + pos[s]);  rows (optional): chunk-row table [B][OASR_ROWTAB] -- x row of (b, s) =
 // rows[b][s >> 6] + (s & 63) instead of b*S + s
 int launch_embedding_fwd(const int64_t* tok, const float* E, const float* pos, bf16_t* x, int B, int S, int d, long n_embed,
@@ -185,7 +186,7 @@ int launch_conv2_col2im_dgelu(const bf16_t* dA /*[B*T2][3d]*/, const bf16_t* u1 
 int launch_axpy_f32(const float* src, float* dst, long n, float a, hipStream_t s);
 // fp32 validation overloads (fp32ref.hip): same contracts with fp32 activations
 int launch_pack_conv_weight(const float* w, float* dst, int co, int ci, int ldk, hipStream_t s);
-int launch_mel_to_time_major(const float* mel, float* out, int B, int n_mels, int T, hipStream_t s);
+int launch_mel_to_time_major(const float* mel, float* out, int B, int n_mels, int T, hipStream_t s, const float* clip_max = nullptr);
 int launch_embedding_fwd(const int64_t* tok, const float* E, const float* pos, float* x, int B, int S, int d, long n_embed, hipStream_t s,
                          const int32_t* rows = nullptr);
 int launch_embedding_bwd(const int64_t* tok, const float* dx, float* dE, float* dpos, int B, int S, int d, long pad_id, long n_embed,

@@ -581,8 +581,28 @@ static int ensure_tables(int device, MelTables** t_out) {
 
 extern "C" size_t oasr_log_mel_workspace_bytes(int B) { return (size_t)((B * 4 + 255) / 256) * 256; }
 
+__global__ __launch_bounds__(256) void logmel_clipmax_kernel(const unsigned* __restrict__ clipmax, float* __restrict__ out, int B) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b < B) out[b] = ord2f(clipmax[b]);
+}
+
+static int log_mel_impl(const void* pcm, int pcm_dtype, int B, int n_samples, float* mel, void* workspace, hipStream_t stream,
+                        float* clip_max_out);
 extern "C" int oasr_log_mel(const void* pcm, int pcm_dtype, int B, int n_samples, float* mel, void* workspace,
                             hipStream_t stream) {
+  return log_mel_impl(pcm, pcm_dtype, B, n_samples, mel, workspace, stream, nullptr);
+}
+// The same front end WITHOUT its last pass: mel_raw = log10(max(mel power, 1e-10)) and clip_max[b] = the clip's maximum of it (device
+// f32 [B]).  whisper's last two lines -- log_spec = max(log_spec, log_spec.max() - 8); (log_spec + 4) / 4 -- need the clip maximum, i.e.
+// a second pass over the tensor; a consumer that reads the tensor anyway applies them on the fly instead
+// (oasr_train_fwd_bwd_span's mel_clip_max: the encoder's time-major transpose), which halves this front end's HBM traffic.
+extern "C" int oasr_log_mel_raw(const void* pcm, int pcm_dtype, int B, int n_samples, float* mel_raw, float* clip_max, void* workspace,
+                                hipStream_t stream) {
+  OASR_REQUIRE(clip_max, "oasr_log_mel_raw: null clip_max");
+  return log_mel_impl(pcm, pcm_dtype, B, n_samples, mel_raw, workspace, stream, clip_max);
+}
+static int log_mel_impl(const void* pcm, int pcm_dtype, int B, int n_samples, float* mel, void* workspace, hipStream_t stream,
+                        float* clip_max_out) {
   OASR_REQUIRE(pcm && mel && workspace, "null pointer");
   OASR_REQUIRE(pcm_dtype == 0 || pcm_dtype == 1, "pcm_dtype must be 0 (f32) or 1 (i16)");
   OASR_REQUIRE(B > 0 && n_samples > NFFT / 2, "need B > 0 and n_samples > 200 (reflect padding), got %d, %d", B, n_samples);
@@ -615,7 +635,8 @@ extern "C" int oasr_log_mel(const void* pcm, int pcm_dtype, int B, int n_samples
                          t->mel_span, mel, clipmax);
     }
     OASR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(logmel_finalize, g2, dim3(256), 0, stream, mel, clipmax, per_clip);
+    if (clip_max_out) hipLaunchKernelGGL(logmel_clipmax_kernel, dim3(cdiv(B, 256)), dim3(256), 0, stream, clipmax, clip_max_out, B);
+    else hipLaunchKernelGGL(logmel_finalize, g2, dim3(256), 0, stream, mel, clipmax, per_clip);
     OASR_LAUNCH_CHECK();
     return OASR_OK;
   }
@@ -635,7 +656,8 @@ extern "C" int oasr_log_mel(const void* pcm, int pcm_dtype, int B, int n_samples
                        t->melfilt, mel, clipmax);
   }
   OASR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(logmel_finalize, g2, dim3(256), 0, stream, mel, clipmax, per_clip);
+  if (clip_max_out) hipLaunchKernelGGL(logmel_clipmax_kernel, dim3(cdiv(B, 256)), dim3(256), 0, stream, clipmax, clip_max_out, B);
+  else hipLaunchKernelGGL(logmel_finalize, g2, dim3(256), 0, stream, mel, clipmax, per_clip);
   OASR_LAUNCH_CHECK();
   return OASR_OK;
 }

@@ -766,7 +766,7 @@ class OLMoASR(nn.Module):
     def loss_and_backward(self, mel: Tensor, tokens: Tensor, targets: Tensor, text_len: Tensor, *, loss_scale: float = 1.0,
                           accumulation_steps: int = 1, loss_out: Optional[Tensor] = None, accumulate_loss: bool = False,
                           return_logits: bool = False, segment_events=None, text_ctx: Optional[int] = None, span=None,
-                          span_forward: bool = False):
+                          span_forward: bool = False, mel_clip_max: Optional[Tensor] = None):
         """forward + F.cross_entropy(ignore_index=51864)/accumulation_steps + backward of (loss * loss_scale)
         (train_timestamps.py:1440-1454).  Gradients accumulate into ``flat_grads``.  Returns (loss tensor [1], logits|None).
 
@@ -775,6 +775,8 @@ class OLMoASR(nn.Module):
         derive it here from ``targets`` / ``text_len`` (one small device->host copy); a HOST int sequence / CPU tensor [B]: the
         caller's own bound (the data loader knows the token counts: every target at or past ``span[b]`` must be the ignore
         index and ``span[b] >= text_len[b]``); ``None`` / ``False``: the plain step.  Not combinable with ``return_logits`` / ``text_ctx``.
+        ``mel_clip_max`` (with ``span``): ``mel`` is ``ops.log_mel(pcm, finalize=False)``'s un-finalized tensor and this is its per-clip
+        maximum [B]; whisper's floor / scale lines are applied while the encoder transposes it (bit-identical input, one pass less).
         ``span_forward=True`` (opt-in, with ``span``): the decoder's forward leaves the positions past the span out as well -- the
         reference computes their logits (it pads every sample to 448) and nothing reads them; loss and gradients are unchanged.
 
@@ -810,13 +812,20 @@ class OLMoASR(nn.Module):
             span_h = self.supervised_span(targets, text_len) if span is True else torch.as_tensor(span, dtype=torch.int32, device="cpu")
             span_h = span_h.to(torch.int32).contiguous()
             assert span_h.numel() == B and not span_h.is_cuda
+            if mel_clip_max is not None:
+                N.require_gpu(mel_clip_max, "mel_clip_max")
+                mel_clip_max = mel_clip_max.float().contiguous()
+                assert mel_clip_max.numel() == B
             with torch.cuda.device(mel.device):
                 N.check(N.lib().oasr_train_fwd_bwd_span(self._ctx, N.ptr(mel), N.ptr(tokens), N.ptr(targets), N.ptr(text_len),
-                                                        C.c_void_p(span_h.data_ptr()), int(bool(span_forward)), B, float(loss_scale),
+                                                        C.c_void_p(span_h.data_ptr()), int(bool(span_forward)), N.ptr(mel_clip_max), B,
+                                                        float(loss_scale),
                                                         1.0 / accumulation_steps,
                                                         N.ptr(loss_out), int(accumulate_loss), ev, N.ptr(ws), ws.numel(), N.stream_ptr()),
                         "oasr_train_fwd_bwd_span")
             return loss_out, None
+        if mel_clip_max is not None:
+            raise ValueError("mel_clip_max needs span= (the un-finalized log-mel is consumed by oasr_train_fwd_bwd_span only)")
         with torch.cuda.device(mel.device):
             N.check(N.lib().oasr_train_fwd_bwd_s(self._ctx, N.ptr(mel), N.ptr(tokens), N.ptr(targets), N.ptr(text_len), B, S,
                                                  float(loss_scale), 1.0 / accumulation_steps, N.ptr(loss_out), int(accumulate_loss),

@@ -211,8 +211,9 @@ def cast_bf16(x):
     return out
 
 
-def log_mel(pcm):
-    """pcm int16 or float32 [B, n] on the GPU -> float32 [B, 80, n // 160]."""
+def log_mel(pcm, finalize: bool = True):
+    """pcm int16 or float32 [B, n] on the GPU -> float32 [B, 80, n // 160].  ``finalize=False``: returns (mel_raw, clip_max [B]) --
+    whisper's last two lines (floor at the clip maximum - 8, (x + 4) / 4) left to the consumer (``loss_and_backward(mel_clip_max=...)``)."""
     N.require_gpu(pcm, "pcm")
     assert pcm.dim() == 2 and pcm.is_contiguous()
     B, n = pcm.shape
@@ -224,6 +225,10 @@ def log_mel(pcm):
         raise N.NativeError(f"log_mel: unsupported dtype {pcm.dtype}")
     mel = torch.empty(B, 80, n // 160, device=pcm.device, dtype=torch.float32)
     ws = torch.empty(N.lib().oasr_log_mel_workspace_bytes(B), device=pcm.device, dtype=torch.uint8)
+    if not finalize:
+        cm = torch.empty(B, device=pcm.device, dtype=torch.float32)
+        N.check(N.lib().oasr_log_mel_raw(N.ptr(pcm), dt, B, n, N.ptr(mel), N.ptr(cm), N.ptr(ws), N.stream_ptr()), "oasr_log_mel_raw")
+        return mel, cm
     N.check(N.lib().oasr_log_mel(N.ptr(pcm), dt, B, n, N.ptr(mel), N.ptr(ws), N.stream_ptr()), "oasr_log_mel")
     return mel
 

@@ -415,13 +415,15 @@ def main(argv=None):
             cursor += args.train_batch_size  # (position in this rank's epoch order; a short last batch also ends the epoch)
             if cursor >= per_rank:
                 cursor, epoch = 0, epoch + 1
-            mel = ops.log_mel(pcm)
             last = i == accum - 1
-            # (a logging step wants the logits back: it takes the plain step; every other step limits the decoder's backward to the span)
+            # (a logging step wants the logits back: it takes the plain step; every other step limits the decoder's backward to the span
+            # and lets the encoder's transpose apply the log-mel floor / scale instead of a second pass over the tensor)
+            use_span = bool(args.span_backward) and not log_now
+            mel, clip_max = ops.log_mel(pcm, finalize=False) if use_span else (ops.log_mel(pcm), None)
             _, logits = net.loss_and_backward(mel, ti, ty, tl, loss_scale=scaler.scale, accumulation_steps=accum, loss_out=loss_buf,
                                               accumulate_loss=i > 0, return_logits=log_now,
                                               segment_events=reducer.segment_events() if (reducer and last) else None,
-                                              span=True if (args.span_backward and not log_now) else None)
+                                              span=True if use_span else None, mel_clip_max=clip_max)
             if log_now:
                 p_, t_ = gen_pred(logits, ty)
                 preds += p_

@@ -229,3 +229,34 @@ def test_span_step_rejects_bad_spans_and_falls_back():
         net.loss_and_backward(mel, ti, ty, tl, span=True, return_logits=True)
     del net
     torch.cuda.empty_cache()
+
+
+def test_unfinalized_log_mel_through_the_span_step_is_bit_identical():
+    """oasr_log_mel_raw + mel_clip_max: whisper's last two lines (floor at the clip maximum - 8, (x + 4) / 4) applied inside the encoder's
+    time-major transpose instead of a second pass over the tensor -- same fp32 operations, so the finalized tensor, the loss and the
+    gradients' bits do not change."""
+    from olmoasr_amd import ops
+    from olmoasr_amd.config.model_dims import VARIANT_TO_DIMS
+    from olmoasr_amd.model import OLMoASR
+    from olmoasr_amd.synth import synth_samples
+    pcm, ti, ty, tl = synth_samples([3, 4, 5], DEV)
+    pcm[1, 200000:] = 0  # a long silent tail: many values at the floor
+    mel = ops.log_mel(pcm)
+    raw, cm = ops.log_mel(pcm, finalize=False)
+    assert torch.equal((torch.maximum(raw, (cm - 8.0)[:, None, None]) + 4.0) * 0.25, mel)
+    assert torch.equal(cm, raw.amax((1, 2)))
+    for dtype in ("bfloat16", "float32"):
+        net = OLMoASR(VARIANT_TO_DIMS["tiny"], device=DEV, seed=0, compute_dtype=dtype)
+        net.zero_grad()
+        l0, _ = net.loss_and_backward(mel, ti, ty, tl, span=True)
+        # (split-K weight-gradient sums are fp32 atomics: compare the deterministic pieces -- loss -- exactly, gradients to 1e-6)
+        g0 = net.flat_grads.clone()
+        net.zero_grad()
+        l1, _ = net.loss_and_backward(raw, ti, ty, tl, span=True, mel_clip_max=cm)
+        torch.cuda.synchronize()
+        assert float(l0) == float(l1), (dtype, float(l0), float(l1))
+        assert _rel(net.flat_grads, g0) < 1e-6
+        with pytest.raises(ValueError):
+            net.loss_and_backward(raw, ti, ty, tl, mel_clip_max=cm)
+        del net
+    torch.cuda.empty_cache()
