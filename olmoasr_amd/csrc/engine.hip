@@ -381,6 +381,9 @@ struct Runner {
       int pp_split = 0;
       if (t256 == 16 && long_tokens) pp_split = 16;
       else if (t256 == 64) pp_split = (long_tokens && N > K) ? 8 : 4;
+      // round 4 (profiles/r04_wgrad_sweep.txt): the cross-attention key|value gradient [2048 x 1024] over the 192k encoder tokens, never swept
+      // before: ping-pong split 8 = 0.687 ms (1173 TFLOP/s) vs 0.754 ms (1068) for the best 256x128 split; [3072 x 1024] stays (1.055 vs 1.081)
+      else if (t256 == 32 && long_tokens) pp_split = 8;
       if (pp_split) {
         g.atomic_on_pp = 1;
         g.split_k = pp_split;

@@ -21,7 +21,8 @@ def main():
         dy = (torch.randn(tokens, 4 * d, device="cuda") * 0.05).to(BF)
         x = torch.randn(tokens, 4 * d, device="cuda").to(BF)
         g32 = torch.zeros(4 * d, 4 * d, device="cuda")
-        for (n, k) in ((1024, 1024), (3072, 1024), (4096, 1024), (1024, 4096)):
+        shapes = [tuple(int(v) for v in a.split('x')) for a in os.environ.get('SHAPES', '1024x1024,3072x1024,4096x1024,1024x4096').split(',')]
+        for (n, k) in shapes:
             flops = 2.0 * tokens * n * k
             res = {}
             splits = [int(a) for a in os.environ.get('SPLITS', '1,2,4,8,16,24,32').split(',')]
