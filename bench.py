@@ -351,7 +351,7 @@ def main():
     ap.add_argument("--micro-batch", type=int, default=0,
                     help="clips per micro-batch (gradient accumulation over per-gpu-batch / micro-batch); 0 = the largest of "
                          "128/64/32/... whose saved activations fit in free HBM with 24 GiB to spare")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r03_hbm_traffic.json"),
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r04_hbm_traffic.json"),
                     help="per-symbol HBM bytes per launch from the rocprofv3 PMC passes (scripts/pmc_traffic.py)")
     ap.add_argument("--bucket-mb", type=float, default=128.0)
     ap.add_argument("--reducer", default="allreduce", choices=["allreduce", "direct"],

@@ -7,7 +7,7 @@
 #   4. rocprofv3 --pmc GRBM_GUI_ACTIVE         -> effective shader clock per kernel under the step's load (scripts/pmc_clock.py)
 # Counter passes never carry --kernel-trace/--stats-unrelated trace domains (gpurun refuses pmc + sys/hip/hsa tracing).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd "$(dirname "$0")/.." || exit 1
