@@ -18,7 +18,7 @@ def main():
     codes = [int(a) for a in sys.argv[2:]] or [2, 4]
     d = 1024
     shapes = []
-    for M in (96000, 28672):
+    for M in [int(a) for a in os.environ.get("MS", "96000,28672").split(",")]:
         x = torch.randn(M, 4 * d, device="cuda").to(BF)
         w = (torch.randn(4 * d, 4 * d, device="cuda") * 0.02).to(BF)
         bias = torch.randn(4 * d, device="cuda")
