@@ -496,6 +496,36 @@ def test_cross_entropy():
     assert float(lg[::7].float().abs().max()) == 0.0
 
 
+def test_cross_entropy_gradient_is_the_fp32_gradient_rounded_once():
+    """d(logits) at ulp level (the end-to-end comparison of the autograd bridge with the fused path allows 2e-2 rel-L2 because the two
+    formulas break bf16 ties differently; this pins the fused kernel's own output): every stored bf16 value is within ONE bf16 ulp of
+    the float64 gradient (softmax - onehot) * g / n_valid, and all but a handful are its correctly rounded value."""
+    rows, V, ld, ignore = 257, 51865, 51968, 51864
+    g = torch.Generator().manual_seed(23)
+    logits = torch.zeros(rows, ld, dtype=BF)
+    logits[:, :V] = (torch.randn(rows, V, generator=g) * 2.5).to(BF)
+    tgt = torch.randint(0, 50257, (rows,), generator=g)
+    tgt[::5] = ignore
+    lg = logits.to(DEV)
+    ops().cross_entropy_(lg, V, tgt.to(DEV), ignore, gscale=1024.0)
+    got = lg[:, :V].float().cpu().double()
+    lf = logits[:, :V].double()
+    p = torch.softmax(lf, -1)
+    onehot = torch.zeros_like(p)
+    valid = tgt != ignore
+    onehot[valid, tgt[valid]] = 1.0
+    want = (p - onehot) * (1024.0 / int(valid.sum()))
+    want[~valid] = 0.0
+    want_bf = want.float().to(BF).double()
+    # one bf16 ulp of |want| (8 bits of precision: 2^(floor(log2|x|) - 7)); zeros must be exact zeros
+    ulp = torch.where(want == 0, torch.zeros_like(want), torch.exp2(torch.floor(torch.log2(want.abs().clamp_min(1e-300))) - 7))
+    err = (got - want).abs()
+    assert bool((err <= ulp * 1.0001 + 1e-300).all()), f"max error {float((err / ulp.clamp_min(1e-300)).max()):.3f} ulp"
+    off = int((got != want_bf).sum())
+    assert off <= 2e-3 * got.numel(), f"{off} of {got.numel()} values are not the correctly rounded gradient"
+    assert float(got[~valid].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("tb", [False, True])
 def test_gemm_fused_column_sum(tb, gemm_path):
     """Bias gradient fused into the dgrad epilogue (NN fast path) and its unfused fallback (other layouts / kernels)."""
