@@ -564,6 +564,24 @@ def main():
         }
         if roof:
             out["roofline"] = roof
+        span_check = None
+        if world == 1 and spans and not args.no_profile:
+            # the step that was timed against the step it replaces, at the benchmarked micro-batch, on this model's weights (outside the
+            # timed region): micro-batch 0 through the plain step (decoder backward over all 448 positions) and through the span step
+            sl = slice(0, mb)
+            net.zero_grad()
+            l_full, _ = net.loss_and_backward(ops.log_mel(pcm[sl]), ti[sl], ty[sl], tl[sl], loss_scale=loss_scale)
+            g_full = net.flat_grads.clone()
+            net.zero_grad()
+            m_raw, m_max = ops.log_mel(pcm[sl], finalize=False)
+            l_span, _ = net.loss_and_backward(m_raw, ti[sl], ty[sl], tl[sl], loss_scale=loss_scale, span=spans[0], span_forward=args.span_forward,
+                                              mel_clip_max=m_max)
+            torch.cuda.synchronize(dev)
+            span_check = {"what": f"micro-batch 0 ({mb} clips) of the timed step: span step vs the plain step (backward over all 448 positions), same weights",
+                          "loss_span": float(l_span), "loss_full": float(l_full),
+                          "grad_rel_l2": float((net.flat_grads.double() - g_full.double()).norm() / g_full.double().norm()),
+                          "active_rows_of_total": round(span_rows_mean / 448.0, 4)}
+            del g_full
         if world == 1 and not args.no_cpu_baseline:
             # parity of the benchmarked model itself (outside the timed region): clip 0 of the oracle's generator through the
             # HIP step and through the fp32 CPU oracle with the SAME weights (taken before the hbm-kernel timings touch them)
@@ -584,6 +602,8 @@ def main():
                              "mean_dlogit": round(float(dl.mean()), 5), "logit_scale": round(float(o_logits[0, :nvalid].abs().max()), 2),
                              "argmax_agree": round(float((p_logits[0, :nvalid].argmax(-1) == o_logits[0, :nvalid].argmax(-1)).float().mean()), 4)}
             del p_logits, o_logits
+        if span_check:
+            out.setdefault("parity", {})["span_step_vs_plain_step"] = span_check
         if world == 1 and not args.no_profile:
             net._workspace = None
             torch.cuda.empty_cache()
