@@ -229,12 +229,6 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
     for (int r = 0; r < 16; ++r) oT[i][r] = 0.f;
   float m_run = NEG;
   f32x2_t l_run2 = {0.f, 0.f};
-#ifdef OASR_ATTN_ONES_SUM
-  f32x16_t lT;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) lT[r] = 0.f;
-  const bf16x8_t ones_frag = __builtin_bit_cast(bf16x8_t, u32x4_t{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
-#endif
 
   // Unconditional prologue (ntiles >= 1 by construction): a guarded one leaves "Q/dO fragment loads may be pending" in
   // the compiler's wait-count state at the loop header, and hipcc then re-waits vmcnt(3..0) in front of the first MFMAs
@@ -293,9 +287,6 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       const f32x2_t a2 = {alpha, alpha};
       l_run2 *= a2;
-#ifdef OASR_ATTN_ONES_SUM
-      lT[0] *= alpha;  // (only row 0 is read)
-#endif
       m_run = m_new;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
@@ -309,9 +300,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
     }
     {
       const float nm = -m_run;
-#ifndef OASR_ATTN_ONES_SUM
       float ps0 = 0.f, ps1 = 0.f;
-#endif
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -320,15 +309,11 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
           const float p1 = __builtin_amdgcn_exp2f(fmaf(sT[kt][r + 1], C, nm));
           sT[kt][r] = p0;
           sT[kt][r + 1] = p1;
-#ifndef OASR_ATTN_ONES_SUM
           ps0 += p0;
           ps1 += p1;
-#endif
         }
-#ifndef OASR_ATTN_ONES_SUM
       l_run2[0] += ps0;
       l_run2[1] += ps1;
-#endif
     }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
@@ -337,9 +322,6 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
         const bf16x8_t pf = pack_half(sT[kt], u);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) oT[dt] = MFMA(frag_cols(vb, kt * 32 + 16 * u, dt * 32, lane), pf, oT[dt]);
-#ifdef OASR_ATTN_ONES_SUM
-        lT = MFMA(ones_frag, pf, lT);  // experiment: the row sums of P through the matrix pipe (every row of lT = sum_k P[k][q])
-#endif
       }
     if (more) {
       char* nb = smem + ((t + 1) & 1) * 2 * TILE;
@@ -349,12 +331,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
     __syncthreads();
   }
 
-#ifdef OASR_ATTN_ONES_SUM
-  const float l_tot = lT[0] + 0.f * (l_run2[0] + l_run2[1]);  // (the MFMA already summed over all 32 keys of each step: no lane exchange)
-#else
   const float l_run = l_run2[0] + l_run2[1];
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-#endif
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
   {
     // (the loop ended on a barrier: the K/V stages are free; 4 KiB of staging per wave)
