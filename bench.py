@@ -501,8 +501,8 @@ def main():
         ms = (ctypes.c_double * 4)()
         fl = (ctypes.c_double * 4)()
         cnt = (ctypes.c_int64 * 4)()
-        buf = ctypes.create_string_buffer(16384)
-        N.check(lib.oasr_profile_gemm_collect(ms, fl, cnt, buf, 16384), "profile_collect")
+        buf = ctypes.create_string_buffer(65536)
+        N.check(lib.oasr_profile_gemm_collect(ms, fl, cnt, buf, 65536), "profile_collect")
         lib.oasr_profile_gemm(0)
         sym = {}
         for line in buf.value.decode().strip().split("\n"):

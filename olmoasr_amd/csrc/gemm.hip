@@ -41,6 +41,7 @@ struct GemmProfile {
     int kind;
     double flops;
     const char* name;  // kernel symbol as rocprofv3 prints it (template arguments included)
+    int M = 0, N = 0, K = 0, epi = 0;  // shape + epilogue summary (bit 0 bias, 1 residual, 2 GELU, 3 GELU' input, 4 colsum, 5 atomic/split-K)
   };
   std::vector<Rec> recs;
 };
@@ -1250,7 +1251,8 @@ int launch_fast_cfg(const GemmArgs& a, hipStream_t stream) {
     auto tf = [](bool b) { return b ? "true" : "false"; };
     static const std::string name = std::string("oasr_gemm_fast_kernel<") + tf(TA) + ", " + tf(TB) + ", " + std::to_string(FBN) + ", " +
                                     std::to_string(NWN) + ", " + std::to_string(NSTAGE) + ", " + tf(SWAP) + ", " + tf(CSUM) + ">";
-    g_prof.recs.push_back({(TA ? 2 : 0) + (TB ? 1 : 0), 2.0 * (double)a.M * (double)a.N * (double)a.K, name.c_str()});
+    g_prof.recs.push_back({(TA ? 2 : 0) + (TB ? 1 : 0), 2.0 * (double)a.M * (double)a.N * (double)a.K, name.c_str(), a.M, a.N, a.K,
+                           (a.bias ? 1 : 0) | (a.resid ? 2 : 0) | (a.act ? 4 : 0) | (a.dgelu_u ? 8 : 0) | (a.colsum ? 16 : 0) | (a.atomic ? 32 : 0)});
     OASR_CHECK_HIP(hipEventRecord(e0, stream));
   }
   hipLaunchKernelGGL((oasr_gemm_fast_kernel<TA, TB, FBN, NWN, NSTAGE, SWAP, CSUM>), grid, dim3(128 * NWN), lds, stream, a);
@@ -1300,7 +1302,8 @@ int launch_pp_variant(const GemmArgs& a, hipStream_t stream) {
     auto tf = [](bool b) { return b ? "true" : "false"; };
     static const std::string name = std::string("oasr_gemm_pp_kernel<") + tf(TA) + ", " + tf(TB) + ", " + tf(SWAP) + ", " + tf(CSUM) +
                                     ", " + std::to_string(DMA) + ">";
-    g_prof.recs.push_back({(TA ? 2 : 0) + (TB ? 1 : 0), 2.0 * (double)a.M * (double)a.N * (double)a.K, name.c_str()});
+    g_prof.recs.push_back({(TA ? 2 : 0) + (TB ? 1 : 0), 2.0 * (double)a.M * (double)a.N * (double)a.K, name.c_str(), a.M, a.N, a.K,
+                           (a.bias ? 1 : 0) | (a.resid ? 2 : 0) | (a.act ? 4 : 0) | (a.dgelu_u ? 8 : 0) | (a.colsum ? 16 : 0) | (a.atomic ? 32 : 0)});
     OASR_CHECK_HIP(hipEventRecord(e0, stream));
   }
   hipLaunchKernelGGL((oasr_gemm_pp_kernel<TA, TB, SWAP, CSUM, DMA>), grid, dim3(512), lds, stream, pa);
@@ -1542,7 +1545,14 @@ int gemm_profile_collect(double ms[4], double flops[4], long count[4], char* by_
     ms[k] += t;
     flops[k] += g_prof.recs[i].flops;
     count[k] += 1;
-    Agg& a = agg[g_prof.recs[i].name];
+    static const bool by_shape = getenv("OASR_PROF_SHAPES") != nullptr;  // experiments: one line per (symbol, shape, epilogue)
+    std::string key = g_prof.recs[i].name;
+    if (by_shape) {
+      char sfx[96];
+      snprintf(sfx, sizeof(sfx), " M=%d N=%d K=%d epi=%d", g_prof.recs[i].M, g_prof.recs[i].N, g_prof.recs[i].K, g_prof.recs[i].epi);
+      key += sfx;
+    }
+    Agg& a = agg[key];
     a.n += 1;
     a.ms += t;
     a.flops += g_prof.recs[i].flops;
