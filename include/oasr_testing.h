@@ -1,6 +1,9 @@
 /* liboasr -- measurement and test hooks.  Exported by liboasr.so next to the product ABI of include/oasr.h, but NOT part of
  * the drop-in surface: nothing on the training / decoding path calls them.  Users: bench.py (live GEMM roofline), tests/
- * (kernel-path forcing, hardware-behaviour probes that pin what the kernels rely on), scripts/ (A/B experiments). */
+ * (kernel-path forcing, hardware-behaviour probes that pin what the kernels rely on), scripts/ (A/B experiments).
+ * The setters that change process-wide kernel selection (oasr_gemm_set_variant / _set_stagger / _force_general,
+ * oasr_attention_set_pingpong, oasr_decode_set_ln_fold) are INERT unless the process opts in with OASR_TESTING_HOOKS=1 in its
+ * environment: without it they return OASR_ESTATE and change nothing, so a production process cannot be steered through them. */
 #ifndef OASR_TESTING_H
 #define OASR_TESTING_H
 #include "oasr.h"

@@ -143,6 +143,11 @@ def lib():
     return _lib
 
 
+def enable_testing_hooks():
+    """Opt this process in to the kernel-selection setters of include/oasr_testing.h (they are inert otherwise)."""
+    os.environ["OASR_TESTING_HOOKS"] = "1"
+
+
 def check(rc, what=""):
     if rc != 0:
         msg = lib().oasr_last_error()

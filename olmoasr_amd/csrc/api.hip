@@ -56,23 +56,42 @@ extern "C" int oasr_gemm(const oasr_gemm_args* a, void* stream) {
   return launch_gemm(g, (hipStream_t)stream);
 }
 
+// The setters below change process-wide kernel-selection state (A/B experiments, forcing a kernel path in a parity test).  They live in
+// the same library as the product ABI, so they are inert unless the process opts in: OASR_TESTING_HOOKS=1 in the environment
+// (tests/conftest.py and the scripts/ that use them set it); without it they fail and change nothing.
+static int hooks_enabled(const char* what) {
+  const char* e = getenv("OASR_TESTING_HOOKS");
+  if (e && e[0] == '1') return OASR_OK;
+  oasr_set_error("%s: testing hook called without OASR_TESTING_HOOKS=1 (include/oasr_testing.h)", what);
+  return OASR_ESTATE;
+}
+#define OASR_HOOK_GATE(name)          \
+  do {                                \
+    const int g_ = hooks_enabled(name); \
+    if (g_) return g_;                \
+  } while (0)
+
 extern "C" int oasr_profile_gemm(int enable) {
   gemm_profile_enable(enable);
   return OASR_OK;
 }
 extern "C" int oasr_gemm_set_variant(int dma_in_mma) {
+  OASR_HOOK_GATE("oasr_gemm_set_variant");
   gemm_set_variant(dma_in_mma);
   return OASR_OK;
 }
 extern "C" int oasr_gemm_set_stagger(int sleeps, int phases) {
+  OASR_HOOK_GATE("oasr_gemm_set_stagger");
   gemm_set_stagger(sleeps, phases);
   return OASR_OK;
 }
 extern "C" int oasr_attention_set_pingpong(int on) {
+  OASR_HOOK_GATE("oasr_attention_set_pingpong");
   attention_set_pingpong(on);
   return OASR_OK;
 }
 extern "C" int oasr_gemm_force_general(int on) {
+  OASR_HOOK_GATE("oasr_gemm_force_general");
   gemm_force_general(on);
   return OASR_OK;
 }

@@ -925,6 +925,13 @@ KvLayer<T> kv_layer(const oasr_ctx* c, void* cache, int B, int layer) {
 int g_decode_ln_fold = -1;
 }  // namespace
 extern "C" int oasr_decode_set_ln_fold(int mode) {
+  {  // a testing hook (include/oasr_testing.h): inert without OASR_TESTING_HOOKS=1
+    const char* e = getenv("OASR_TESTING_HOOKS");
+    if (!(e && e[0] == '1')) {
+      oasr_set_error("oasr_decode_set_ln_fold: testing hook called without OASR_TESTING_HOOKS=1 (include/oasr_testing.h)");
+      return OASR_ESTATE;
+    }
+  }
   g_decode_ln_fold = mode < 0 ? -1 : (mode ? 1 : 0);
   return OASR_OK;
 }

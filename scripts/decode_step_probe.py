@@ -12,6 +12,7 @@ from olmoasr_amd.model import OLMoASR  # noqa: E402
 
 def main():
     from olmoasr_amd import _native as N
+N.enable_testing_hooks()  # noqa: E402 -- this script steers kernel selection (include/oasr_testing.h)
     net = OLMoASR(VARIANT_TO_DIMS[os.environ.get("OASR_PROBE_MODEL", "small")], device="cuda", seed=0, inference=True)
     for B in [int(a) for a in sys.argv[1:]] or [20]:
         for fold in (0, 1):

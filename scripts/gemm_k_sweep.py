@@ -7,6 +7,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from olmoasr_amd import _native as N  # noqa: E402
+N.enable_testing_hooks()  # noqa: E402 -- this script steers kernel selection (include/oasr_testing.h)
 from olmoasr_amd import ops  # noqa: E402
 
 DEV, BF = "cuda", torch.bfloat16

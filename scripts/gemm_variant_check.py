@@ -2,6 +2,7 @@ import sys, os, torch
 sys.path.insert(0, '/root/repo')
 sys.path.insert(0, os.getcwd())
 from olmoasr_amd import _native as N, ops
+N.enable_testing_hooks()  # noqa: E402 -- this script steers kernel selection (include/oasr_testing.h)
 torch.manual_seed(0)
 BF=torch.bfloat16
 ok=True

@@ -8,6 +8,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+os.environ.setdefault("OASR_TESTING_HOOKS", "1")  # the kernel-path setters of include/oasr_testing.h are inert without it
 
 
 def pytest_configure(config):

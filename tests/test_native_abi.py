@@ -164,3 +164,16 @@ def test_module_forward_mask_mapping():
             _mask_to_native(bad, 2, T, T)
     with pytest.raises(N.NativeError):
         _mask_to_native(causal, 2, T, T + 1)
+
+
+def test_testing_hooks_are_inert_without_the_opt_in(native, monkeypatch):
+    """The kernel-selection setters of include/oasr_testing.h live in the product library; without OASR_TESTING_HOOKS=1 in the
+    process environment they must fail and change nothing (host logic only: no GPU needed)."""
+    lib = native.lib()
+    monkeypatch.delenv("OASR_TESTING_HOOKS", raising=False)
+    for fn, args in ((lib.oasr_gemm_force_general, (1,)), (lib.oasr_attention_set_pingpong, (0,)), (lib.oasr_gemm_set_stagger, (1, 2)),
+                     (lib.oasr_gemm_set_variant, (1,)), (lib.oasr_decode_set_ln_fold, (0,))):
+        assert fn(*args) != 0
+        assert b"OASR_TESTING_HOOKS" in lib.oasr_last_error()
+    monkeypatch.setenv("OASR_TESTING_HOOKS", "1")
+    assert lib.oasr_gemm_force_general(0) == 0 and lib.oasr_attention_set_pingpong(1) == 0 and lib.oasr_decode_set_ln_fold(-1) == 0
