@@ -13,7 +13,7 @@
 // the backward: dK/dV kernel computes S[q][k] with the key lane-local, dQ kernel computes S^T with the query
 // lane-local; P and dS feed the second-stage MFMAs straight from registers.
 //
-// forward : grid (ceil(Tq/128), B*H), 4 waves x 32 queries, KV tiles of 64 keys double-buffered in LDS.
+// forward : grid (ceil(Tq/128), B*H), 4 waves x 32 queries, KV tiles of 64 keys through a 3-stage LDS-DMA ring.
 // backward: bwd_dq   grid (ceil(Tq/128), B*H)  -- also produces delta = rowsum(dO * O)
 //           bwd_dkdv grid (ceil(Tk/128), B*H)  -- loops over 64-query tiles of Q / dO / lse / delta.
 #include "kernels.h"
@@ -184,12 +184,59 @@ __device__ __forceinline__ f32x2_t pk_exp2(f32x2_t a) {
 // the wave grows past it by more than this; until then P = exp2(s - m_ref) <= 2^8, harmless in fp32 / bf16.
 constexpr float RESCALE_THR = 8.0f;
 
+// ---- LDS-DMA ring helpers (used by the forward below and by the ping-pong backward kernels further down, where the scheme is described) ----
+#define ATTN_FENCE() __builtin_amdgcn_sched_barrier(0)
+constexpr int PNS = 4;          // ring stages
+constexpr int PSTG = 2 * TILE;  // two 64-row tiles per stage
+
+// The DMA is issued from inline assembly on purpose: hipcc orders every later ds_read behind a compiler-visible LDS-DMA with
+// s_waitcnt vmcnt(0) (it cannot tell the ring stages apart), which would drain the tiles in flight at every step.  The loops
+// count their own pieces (s_waitcnt vmcnt(n) + s_barrier before a stage is read); in-order return makes any compiler-placed
+// vmcnt for its own loads merely conservative.  (m0 is reserved: the compiler-generated code of these kernels has no other user.)
+__device__ __forceinline__ void glds16_asm(const u32x4_t rs, unsigned lds_addr, unsigned voff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory");
+}
+struct PipeSrc1 {
+  u32x4_t rs;  // raw buffer descriptor over rows [0, rmax) of this (batch, head) slice, 64 columns
+  unsigned voff;
+  unsigned tile_bytes;
+};
+// Piece p (1 KiB = 8 rows) of a 64-row tile lands at LDS bytes [p * 1024, +1024) of the tile; lane l writes chunk c' = l & 7 of row
+// 8p + (l >> 3), which under tile_addr's swizzle holds source chunk c' ^ g(row).  Wave w of 8 moves piece w of each tile.
+__device__ __forceinline__ PipeSrc1 pipe_src1(const bf16_t* base, long ld, int rmax, int wave, int lane) {
+  PipeSrc1 t;
+  const unsigned long addr = (unsigned long)base;
+  t.rs[0] = (unsigned)addr;
+  t.rs[1] = (unsigned)(addr >> 32) & 0xffffu;  // stride 0: raw buffer
+  t.rs[2] = (unsigned)(((long)(rmax - 1) * ld + 64) * 2);
+  t.rs[3] = 0x00020000u;
+  t.tile_bytes = (unsigned)(64 * ld * 2);
+  const int row = wave * 8 + (lane >> 3);
+  const int x = (row >> 1) & 7;
+  const int c = (lane & 7) ^ x ^ ((x & 1) << 2);
+  t.voff = (unsigned)(row * ld * 2 + c * 16);  // the tile offset is added here too: the range check does not cover soffset
+  return t;
+}
+#define ATTN_BARRIER()                          \
+  do {                                          \
+    ATTN_FENCE();                               \
+    asm volatile("s_barrier" ::: "memory");     \
+    ATTN_FENCE();                               \
+  } while (0)
+
+
 // ------------------------------------------------------------------------------------------------------------
 // ROWS: the query side (and, when a.k_rows is set, the key side) lives in chunked token rows (kernels.h) -- the decoder of a
 // span-limited training step.  ROWS == false is the plain strided layout and compiles to exactly the code it always was.
 template <bool CAUSAL, bool ROWS>
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE];  // stage s: K at 2s*TILE, V at (2s+1)*TILE
+  // K/V tiles move global -> LDS by DMA, two tiles ahead through a 3-stage ring (3 x 16 KiB per workgroup, three workgroups per CU): no staging
+  // registers, no commit stores, and a tile has a whole iteration to land before anybody waits for it.  The ONE barrier of an iteration sits
+  // between the softmax and the O^T MFMAs: it releases tile t+1, whose first four K fragments are then read under the O^T MFMAs of tile t, so the
+  // next iteration's S^T MFMAs start without an LDS round trip.  (In-kernel cycle stamps of the register-staged form it replaces,
+  // profiles/r04_attention_forward_stamps.txt: of a wave's 3400 cycles per tile 600 went into waiting for the next tile's global loads and
+  // writing them to LDS, 870 into the K fragment round trip + S^T issue.  Results are bit-identical to that form: scripts/attn_fwd_crc.py.)
+  __shared__ __attribute__((aligned(1024))) char smem[3 * 2 * TILE];  // stage s: K at 2s*TILE, V at (2s+1)*TILE
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
   // 1-D grid, XCD-aware: all query blocks of one (batch, head) run on the same XCD so K/V are filled into that XCD's
   // L2 once and re-used by the other query blocks (round-robin dispatch would fetch them through all 8 L2s).
@@ -217,10 +264,27 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
   if (CAUSAL) kv_end = kv_end < q0 + 128 ? kv_end : q0 + 128;
   const int ntiles = kv_end > 0 ? (kv_end + 63) >> 6 : 1;  // >= 1: a fully masked tile yields l = 0 -> O = 0
 
-  const TileSrc ksrc = krows ? tile_src(a.k + h * 64, a.ldk, a.B * a.Tk, tid) : tile_src(a.k + (long)b * a.bsk + h * 64, a.ldk, a.Tk, tid);
-  const TileSrc vsrc = krows ? tile_src(a.v + h * 64, a.ldv, a.B * a.Tk, tid) : tile_src(a.v + (long)b * a.bsv + h * 64, a.ldv, a.Tk, tid);
   // first row of key tile t (64 keys = one chunk)
   auto krow0 = [&](int t) { return krows ? __builtin_amdgcn_readfirstlane(a.k_rows[b * OASR_ROWTAB + t]) : t * 64; };
+  const PipeSrc1 ksrc = krows ? pipe_src1(a.k + h * 64, a.ldk, a.B * a.Tk, wave, lane) : pipe_src1(a.k + (long)b * a.bsk + h * 64, a.ldk, a.Tk, wave, lane);
+  const PipeSrc1 vsrc = krows ? pipe_src1(a.v + h * 64, a.ldv, a.B * a.Tk, wave, lane) : pipe_src1(a.v + (long)b * a.bsv + h * 64, a.ldv, a.Tk, wave, lane);
+  const unsigned smem_a = (unsigned)(size_t)smem;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);  // (the DMA's LDS base travels in m0: a scalar)
+  const unsigned krb = (unsigned)(a.ldk * 2), vrb = (unsigned)(a.ldv * 2);
+  // this wave's four 1 KiB pieces of key tile t2 (rows 8w.. and 32+8w.. of K and of V); tiles past the last one read as zeros (offset out of range)
+  auto dma_tile = [&](int t2, int stage) {
+    unsigned ko = 0x7fffff00u, vo = 0x7fffff00u;
+    if (t2 < ntiles) {
+      const unsigned r0 = (unsigned)krow0(t2);
+      ko = ksrc.voff + r0 * krb;
+      vo = vsrc.voff + r0 * vrb;
+    }
+    const unsigned dst = smem_a + stage * 2 * TILE + wave_u * 1024;
+    glds16_asm(ksrc.rs, dst, ko);
+    glds16_asm(ksrc.rs, dst + 4096, ko + 32 * krb);
+    glds16_asm(vsrc.rs, dst + TILE, vo);
+    glds16_asm(vsrc.rs, dst + TILE + 4096, vo + 32 * vrb);
+  };
 
   f32x16_t oT[2];
 #pragma unroll
@@ -230,32 +294,31 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
   float m_run = NEG;
   f32x2_t l_run2 = {0.f, 0.f};
 
-  // Unconditional prologue (ntiles >= 1 by construction): a guarded one leaves "Q/dO fragment loads may be pending" in
-  // the compiler's wait-count state at the loop header, and hipcc then re-waits vmcnt(3..0) in front of the first MFMAs
-  // of EVERY iteration -- i.e. for the K/V prefetch it has just issued -- serialising the load latency into the loop.
-  u32x4_t rk[2], rv[2];
-  tile_issue(ksrc, krow0(0), rk);
-  tile_issue(vsrc, krow0(0), rv);
-  tile_commit(smem, tid, rk);
-  tile_commit(smem + TILE, tid, rv);
-  __syncthreads();
-
+  // Ring protocol (every wave issues 4 pieces per tile; vmcnt counts them in order):
+  //   prologue      : tiles 0, 1 in flight; wait for tile 0 (vmcnt(4)) + barrier; K fragments (first 32 keys) of tile 0
+  //   iteration t   : S^T MFMAs on tile t | softmax | vmcnt(0) + barrier: tile t+1 has landed for everybody and everybody is past its reads of
+  //                   tile t-1 | DMA of tile t+2 into tile t-1's stage | K fragments of tile t+1 | O^T MFMAs on tile t
+  asm volatile("" ::"v"(qf[0]), "v"(qf[1]), "v"(qf[2]), "v"(qf[3]));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the Q fragments; from here on the loop counts its own DMA pieces)
+  dma_tile(0, 0);
+  dma_tile(1, 1);
+  int stg = 0;
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  ATTN_BARRIER();
+  bf16x8_t kf0[4];
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) kf0[ds] = frag_rows(smem, 0, ds, lane);
   for (int t = 0; t < ntiles; ++t) {
-    const char* kb = smem + (t & 1) * 2 * TILE;
+    const char* kb = smem + stg * 2 * TILE;
     const char* vb = kb + TILE;
-    const bool more = t + 1 < ntiles;
-    if (more) {
-      const int r0 = krow0(t + 1);
-      tile_issue(ksrc, r0, rk);
-      tile_issue(vsrc, r0, rv);
-    }
+    stg = stg == 2 ? 0 : stg + 1;
     f32x16_t sT[2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) sT[kt][r] = 0.f;
 #pragma unroll
-      for (int ds = 0; ds < 4; ++ds) sT[kt] = MFMA(frag_rows(kb, kt * 32, ds, lane), qf[ds], sT[kt]);
+      for (int ds = 0; ds < 4; ++ds) sT[kt] = MFMA(kt == 0 ? kf0[ds] : frag_rows(kb, 32, ds, lane), qf[ds], sT[kt]);
     }
     // Only boundary tiles need the per-element mask (wave-uniform test): last partial tile of kv_len, and for the
     // causal case the tiles that cross this wave's diagonal.  Scores stay raw; the softmax scale rides in the fma.
@@ -315,6 +378,13 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
       l_run2[0] += ps0;
       l_run2[1] += ps1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile t+1 have landed
+    ATTN_BARRIER();                                    // ... and everybody's; everybody is past the O^T reads of tile t-1: its stage is free
+    dma_tile(t + 2, stg == 2 ? 0 : stg + 1);           // (stg already names tile t+1's stage)
+    if (t + 1 < ntiles) {
+#pragma unroll
+      for (int ds = 0; ds < 4; ++ds) kf0[ds] = frag_rows(smem + stg * 2 * TILE, 0, ds, lane);
+    }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -323,13 +393,9 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) oT[dt] = MFMA(frag_cols(vb, kt * 32 + 16 * u, dt * 32, lane), pf, oT[dt]);
       }
-    if (more) {
-      char* nb = smem + ((t + 1) & 1) * 2 * TILE;
-      tile_commit(nb, tid, rk);
-      tile_commit(nb + TILE, tid, rv);
-    }
-    __syncthreads();
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail pieces (zeros) must not land on the staging tiles below
+  __syncthreads();
 
   const float l_run = l_run2[0] + l_run2[1];
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -547,45 +613,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 //   LOAD(j)   : operand fragments of step j+1, transposed fragments of step j-1; on even j the DMA of tile j/2+2 and the wait for
 //               this wave's pieces of tile j/2+1
 //   COMPUTE(j): first-stage MFMAs of step j+1, softmax VALU of step j, second-stage MFMAs of step j-1
-#define ATTN_FENCE() __builtin_amdgcn_sched_barrier(0)
-constexpr int PNS = 4;          // ring stages
-constexpr int PSTG = 2 * TILE;  // two 64-row tiles per stage
-
-// The DMA is issued from inline assembly on purpose: hipcc orders every later ds_read behind a compiler-visible LDS-DMA with
-// s_waitcnt vmcnt(0) (it cannot tell the ring stages apart), which would drain the tiles in flight at every step.  The loops
-// count their own pieces (s_waitcnt vmcnt(n) + s_barrier before a stage is read); in-order return makes any compiler-placed
-// vmcnt for its own loads merely conservative.  (m0 is reserved: the compiler-generated code of these kernels has no other user.)
-__device__ __forceinline__ void glds16_asm(const u32x4_t rs, unsigned lds_addr, unsigned voff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory");
-}
-struct PipeSrc1 {
-  u32x4_t rs;  // raw buffer descriptor over rows [0, rmax) of this (batch, head) slice, 64 columns
-  unsigned voff;
-  unsigned tile_bytes;
-};
-// Piece p (1 KiB = 8 rows) of a 64-row tile lands at LDS bytes [p * 1024, +1024) of the tile; lane l writes chunk c' = l & 7 of row
-// 8p + (l >> 3), which under tile_addr's swizzle holds source chunk c' ^ g(row).  Wave w of 8 moves piece w of each tile.
-__device__ __forceinline__ PipeSrc1 pipe_src1(const bf16_t* base, long ld, int rmax, int wave, int lane) {
-  PipeSrc1 t;
-  const unsigned long addr = (unsigned long)base;
-  t.rs[0] = (unsigned)addr;
-  t.rs[1] = (unsigned)(addr >> 32) & 0xffffu;  // stride 0: raw buffer
-  t.rs[2] = (unsigned)(((long)(rmax - 1) * ld + 64) * 2);
-  t.rs[3] = 0x00020000u;
-  t.tile_bytes = (unsigned)(64 * ld * 2);
-  const int row = wave * 8 + (lane >> 3);
-  const int x = (row >> 1) & 7;
-  const int c = (lane & 7) ^ x ^ ((x & 1) << 2);
-  t.voff = (unsigned)(row * ld * 2 + c * 16);  // the tile offset is added here too: the range check does not cover soffset
-  return t;
-}
-#define ATTN_BARRIER()                          \
-  do {                                          \
-    ATTN_FENCE();                               \
-    asm volatile("s_barrier" ::: "memory");     \
-    ATTN_FENCE();                               \
-  } while (0)
-
 // ROWS: the query side lives in chunked token rows and is limited to q_span (kernels.h): the cross-attention of a span-limited step
 template <bool ROWS>
 __global__ __launch_bounds__(512, 1) void attn_bwd_dq_pp_kernel(AttnArgs a) {
