@@ -94,6 +94,28 @@ __global__ __launch_bounds__(NW * 64, 1) void quad(const char* __restrict__ src,
   if (s == 12345.678f) sink[threadIdx.x] = s;
 }
 
+// sustained rate under the package power cap: back-to-back launches for ~seconds (the clock settles to what the stream's energy per flop allows)
+template <int MODE, int NW>
+static void sustained(const char* name, const char* src, float* sink, int nt, float seconds) {
+  CK(hipFuncSetAttribute((const void*)quad<MODE, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  hipLaunchKernelGGL((quad<MODE, NW>), dim3(256), dim3(NW * 64), 131072, 0, src, sink, nt, 1);
+  CK(hipDeviceSynchronize());
+  const int n = (int)(seconds / 0.33e-3f);
+  // first half warms the package up, second half is timed
+  for (int i = 0; i < n / 2; ++i) hipLaunchKernelGGL((quad<MODE, NW>), dim3(256), dim3(NW * 64), 131072, 0, src, sink, nt, 1);
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < n / 2; ++i) hipLaunchKernelGGL((quad<MODE, NW>), dim3(256), dim3(NW * 64), 131072, 0, src, sink, nt, 1);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  const double flops = 256.0 * nt * 256.0 * 256.0 * 64.0 * 2.0 * (n / 2);
+  printf("%-64s %8.1f ms for %d launches  %7.0f TFLOP/s-equivalent sustained\n", name, ms, n / 2, flops / ms / 1e9);
+}
+
 template <int MODE, int NW>
 static void run(const char* name, const char* src, float* sink, int nt, int shared_src) {
   CK(hipFuncSetAttribute((const void*)quad<MODE, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
@@ -120,6 +142,16 @@ int main() {
   float* sink;
   CK(hipMalloc(&src, (size_t)256 * nt << 16));
   CK(hipMemset(src, 0, (size_t)256 * nt << 16));
+  {  // the shared 1 MiB that the L2-resident runs read: random bf16 in +-[0.5, 1) -- matrix-core power depends on the operands' toggling, zeros would flatter every stream
+    unsigned short* h = (unsigned short*)malloc(1 << 20);
+    unsigned x = 12345u;
+    for (int i = 0; i < (1 << 19); ++i) {
+      x = x * 1664525u + 1013904223u;
+      h[i] = (unsigned short)(((x >> 16) & 0x807Fu) | 0x3F00u);
+    }
+    CK(hipMemcpy(src, h, 1 << 20, hipMemcpyHostToDevice));
+    free(h);
+  }
   CK(hipMalloc(&sink, 4096));
   printf("operand tiles SHARED by all workgroups (1 MiB, L2-resident: the reuse a GEMM's rasterisation gives)\n");
   printf("-- 4 waves x 128x128 outputs (one wave per SIMD: 64 MFMAs, 32 fragment reads, 16 DMA pieces per wave and K-tile)\n");
@@ -139,6 +171,13 @@ int main() {
   run<15, 8>("8 waves, all", src, sink, nt, 1);
   run<15, 4>("4 waves, all", src, sink, nt, 1);
   run<15, 8>("8 waves, all", src, sink, nt, 1);
+  printf("-- sustained (3 s each, second half timed; L2-resident operands): what the power cap leaves of each stream\n");
+  sustained<1, 4>("4 waves, MFMAs only", src, sink, nt, 3.0f);
+  sustained<1, 8>("8 waves, MFMAs only", src, sink, nt, 3.0f);
+  sustained<15, 4>("4 waves, all", src, sink, nt, 3.0f);
+  sustained<15, 8>("8 waves, all", src, sink, nt, 3.0f);
+  sustained<15, 4>("4 waves, all", src, sink, nt, 3.0f);
+  sustained<15, 8>("8 waves, all", src, sink, nt, 3.0f);
   printf("operand tiles private per workgroup (4 MiB each: pure HBM streaming, 1 GiB per launch)\n");
   run<15, 4>("4 waves, all", src, sink, nt, 0);
   run<15, 8>("8 waves, all", src, sink, nt, 0);
