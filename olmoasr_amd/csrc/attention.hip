@@ -836,11 +836,11 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dq_pp_kernel(AttnArgs a) {
 #pragma unroll
     for (int st = 0; st < PNS; ++st) {
       const int t = g * PNS + st;
-      compute_seg(0);
+      if (w_act) compute_seg(0);  // (a wave whose 32 queries lie past the span has nothing to compute: it keeps its DMA / barrier duties only)
       ATTN_BARRIER();
       load_seg(t, st, 1);
       ATTN_BARRIER();
-      compute_seg(1);
+      if (w_act) compute_seg(1);
       ATTN_BARRIER();
       load_seg(t + 1, (st + 1) & 3, 0);
       ATTN_BARRIER();
