@@ -109,19 +109,41 @@ def train_flops_per_sample(d, L, T=1500, S=448, V=51865, F=3000, n_mels=80):
     return 3 * (conv + L * enc_layer + L * dec_layer + logits)
 
 
-def executed_flops_per_sample(d, L, span_rows_mean, T=1500, S=448, V=51865, F=3000, n_mels=80):
-    """FLOPs the supervised-span step actually executes per sample: the forward over all S positions, the decoder's backward (2 x
-    forward) over `span_rows_mean` = mean_b ceil64(span_b) token rows.  Attention backward of the decoder: the query side shrinks
-    to the span (self-attention: keys too)."""
+STEP_MODES = ("span-forward", "span-backward", "plain")
+
+
+def decoder_rows(mode, spans, S=448):
+    """(forward rows, backward rows) of the decoder's token-row matrices for one batch under each step mode.  `spans` = per-sample
+    supervised span (one past the last position that can carry gradient); the span steps round it up to whole 64-position chunks.
+      plain          the reference's computation shape: every sample padded to S positions, forward and backward
+      span-backward  forward over S positions, backward over the chunks that can carry gradient (round 4's step)
+      span-forward   forward AND backward over those chunks (the padded positions' logits are nobody's output) -- the default
+    A batch whose every span reaches the last chunk (e.g. every text_len = 447) makes all three the same."""
+    assert mode in STEP_MODES, mode
+    B = len(spans)
+    act = sum((int(x) + 63) // 64 * 64 for x in spans)
+    act = min(act, B * S)
+    return (B * S if mode != "span-forward" else act), (B * S if mode == "plain" else act)
+
+
+def executed_flops_per_sample(d, L, bwd_rows_mean, fwd_rows_mean=448, T=1500, S=448, V=51865, F=3000, n_mels=80):
+    """FLOPs a step actually executes per sample: the decoder's forward over `fwd_rows_mean` token rows per clip, its backward (2 x
+    forward) over `bwd_rows_mean` (decoder_rows() / B).  Attention of the decoder: the query side shrinks with the rows (self-attention:
+    keys too); the encoder side and the cross-attention K / V projections always run in full."""
     conv = 2 * F * n_mels * 3 * d + 2 * T * d * 3 * d
     enc_layer = 24 * T * d * d + 4 * T * T * d
 
-    def dec(Sq, cross_kv=True):
-        return (8 * Sq * d * d + 4 * Sq * Sq * d) + (4 * Sq * d * d + (4 * T * d * d if cross_kv else 0) + 4 * Sq * T * d) + 16 * Sq * d * d
-    fwd = conv + L * enc_layer + L * dec(S) + 2 * S * d * V
-    R = span_rows_mean
-    bwd = 2 * (conv + L * enc_layer + L * dec(R) + 2 * R * d * V)
+    def dec(Sq):
+        return (8 * Sq * d * d + 4 * Sq * Sq * d) + (4 * Sq * d * d + 4 * T * d * d + 4 * Sq * T * d) + 16 * Sq * d * d
+    fwd = conv + L * enc_layer + L * dec(fwd_rows_mean) + 2 * fwd_rows_mean * d * V
+    bwd = 2 * (conv + L * enc_layer + L * dec(bwd_rows_mean) + 2 * bwd_rows_mean * d * V)
     return fwd + bwd
+
+
+def spread(ms):
+    """min / median / max of a list of per-step milliseconds (HIP events between the steps of the timed region)."""
+    import statistics
+    return {"min": round(min(ms), 2), "median": round(statistics.median(ms), 2), "max": round(max(ms), 2), "n": len(ms)}
 
 
 def synth_batch(indices, device):
@@ -304,38 +326,61 @@ def self_launch(n, argv, module="torch.distributed.run", extra_env=None):
 
 def stub_main(args):
     """OASR_BENCH_STUB=1: everything bench.py does AROUND the step -- rank environment, process group, warm-up, barrier-bracketed
-    timing of exactly K steps, max over ranks, one JSON line from rank 0 -- with a stand-in step (a gloo all-reduce), so the
-    multi-rank launch path is covered on a machine without GPUs.  Never a measurement."""
+    timing of exactly K steps, max / min over ranks, the `ddp` block of the line, `--reducer both`, one JSON line from rank 0 -- with a
+    stand-in step (the real GradReducer over gloo on a small CPU arena), so the multi-rank launch path is covered on a machine without
+    GPUs.  Never a measurement."""
+    from olmoasr_amd import ddp
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    buf = torch.ones(1024)
+    buf = torch.ones(4096)
+    segs = [(0, 1024), (1024, 2048), (3072, 1024)]
+    algos = ("allreduce", "direct") if args.reducer == "both" else (args.reducer,)
+    reducers = {a: ddp.GradReducer(buf, segs, bucket_cap_mb=args.bucket_mb, algo=a, timing=True) for a in algos} if world > 1 else {}
 
-    def one_step():
+    def one_step(algo):
         if world > 1:
-            dist.all_reduce(buf)
+            reducers[algo].reduce()
             buf.div_(world)
         time.sleep(0.002)
-    for _ in range(args.warmup):
-        one_step()
+
+    def timed(algo):
+        for _ in range(args.warmup):
+            one_step(algo)
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        per = []
+        for _ in range(args.steps):
+            t1 = time.perf_counter()
+            one_step(algo)
+            per.append(1000.0 * (time.perf_counter() - t1))
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        lo = hi = el
+        if world > 1:
+            t = torch.tensor([el, -el], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            hi, lo = float(t[0]), float(-t[1])
+        return hi, lo, per
+    elapsed, lo, per = timed(algos[0])
+    block = None
     if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
+        block = {"reducer": algos[0], "bucket_mb": args.bucket_mb, "buckets": len(reducers[algos[0]].buckets),
+                 "rank_step_ms_min": round(1000 * lo / args.steps, 3), "rank_step_ms_max": round(1000 * elapsed / args.steps, 3),
+                 **reducers[algos[0]].comm_report()}
+        if len(algos) > 1:
+            el2, _, per2 = timed(algos[1])
+            block["reducer_ab"] = {algos[0]: {"ms_per_step": round(1000 * elapsed / args.steps, 3)},
+                                   algos[1]: {"ms_per_step": round(1000 * el2 / args.steps, 3), "per_step_ms": spread(per2), **reducers[algos[1]].comm_report()}}
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps({"metric": "stub", "value": round(world * args.steps / elapsed, 3), "unit": "steps/sec", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 3),
+                          "per_step_ms": spread(per), "ddp": block,
                           "data": "stub (OASR_BENCH_STUB=1: launch-path rehearsal on CPU, not a measurement)",
                           "buf_ok": bool(float(buf[0]) == 1.0)}), flush=True)
     return 0
@@ -350,21 +395,26 @@ def main():
     ap.add_argument("--per-gpu-batch", type=int, default=256)
     ap.add_argument("--micro-batch", type=int, default=0,
                     help="clips per micro-batch (gradient accumulation over per-gpu-batch / micro-batch); 0 = the largest of "
-                         "128/64/32/... whose saved activations fit in free HBM with 24 GiB to spare")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r04_hbm_traffic.json"),
+                         "128/64/32/... whose saved activations fit in free HBM with --hbm-margin-gib to spare (the SAME rule at every N)")
+    ap.add_argument("--hbm-margin-gib", type=float, default=16.0,
+                    help="HBM left free beside the saved-activation workspace when the micro-batch is chosen: transient tensors of a step "
+                         "(< 1 GiB) + RCCL's channel buffers at N > 1 (~1-2 GiB); one world-independent number so N = 1 and N = 8 pick the same micro-batch")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r05_hbm_traffic.json"),
                     help="per-symbol HBM bytes per launch from the rocprofv3 PMC passes (scripts/pmc_traffic.py)")
     ap.add_argument("--bucket-mb", type=float, default=128.0)
-    ap.add_argument("--reducer", default="allreduce", choices=["allreduce", "direct"],
-                    help="gradient exchange per bucket: one RCCL all-reduce, or reduce-scatter + all-gather as all-to-alls (all xGMI links)")
+    ap.add_argument("--reducer", default="allreduce", choices=["allreduce", "direct", "both"],
+                    help="gradient exchange per bucket: one RCCL all-reduce, or reduce-scatter + all-gather in place (all xGMI links); "
+                         "'both' times the two back to back in one launch (headline = allreduce, the other under `reducer_ab`)")
     ap.add_argument("--trim-padding", action="store_true",
                     help="opt-in, NOT the reference's computation shape: run the decoder over ceil16(max text_len) of each "
                          "micro-batch instead of the padded 448 positions (same loss and gradients; see DESIGN.md)")
-    ap.add_argument("--full-backward", action="store_true",
-                    help="A/B: run the decoder's backward over all 448 padded positions (the plain step) instead of the supervised "
-                         "span (oasr_train_fwd_bwd_span: same loss and gradients, the forward covers 448 positions either way)")
-    ap.add_argument("--span-forward", action="store_true",
-                    help="opt-in, NOT the reference's computation shape: the decoder's FORWARD leaves the positions past the supervised "
-                         "span out as well (their logits are computed by the reference and read by nothing; same loss and gradients)")
+    ap.add_argument("--reference-shape", "--full-backward", dest="reference_shape", action="store_true",
+                    help="headline = the PLAIN step: decoder forward and backward over all 448 padded positions, the reference's computation shape")
+    ap.add_argument("--span-backward-only", action="store_true",
+                    help="headline = round 4's step: decoder forward over all 448 positions, backward over the supervised span")
+    ap.add_argument("--span-forward", action="store_true", help="(the default since round 5; accepted for old command lines)")
+    ap.add_argument("--ab-steps", type=int, default=-1,
+                    help="steps timed for each of the two NON-headline step modes in the same process (1 warm-up each); -1 = min(steps, 3), 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
@@ -405,29 +455,36 @@ def main():
     ddp.broadcast_parameters(net.flat_params)
     net.refresh_shadow()
     net.init_optimizer_state()
-    reducer = ddp.GradReducer(net.flat_grads, net.grad_segments, bucket_cap_mb=args.bucket_mb, algo=args.reducer,
-                              force=world == 1) if ddp_path else None
+    reducers = {}
+    if ddp_path:
+        for algo in (("allreduce", "direct") if args.reducer == "both" else (args.reducer,)):
+            reducers[algo] = ddp.GradReducer(net.flat_grads, net.grad_segments, bucket_cap_mb=args.bucket_mb, algo=algo, force=world == 1, timing=True)
+    head_algo = "allreduce" if args.reducer == "both" else args.reducer
 
     B = args.per_gpu_batch
+    free_gib = torch.cuda.mem_get_info(dev)[0] / 2**30
+    ws_gib = lambda cand: N.lib().oasr_workspace_bytes(net._ctx, cand, dims.n_text_ctx, 1) / 2**30  # noqa: E731
     if args.micro_batch > 0:
-        mb = min(args.micro_batch, B)
+        mb, mb_rule = min(args.micro_batch, B), "--micro-batch"
     else:  # no-recompute training keeps ~1.9 GiB of activations per medium clip: 128 clips = 240 GiB of the 288
-        free = torch.cuda.mem_get_info(dev)[0]
+        # ONE margin for every world size (round 4 added 8 GiB at N > 1, which put the 8-GPU choice within 1 GiB of flipping to 64 and
+        # would have booked a micro-batch change as scaling loss): the candidates are tried in the same order against the same rule
         mb = 1
-        # head-room beside the saved activations: 24 GiB for the transient tensors of a step; with more than one rank RCCL's channel /
-        # proxy buffers (a few hundred MiB per peer over 7 xGMI links) and its staging for the bucketed exchange come out of the same
-        # HBM -- 8 GiB more, so a short box drops to micro-batch 64 instead of failing inside the first collective
-        margin = (24 << 30) + ((8 << 30) if world > 1 else 0)
         for cand in (128, 64, 32, 16, 8, 4, 2):
-            if cand <= B and B % cand == 0 and N.lib().oasr_workspace_bytes(net._ctx, cand, dims.n_text_ctx, 1) + margin <= free:
+            if cand <= B and B % cand == 0 and ws_gib(cand) + args.hbm_margin_gib <= free_gib:
                 mb = cand
                 break
+        mb_rule = f"largest of 128/64/.. with workspace + {args.hbm_margin_gib:g} GiB <= free HBM"
         if ddp_path:  # same choice on every rank
             t = torch.tensor([mb], device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             mb = int(t)
     assert B % mb == 0
     accum = B // mb
+    mb_pref = next((c for c in (128, 64, 32, 16, 8, 4, 2, 1) if c <= B and B % c == 0), 1)
+    if mb < mb_pref and args.micro_batch <= 0 and rank == 0:  # loud: a smaller micro-batch is ~3 % of the step and must not pass for scaling loss
+        print(f"bench.py: WARNING micro-batch {mb} < {mb_pref}: free HBM {free_gib:.1f} GiB < workspace {ws_gib(mb_pref):.1f} + margin "
+              f"{args.hbm_margin_gib:g} GiB; lines at different N are comparable only at equal micro_batch", file=sys.stderr, flush=True)
     # sample i of the global batch goes to rank i % world (DistributedSampler rule, shuffle off)
     pcm, ti, ty, tl = synth_batch(range(rank, B * world, world), dev)
     loss_buf = torch.zeros(1, device=dev)
@@ -438,27 +495,31 @@ def main():
     ctx = [None] * accum
     if args.trim_padding:
         ctx = [min(448, (int(tl[i * mb:(i + 1) * mb].max()) + 15) // 16 * 16) for i in range(accum)]
-    # supervised span per sample, on the HOST like the loader has it (train_timestamps.py:238-343 builds the sequences there):
-    # one past the last position whose target is not the ignore index, >= text_len
-    spans = None
-    if not args.full_backward and not args.trim_padding:
-        sp = OLMoASR.supervised_span(ty, tl)
-        spans = [sp[i * mb:(i + 1) * mb].contiguous() for i in range(accum)]
-        span_rows_mean = float(((sp + 63) // 64 * 64).float().mean())
+    # supervised span per sample, on the HOST like the loaders hand it out (olmoasr_amd/synth.py::supervised_span_host,
+    # train_timestamps.py:238-343 builds the sequences there): one past the last position whose target is not the ignore index
+    sp = OLMoASR.supervised_span(ty, tl)
+    spans = [sp[i * mb:(i + 1) * mb].contiguous() for i in range(accum)]
+    head_mode = "plain" if (args.reference_shape or args.trim_padding) else ("span-backward" if args.span_backward_only else "span-forward")
+    rows = {m: decoder_rows(m, sp.tolist(), dims.n_text_ctx) for m in STEP_MODES}
 
-    def one_step():
+    def one_step(mode=head_mode, reducer_name=head_algo):
+        reducer = reducers.get(reducer_name)
         state["step"] += 1
         net.zero_grad()
         for i in range(accum):
             sl = slice(i * mb, (i + 1) * mb)
-            # (span step: whisper's floor-at-max-minus-8 / (x + 4) / 4 lines ride in the encoder's time-major transpose instead of a
-            # second pass over the log-mel tensor)
-            mel, clip_max = ops.log_mel(pcm[sl], finalize=False) if spans else (ops.log_mel(pcm[sl]), None)
             last = i == accum - 1
-            net.loss_and_backward(mel, ti[sl], ty[sl], tl[sl], loss_scale=loss_scale, accumulation_steps=accum, loss_out=loss_buf,
-                                  accumulate_loss=i > 0, segment_events=reducer.segment_events() if (reducer and last) else None,
-                                  text_ctx=ctx[i], span=spans[i] if spans else None, span_forward=bool(spans) and args.span_forward,
-                                  mel_clip_max=clip_max)
+            seg = reducer.segment_events() if (reducer and last) else None
+            if mode == "plain":
+                net.loss_and_backward(ops.log_mel(pcm[sl]), ti[sl], ty[sl], tl[sl], loss_scale=loss_scale, accumulation_steps=accum,
+                                      loss_out=loss_buf, accumulate_loss=i > 0, segment_events=seg, text_ctx=ctx[i])
+            else:
+                # (span steps: whisper's floor-at-max-minus-8 / (x + 4) / 4 lines ride in the encoder's time-major transpose instead of
+                # a second pass over the log-mel tensor)
+                mel, clip_max = ops.log_mel(pcm[sl], finalize=False)
+                net.loss_and_backward(mel, ti[sl], ty[sl], tl[sl], loss_scale=loss_scale, accumulation_steps=accum, loss_out=loss_buf,
+                                      accumulate_loss=i > 0, segment_events=seg, span=spans[i], span_forward=mode == "span-forward",
+                                      mel_clip_max=clip_max)
         div = 1.0
         if reducer:
             reducer.reduce()
@@ -471,20 +532,49 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        one_step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if ddp_path:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
+    def timed(n_warm, n_steps, **kw):
+        """n_warm untimed steps, then EXACTLY n_steps between barrier + synchronize on both sides (wall clock, max over ranks);
+        one HIP event between the steps gives the per-step spread of this rank without a host synchronisation inside the region."""
+        for _ in range(n_warm):
+            one_step(**kw)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps + 1)]
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(n_steps):
+            evs[k].record()
+            one_step(**kw)
+        evs[n_steps].record()
+        barrier()
+        el = time.perf_counter() - t0
+        per = [evs[k].elapsed_time(evs[k + 1]) for k in range(n_steps)]
+        rank_el = [el, el]
+        if ddp_path:
+            t = torch.tensor([el, -el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el, rank_el = float(t[0]), [float(-t[1]), float(t[0])]
+        return el, per, rank_el
+
+    elapsed, per_step_ms, rank_el = timed(args.warmup, args.steps)
     final_loss = float(loss_buf)
     found_inf = float(net._opt_stats[1])
+    comm = None
+    if ddp_path:
+        comm = reducers[head_algo].comm_report()  # of the LAST timed step (HIP events recorded inside reduce())
+
+    # ---- the other two step modes, a few steps each, SAME process / box / clock regime (outside the headline's timed region):
+    # the exact A/B the headline rests on travels with the line instead of living in a builder-run profile
+    ab = {}
+    n_ab = min(args.steps, 3) if args.ab_steps < 0 else args.ab_steps
+    if n_ab > 0 and not args.trim_padding:
+        for m in STEP_MODES:
+            if m != head_mode:
+                el_m, per_m, _ = timed(1, n_ab, mode=m)
+                ab[m] = {"ms_per_step": round(1000.0 * el_m / n_ab, 2), "steps": n_ab, "per_step_ms": spread(per_m), "final_loss": round(float(loss_buf), 4)}
+    reducer_ab = None
+    if args.reducer == "both" and ddp_path:
+        reducer_ab = {"allreduce": {"ms_per_step": round(1000.0 * elapsed / args.steps, 2), **(comm or {})}}
+        el_d, per_d, _ = timed(1, args.steps, reducer_name="direct")
+        reducer_ab["direct"] = {"ms_per_step": round(1000.0 * el_d / args.steps, 2), "per_step_ms": spread(per_d), **reducers["direct"].comm_report()}
 
     # ---- live roofline of the dominant kernel: one more identical step with every GEMM launch bracketed by HIP events
     # on the launch stream (olmoasr_amd/csrc/gemm.hip); aggregated by kernel SYMBOL so it can be compared line by line
@@ -537,9 +627,24 @@ def main():
     if rank == 0:
         ms_per_step = 1000.0 * elapsed / args.steps
         value = world * B * 30.0 * args.steps / elapsed
-        fl_sample = sum(train_flops_per_sample(dims.n_audio_state, dims.n_audio_layer, S=(c or 448)) for c in ctx) / len(ctx)
+        d_, L_ = dims.n_audio_state, dims.n_audio_layer
+        fl_sample = sum(train_flops_per_sample(d_, L_, S=(c or 448)) for c in ctx) / len(ctx)
         step_tflops = B * fl_sample / (elapsed / args.steps) / 1e12  # ALGORITHMIC flops (3 x forward over the padded context) per second
-        fl_exec = executed_flops_per_sample(dims.n_audio_state, dims.n_audio_layer, span_rows_mean) if spans else fl_sample
+
+        def fl_exec_of(mode):
+            if args.trim_padding:
+                return fl_sample
+            fr, br = rows[mode]
+            return executed_flops_per_sample(d_, L_, br / B, fr / B)
+        fl_exec = fl_exec_of(head_mode)
+        shape_txt = {"plain": "448 (padded, as the reference), forward and backward",
+                     "span-backward": "448 forward (padded, as the reference); backward over the supervised span",
+                     "span-forward": "forward AND backward over the supervised span (the padded positions' logits are computed by the reference "
+                                     "and read by nothing: train_timestamps.py:1440-1450 sees them only through ignore_index)"}[head_mode]
+        if head_mode != "plain":
+            shape_txt += f": mean {rows[head_mode][1] / B:.1f} of 448 token rows per clip (whole 64-position chunks; exact: the rows left out are zeros)"
+        if args.trim_padding:
+            shape_txt = "trimmed to ceil16(max text_len) per micro-batch: %s (opt-in, not the reference shape)" % ctx
         out = {
             "metric": "audio-seconds/sec/node (train step)", "value": round(value, 1), "unit": "audio-seconds/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
@@ -547,40 +652,58 @@ def main():
             "data": "synthetic (SURVEY 8d generator: sample i = seed 1234 + i on the host, sample i -> rank i mod world; random-init weights)",
             "config": {"workload": f"OLMoASR-{args.variant} bf16 train step, {B} x 30 s synthetic clips per GPU "
                                    f"({accum} micro-batches of {mb}, grad accumulation), global batch {world * B}",
-                       "global_batch": world * B, "micro_batch": mb, "parallelism": f"dp{world}" + (f" ({args.reducer} gradient exchange, {args.bucket_mb:g} MiB buckets)" if world > 1 else ""),
+                       "global_batch": world * B, "micro_batch": mb, "micro_batch_rule": mb_rule, "micro_batch_auto_reduced": bool(mb < mb_pref and args.micro_batch <= 0),
+                       "free_hbm_gib": round(free_gib, 2), "workspace_gib": round(ws_gib(mb), 2), "hbm_margin_gib": args.hbm_margin_gib,
+                       "parallelism": f"dp{world}" + (f" ({head_algo} gradient exchange, {args.bucket_mb:g} MiB buckets)" if world > 1 else ""),
                        "optimizer": "AdamW fused (unscale+clip+step), loss scale 65536",
-                       "decoder_positions": ("trimmed to ceil16(max text_len) per micro-batch: %s (opt-in, not the reference shape)" % ctx)
-                       if args.trim_padding else (("forward AND backward over the supervised span (opt-in --span-forward, not the reference shape): mean "
-                                                   if args.span_forward else "448 forward (padded, as the reference); backward over the supervised span: mean ")
-                                                  + f"{span_rows_mean:.1f} of 448 token rows per clip (exact: the rows left out are zeros)" if spans
-                                                  else "448 (padded, as the reference), forward and backward")},
+                       "step_mode": head_mode, "decoder_positions": shape_txt},
+            # per-step spread of the timed region on rank 0 (HIP events between the steps): a 1 % kernel change vs box noise
+            "per_step_ms": spread(per_step_ms),
+            # the same process timed the other step modes right after the headline (a few steps each): what the headline's shape buys
+            "plain_step_ms": ab.get("plain", {}).get("ms_per_step") if head_mode != "plain" else round(ms_per_step, 2),
+            "span_bwd_ms": ab.get("span-backward", {}).get("ms_per_step") if head_mode != "span-backward" else round(ms_per_step, 2),
+            "span_fwd_ms": ab.get("span-forward", {}).get("ms_per_step") if head_mode != "span-forward" else round(ms_per_step, 2),
+            "step_modes_same_run": ab,
+            # TWO fractions, to be read together.  *_algorithmic prices the reference's work (3 x forward over 448 padded positions =
+            # SURVEY 8(d)'s FLOPs/sample) -- the MFU-style number the north_star target is written in; *_executed prices only the
+            # multiplications this step really performs (rows that are exact zeros in the reference are not multiplied)
             "step_model_tflops_per_gpu": round(step_tflops, 1),
             "step_frac_of_mfma_peak": round(step_tflops / PEAK_BF16_TFLOPS, 4),
-            # the roofline fraction above prices the reference's ALGORITHMIC work (3 x forward over 448 padded positions); the
-            # span step executes less: rows whose gradient is exactly zero are not multiplied
+            "step_frac_algorithmic": round(step_tflops / PEAK_BF16_TFLOPS, 4),
+            "step_frac_executed": round(B * fl_exec / (elapsed / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
             "executed_over_algorithmic_flops": round(fl_exec / fl_sample, 4),
             "step_executed_tflops_per_gpu": round(B * fl_exec / (elapsed / args.steps) / 1e12, 1),
+            "decoder_rows_fwd_bwd": {m: list(rows[m]) for m in STEP_MODES},
             "final_loss": round(final_loss, 4), "found_inf": found_inf,
         }
+        for m, r in ab.items():
+            r["step_frac_executed"] = round(B * fl_exec_of(m) / (r["ms_per_step"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)
+        if ddp_path:
+            # what a multi-rank line needs to diagnose itself (DESIGN section 6 says which key answers which question)
+            out["ddp"] = {"reducer": head_algo, "bucket_mb": args.bucket_mb, "buckets": len(reducers[head_algo].buckets),
+                          "rank_step_ms_min": round(1000.0 * rank_el[0] / args.steps, 2), "rank_step_ms_max": round(1000.0 * rank_el[1] / args.steps, 2),
+                          **(comm or {})}
+            if reducer_ab:
+                out["ddp"]["reducer_ab"] = reducer_ab
         if roof:
             out["roofline"] = roof
         span_check = None
-        if world == 1 and spans and not args.no_profile:
+        if world == 1 and head_mode != "plain" and not args.no_profile:
             # the step that was timed against the step it replaces, at the benchmarked micro-batch, on this model's weights (outside the
-            # timed region): micro-batch 0 through the plain step (decoder backward over all 448 positions) and through the span step
+            # timed region): micro-batch 0 through the plain step (decoder forward + backward over all 448 positions) and through the headline step
             sl = slice(0, mb)
             net.zero_grad()
             l_full, _ = net.loss_and_backward(ops.log_mel(pcm[sl]), ti[sl], ty[sl], tl[sl], loss_scale=loss_scale)
             g_full = net.flat_grads.clone()
             net.zero_grad()
             m_raw, m_max = ops.log_mel(pcm[sl], finalize=False)
-            l_span, _ = net.loss_and_backward(m_raw, ti[sl], ty[sl], tl[sl], loss_scale=loss_scale, span=spans[0], span_forward=args.span_forward,
+            l_span, _ = net.loss_and_backward(m_raw, ti[sl], ty[sl], tl[sl], loss_scale=loss_scale, span=spans[0], span_forward=head_mode == "span-forward",
                                               mel_clip_max=m_max)
             torch.cuda.synchronize(dev)
-            span_check = {"what": f"micro-batch 0 ({mb} clips) of the timed step: span step vs the plain step (backward over all 448 positions), same weights",
+            span_check = {"what": f"micro-batch 0 ({mb} clips) of the timed step: the {head_mode} step vs the plain step (forward + backward over all 448 positions), same weights",
                           "loss_span": float(l_span), "loss_full": float(l_full),
                           "grad_rel_l2": float((net.flat_grads.double() - g_full.double()).norm() / g_full.double().norm()),
-                          "active_rows_of_total": round(span_rows_mean / 448.0, 4)}
+                          "active_rows_of_total": round(rows[head_mode][1] / (B * 448.0), 4)}
             del g_full
         if world == 1 and not args.no_cpu_baseline:
             # parity of the benchmarked model itself (outside the timed region): clip 0 of the oracle's generator through the

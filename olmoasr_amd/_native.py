@@ -133,13 +133,21 @@ def lib():
             _lib = C.CDLL(LIB_PATH)
         except OSError as e:  # pragma: no cover
             raise NativeError(f"cannot load {LIB_PATH}: {e}") from e
-        EXPORTS = _declare(_lib)
-        # a library of another ABI generation reads structs of a different size through the same pointers: refuse it up front
-        ver = _lib.oasr_version()
-        if ver != ABI_VERSION or _lib.oasr_sizeof_attn_args() != C.sizeof(AttnArgs):
-            bad, _lib = _lib, None
-            raise NativeError(f"{LIB_PATH}: ABI version {ver} / oasr_attn_args of {bad.oasr_sizeof_attn_args()} bytes, this binding "
-                              f"is written for version {ABI_VERSION} / {C.sizeof(AttnArgs)} bytes -- rebuild (__graft_entry__.build())")
+        handle, _lib = _lib, None  # published only once it has passed every check below (a failed load must not leave a half-declared CDLL behind)
+        # a library of another ABI generation reads structs of a different size through the same pointers, and may lack symbols this
+        # binding declares: check the version FIRST (oasr_version exists in every generation), then the struct size, then declare
+        vfn = getattr(handle, "oasr_version", None)
+        ver = int(vfn()) if vfn is not None else None
+        sfn = getattr(handle, "oasr_sizeof_attn_args", None)
+        size = int(sfn()) if sfn is not None else None
+        if ver != ABI_VERSION or size != C.sizeof(AttnArgs):
+            raise NativeError(f"{LIB_PATH}: ABI version {ver} / oasr_attn_args of {size} bytes, this binding is written for version "
+                              f"{ABI_VERSION} / {C.sizeof(AttnArgs)} bytes -- rebuild (__graft_entry__.build())")
+        try:
+            exports = _declare(handle)
+        except AttributeError as e:
+            raise NativeError(f"{LIB_PATH} (ABI {ver}) lacks an entry point this binding declares: {e} -- rebuild (__graft_entry__.build())") from e
+        _lib, EXPORTS = handle, exports
     return _lib
 
 

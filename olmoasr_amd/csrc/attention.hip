@@ -1495,27 +1495,12 @@ int launch_attention_bwd(const AttnArgs& a, hipStream_t s) {
   } else {
     // the ping-pong kernels take the unmasked case; with chunked rows only the cross-attention form (plain key side, <= 8 query tiles)
     const bool pp = !a.kv_len && g_attn_pingpong && (!rows || (!a.k_rows && a.Tq <= 512));
-    // The chunked-row case is the cross-attention backward of a span step: ~2 active 64-query tiles per sample.  bit 0 / bit 1 = its dQ /
-    // dK-dV kernel on the ping-pong kernels.  Measured (profiles/r04_cross_attention_kernel_choice.txt, whole step, same box): both 1363.5 /
+    // The chunked-row case is the cross-attention backward of a span step: ~2 active 64-query tiles per sample.  Kernel choice per side measured with an
+    // experiment build (bit 0 / bit 1 = dQ / dK-dV on the ping-pong kernels; (profiles/r04_cross_attention_kernel_choice.txt, whole step, same box): both 1363.5 /
     // 1367.1 ms, dQ ping-pong + dK/dV general 1358.8, dQ general + dK/dV ping-pong 1377.2, both general 1371.6.  The 0.3-0.6 % of "1" are
     // NOT taken: with the same kernels on both sides the span step reproduces the plain step's arithmetic row by row (gradients equal to
     // 1e-7, fp32 summation order only; tests/test_gpu_span.py), with a different dK/dV kernel only to bf16 rounding (2.6e-4).
-    static const int rows_pp = [] {
-      const char* e = getenv("OASR_ATTN_ROWS_PP");
-      return e ? atoi(e) : 3;
-    }();
-    if (pp && rows && rows_pp != 3) {
-      if (rows_pp & 1) hipLaunchKernelGGL(attn_bwd_dq_pp_kernel<true>, dim3(cdiv(a.Tq, 256) * a.B * a.H), dim3(512), 0, s, a);
-      else hipLaunchKernelGGL((attn_bwd_dq_kernel<false, true>), gq, dim3(256), 0, s, a);
-      if (rows_pp & 2) {
-        static LdsAttrOnce attr_x;
-        rc = ensure_dynamic_lds(attr_x, (const void*)attn_bwd_dkdv_pp_kernel<true>, KLDS);
-        if (rc) return rc;
-        hipLaunchKernelGGL(attn_bwd_dkdv_pp_kernel<true>, dim3(cdiv(a.Tk, 256) * a.B * a.H), dim3(512), KLDS, s, a);
-      } else {
-        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<false, true>), gk, dim3(256), 0, s, a);
-      }
-    } else if (pp) {
+    if (pp) {
       if (rows) hipLaunchKernelGGL(attn_bwd_dq_pp_kernel<true>, dim3(cdiv(a.Tq, 256) * a.B * a.H), dim3(512), 0, s, a);
       else hipLaunchKernelGGL(attn_bwd_dq_pp_kernel<false>, dim3(cdiv(a.Tq, 256) * a.B * a.H), dim3(512), 0, s, a);
       static LdsAttrOnce attr_rows, attr_plain;

@@ -1231,7 +1231,7 @@ template <typename T>
 static int oasr_train_fwd_bwd_s_impl(oasr_ctx* c, const float* mel, const int64_t* tokens, const int64_t* targets,
                                     const int32_t* text_len, int B, int S, float loss_scale, float inv_accum, float* loss_out,
                                     int accumulate_loss, float* logits_out, void** ev, void* workspace, size_t workspace_bytes,
-                                    void* stream) {
+                                    void* stream, const float* mel_clip_max = nullptr) {
   RC(check_bound(c, true));
   OASR_REQUIRE(S > 0 && S <= c->S_max, "oasr_train_fwd_bwd: S=%d outside (0, n_text_ctx=%d]", S, c->S_max);
   OASR_REQUIRE(mel && tokens && targets && text_len && loss_out && workspace && B > 0, "oasr_train_fwd_bwd: bad args");
@@ -1243,6 +1243,7 @@ static int oasr_train_fwd_bwd_s_impl(oasr_ctx* c, const float* mel, const int64_
   typename Engine<T>::Runner r{c, (hipStream_t)stream, B, S, text_len};
   r.train = true;
   r.cs_scratch = p.gemm_cs_scratch;
+  r.mel_clip_max = mel_clip_max;  // un-finalized log-mel (oasr_log_mel_raw): the floor / scale lines ride in the encoder's transpose
   hipStream_t st = r.st;
   // ---------------- forward ----------------
   RC(r.encoder_fwd(p, mel));
@@ -1306,9 +1307,12 @@ extern "C" int oasr_train_fwd_bwd_span(oasr_ctx* c, const float* mel, const int6
   OASR_REQUIRE(mel && tokens && targets && text_len && span_host && loss_out && workspace && B > 0, "oasr_train_fwd_bwd_span: bad args");
   OASR_REQUIRE(forward_rows == OASR_SPAN_FORWARD_ALL || forward_rows == OASR_SPAN_FORWARD_ACTIVE, "oasr_train_fwd_bwd_span: forward_rows");
   OASR_REQUIRE(workspace_bytes >= oasr_workspace_bytes(c, B, c->S_max, OASR_MODE_TRAIN), "oasr_train_fwd_bwd_span: workspace too small");
-  if (((c->S_max % 64) != 0 || c->S_max > 64 * OASR_ROWTAB || B > 512) && !mel_clip_max)  // no chunking for this shape: the plain step (same results)
-    return oasr_train_fwd_bwd_s(c, mel, tokens, targets, text_len, B, c->S_max, loss_scale, inv_accum, loss_out, accumulate_loss, nullptr, ev,
-                                workspace, workspace_bytes, stream);
+  if ((c->S_max % 64) != 0 || c->S_max > 64 * OASR_ROWTAB || B > 512) {  // no chunking for this shape: the plain step (same results)
+    return c->f32 ? oasr_train_fwd_bwd_s_impl<float>(c, mel, tokens, targets, text_len, B, c->S_max, loss_scale, inv_accum, loss_out,
+                                                     accumulate_loss, nullptr, ev, workspace, workspace_bytes, stream, mel_clip_max)
+                  : oasr_train_fwd_bwd_s_impl<bf16_t>(c, mel, tokens, targets, text_len, B, c->S_max, loss_scale, inv_accum, loss_out,
+                                                      accumulate_loss, nullptr, ev, workspace, workspace_bytes, stream, mel_clip_max);
+  }
   return c->f32 ? oasr_train_fwd_bwd_span_impl<float>(c, mel, tokens, targets, text_len, span_host, forward_rows, mel_clip_max, B, loss_scale,
                                                       inv_accum, loss_out, accumulate_loss, ev, workspace, workspace_bytes, stream)
                 : oasr_train_fwd_bwd_span_impl<bf16_t>(c, mel, tokens, targets, text_len, span_host, forward_rows, mel_clip_max, B, loss_scale,

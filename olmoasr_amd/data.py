@@ -29,7 +29,7 @@ from typing import Callable, Dict, List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from .synth import N_SAMPLES, N_TEXT_CTX, PAD_ID, _layout
+from .synth import N_SAMPLES, N_TEXT_CTX, PAD_ID, _layout, supervised_span_host
 
 
 def convert_to_milliseconds(timestamp: str) -> int:
@@ -180,6 +180,7 @@ class ShardLoader:
         self.pending = []                 # [slot, futures, upload issued?, rows]
         self.next_slot = 0
         self.last = None                  # slot handed out by the previous __next__
+        self.last_span = None             # HOST int32 [b]: supervised span of the batch the last __next__ returned (synth.supervised_span_host)
         self._fill()
 
     def _load_into(self, slot: int, row: int, index: int):
@@ -235,6 +236,9 @@ class ShardLoader:
         if not entry[2]:
             self._upload(entry)
         slot = entry[0]
+        # the token rows are still in the host slot (it is recycled n_slot batches later): the span the training step wants as a HOST
+        # array comes from there, not from a device read-back
+        self.last_span = supervised_span_host(self.h[slot]["ty"][:entry[3]], self.h[slot]["tl"][:entry[3]])
         if self.cuda:
             torch.cuda.current_stream(self.device).wait_event(self.uploaded[slot])
         self._fill()

@@ -52,8 +52,12 @@ class GradReducer:
     available to time it against RCCL's own all-reduce; numerically it is a different summation order."""
 
     def __init__(self, flat_grads: torch.Tensor, segments: Sequence[Tuple[int, int]], bucket_cap_mb: float = 128.0,
-                 group: Optional[dist.ProcessGroup] = None, force: bool = False, algo: str = "allreduce"):
+                 group: Optional[dist.ProcessGroup] = None, force: bool = False, algo: str = "allreduce", timing: bool = False):
         assert algo in ("allreduce", "direct")
+        # timing=True (bench.py): every reduce() brackets the exchange with three timing-enabled HIP events -- backward enqueued to its end
+        # on the compute stream, first bucket started / last bucket done on the communication stream -- read back by comm_report()
+        self.timing = bool(timing) and flat_grads.is_cuda
+        self._tev = None
         self.algo = algo
         self.flat = flat_grads
         self.force = force  # run the collectives even at world_size 1 (single-GPU test of the event/stream path)
@@ -120,12 +124,35 @@ class GradReducer:
         main = torch.cuda.current_stream(self.flat.device)
         if not use_events:
             self.comm_stream.wait_stream(main)
+        tev = None
+        if self.timing:
+            tev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            tev[0].record(main)  # every kernel of the backward has been enqueued in front of this
         with torch.cuda.stream(self.comm_stream):
-            for off, n, last in self.buckets:
+            for k, (off, n, last) in enumerate(self.buckets):
                 if use_events:
                     self.comm_stream.wait_event(self.events[last])
+                if tev is not None and k == 0:
+                    tev[1].record(self.comm_stream)
                 self._sum_bucket(self.flat[off:off + n])
+            if tev is not None:
+                tev[2].record(self.comm_stream)
+        self._tev = tev
         main.wait_stream(self.comm_stream)
+
+    def comm_report(self) -> dict:
+        """Of the most recent ``reduce()`` (``timing=True``; synchronises on its last event):
+          exposed_comm_ms -- end of the backward on the compute stream -> last bucket done: the part of the exchange the optimizer step
+                             had to WAIT for, i.e. what overlap did not hide (0 when the last bucket finished before the backward did)
+          comm_span_ms    -- first bucket started -> last bucket done: how long the exchange was in flight (overlapped or not)
+          comm_lead_ms    -- first bucket started -> end of the backward: how much backward the exchange had to hide under"""
+        if not self._tev:
+            return {"exposed_comm_ms": None, "comm_span_ms": None, "comm_lead_ms": None}
+        e_bwd, e_first, e_done = self._tev
+        e_done.synchronize()
+        e_bwd.synchronize()
+        return {"exposed_comm_ms": round(max(0.0, e_bwd.elapsed_time(e_done)), 3), "comm_span_ms": round(e_first.elapsed_time(e_done), 3),
+                "comm_lead_ms": round(e_first.elapsed_time(e_bwd), 3)}
 
 
 class DistributedDataParallel(torch.nn.Module):

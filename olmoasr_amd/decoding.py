@@ -140,7 +140,9 @@ def _timestamp_rules(logits: torch.Tensor, tokens: torch.Tensor, sample_begin: i
     logits[:, :TIMESTAMP_BEGIN].masked_fill_(force[:, None], ninf)  # the timestamp mass beats every text token: sample a timestamp
 
 
-@torch.no_grad()
+MAX_BEAM_SIZE = 15  # oasr_topk_tokens: K = beam_size + 1 <= 16
+
+
 def compression_ratio(text: str) -> float:
     """whisper.utils.compression_ratio: utf-8 bytes over their zlib-compressed size -- high for repetitive text (the "too repetitive"
     test of olmoasr/transcribe.py:213-217)."""
@@ -162,6 +164,7 @@ def resolve_tokenizer(model, tokenizer=None, language: str = "en", task: str = "
     return get_tokenizer(getattr(model, "is_multilingual", False), num_languages=getattr(model, "num_languages", 0), language=language, task=task)
 
 
+@torch.no_grad()
 def decode(model, mel: torch.Tensor, options: Optional[DecodingOptions] = None, *, tokenizer=None, **kwargs):
     """``mel``: [80, 3000] or [n, 80, 3000] windows (or already-encoded audio features).  Returns DecodingResult / list.
     With a ``tokenizer`` (see ``resolve_tokenizer``) the results carry ``text`` and ``compression_ratio`` exactly as
@@ -176,6 +179,10 @@ def decode(model, mel: torch.Tensor, options: Optional[DecodingOptions] = None, 
         raise ValueError("best_of with greedy sampling (T=0) is not compatible")
     if options.patience is not None and options.beam_size is None:
         raise ValueError("patience requires beam_size to be given")
+    if options.beam_size is not None and not 1 <= options.beam_size <= MAX_BEAM_SIZE:
+        # the selection kernel keeps beam_size + 1 candidates per row in registers (csrc/loss.hip: topk_ts_kernel, K <= 16); whisper and
+        # the reference's eval use 5 (eval.py:2077-2084).  Refused up front instead of failing inside the first step.
+        raise ValueError(f"beam_size must be in [1, {MAX_BEAM_SIZE}] on the native selection kernel, got {options.beam_size}")
     if options.length_penalty is not None and not (0 <= options.length_penalty <= 1):
         raise ValueError("length_penalty (alpha) should be a value between 0 and 1")
     single = mel.dim() == 2

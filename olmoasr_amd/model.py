@@ -766,7 +766,7 @@ class OLMoASR(nn.Module):
     def loss_and_backward(self, mel: Tensor, tokens: Tensor, targets: Tensor, text_len: Tensor, *, loss_scale: float = 1.0,
                           accumulation_steps: int = 1, loss_out: Optional[Tensor] = None, accumulate_loss: bool = False,
                           return_logits: bool = False, segment_events=None, text_ctx: Optional[int] = None, span=None,
-                          span_forward: bool = False, mel_clip_max: Optional[Tensor] = None):
+                          span_forward: Optional[bool] = None, mel_clip_max: Optional[Tensor] = None):
         """forward + F.cross_entropy(ignore_index=51864)/accumulation_steps + backward of (loss * loss_scale)
         (train_timestamps.py:1440-1454).  Gradients accumulate into ``flat_grads``.  Returns (loss tensor [1], logits|None).
 
@@ -777,8 +777,10 @@ class OLMoASR(nn.Module):
         index and ``span[b] >= text_len[b]``); ``None`` / ``False``: the plain step.  Not combinable with ``return_logits`` / ``text_ctx``.
         ``mel_clip_max`` (with ``span``): ``mel`` is ``ops.log_mel(pcm, finalize=False)``'s un-finalized tensor and this is its per-clip
         maximum [B]; whisper's floor / scale lines are applied while the encoder transposes it (bit-identical input, one pass less).
-        ``span_forward=True`` (opt-in, with ``span``): the decoder's forward leaves the positions past the span out as well -- the
-        reference computes their logits (it pads every sample to 448) and nothing reads them; loss and gradients are unchanged.
+        ``span_forward`` (with ``span``; default ``None`` = True): the decoder's forward leaves the positions past the span out as well --
+        the reference computes their logits (it pads every sample to 448) and nothing reads them (this fused step never returns logits,
+        train_timestamps.py:1440-1450 sees them only through ``ignore_index``); loss and gradients are unchanged.  ``False``: the forward
+        covers all 448 positions like the reference's (round 4's step).
 
         ``text_ctx`` (opt-in, not in the reference): run the decoder over the first ``text_ctx`` positions only.  With
         ``text_ctx >= max(text_len)`` the loss and gradients equal the full-context ones (the rest is padding the
@@ -818,7 +820,7 @@ class OLMoASR(nn.Module):
                 assert mel_clip_max.numel() == B
             with torch.cuda.device(mel.device):
                 N.check(N.lib().oasr_train_fwd_bwd_span(self._ctx, N.ptr(mel), N.ptr(tokens), N.ptr(targets), N.ptr(text_len),
-                                                        C.c_void_p(span_h.data_ptr()), int(bool(span_forward)), N.ptr(mel_clip_max), B,
+                                                        C.c_void_p(span_h.data_ptr()), int(span_forward is None or bool(span_forward)), N.ptr(mel_clip_max), B,
                                                         float(loss_scale),
                                                         1.0 / accumulation_steps,
                                                         N.ptr(loss_out), int(accumulate_loss), ev, N.ptr(ws), ws.numel(), N.stream_ptr()),

@@ -59,6 +59,18 @@ def synth_sample(index: int, timestamps: bool = False):
     return (pcm,) + _layout(torch.cat(parts))
 
 
+def supervised_span_host(text_y: torch.Tensor, text_len: torch.Tensor) -> torch.Tensor:
+    """HOST int32 [B] from HOST token tensors: per sample one past the last position that can carry gradient = max(text_len, index of
+    the last target != 51864 + 1) -- the bound ``OLMoASR.loss_and_backward(span=...)`` / ``oasr_train_fwd_bwd_span`` take.  The loaders
+    build the token sequences on the host (like AudioTextDataset.preprocess_text, train_timestamps.py:238-343) and hand this out with
+    every batch (``loader.last_span``), so the training loop never reads it back from the device."""
+    assert not text_y.is_cuda and not text_len.is_cuda
+    S = text_y.shape[1]
+    pos = torch.arange(1, S + 1, dtype=torch.int32)
+    last = ((text_y != PAD_ID).to(torch.int32) * pos).amax(dim=1)
+    return torch.maximum(last, text_len.to(torch.int32).clamp(max=S)).contiguous()
+
+
 def synth_samples(indices, device, timestamps: bool = False):
     items = [synth_sample(int(i), timestamps) for i in indices]
     pcm = torch.stack([it[0] for it in items]).to(device, non_blocking=True)
@@ -82,6 +94,7 @@ class SynthLoader:
         self.pool = ThreadPoolExecutor(max_workers=max(1, workers))
         self.depth = max(1, depth)
         self.pending = []
+        self.last_span = None  # HOST int32 [B]: supervised span of the batch the last __next__ returned (supervised_span_host)
         self._fill()
 
     def _submit(self, indices):
@@ -107,10 +120,13 @@ class SynthLoader:
 
         def up(t):
             return (t.pin_memory() if pin else t).to(self.device, non_blocking=True)
+        ty_h = torch.stack([it[2] for it in items])
+        tl_h = torch.tensor([it[3] for it in items], dtype=torch.int32)
+        self.last_span = supervised_span_host(ty_h, tl_h)
         pcm = up(torch.stack([it[0] for it in items]))
         ti = up(torch.stack([it[1] for it in items]))
-        ty = up(torch.stack([it[2] for it in items]))
-        tl = up(torch.tensor([it[3] for it in items], dtype=torch.int32))
+        ty = up(ty_h)
+        tl = up(tl_h)
         return pcm, ti, ty, tl
 
     def close(self):

@@ -369,12 +369,20 @@ def test_bench_self_launches_ranks_without_torchrun():
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-profile",
-                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
+                        "--no-cpu-baseline", "--reducer", "both"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout  # exactly one JSON line, from rank 0
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["buf_ok"] is True
+    # a multi-rank line diagnoses itself: per-step spread, the `ddp` block (exchange shape, slowest / fastest rank, exposed communication --
+    # null on gloo, HIP events on RCCL) and, with --reducer both, the two exchange spellings timed back to back in the one launch
+    assert set(out["per_step_ms"]) == {"min", "median", "max", "n"} and out["per_step_ms"]["n"] == 3
+    d = out["ddp"]
+    for k in ("reducer", "bucket_mb", "buckets", "rank_step_ms_min", "rank_step_ms_max", "exposed_comm_ms", "comm_span_ms", "comm_lead_ms", "reducer_ab"):
+        assert k in d, k
+    assert d["reducer"] == "allreduce" and d["buckets"] >= 1 and d["rank_step_ms_min"] <= d["rank_step_ms_max"]
+    assert set(d["reducer_ab"]) == {"allreduce", "direct"} and d["reducer_ab"]["direct"]["ms_per_step"] > 0
     # the real path on a machine with fewer devices than ranks: a message and a non-zero exit code
     import torch
     if torch.cuda.device_count() < 2:

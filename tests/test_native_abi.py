@@ -177,3 +177,20 @@ def test_testing_hooks_are_inert_without_the_opt_in(native, monkeypatch):
         assert b"OASR_TESTING_HOOKS" in lib.oasr_last_error()
     monkeypatch.setenv("OASR_TESTING_HOOKS", "1")
     assert lib.oasr_gemm_force_general(0) == 0 and lib.oasr_attention_set_pingpong(1) == 0 and lib.oasr_decode_set_ln_fold(-1) == 0
+
+
+def test_a_library_of_another_abi_generation_is_refused_before_any_symbol_is_declared(native, tmp_path, monkeypatch):
+    """a stale liboasr.so (older ABI: no oasr_sizeof_attn_args, fewer entry points) must be refused by the VERSION check --
+    not die with an AttributeError inside the declarations -- and must not stay cached as a half-declared handle."""
+    import subprocess
+    import pytest
+    src = tmp_path / "stale.c"
+    src.write_text("int oasr_version(void) { return 100; }\nconst char* oasr_last_error(void) { return \"\"; }\n")
+    so = tmp_path / "liboasr_stale.so"
+    subprocess.run(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)], check=True)
+    monkeypatch.setattr(native, "LIB_PATH", str(so))
+    monkeypatch.setattr(native, "_lib", None)
+    for _ in range(2):  # the second call must fail the same way (nothing cached)
+        with pytest.raises(native.NativeError, match="ABI version 100"):
+            native.lib()
+        assert native._lib is None
