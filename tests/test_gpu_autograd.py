@@ -48,7 +48,7 @@ def test_autograd_backward_equals_the_fused_step(tiny_case, dtype):
     # on bf16 rounding ties (e.g. 0.013275150 between 0.0132446 and 0.0133057), which the two formulas break differently for ~450 of
     # 5.4 M elements; one such ulp re-rounds the activations of every layer below: 2e-3 median / 6e-3 worst per-tensor rel-L2 at tiny,
     # the size of any other bf16 reordering (e.g. the two attention-backward kernel families, same test case: 6e-3).
-    tol = 2e-5 if dtype == "float32" else 2e-2
+    tol = 2e-5 if dtype == "float32" else 9e-3  # bf16: 1.5 x the measured worst tensor (6e-3)
     worst = 0.0
     for n, p in net.named_parameters():
         assert p.grad is not None

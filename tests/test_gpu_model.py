@@ -82,6 +82,10 @@ def test_forward_logits_vs_oracle_and_golden(native_tiny, oracle_tiny, tiny_case
     print(f"native-vs-bf16-mirror (valid positions): max {float(em.max()):.4f} mean {float(em.mean()):.5f}  |  vs fp32: max {float(ef.max()):.4f} "
           f"mean {float(ef.mean()):.5f}")
     assert float(em.mean()) <= float(ef.mean())
+    # the same comparison as a hard bound in bf16 ulps of the logit scale (tests/test_gpu_parity_sizes.py::bf16_ulp_report)
+    from test_gpu_parity_sizes import bf16_ulp_report
+    within2, worst_ulp = bf16_ulp_report(logits, mirror, valid, "tiny")
+    assert within2 >= 0.999 and worst_ulp <= 4.0, (within2, worst_ulp)
 
 
 def test_loss_and_grads_vs_oracle(native_tiny, oracle_tiny, tiny_case):
