@@ -19,9 +19,14 @@ int oasr_profile_gemm(int enable);
 /* experiments on the 256x256 kernel.  v < 0: defaults.  bits 0-3: schedule variant (8 = per-layout default); bits 4-5: 1 = plain
  * launches, 2 = persistent launches (next tile's prologue ahead of the epilogue); bit 6 / 7: non-temporal epilogue stores / side loads */
 int oasr_gemm_set_variant(int v);
-/* tests / A-B of the KV-cached step's LayerNorm placement: 1 = folded into the projections' operand loads for every B <= 32,
- * 0 = always separate kernels, -1 = default (folded up to 4 sequences).  Bit-identical (tests/test_gpu_decode_step.py). */
+/* tests / A-B of the KV-cached step engine: -1 = default (up to 4 sequences on the bf16 engine: the ONE-launch engine of
+ * csrc/decode_xcd.hip on the 32 CUs of one XCD; more: separate kernels), 0 = separate LayerNorm kernels, 1 = LayerNorm folded into the
+ * projections' operand loads for every B <= 32, 2 = one launch on one XCD, 3 / 4 = one launch with 32 / 64 workgroups spread over the
+ * chip.  All bit-identical (tests/test_gpu_decode_step.py). */
 int oasr_decode_set_ln_fold(int mode);
+/* tests (CPU): the static block stream of workgroup `wg` of the one-launch step engine as its cursors generate it: out[4 i ..] = layer,
+ * segment (0 qkv, 1 attn.out, 2 cross q, 3 cross K/V, 4 cross out, 5 mlp.0, 6 mlp.2), tile / item ordinal, block; returns the count. */
+int oasr_xcd_plan_debug(int d, int H, int Te, int M, int L, int team, int wg, int* out, int max_blocks);
 /* tests / A-B: 1 (default) = the unmasked attention cases (encoder self-, cross-attention) run the 8-wave ping-pong kernels,
  * 0 = the general (maskable) kernels run everything.  Same results up to accumulation order (tests/test_gpu_ops.py). */
 int oasr_attention_set_pingpong(int on);

@@ -16,7 +16,7 @@
 // forward : grid (ceil(Tq/128), B*H), 4 waves x 32 queries, KV tiles of 64 keys through a 3-stage LDS-DMA ring.
 // backward: bwd_dq   grid (ceil(Tq/128), B*H)  -- also produces delta = rowsum(dO * O)
 //           bwd_dkdv grid (ceil(Tk/128), B*H)  -- loops over 64-query tiles of Q / dO / lse / delta.
-#include "kernels.h"
+#include "decode_shared.h"
 
 namespace {
 
@@ -1349,8 +1349,11 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkdv_pp_kernel(AttnArgs a) {
 // workgroup's prologue/epilogue on one row (measured 16 us per call, 27 % of a decode step); here a workgroup streams
 // the K rows once (8 lanes x 16 bytes per key, 32 keys per pass), keeps the scores in LDS, and streams V once.
 // Numerics as the tiled kernel: fp32 scores and normaliser, P rounded to bf16 before it multiplies V.
+// Keys are taken in segments of <= dec::SEG_KEYS with their own maximum, merged in order (decode_shared.h): the arithmetic the
+// one-launch step engine (decode_xcd.hip) spreads over workgroups -- the two are bit-identical; one segment (every self-attention)
+// is the plain two-pass softmax.
 __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
-  __shared__ float sc[1536];
+  __shared__ float sc[dec::SEG_KEYS];
   __shared__ float red[32][64];
   __shared__ float lsum[32];
   __shared__ float wmax[4];
@@ -1358,78 +1361,69 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
   const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
   int Tk = a.kv_len ? a.kv_len[b] : a.Tk;
   Tk = Tk < a.Tk ? Tk : a.Tk;
-  const u32x4_t q4 = *(const u32x4_t*)(a.q + (long)b * a.bsq + h * 64 + l8 * 8);
   float qv[8];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    qv[2 * i] = bf_lo(q4[i]);
-    qv[2 * i + 1] = bf_hi(q4[i]);
-  }
+  dec::load_q8(*(const u32x4_t*)(a.q + (long)b * a.bsq + h * 64 + l8 * 8), qv);
   const bf16_t* kp = a.k + (long)b * a.bsk + h * 64 + l8 * 8;
   const bf16_t* vp = a.v + (long)b * a.bsv + h * 64 + l8 * 8;
-  float mx = NEG;
-  for (int t0 = grp; t0 < Tk; t0 += 32 * 8) {  // 8 independent 16-byte loads in flight per lane
-    u32x4_t k4[8];
+  const int ns = dec::n_segments(a.Tk);  // (the segmentation follows the cache extent, not kv_len: a row's result does not depend on its neighbours)
+  float m_s[dec::MAX_SEG] = {NEG, NEG}, l_s[dec::MAX_SEG] = {0.f, 0.f}, o_s[dec::MAX_SEG] = {0.f, 0.f};
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int t = t0 + 32 * u;
-      k4[u] = *(const u32x4_t*)(kp + (long)(t < Tk ? t : Tk - 1) * a.ldk);
-    }
+  for (int sg = 0; sg < dec::MAX_SEG; ++sg) {
+    if (sg >= ns) break;
+    const int k0 = sg * dec::SEG_KEYS;
+    int n = Tk - k0;  // keys of this segment
+    n = n < 0 ? 0 : (n > dec::SEG_KEYS ? dec::SEG_KEYS : n);
+    float mx = NEG;
+    for (int t0 = grp; t0 < n; t0 += 32 * 8) {  // 8 independent 16-byte loads in flight per lane
+      u32x4_t k4[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int t = t0 + 32 * u;
-      float d = 0.f;
+      for (int u = 0; u < 8; ++u) {
+        const int t = t0 + 32 * u;
+        k4[u] = *(const u32x4_t*)(kp + (long)(k0 + (t < n ? t : n - 1)) * a.ldk);
+      }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) d += qv[2 * i] * bf_lo(k4[u][i]) + qv[2 * i + 1] * bf_hi(k4[u][i]);
-      d += __shfl_xor(d, 1, 64);
-      d += __shfl_xor(d, 2, 64);
-      d += __shfl_xor(d, 4, 64);
-      const float s2 = d * (SCALE * LOG2E);
-      if (t < Tk) {
-        if (l8 == 0) sc[t] = s2;
-        mx = fmaxf(mx, s2);
+      for (int u = 0; u < 8; ++u) {
+        const int t = t0 + 32 * u;
+        const float s2 = dec::score8(qv, k4[u]);
+        if (t < n) {
+          if (l8 == 0) sc[t] = s2;
+          mx = fmaxf(mx, s2);
+        }
       }
     }
-  }
-  mx = wave_max(mx);
-  if (lane == 0) wmax[wave] = mx;
-  __syncthreads();
-  const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-  float l = 0.f, o[8];
+    mx = wave_max(mx);
+    if (lane == 0) wmax[wave] = mx;
+    __syncthreads();
+    const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    float l = 0.f, o[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) o[j] = 0.f;
-  for (int t0 = grp; t0 < Tk; t0 += 32 * 8) {
-    u32x4_t v4[8];
+    for (int j = 0; j < 8; ++j) o[j] = 0.f;
+    for (int t0 = grp; t0 < n; t0 += 32 * 8) {
+      u32x4_t v4[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int t = t0 + 32 * u;
-      v4[u] = *(const u32x4_t*)(vp + (long)(t < Tk ? t : Tk - 1) * a.ldv);
-    }
+      for (int u = 0; u < 8; ++u) {
+        const int t = t0 + 32 * u;
+        v4[u] = *(const u32x4_t*)(vp + (long)(k0 + (t < n ? t : n - 1)) * a.ldv);
+      }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int t = t0 + 32 * u;
-      const float p = t < Tk ? __builtin_amdgcn_exp2f(sc[t] - m) : 0.f;
-      l += p;
-      const float pb = bf_round(p);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        o[2 * i] += pb * bf_lo(v4[u][i]);
-        o[2 * i + 1] += pb * bf_hi(v4[u][i]);
+      for (int u = 0; u < 8; ++u) {
+        const int t = t0 + 32 * u;
+        dec::accum_pv(t < n ? __builtin_amdgcn_exp2f(sc[t] - m) : 0.f, v4[u], l, o);
       }
     }
-  }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) red[grp][l8 * 8 + j] = o[j];
-  if (l8 == 0) lsum[grp] = l;
-  __syncthreads();
+    for (int j = 0; j < 8; ++j) red[grp][l8 * 8 + j] = o[j];
+    if (l8 == 0) lsum[grp] = l;
+    __syncthreads();
+    if (tid < 64) {
+      dec::reduce_groups(red, lsum, tid, o_s[sg], l_s[sg]);
+      m_s[sg] = m;
+    }
+    __syncthreads();  // sc / red / lsum / wmax are reused by the next segment
+  }
   if (tid < 64) {
-    float acc = 0.f, lt = 0.f;
-#pragma unroll 8
-    for (int g = 0; g < 32; ++g) {
-      acc += red[g][tid];
-      lt += lsum[g];
-    }
-    const float val = lt > 0.f ? acc / lt : 0.f;
+    float m, lt;
+    const float val = dec::merge_segments(m_s, l_s, o_s, ns, m, lt);
     const float nb = __shfl_xor(val, 1, 64);
     if ((tid & 1) == 0) *(uint32_t*)(a.o + (long)b * a.bso + h * 64 + tid) = pack_bf2(val, nb);
     if (tid == 0 && a.lse) a.lse[(long)b * a.H + h] = lt > 0.f ? (m + __builtin_amdgcn_logf(lt)) * LN2 : NEG;

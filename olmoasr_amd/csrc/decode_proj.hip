@@ -10,72 +10,38 @@
 // statistics cost more than the launches they save (+20 %, profiles/r02_decode_step.txt), so larger batches keep the separate
 // LayerNorm kernels.  (Round 2 also carried a ONE-launch step built on this phase body with device-wide barriers between phases;
 // it was 1.7x slower on the 8-XCD part -- an L2 write-back + invalidate per barrier per workgroup -- and was removed in round 3.)
-#include "kernels.h"
+#include "decode_shared.h"
 
 namespace {
 
-constexpr int MAXC = 4;  // LayerNorm: 16-byte chunks per lane (d <= 2048)
+using dec::MAXC;
+using dec::unpack8;
+using dec::Epi;
 
 struct ProjSmem {
   float red[4][16][64];  // K-split partial accumulators of a projection tile
   float mean[32], rstd[32];
 };
-__device__ __forceinline__ void unpack8(const u32x4_t& p, float (&f)[8]) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    f[2 * i] = bf_lo(p[i]);
-    f[2 * i + 1] = bf_hi(p[i]);
-  }
-}
-
 // Row statistics of x [M][d] (bf16) into LDS: wave w takes rows w, w + 4, ...  Same arithmetic as ln_fwd_kernel (norm.hip).
 __device__ __forceinline__ void ln_stats(const bf16_t* x, int M, int d, ProjSmem& sm) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = d >> 3;
   for (int row = wave; row < M; row += 4) {
     float v[MAXC][8];
-    float s = 0.f;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
       const int ch = lane + 64 * c;
-      if (ch < nchunk) {
-        unpack8(*(const u32x4_t*)(x + (long)row * d + ch * 8), v[c]);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) s += v[c][i];
-      }
+      if (ch < nchunk) unpack8(*(const u32x4_t*)(x + (long)row * d + ch * 8), v[c]);
     }
-    const float mean = wave_sum(s) / (float)d;
-    float q = 0.f;
-#pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
-      const int ch = lane + 64 * c;
-      if (ch < nchunk) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float t = v[c][i] - mean;
-          q += t * t;
-        }
-      }
-    }
-    const float var = wave_sum(q) / (float)d;
+    float mean, rstd;
+    dec::row_stats(v, lane, nchunk, d, mean, rstd);
     if (lane == 0) {
       sm.mean[row] = mean;
-      sm.rstd[row] = rsqrtf(var + 1e-5f);
+      sm.rstd[row] = rstd;
     }
   }
   __syncthreads();
 }
-
-struct Epi {
-  const float* bias;    // [N] or null
-  int gelu;             // GELU after the bf16 rounding of the Linear output
-  const bf16_t* resid;  // [M][ldr] or null: added after the rounding
-  long ldr;
-  bf16_t* out;          // bf16 [M][ldc] or null
-  long ldc;
-  float* out_f32;       // fp32 [M][ldf] or null (logits)
-  long ldf;
-};
 
 // out[M][N] = epi( LN?(x)[M][K] . W[N][K]^T ) over the work items (32-column tiles) of this workgroup.
 template <bool LN>
@@ -108,20 +74,7 @@ __device__ __forceinline__ void proj_phase(const bf16_t* x, int M, int K, const 
       }
       if (LN) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int kk = k + 16 * j + h * 8;
-          const f32x4_t g0 = *(const f32x4_t*)(g + kk), g1 = *(const f32x4_t*)(g + kk + 4);
-          const f32x4_t b0 = *(const f32x4_t*)(bta + kk), b1 = *(const f32x4_t*)(bta + kk + 4);
-          float v[8];
-          unpack8(xq[j], v);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            v[i] = (v[i] - mu) * rs * g0[i] + b0[i];
-            v[4 + i] = (v[4 + i] - mu) * rs * g1[i] + b1[i];
-          }
-#pragma unroll
-          for (int i = 0; i < 4; ++i) xq[j][i] = pack_bf2(v[2 * i], v[2 * i + 1]);
-        }
+        for (int j = 0; j < 4; ++j) xq[j] = dec::ln_apply8(xq[j], mu, rs, g, bta, k + 16 * j + h * 8);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j)  // D'[n][m]: lane owns output row m = lane & 31
@@ -130,20 +83,7 @@ __device__ __forceinline__ void proj_phase(const bf16_t* x, int M, int K, const 
     for (; k < k_end; k += 16) {
       const u32x4_t wq = __builtin_nontemporal_load((const u32x4_t*)(wp + k));
       u32x4_t xq = *(const u32x4_t*)(xp + k);
-      if (LN) {
-        const int kk = k + h * 8;
-        const f32x4_t g0 = *(const f32x4_t*)(g + kk), g1 = *(const f32x4_t*)(g + kk + 4);
-        const f32x4_t b0 = *(const f32x4_t*)(bta + kk), b1 = *(const f32x4_t*)(bta + kk + 4);
-        float v[8];
-        unpack8(xq, v);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          v[i] = (v[i] - mu) * rs * g0[i] + b0[i];
-          v[4 + i] = (v[4 + i] - mu) * rs * g1[i] + b1[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xq[i] = pack_bf2(v[2 * i], v[2 * i + 1]);
-      }
+      if (LN) xq = dec::ln_apply8(xq, mu, rs, g, bta, k + h * 8);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wq), __builtin_bit_cast(bf16x8_t, xq), acc, 0, 0, 0);
     }
 #pragma unroll
@@ -159,14 +99,11 @@ __device__ __forceinline__ void proj_phase(const bf16_t* x, int M, int K, const 
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (n + i < N) {
-          float y = v[i] + (e.bias ? e.bias[n + i] : 0.f);
-          if (e.out_f32) e.out_f32[(long)m * e.ldf + n + i] = bf_round(y);  // (the bf16 logits of the autocast Linear, widened)
-          if (e.out) {
-            y = bf_round(y);  // the Linear's bf16 output
-            if (e.gelu) y = gelu_f(y);
-            if (e.resid) y = bf_round(y) + bf2f(e.resid[(long)m * e.ldr + n + i]);
-            e.out[(long)m * e.ldc + n + i] = f2bf_dev(y);
-          }
+          const float bias = e.bias ? e.bias[n + i] : 0.f;
+          if (e.out_f32) e.out_f32[(long)m * e.ldf + n + i] = dec::epi_logit(v[i], bias);
+          if (e.out)
+            e.out[(long)m * e.ldc + n + i] =
+                f2bf_dev(dec::epi_value(v[i], bias, e.gelu != 0, e.resid != nullptr, e.resid ? bf2f(e.resid[(long)m * e.ldr + n + i]) : 0.f));
         }
       }
     }

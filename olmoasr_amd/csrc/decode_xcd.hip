@@ -1,0 +1,693 @@
+// One-launch KV-cached decoder step for a handful of sequences (B <= 4: the timestamp-mode transcribe loop decodes ONE window at a
+// time) on gfx950 -- TextDecoder.forward for one new token per sequence, olmoasr/model.py:786-817 with the kv_cache hooks of :925-964
+// (inference twin: olmoasr/inf_model.py:150-196, 320-362).
+//
+// Why: the multi-launch step (engine.hip::oasr_decode_step_impl) is ~8 dependent launches per layer, each a 4.7 us dispatch floor plus a
+// chain of dependent memory round trips (weights that must first miss to HBM, a reduction, a store): 2.4 ms per token at medium = 0.05
+// of the HBM roof (profiles/r02_decode_step.txt, r03_decode_xcd.txt).  What those measurements asked for is built here:
+//   * ONE persistent launch; the `team` workgroups (one per CU, by default the 32 CUs of ONE XCD: blockIdx % 8 == 0) walk the 8 phases
+//     of every layer and meet at a team barrier (relaxed agent-scope counter, 1.2 us inside an XCD against 4.7 us per launch and 12 us for
+//     a device-wide release/acquire barrier);
+//   * everything that does NOT depend on the token -- the weight tiles and the cross-attention K/V a workgroup will consume -- is a STATIC
+//     per-wave stream that runs AHEAD of the phases through a wave-private LDS ring (buffer_load ... lds issued from inline assembly, one
+//     counted vmcnt per block, never drained): while a workgroup waits at a barrier its next XR blocks are already landing, so a phase
+//     costs one round trip on the activations instead of five;
+//   * a fifth "helper" wave per workgroup owns everything that is NOT streaming: the barrier, the activation rows (LayerNorm folded into the
+//     operand exactly like decode_proj.hip), the K-split reduction + epilogue and the stores -- the four streaming waves issue no other
+//     vector-memory instruction, so their vmcnt counts ring blocks only.
+// Data crosses workgroups ONLY through agent-scope (sc1) atomic loads / stores, so results do not depend on where the team's workgroups
+// land; the XCD placement is a speed matter (recorded in ctrl[3]).  Arithmetic is decode_shared.h's: bit-identical to the multi-launch step.
+#include "decode_shared.h"
+
+namespace {
+
+constexpr int XR = 6;        // ring slots per streaming wave
+constexpr int SLOT = 4096;   // bytes per slot: 4 DMA instructions of 64 lanes x 16 B
+constexpr int XMAXM = 4;     // sequences this engine takes
+constexpr int XMAXL = 32;    // decoder layers
+constexpr int NSEG = 7;      // streamed segments per layer (the self-attention phase streams nothing)
+constexpr unsigned SPIN_LIMIT = 1u << 21;
+constexpr int XPART = 22;   // cross-attention partial floats per lane and batch (two batches per row: H * ns * 66 <= 128 * XPART floats = the sc | ared staging area)
+
+struct XLayer {  // element offsets of one decoder layer: w* into the bf16 shadow, the rest into the fp32 parameter arena / aux region
+  long ln1g, ln1b, wqkv, bqkv_aux, wo, bo, lncg, lncb, wcq, bcq, wco, bco, ln2g, ln2b, w1, b1, w2, b2;
+};
+struct XArgs {
+  const bf16_t* wflat;
+  const float* params;
+  const float* aux;
+  bf16_t* cache;       // per layer: self q|k|v [M, S_max, 3d] then cross k|v [M, Te, 2d]
+  long cache_lstride;  // elements
+  bf16_t *x, *x2, *x3, *q, *o, *hg;  // activation rows [M][d] ([M][4d] for hg), exchanged through agent-scope accesses
+  float* part;         // cross-attention partials [M * H * ns][66]: m, l, o[64]
+  unsigned* ctrl;      // [0] team barrier counter  [1] error flag  [2] epoch base  [3] XCC ids seen (bit mask)
+  int d, H, Te, S_max, L, M, pos, team, stride;
+  XLayer l0;             // decoder layer 0; layer l = l0 + l * (lstride | astride): the blocks are laid out back to back (host-checked)
+  long lstride, astride;
+};
+__host__ __device__ __forceinline__ XLayer layer_of(const XArgs& a, int l) {
+  XLayer y = a.l0;
+  const long s = (long)l * a.lstride;
+  y.ln1g += s, y.ln1b += s, y.wqkv += s, y.wo += s, y.bo += s, y.lncg += s, y.lncb += s, y.wcq += s, y.bcq += s, y.wco += s, y.bco += s;
+  y.ln2g += s, y.ln2b += s, y.w1 += s, y.b1 += s, y.w2 += s, y.b2 += s;
+  y.bqkv_aux += (long)l * a.astride;
+  return y;
+}
+
+// ---- the static block sequence of one workgroup (identical for its four streaming waves) ---------------------------------------------
+struct XGeom {
+  int d, H, Te, M, team, wg, L, ns;
+  int nst_d, nst_4d;  // k16 steps per wave and tile for K = d / 4d
+  int nkb_d, nkb_4d;  // ring blocks per wave and tile
+  int cnt_qkv, cnt_d, cnt_4d, cnt_it;  // tiles of this workgroup in a phase of 3d/32, d/32, 4d/32 tiles; cross-attention items
+};
+__host__ __device__ __forceinline__ int cnt_of(int n, int wg, int team) { return wg < n ? (n - wg + team - 1) / team : 0; }
+__host__ __device__ __forceinline__ XGeom make_geom(int d, int H, int Te, int M, int L, int team, int wg) {
+  XGeom g;
+  g.d = d, g.H = H, g.Te = Te, g.M = M, g.team = team, g.wg = wg, g.L = L;
+  g.ns = (Te + dec::SEG_KEYS - 1) / dec::SEG_KEYS;
+  g.nst_d = d / 64, g.nst_4d = d / 16;
+  g.nkb_d = (g.nst_d + 3) / 4, g.nkb_4d = (g.nst_4d + 3) / 4;
+  g.cnt_qkv = cnt_of(3 * d / 32, wg, team);
+  g.cnt_d = cnt_of(d / 32, wg, team);
+  g.cnt_it = cnt_of(M * H * g.ns, wg, team);
+  g.cnt_4d = cnt_of(4 * d / 32, wg, team);
+  return g;
+}
+// tiles (items for segment 3) of this workgroup in streamed segment `seg` (selects, not a table: the cursors live in SGPRs)
+__host__ __device__ __forceinline__ int seg_cnt(const XGeom& g, int seg) { return seg == 0 ? g.cnt_qkv : seg == 3 ? g.cnt_it : seg == 5 ? g.cnt_4d : g.cnt_d; }
+struct XItem {
+  int b, h, sg, n, kvb;  // sequence, head, key segment, keys in it, ring blocks per K (or V) stream
+};
+__host__ __device__ __forceinline__ XItem item_of(const XGeom& g, int idx) {
+  const int id = g.wg + g.team * idx;
+  XItem it;
+  it.b = id / (g.H * g.ns);
+  const int rem = id - it.b * (g.H * g.ns);
+  it.h = rem / g.ns;
+  it.sg = rem - it.h * g.ns;
+  int n = g.Te - it.sg * dec::SEG_KEYS;
+  it.n = n > dec::SEG_KEYS ? dec::SEG_KEYS : n;
+  it.kvb = ((it.n + 31) / 32 + 3) / 4;
+  return it;
+}
+struct XCur {
+  int layer, seg, idx, sub;
+};
+__host__ __device__ __forceinline__ int nsub_of(const XGeom& g, int seg, int idx) {
+  if (seg == 3) return 2 * item_of(g, idx).kvb;
+  return seg == 6 ? g.nkb_4d : g.nkb_d;
+}
+// skip empty segments; returns false past the last layer
+__host__ __device__ __forceinline__ bool cur_normalise(const XGeom& g, XCur& c) {
+  while (c.layer < g.L && c.idx >= seg_cnt(g, c.seg)) {
+    c.idx = 0;
+    if (++c.seg == NSEG) c.seg = 0, ++c.layer;
+  }
+  return c.layer < g.L;
+}
+__host__ __device__ __forceinline__ bool cur_advance(const XGeom& g, XCur& c) {
+  if (++c.sub >= nsub_of(g, c.seg, c.idx)) c.sub = 0, ++c.idx;
+  return cur_normalise(g, c);
+}
+
+// ---- agent-scope data accesses (coherent across workgroups wherever they run) ---------------------------------------------------------
+__device__ __forceinline__ uint64_t ld8_agent(const void* p) {
+  return __hip_atomic_load((const uint64_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u32x4_t ld16_agent(const void* p) {
+  const uint64_t a = ld8_agent(p), b = ld8_agent((const char*)p + 8);
+  u32x4_t r;
+  r[0] = (unsigned)a, r[1] = (unsigned)(a >> 32), r[2] = (unsigned)b, r[3] = (unsigned)(b >> 32);
+  return r;
+}
+__device__ __forceinline__ float ldf_agent(const float* p) {
+  return __uint_as_float(__hip_atomic_load((const unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st4_agent(void* p, unsigned v) { __hip_atomic_store((unsigned*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// ---- LDS-DMA of one ring block (4 x 1 KiB), issued from inline assembly (hipcc would otherwise order every later ds_read behind it with
+// s_waitcnt vmcnt(0) and drain the ring) ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dma16(const u32x4_t rs, unsigned lds_addr, unsigned voff, unsigned soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(voff), "s"(rs),
+               "s"(__builtin_amdgcn_readfirstlane(soff))
+               : "memory");
+}
+__device__ __forceinline__ u32x4_t rsrc_of(const void* base) {
+  const unsigned long addr = (unsigned long)base;
+  u32x4_t rs;  // (readfirstlane: the descriptor must sit in SGPRs; the inline-asm "s" constraint does not move it there by itself)
+  rs[0] = __builtin_amdgcn_readfirstlane((unsigned)addr);
+  rs[1] = __builtin_amdgcn_readfirstlane((unsigned)(addr >> 32) & 0xffffu);  // stride 0: raw buffer
+  rs[2] = 0x7fffffffu;
+  rs[3] = 0x00020000u;
+  return rs;
+}
+#define XWAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+#define XBAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+struct XStream {  // per streaming wave (all fields wave-uniform)
+  XCur pc;        // producer cursor: next block to issue
+  bool more;      // the producer has blocks left
+  int issued, consumed;
+};
+
+// issue the block the producer cursor points at into ring slot (issued % XR), then advance the cursor
+__device__ __forceinline__ void ring_issue(const XArgs& a, const XGeom& g, XStream& st, int wave, int lane, unsigned ring_lds) {
+  if (!st.more) return;
+  const XCur c = st.pc;
+  const XLayer ly = layer_of(a, c.layer);
+  const unsigned dst = ring_lds + (unsigned)(st.issued % XR) * SLOT;
+  const int r8 = lane >> 3, l8 = lane & 7;
+  if (c.seg == 3) {
+    const XItem it = item_of(g, c.idx);
+    const bool is_v = c.sub >= it.kvb;
+    const int p0 = (is_v ? c.sub - it.kvb : c.sub) * 4;  // first pass (32 keys each) of this block
+    const bf16_t* ckv = a.cache + (long)c.layer * a.cache_lstride + (long)3 * a.M * a.S_max * a.d;
+    const u32x4_t rs = rsrc_of(ckv);
+    const unsigned soff = (unsigned)((((long)it.b * a.Te + (long)it.sg * dec::SEG_KEYS) * 2 * a.d + it.h * 64 + (is_v ? a.d : 0)) * 2);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int t = 32 * (p0 + q) + 8 * wave + r8;
+      t = t < it.n ? t : it.n - 1;
+      dma16(rs, dst + q * 1024, (unsigned)(((long)t * 2 * a.d + l8 * 8) * 2), soff);
+    }
+  } else {
+    const long woff = c.seg == 0 ? ly.wqkv : c.seg == 1 ? ly.wo : c.seg == 2 ? ly.wcq : c.seg == 4 ? ly.wco : c.seg == 5 ? ly.w1 : ly.w2;
+    const int K = c.seg == 6 ? 4 * a.d : a.d;
+    const int nst = c.seg == 6 ? g.nst_4d : g.nst_d;
+    int steps = nst - c.sub * 4;
+    steps = steps > 4 ? 4 : steps;
+    const int tile = g.wg + g.team * c.idx;
+    const u32x4_t rs = rsrc_of(a.wflat + woff);
+    const unsigned soff = (unsigned)((((long)tile * 32) * K + (long)wave * (K >> 2) + c.sub * 64) * 2);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int c16 = l8 ^ ((q * 4 + (r8 >> 1)) & 7);
+      c16 = c16 < 2 * steps ? c16 : 2 * steps - 1;
+      dma16(rs, dst + q * 1024, (unsigned)(((long)(q * 8 + r8) * K + c16 * 8) * 2), soff);
+    }
+  }
+  ++st.issued;
+  st.more = cur_advance(g, st.pc);
+}
+// block `consumed` has landed: at most (issued - consumed - 1) younger blocks may still be in flight (loads return in order)
+__device__ __forceinline__ void ring_wait(const XStream& st) {
+  const int younger = st.issued - st.consumed - 1;
+  if (younger >= 5) XWAIT_VM(20);
+  else if (younger == 4) XWAIT_VM(16);
+  else if (younger == 3) XWAIT_VM(12);
+  else if (younger == 2) XWAIT_VM(8);
+  else if (younger == 1) XWAIT_VM(4);
+  else XWAIT_VM(0);
+}
+
+// ---- team barrier (helper wave) ----------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void team_arrive(unsigned* ctrl) {
+  XWAIT_VM(0);  // this workgroup's stores of the phase have been acknowledged
+  if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(ctrl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void team_wait(unsigned* ctrl, unsigned target) {
+  if ((threadIdx.x & 63) == 0) {  // one lane polls; the wave reconverges behind it
+    unsigned spins = 0;
+    while ((int)(__hip_atomic_load(ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > SPIN_LIMIT || ((spins & 63) == 0 && __hip_atomic_load(ctrl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+        __hip_atomic_fetch_or(ctrl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // a team member never arrived: poison, do not hang
+        break;
+      }
+    }
+  }
+}
+
+struct XSmem {  // byte offsets into the dynamic LDS block
+  unsigned ring, xbuf, xs, red, sc, ared, lsum, wmax, aout, stat;
+};
+__host__ __device__ __forceinline__ XSmem smem_layout(int d, unsigned& total) {
+  XSmem s;
+  unsigned o = 0;
+  s.ring = o, o += 4 * XR * SLOT;
+  s.xs = (unsigned)(4 * d * 2 + 16);  // row stride of the activation operand (bytes): K_max = 4d, + 16 so the rows sit on different banks
+  s.xbuf = o, o += XMAXM * s.xs;
+  s.red = o, o += 2 * 4 * 16 * XMAXM * 2 * 4;
+  s.sc = o, o += dec::SEG_KEYS * 4;
+  s.ared = o, o += 32 * 64 * 4;
+  s.lsum = o, o += 32 * 4;
+  s.wmax = o, o += 4 * 4;
+  s.aout = o, o += 66 * 4 + 8;
+  s.stat = o, o += 64;
+  total = (o + 15) & ~15u;
+  return s;
+}
+
+struct XGemv {  // one projection phase
+  int seg;
+  const bf16_t* xin;    // activation rows [M][K] (global)
+  int K, N;
+  const float *ln_g, *ln_b;  // LayerNorm folded into the operand, or null
+  bool merge_attn;      // the operand is the merged cross-attention output (a.part), not xin
+  const float* bias;
+  bool gelu;
+  const bf16_t* resid;  // [M][d] or null
+  bf16_t* out;
+  long ldc;
+};
+
+// helper wave: activation rows of a projection phase -> LDS operand rows (bf16).  Every global load of a row is issued before the first
+// one is used: ONE round trip per row, not one per chunk.
+constexpr int XCH = 4;  // 16-byte chunks per lane and batch of a plain operand row (register budget: the kernel sits at 254 of 256 VGPRs)
+__device__ __forceinline__ void helper_operand(const XArgs& a, const XGeom& g, const XGemv& ph, char* smem, const XSmem& L, int lane) {
+  if (ph.merge_attn) {  // rows = merge of the cross-attention segments' partials (decode_shared.h), dimension `lane` of every head
+    float* stage = (float*)(smem + L.sc);  // (sc | ared are contiguous and idle outside the attention phases)
+    const int per_row = a.H * g.ns * 66;
+    for (int b = 0; b < a.M; ++b) {
+      const float* src = a.part + (long)b * per_row;
+      for (int base = 0; base < per_row; base += 64 * XPART) {  // (two round trips per row)
+        float t[XPART];
+#pragma unroll
+        for (int i = 0; i < XPART; ++i)
+          if (base + lane + 64 * i < per_row) t[i] = ldf_agent(src + base + lane + 64 * i);
+#pragma unroll
+        for (int i = 0; i < XPART; ++i)
+          if (base + lane + 64 * i < per_row) stage[base + lane + 64 * i] = t[i];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one wave: its own LDS writes are visible to it once retired)
+      for (int h = 0; h < a.H; ++h) {
+        float m_s[dec::MAX_SEG] = {dec::NEG, dec::NEG}, l_s[dec::MAX_SEG] = {0.f, 0.f}, o_s[dec::MAX_SEG] = {0.f, 0.f};
+#pragma unroll
+        for (int sg = 0; sg < dec::MAX_SEG; ++sg) {
+          if (sg < g.ns) {
+            const float* p = stage + (h * g.ns + sg) * 66;
+            m_s[sg] = p[0], l_s[sg] = p[1], o_s[sg] = p[2 + lane];
+          }
+        }
+        float m, lt;
+        const float val = dec::merge_segments(m_s, l_s, o_s, g.ns, m, lt);
+        const float nb = __shfl_xor(val, 1, 64);
+        if ((lane & 1) == 0) *(uint32_t*)(smem + L.xbuf + b * L.xs + (h * 64 + lane) * 2) = pack_bf2(val, nb);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the stage is rewritten for the next row
+    }
+    return;
+  }
+  const int nchunk = ph.K >> 3;
+  for (int b = 0; b < a.M; ++b) {
+    if (ph.ln_g) {  // K == d <= 2048: the row fits MAXC chunks per lane
+      u32x4_t raw[dec::MAXC];
+      float v[dec::MAXC][8];
+#pragma unroll
+      for (int c = 0; c < dec::MAXC; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nchunk) raw[c] = ld16_agent(ph.xin + (long)b * ph.K + ch * 8);
+      }
+#pragma unroll
+      for (int c = 0; c < dec::MAXC; ++c)
+        if (lane + 64 * c < nchunk) dec::unpack8(raw[c], v[c]);
+      float mean, rstd;
+      dec::row_stats(v, lane, nchunk, ph.K, mean, rstd);
+#pragma unroll
+      for (int c = 0; c < dec::MAXC; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nchunk) *(u32x4_t*)(smem + L.xbuf + b * L.xs + ch * 16) = dec::ln_apply8(raw[c], mean, rstd, ph.ln_g, ph.ln_b, ch * 8);
+      }
+    } else {
+      for (int c0 = 0; c0 * 64 < nchunk; c0 += XCH) {  // (K = 4096: two batches)
+        u32x4_t raw[XCH];
+#pragma unroll
+        for (int c = 0; c < XCH; ++c)
+          if (lane + 64 * (c0 + c) < nchunk) raw[c] = ld16_agent(ph.xin + (long)b * ph.K + (lane + 64 * (c0 + c)) * 8);
+#pragma unroll
+        for (int c = 0; c < XCH; ++c)
+          if (lane + 64 * (c0 + c) < nchunk) *(u32x4_t*)(smem + L.xbuf + b * L.xs + (lane + 64 * (c0 + c)) * 16) = raw[c];
+      }
+    }
+  }
+}
+// helper wave: query rows of an attention phase -> LDS
+__device__ __forceinline__ void helper_query_rows(const XArgs& a, const bf16_t* src, long row_stride, char* smem, const XSmem& L, int lane) {
+  const int nchunk = a.d >> 3;
+  for (int b = 0; b < a.M; ++b) {
+    u32x4_t raw[dec::MAXC];
+#pragma unroll
+    for (int c = 0; c < dec::MAXC; ++c)
+      if (lane + 64 * c < nchunk) raw[c] = ld16_agent(src + (long)b * row_stride + (lane + 64 * c) * 8);
+#pragma unroll
+    for (int c = 0; c < dec::MAXC; ++c)
+      if (lane + 64 * c < nchunk) *(u32x4_t*)(smem + L.xbuf + b * L.xs + (lane + 64 * c) * 16) = raw[c];
+  }
+}
+
+// helper wave: K-split reduction + epilogue + store of one 32-column tile (lane: row m = lane >> 4, columns 2 (lane & 15), + 1).
+// The residual pair and the two biases do not depend on the tile's accumulators: they are requested BEFORE the workgroup barrier that
+// releases the accumulators (helper_epilogue_inputs), so the epilogue itself is LDS reads + one store.
+struct XEpiIn {
+  unsigned rz;
+  float b0, b1;
+};
+__device__ __forceinline__ XEpiIn helper_epilogue_inputs(const XArgs& a, const XGemv& ph, int n0, int lane) {
+  const int m = lane >> 4, cp = lane & 15;
+  XEpiIn in{0u, 0.f, 0.f};
+  if (m >= a.M) return in;
+  if (ph.resid) in.rz = __hip_atomic_load((const unsigned*)(ph.resid + (long)m * a.d + n0 + 2 * cp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (ph.bias) in.b0 = ph.bias[n0 + 2 * cp], in.b1 = ph.bias[n0 + 2 * cp + 1];
+  return in;
+}
+__device__ __forceinline__ void helper_epilogue(const XArgs& a, const XGemv& ph, const XEpiIn& in, const char* smem, const XSmem& L, int buf, int n0,
+                                                int lane) {
+  const int m = lane >> 4, cp = lane & 15;
+  if (m >= a.M) return;
+  const float* red = (const float*)(smem + L.red) + buf * (4 * 16 * XMAXM * 2);
+  float y[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int c = 2 * cp + e;
+    const int r = (c >> 3) * 4 + (c & 3), h = (c >> 2) & 1;
+    const int idx = (r * XMAXM + m) * 2 + h;
+    const float acc = red[0 * 16 * XMAXM * 2 + idx] + red[1 * 16 * XMAXM * 2 + idx] + red[2 * 16 * XMAXM * 2 + idx] + red[3 * 16 * XMAXM * 2 + idx];
+    y[e] = dec::epi_value(acc, e ? in.b1 : in.b0, ph.gelu, ph.resid != nullptr, e ? bf_hi(in.rz) : bf_lo(in.rz));
+  }
+  st4_agent(ph.out + (long)m * ph.ldc + n0 + 2 * cp, pack_bf2(y[0], y[1]));
+}
+
+// streaming waves: one projection tile = this wave's K quarter of 32 weight rows against the operand rows, through the ring
+__device__ __forceinline__ void stream_tile(const XArgs& a, const XGeom& g, XStream& st, XCur& cc, const XGemv& ph, char* smem, const XSmem& L,
+                                            unsigned ring_lds, int wave, int lane, int buf, int tile_idx) {
+  const int nst = ph.seg == 6 ? g.nst_4d : g.nst_d, nkb = ph.seg == 6 ? g.nkb_4d : g.nkb_d;
+  const int row = lane & 31, kc = lane >> 5;
+  const int kq0 = wave * (ph.K >> 2);
+  f32x16_t acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const char* xrow = smem + L.xbuf + (row & (XMAXM - 1)) * L.xs + (kq0 + kc * 8) * 2;
+  for (int kb = 0; kb < nkb; ++kb) {
+    if (cc.seg != ph.seg || cc.idx != tile_idx || cc.sub != kb) __hip_atomic_fetch_or(a.ctrl + 1, 0x100u | (unsigned)ph.seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ring_wait(st);
+    const char* slot = smem + L.ring + (wave * XR + st.consumed % XR) * SLOT;
+    int steps = nst - kb * 4;
+    steps = steps > 4 ? 4 : steps;
+    for (int s = 0; s < steps; ++s) {
+      const bf16x8_t wf = *(const bf16x8_t*)(slot + row * 128 + (((2 * s + kc) ^ ((row >> 1) & 7)) << 4));
+      const bf16x8_t xf = *(const bf16x8_t*)(xrow + (kb * 4 + s) * 32);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc, 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slot's reads have retired before it is re-staged
+    ++st.consumed;
+    cur_advance(g, cc);
+    ring_issue(a, g, st, wave, lane, ring_lds);
+  }
+  if (row < XMAXM) {
+    float* red = (float*)(smem + L.red) + buf * (4 * 16 * XMAXM * 2) + wave * (16 * XMAXM * 2);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(r * XMAXM + row) * 2 + kc] = acc[r];
+  }
+}
+
+__device__ __forceinline__ XGemv gemv_of(const XArgs& a, int layer, int ph) {
+  const XLayer ly = layer_of(a, layer);
+  bf16_t* self = a.cache + (long)layer * a.cache_lstride;
+  XGemv p;
+  p.merge_attn = false, p.gelu = false, p.ln_g = p.ln_b = nullptr, p.resid = nullptr, p.K = a.d, p.N = a.d, p.ldc = a.d;
+  switch (ph) {
+    case 0:  // attn_ln -> q | k | v of position pos, straight into the cache row
+      p.seg = 0, p.xin = a.x, p.N = 3 * a.d, p.ln_g = a.params + ly.ln1g, p.ln_b = a.params + ly.ln1b, p.bias = a.aux + ly.bqkv_aux;
+      p.out = self + (long)a.pos * 3 * a.d, p.ldc = (long)a.S_max * 3 * a.d;
+      break;
+    case 2:  // self-attention output projection + residual
+      p.seg = 1, p.xin = a.o, p.bias = a.params + ly.bo, p.resid = a.x, p.out = a.x2;
+      break;
+    case 3:  // cross_attn_ln -> cross query
+      p.seg = 2, p.xin = a.x2, p.ln_g = a.params + ly.lncg, p.ln_b = a.params + ly.lncb, p.bias = a.params + ly.bcq, p.out = a.q;
+      break;
+    case 5:  // cross-attention output projection + residual (operand = merged segment partials)
+      p.seg = 4, p.xin = nullptr, p.merge_attn = true, p.bias = a.params + ly.bco, p.resid = a.x2, p.out = a.x3;
+      break;
+    case 6:  // mlp_ln -> mlp.0 + GELU
+      p.seg = 5, p.xin = a.x3, p.N = 4 * a.d, p.ln_g = a.params + ly.ln2g, p.ln_b = a.params + ly.ln2b, p.bias = a.params + ly.b1, p.gelu = true;
+      p.out = a.hg, p.ldc = 4 * a.d;
+      break;
+    default:  // 7: mlp.2 + residual
+      p.seg = 6, p.xin = a.hg, p.K = 4 * a.d, p.bias = a.params + ly.b2, p.resid = a.x3, p.out = a.x;
+      break;
+  }
+  return p;
+}
+__global__ __launch_bounds__(320) void decode_xcd_kernel(XArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  if (a.stride > 1 && (blockIdx.x % a.stride) != 0) return;
+  const int wg = blockIdx.x / a.stride;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool helper = wave == 4;
+  unsigned total;
+  const XSmem L = smem_layout(a.d, total);
+  const XGeom g = make_geom(a.d, a.H, a.Te, a.M, a.L, a.team, wg);
+  const unsigned base = a.ctrl[2];  // epoch: the counter is never reset, every launch adds (phases x team) to it
+  const unsigned ring_lds = (unsigned)(size_t)(smem + L.ring) + (unsigned)wave * XR * SLOT;
+  unsigned gphase = 0;  // phases completed by the whole team before the current one
+
+  XStream st;
+  XCur cc;  // consumer's mirror of the block sequence (a desynchronised producer is reported, not silently consumed)
+  st.pc = XCur{0, 0, 0, 0}, st.issued = st.consumed = 0;
+  cc = XCur{0, 0, 0, 0};
+  if (!helper) {
+    st.more = cur_normalise(g, st.pc);
+    cur_normalise(g, cc);
+    for (int i = 0; i < XR; ++i) ring_issue(a, g, st, wave, lane, ring_lds);
+  } else {
+    st.more = false;
+    if (lane == 0) {
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      __hip_atomic_fetch_or(a.ctrl + 3, 1u << (xcc & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int i = lane; i < (int)(XMAXM * L.xs / 4); i += 64) ((unsigned*)(smem + L.xbuf))[i] = 0u;  // operand rows >= M read as zeros
+  }
+
+  for (int layer = 0; layer < a.L; ++layer) {
+    for (int ph = 0; ph < 8; ++ph, ++gphase) {
+      const unsigned target = base + gphase * (unsigned)a.team;
+      if (ph == 1 || ph == 4) {
+        // ---------------- attention: items (b, h[, key segment]) of this workgroup ----------------
+        const bool cross = ph == 4;
+        const int nitem = cross ? g.cnt_it : cnt_of(a.M * a.H, wg, a.team);
+        const bf16_t* self = a.cache + (long)layer * a.cache_lstride;
+        if (helper) {
+          team_wait(a.ctrl, target);
+          // query rows -> LDS (self: the q third of cache row pos; cross: the cross query)
+          if (cross) helper_query_rows(a, a.q, a.d, smem, L, lane);
+          else helper_query_rows(a, self + (long)a.pos * 3 * a.d, (long)a.S_max * 3 * a.d, smem, L, lane);
+          XBAR();  // A
+          for (int j = 0; j < nitem; ++j) {
+            XBAR();  // 1
+            XBAR();  // 2
+            XBAR();  // 3: the item's result is in L.aout
+            const float* ao = (const float*)(smem + L.aout);
+            if (cross) {
+              const XItem it = item_of(g, j);
+              float* dst = a.part + ((long)(it.b * a.H + it.h) * g.ns + it.sg) * 66;
+              st4_agent(dst + 2 + lane, __float_as_uint(ao[2 + lane]));
+              if (lane < 2) st4_agent(dst + lane, __float_as_uint(ao[lane]));
+            } else {
+              const int id = wg + a.team * j, b = id / a.H, h = id - b * a.H;
+              const float val = ao[2 + lane], nb = __shfl_xor(val, 1, 64);
+              if ((lane & 1) == 0) st4_agent(a.o + (long)b * a.d + h * 64 + lane, pack_bf2(val, nb));
+            }
+          }
+          team_arrive(a.ctrl);
+        } else {
+          XBAR();  // A
+          float* sc = (float*)(smem + L.sc);
+          float(*ared)[64] = (float(*)[64])(smem + L.ared);
+          float* lsum = (float*)(smem + L.lsum);
+          float* wmax = (float*)(smem + L.wmax);
+          float* ao = (float*)(smem + L.aout);
+          const int l8 = tid & 7, grp = tid >> 3;
+          for (int j = 0; j < nitem; ++j) {
+            int b, h, n;
+            XItem it;
+            if (cross) {
+              it = item_of(g, j);
+              b = it.b, h = it.h, n = it.n;
+            } else {
+              const int id = wg + a.team * j;
+              b = id / a.H, h = id - b * a.H, n = a.pos + 1;
+            }
+            float qv[8];
+            dec::load_q8(*(const u32x4_t*)(smem + L.xbuf + b * L.xs + (h * 64 + l8 * 8) * 2), qv);
+            float mx = dec::NEG, l = 0.f, o[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) o[jj] = 0.f;
+            if (cross) {
+              // K blocks, then V blocks, of this wave's keys (t == 8 wave + (lane >> 3) mod 32) through the ring
+              for (int kb = 0; kb < it.kvb; ++kb) {
+                if (cc.seg != 3 || cc.idx != j || cc.sub != kb) __hip_atomic_fetch_or(a.ctrl + 1, 0x103u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ring_wait(st);
+                const char* slot = smem + L.ring + (wave * XR + st.consumed % XR) * SLOT;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  const int t = 32 * (kb * 4 + q) + grp;
+                  const float s2 = dec::score8(qv, *(const u32x4_t*)(slot + q * 1024 + lane * 16));
+                  if (t < n) {
+                    if (l8 == 0) sc[t] = s2;
+                    mx = fmaxf(mx, s2);
+                  }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                ++st.consumed;
+                cur_advance(g, cc);
+                ring_issue(a, g, st, wave, lane, ring_lds);
+              }
+            } else {
+              // self-attention: <= S_max cached keys, q | k | v rows of this sequence (agent-scope: row pos was written in this launch)
+              const bf16_t* kp = self + (long)b * a.S_max * 3 * a.d + a.d + h * 64 + l8 * 8;
+              for (int t0 = grp; t0 < n; t0 += 32 * 8) {
+                u32x4_t k4[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                  const int t = t0 + 32 * u;
+                  k4[u] = ld16_agent(kp + (long)(t < n ? t : n - 1) * 3 * a.d);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                  const int t = t0 + 32 * u;
+                  const float s2 = dec::score8(qv, k4[u]);
+                  if (t < n) {
+                    if (l8 == 0) sc[t] = s2;
+                    mx = fmaxf(mx, s2);
+                  }
+                }
+              }
+            }
+            mx = wave_max(mx);
+            if (lane == 0) wmax[wave] = mx;
+            XBAR();  // 1
+            const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+            if (cross) {
+              for (int kb = 0; kb < it.kvb; ++kb) {
+                if (cc.seg != 3 || cc.idx != j || cc.sub != it.kvb + kb) __hip_atomic_fetch_or(a.ctrl + 1, 0x113u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ring_wait(st);
+                const char* slot = smem + L.ring + (wave * XR + st.consumed % XR) * SLOT;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  const int t = 32 * (kb * 4 + q) + grp;
+                  dec::accum_pv(t < n ? __builtin_amdgcn_exp2f(sc[t] - m) : 0.f, *(const u32x4_t*)(slot + q * 1024 + lane * 16), l, o);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                ++st.consumed;
+                cur_advance(g, cc);
+                ring_issue(a, g, st, wave, lane, ring_lds);
+              }
+            } else {
+              const bf16_t* vp = self + (long)b * a.S_max * 3 * a.d + 2 * a.d + h * 64 + l8 * 8;
+              for (int t0 = grp; t0 < n; t0 += 32 * 8) {
+                u32x4_t v4[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                  const int t = t0 + 32 * u;
+                  v4[u] = ld16_agent(vp + (long)(t < n ? t : n - 1) * 3 * a.d);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                  const int t = t0 + 32 * u;
+                  dec::accum_pv(t < n ? __builtin_amdgcn_exp2f(sc[t] - m) : 0.f, v4[u], l, o);
+                }
+              }
+            }
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) ared[grp][l8 * 8 + jj] = o[jj];
+            if (l8 == 0) lsum[grp] = l;
+            XBAR();  // 2
+            if (tid < 64) {
+              float acc, lt;
+              dec::reduce_groups(ared, lsum, tid, acc, lt);
+              if (cross) {  // the segment's partial, merged by the consumer phase
+                ao[2 + tid] = acc;
+                if (tid == 0) ao[0] = m, ao[1] = lt;
+              } else {
+                float m_s[dec::MAX_SEG] = {m, dec::NEG}, l_s[dec::MAX_SEG] = {lt, 0.f}, o_s[dec::MAX_SEG] = {acc, 0.f};
+                float mo, lo;
+                ao[2 + tid] = dec::merge_segments(m_s, l_s, o_s, 1, mo, lo);
+              }
+            }
+            XBAR();  // 3
+          }
+        }
+      } else {
+        // ---------------- projection: tiles t = wg, wg + team, ... ----------------
+        const XGemv p = gemv_of(a, layer, ph);
+        const int ntile = seg_cnt(g, p.seg);
+        if (helper) {
+          team_wait(a.ctrl, target);
+          if (ntile > 0) helper_operand(a, g, p, smem, L, lane);
+          XBAR();  // A: operand rows ready
+          for (int i = 0; i < ntile; ++i) {
+            const int n0 = (wg + a.team * i) * 32;
+            const XEpiIn in = helper_epilogue_inputs(a, p, n0, lane);
+            XBAR();  // B_i: the tile's four K-quarter accumulators are in red[i & 1]
+            helper_epilogue(a, p, in, smem, L, i & 1, n0, lane);
+          }
+          team_arrive(a.ctrl);
+        } else {
+          XBAR();  // A
+          for (int i = 0; i < ntile; ++i) {
+            stream_tile(a, g, st, cc, p, smem, L, ring_lds, wave, lane, i & 1, i);
+            XBAR();  // B_i
+          }
+        }
+      }
+    }
+  }
+  if (helper) {
+    if (wg == 0) {  // everybody has read the epoch base long ago; publish the next launch's once the whole team is through
+      team_wait(a.ctrl, base + gphase * (unsigned)a.team);
+      if (lane == 0) a.ctrl[2] = base + gphase * (unsigned)a.team;
+    }
+  }
+}
+
+}  // namespace
+
+// ---- host side ----------------------------------------------------------------------------------------------------------------------
+size_t decode_xcd_part_floats(int M, int H, int Te) { return (size_t)M * H * dec::n_segments(Te) * 66; }
+
+bool decode_xcd_supports(int d, int H, int Te, int S_max, int L, int M) {
+  unsigned total;
+  smem_layout(d, total);
+  return M >= 1 && M <= XMAXM && L >= 1 && L <= XMAXL && d % 64 == 0 && d == H * 64 && d <= 2048 && total <= 160 * 1024 && S_max <= dec::SEG_KEYS &&
+         Te <= dec::MAX_SEG * dec::SEG_KEYS && Te >= 1 && H * dec::n_segments(Te) * 66 <= 128 * XPART && 128 * XPART <= dec::SEG_KEYS + 32 * 64;
+}
+
+// Debug / CPU test: the block sequence (seg, idx, sub) of workgroup `wg` as the kernel's cursors generate it
+extern "C" int oasr_xcd_plan_debug(int d, int H, int Te, int M, int L, int team, int wg, int* out, int max_blocks) {
+  const XGeom g = make_geom(d, H, Te, M, L, team, wg);
+  XCur c{0, 0, 0, 0};
+  int n = 0;
+  bool more = cur_normalise(g, c);
+  while (more) {
+    if (n < max_blocks) out[4 * n] = c.layer, out[4 * n + 1] = c.seg, out[4 * n + 2] = c.idx, out[4 * n + 3] = c.sub;
+    ++n;
+    more = cur_advance(g, c);
+  }
+  return n;
+}
+
+int launch_decode_xcd(const DecodeXcdArgs& h, hipStream_t s) {
+  OASR_REQUIRE(decode_xcd_supports(h.d, h.H, h.Te, h.S_max, h.L, h.M), "decode_xcd: unsupported shape (d=%d H=%d Te=%d S=%d L=%d M=%d)", h.d, h.H,
+               h.Te, h.S_max, h.L, h.M);
+  OASR_REQUIRE(h.team >= 1 && h.team <= 256 && (h.stride == 1 || h.stride == 8) && h.pos >= 0 && h.pos < h.S_max, "decode_xcd: bad launch shape");
+  XArgs a;
+  a.wflat = h.wflat, a.params = h.params, a.aux = h.aux, a.cache = h.cache, a.cache_lstride = h.cache_lstride;
+  a.x = h.x, a.x2 = h.x2, a.x3 = h.x3, a.q = h.q, a.o = h.o, a.hg = h.hg, a.part = h.part, a.ctrl = h.ctrl;
+  a.d = h.d, a.H = h.H, a.Te = h.Te, a.S_max = h.S_max, a.L = h.L, a.M = h.M, a.pos = h.pos, a.team = h.team, a.stride = h.stride;
+  {
+    const int64_t* o = h.layer_offsets;  // layer 0
+    a.l0 = XLayer{o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], o[8], o[9], o[10], o[11], o[12], o[13], o[14], o[15], o[16], o[17]};
+    a.lstride = h.lstride, a.astride = h.astride;
+  }
+  unsigned lds;
+  smem_layout(h.d, lds);
+  static LdsAttrOnce attr;
+  { const int rc_ = ensure_dynamic_lds(attr, (const void*)decode_xcd_kernel, (int)lds); if (rc_) return rc_; }
+  hipLaunchKernelGGL(decode_xcd_kernel, dim3(h.team * h.stride), dim3(320), lds, s, a);
+  OASR_LAUNCH_CHECK();
+  return OASR_OK;
+}

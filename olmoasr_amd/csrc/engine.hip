@@ -56,6 +56,8 @@ struct oasr_ctx {
   size_t sh_flat, sh_w1p, sh_w2p, sh_aux, sh_total;
   int64_t aux_floats;
   int f32 = 0;  // compute_dtype: 0 = bf16 production kernels, 1 = fp32 validation kernels (fp32ref.hip)
+  std::vector<int64_t> xcd_offsets;  // decoder layer 0's 18 tensor offsets in decode_xcd.hip::XLayer order (empty: irregular layout, engine off)
+  int64_t xcd_lstride = 0, xcd_astride = 0;  // layer l = layer 0 + l * stride
   // compute copy of the weight at arena offset `off`: the bf16 shadow, or -- fp32 validation -- the master weights themselves
   template <typename T>
   const T* Wt(int64_t off) const;
@@ -733,6 +735,28 @@ extern "C" oasr_ctx* oasr_create_ex2(const oasr_dims* dm, int embed_rows, int co
   c->tok_emb = b.add("decoder.token_embedding.weight", {c->V, d});
   c->segments[emb_seg] = {c->tok_emb, (int64_t)c->V * d};
   c->numel = b.cur;
+  {  // decoder layer 0's tensor offsets (decode_xcd.hip::XLayer order) + the per-layer strides: the one-launch step engine derives every
+     // layer's addresses from them, so the blocks must be laid out back to back with one stride -- checked here, engine off otherwise
+    auto offs = [](const BlockP& bp) {
+      return std::vector<int64_t>{bp.attn_ln_w, bp.attn_ln_b, bp.attn.qw, bp.attn.fused_bias, bp.attn.ow, bp.attn.ob, bp.cln_w, bp.cln_b, bp.cattn.qw,
+                                  bp.cattn.qb, bp.cattn.ow, bp.cattn.ob, bp.mlp_ln_w, bp.mlp_ln_b, bp.w1, bp.b1, bp.w2, bp.b2};
+    };
+    if (c->L_dec >= 1) {
+      c->xcd_offsets = offs(c->dec[0]);
+      c->xcd_lstride = c->xcd_astride = 0;
+      if (c->L_dec >= 2) {
+        const std::vector<int64_t> o1 = offs(c->dec[1]);
+        c->xcd_lstride = o1[0] - c->xcd_offsets[0];
+        c->xcd_astride = o1[3] - c->xcd_offsets[3];
+      }
+      bool regular = true;
+      for (int l = 0; l < c->L_dec; ++l) {
+        const std::vector<int64_t> ol = offs(c->dec[l]);
+        for (int k = 0; k < 18; ++k) regular = regular && ol[k] == c->xcd_offsets[k] + (int64_t)l * (k == 3 ? c->xcd_astride : c->xcd_lstride);
+      }
+      if (!regular) c->xcd_offsets.clear();
+    }
+  }
   // shadow: [bf16 flat arena + zero pad rows for the padded vocab] [W1p d x 256] [W2p d x 3d] [aux fp32]
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   c->sh_flat = 0;
@@ -920,8 +944,14 @@ KvLayer<T> kv_layer(const oasr_ctx* c, void* cache, int B, int layer) {
   T* base = (T*)cache + per_layer * layer;
   return KvLayer<T>{base, base + (size_t)3 * B * c->S_max * c->d};
 }
-// A/B and test switch of the step's LayerNorm placement: -1 = default (folded into the projections' operand loads for B <= 4, the
-// timestamp-mode transcribe loop; separate kernels above), 1 = folded for every B <= 32, 0 = always separate.  Bit-identical.
+unsigned* kv_ctrl(const oasr_ctx* c, void* cache, int B) {  // 256 bytes behind the last layer (oasr_kv_cache_bytes)
+  const size_t per_layer = ((size_t)3 * B * c->S_max * c->d + (size_t)B * c->Te * 2 * c->d) * (c->f32 ? 4 : 2);
+  return (unsigned*)((char*)cache + per_layer * c->L_dec);
+}
+// A/B and test switch of the step engine: -1 = default (B <= 4 on the bf16 engine: the one-launch engine of decode_xcd.hip, team = the 32
+// CUs of one XCD; larger batches: separate kernels), 0 = separate LayerNorm kernels, 1 = LayerNorm folded into the projections' operand
+// loads (the round-2/3 default for B <= 4) for every B <= 32, 2 = one launch on one XCD, 3 = one launch, 32 workgroups spread over the
+// chip, 4 = the same with 64.  All bit-identical (tests/test_gpu_decode_step.py).
 int g_decode_ln_fold = -1;
 }  // namespace
 extern "C" int oasr_decode_set_ln_fold(int mode) {
@@ -932,14 +962,15 @@ extern "C" int oasr_decode_set_ln_fold(int mode) {
       return OASR_ESTATE;
     }
   }
-  g_decode_ln_fold = mode < 0 ? -1 : (mode ? 1 : 0);
+  g_decode_ln_fold = mode < 0 ? -1 : (mode > 4 ? 1 : mode);
   return OASR_OK;
 }
 
 extern "C" size_t oasr_decode_step_workspace_bytes(const oasr_ctx* c, int B) {
   if (!c || B <= 0) return 0;
   // x, ln, q, o, x2 (5 * B*d) + u, hg (2 * B*4d) + logits (B*Vp) bf16 + stats
-  return ((size_t)B * c->d * 6 + (size_t)B * 8 * c->d + (size_t)B * c->Vp + 9 * 32) * (c->f32 ? 4 : 2) + (size_t)B * c->H * 8 + (size_t)B * 16 + 8192;
+  return ((size_t)B * c->d * 6 + (size_t)B * 8 * c->d + (size_t)B * c->Vp + 9 * 32) * (c->f32 ? 4 : 2) + (size_t)B * c->H * 8 + (size_t)B * 16 + 8192 +
+         (B <= 4 ? decode_xcd_part_floats(B, c->H, c->Te) * 4 + 256 : 0);
 }
 
 template <typename T>
@@ -948,6 +979,8 @@ static int oasr_decode_begin_impl(oasr_ctx* c, const void* xa, int B, void* kv_c
   OASR_REQUIRE(xa && kv_cache && B > 0, "oasr_decode_begin: bad args");
   typename Engine<T>::Runner r{c, (hipStream_t)stream, B, 1, nullptr};
   const int d = c->d;
+  // the one-launch step engine's control words (barrier counter, error flag, epoch base, XCC mask) live in the cache's 256-byte tail
+  OASR_CHECK_HIP(hipMemsetAsync(kv_ctrl(c, kv_cache, B), 0, 256, (hipStream_t)stream));
   for (int i = 0; i < c->L_dec; ++i) {
     const BlockP& bp = c->dec[i];
     KvLayer<T> kl = kv_layer<T>(c, kv_cache, B, i);
@@ -992,8 +1025,30 @@ static int oasr_decode_step_impl(oasr_ctx* c, const int64_t* tokens_last, int B,
   // from B = 16 on (+20 %) -- so only small batches take it (oasr_decode_set_ln_fold forces either side for the A/B and the
   // bit-identity test).
   bool folded = false;
-  if constexpr (std::is_same<T, bf16_t>::value)
+  if constexpr (std::is_same<T, bf16_t>::value) {
     folded = d % 64 == 0 && d <= 2048 && g_decode_ln_fold != 0 && (B <= 4 || (g_decode_ln_fold == 1 && B <= 32));
+    // one launch for the whole decoder stack (decode_xcd.hip): the default for a handful of sequences
+    const int mode = g_decode_ln_fold;
+    if ((mode == -1 || mode >= 2) && !c->xcd_offsets.empty() && decode_xcd_supports(d, c->H, c->Te, S_max, c->L_dec, B)) {
+      DecodeXcdArgs xa;
+      xa.wflat = c->template Wt<bf16_t>(0);
+      xa.params = c->params;
+      xa.aux = c->aux(0);
+      xa.cache = (bf16_t*)kv_cache;
+      xa.cache_lstride = (long)3 * B * S_max * d + (long)B * c->Te * 2 * d;
+      xa.x = x, xa.x2 = x2, xa.x3 = x3, xa.q = q, xa.o = o, xa.hg = hg;
+      xa.part = A.f32(decode_xcd_part_floats(B, c->H, c->Te));
+      xa.ctrl = kv_ctrl(c, kv_cache, B);
+      xa.d = d, xa.H = c->H, xa.Te = c->Te, xa.S_max = S_max, xa.L = c->L_dec, xa.M = B, xa.pos = pos;
+      xa.team = mode == 4 ? 64 : 32;
+      xa.stride = (mode == 3 || mode == 4) ? 1 : 8;
+      xa.layer_offsets = c->xcd_offsets.data();
+      xa.lstride = c->xcd_lstride, xa.astride = c->xcd_astride;
+      RC(launch_decode_xcd(xa, st));
+      return launch_decode_proj(x, B, d, c->template Wt<bf16_t>(c->tok_emb), c->V, c->P(c->dec_ln_w), c->P(c->dec_ln_b), nullptr, 0, nullptr, 0,
+                                nullptr, 0, logits_out, c->V, st);
+    }
+  }
   for (int i = 0; i < c->L_dec; ++i) {
     const BlockP& bp = c->dec[i];
     KvLayer<T> kl = kv_layer<T>(c, kv_cache, B, i);
@@ -1084,6 +1139,13 @@ extern "C" int oasr_decode_step(oasr_ctx* c, const int64_t* tokens_last, int B, 
 extern "C" int oasr_decode_check(oasr_ctx* c, int B, void* kv_cache, void* stream) {
   OASR_REQUIRE(c && kv_cache && B > 0, "oasr_decode_check: bad args");
   OASR_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  unsigned ctrl[4] = {0, 0, 0, 0};  // the one-launch step engine's control words: a poisoned team barrier / a desynchronised stream is an error
+  OASR_CHECK_HIP(hipMemcpy(ctrl, kv_ctrl(c, kv_cache, B), sizeof(ctrl), hipMemcpyDeviceToHost));
+  if (ctrl[1] != 0) {
+    oasr_set_error("oasr_decode_check: the one-launch decoder step reported 0x%x (1 = a team member never reached a barrier, 0x1xx = block stream "
+                   "out of step); XCC mask 0x%x", ctrl[1], ctrl[3]);
+    return OASR_ESTATE;
+  }
   return OASR_OK;
 }
 

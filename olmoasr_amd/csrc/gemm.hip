@@ -1286,7 +1286,14 @@ int launch_pp_variant(const GemmArgs& a, hipStream_t stream) {
   }();
   GemmArgs pa = a;
   pa.vgrid = (int)grid.x;
-  const int want = g_pp_persistent >= 0 ? g_pp_persistent : env_persist;
+  // (experiment: OASR_PP_PERSIST_GELU=1 launches only the GELU-epilogue shapes persistent -- mlp.0 forward and the dgrad through GELU',
+  // whose 12.7 k-cycle epilogues are the largest fixed cost per tile, profiles/r03_gemm_tile_stamps.txt)
+  static const int env_persist_gelu = [] {
+    const char* e = getenv("OASR_PP_PERSIST_GELU");
+    return e ? atoi(e) : 0;
+  }();
+  int want = g_pp_persistent >= 0 ? g_pp_persistent : env_persist;
+  if (want < 0 && env_persist_gelu && (a.act != 0 || a.dgelu_u)) want = 1;
   const bool can_persist = grid.y == 1 && (int)grid.x > n_cu && ((a.K / BK) % a.split_k) == 0;
   if (can_persist && want == 1) grid = dim3(n_cu, 1);
   hipEvent_t e0 = nullptr, e1 = nullptr;

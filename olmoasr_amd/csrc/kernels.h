@@ -153,6 +153,25 @@ int launch_attention_bwd(const AttnArgsF& a, hipStream_t s);
 int launch_decode_proj(const bf16_t* x, int M, int K, const bf16_t* W, int N, const float* ln_g, const float* ln_b, const float* bias,
                        int gelu, const bf16_t* resid, long ldr, bf16_t* out, long ldc, float* out_f32, long ldf, hipStream_t s);
 
+// ---- one-launch decoder step for <= 4 sequences (decode_xcd.hip) -----------------------------------------------
+struct DecodeXcdArgs {
+  const bf16_t* wflat;  // bf16 shadow of the flat parameter arena
+  const float* params;  // fp32 parameter arena (LayerNorm parameters, biases)
+  const float* aux;     // fused [q_bias | 0 | v_bias] rows
+  bf16_t* cache;        // KV cache (per layer: self q|k|v [M, S_max, 3d], cross k|v [M, Te, 2d])
+  long cache_lstride;   // elements per layer
+  bf16_t *x, *x2, *x3, *q, *o, *hg;  // activation rows: x holds the embedded token on entry and the last block's output on return
+  float* part;          // decode_xcd_part_floats() floats
+  unsigned* ctrl;       // 4 words, zeroed once per cache (oasr_decode_begin): barrier counter, error flag, epoch base, XCC mask
+  int d, H, Te, S_max, L, M, pos;
+  int team, stride;     // `team` workgroups; stride 8 = one per CU of ONE XCD (grid 8 x team, blockIdx % 8 == 0), 1 = spread over the chip
+  const int64_t* layer_offsets;   // HOST: [18] element offsets of decoder layer 0 in decode_xcd.hip::XLayer order
+  long lstride, astride;          // layer l = layer 0 + l * lstride (arena / shadow elements), + l * astride for the aux entry
+};
+int launch_decode_xcd(const DecodeXcdArgs& a, hipStream_t s);
+bool decode_xcd_supports(int d, int H, int Te, int S_max, int L, int M);
+size_t decode_xcd_part_floats(int M, int H, int Te);
+
 // ---- elementwise / reductions -------------------------------------------------------------------------
 int launch_cast_f32_bf16(const float* src, bf16_t* dst, long n, hipStream_t s);
 // conv weight [co][ci][3] f32 -> bf16 [co][ldk] with k = kk*ci_n + ci, zero padded to ldk

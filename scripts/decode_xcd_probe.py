@@ -1,0 +1,59 @@
+"""KV-cached decoder step at B sequences: GPU time per step of every step engine (oasr_decode_set_ln_fold modes) at a fixed position, and the
+HBM-roofline fraction of the streamed bytes (bench.py's `decode_step(B=1)` accounting).
+    python scripts/decode_xcd_probe.py [variant=medium] [B=1] [pos=32] [modes=1,2,3,4]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from olmoasr_amd import _native as N  # noqa: E402
+from olmoasr_amd.config.model_dims import VARIANT_TO_DIMS  # noqa: E402
+from olmoasr_amd.model import OLMoASR  # noqa: E402
+
+NAMES = {0: "separate LayerNorm kernels", 1: "multi-launch, LayerNorm folded (round 2-4 default for B <= 4)", 2: "ONE launch, 32 CUs of one XCD",
+         3: "ONE launch, 32 workgroups spread over the chip", 4: "ONE launch, 64 workgroups spread over the chip"}
+
+
+def main():
+    variant = sys.argv[1] if len(sys.argv) > 1 else "medium"
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    pos = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+    modes = [int(m) for m in (sys.argv[4] if len(sys.argv) > 4 else "1,2,3,4").split(",")]
+    N.enable_testing_hooks()
+    dims = VARIANT_TO_DIMS[variant]
+    net = OLMoASR(dims, device="cuda", seed=0, inference=True)
+    d, L, V = dims.n_text_state, dims.n_text_layer, dims.n_vocab
+    xa = torch.randn(B, dims.n_audio_ctx, d, device="cuda").to(torch.bfloat16)
+    tok = torch.full((B,), 50257, device="cuda", dtype=torch.int64)
+    dbytes = 2 * (L * 14 * d * d + V * d) + B * 2 * L * (dims.n_audio_ctx * 2 * d + pos * 2 * d) + 4 * V * B
+    ref = None
+    for mode in modes:
+        N.lib().oasr_decode_set_ln_fold(mode)
+        st = net.kv_cache_begin(xa)
+        outs = []
+        for _ in range(pos):
+            outs.append(net.kv_cache_step(st, tok))
+        net.kv_cache_check(st)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 50
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            st["pos"] = pos
+            last = net.kv_cache_step(st, tok)
+        e1.record()
+        torch.cuda.synchronize()
+        net.kv_cache_check(st)
+        ms = e0.elapsed_time(e1) / n
+        ctrl = st["cache"][-256:].view(torch.int32)[:4].tolist()
+        same = "" if ref is None else f"  logits == mode {modes[0]}: {bool(torch.equal(ref, last))} (max |d| {float((ref - last).abs().max()):.3g})"
+        if ref is None:
+            ref = last.clone()
+        print(f"{variant} B={B} pos={pos} mode {mode} [{NAMES[mode]}]: {ms:.3f} ms/step = {dbytes / ms / 1e6:.0f} GB/s = {dbytes / ms / 1e6 / 8000:.3f} of 8 TB/s; "
+              f"ctrl (counter, flag, epoch, xcc mask) = {ctrl[0]} {ctrl[1]:#x} {ctrl[2]} {ctrl[3]:#x}{same}", flush=True)
+    N.lib().oasr_decode_set_ln_fold(-1)
+
+
+if __name__ == "__main__":
+    main()

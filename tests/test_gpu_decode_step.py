@@ -1,5 +1,6 @@
-"""The KV-cached decoder step's two LayerNorm placements (folded into the projections' operand loads, csrc/decode_proj.hip, vs
-separate kernels) against each other (bit-identical) and against the cache-less decoder.
+"""The KV-cached decoder step's engines -- separate LayerNorm kernels, LayerNorm folded into the projections' operand loads
+(csrc/decode_proj.hip), and the ONE-launch engine of csrc/decode_xcd.hip (up to 4 sequences; on one XCD or spread over the chip) --
+against each other (bit-identical) and against the cache-less decoder.
 Reference semantics: TextDecoder.forward with the kv_cache hooks, olmoasr/model.py:786-817, 925-964."""
 import pytest
 import torch
@@ -14,7 +15,8 @@ def _dims(mo_dims):
 
 
 def _steps(net, xa, toks, mode):
-    """mode: 1 = LayerNorm folded into the projections; 0 = separate LayerNorm / logits-widening kernels."""
+    """mode: 1 = LayerNorm folded into the projections; 0 = separate LayerNorm / logits-widening kernels; 2 / 3 / 4 = one launch for the
+    whole decoder stack (one XCD / 32 / 64 workgroups spread), where the shape allows it (else the call falls back to the folded path)."""
     from olmoasr_amd import _native as N
     N.lib().oasr_decode_set_ln_fold(mode)
     try:
@@ -27,7 +29,8 @@ def _steps(net, xa, toks, mode):
 
 
 @pytest.mark.parametrize("width,heads,layers,B,inference", [(384, 6, 4, 2, True), (384, 6, 2, 7, False), (768, 12, 2, 16, True),
-                                                            (512, 8, 3, 32, True), (1024, 16, 1, 1, False)])
+                                                            (512, 8, 3, 32, True), (1024, 16, 1, 1, False), (768, 12, 2, 1, True), (512, 8, 3, 3, True),
+                                                            (1024, 16, 2, 4, False), (1280, 20, 1, 2, True)])
 def test_step_engines_are_bit_identical(tiny_case, width, heads, layers, B, inference):
     """Same rounding points, same skinny-GEMM accumulation scheme: the two placements must agree to the last bit on every
     position; both must track the cache-less decoder to bf16 accumulation-order noise."""
@@ -51,6 +54,28 @@ def test_step_engines_are_bit_identical(tiny_case, width, heads, layers, B, infe
     # a second window on the same buffers
     again = _steps(net, xa, toks, 1)
     assert torch.equal(again, folded)
+    # the one-launch engine (B <= 4): every placement of its team, twice on the same buffers (the barrier epoch carries over)
+    if B <= 4:
+        for mode in (2, 3, 4, -1, 2):
+            one = _steps(net, xa, toks, mode)
+            assert torch.equal(one, multi), (mode, float((one - multi).abs().max()))
+
+
+def test_one_launch_engine_over_a_long_window(tiny_case):
+    """300 positions on a small-dims model, B = 2: the self-attention of the one-launch engine crosses its 256-key batch boundary, the ring
+    wraps thousands of times, the barrier counter runs up -- logits bit-identical to the multi-launch step at every position."""
+    from olmoasr_amd.model import OLMoASR
+    from oracle import model_oracle as mo
+    dims = mo.Dims(80, 1500, 512, 8, 1, 51864, 448, 512, 8, 2)
+    net = OLMoASR(_dims(dims), device=DEV, seed=3, inference=True)
+    mel = tiny_case["mel"].to(DEV)
+    xa = net.embed_audio(mel)
+    toks = torch.randint(0, 50000, (2, 300), generator=torch.Generator().manual_seed(1)).to(DEV)
+    toks[:, 0] = 50257
+    multi = _steps(net, xa, toks, 1)
+    one = _steps(net, xa, toks, 2)
+    assert torch.isfinite(one).all()
+    assert torch.equal(one, multi), float((one - multi).abs().max())
 
 
 def test_decode_through_every_step_engine(tiny_case):

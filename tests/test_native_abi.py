@@ -194,3 +194,40 @@ def test_a_library_of_another_abi_generation_is_refused_before_any_symbol_is_dec
         with pytest.raises(native.NativeError, match="ABI version 100"):
             native.lib()
         assert native._lib is None
+
+
+@pytest.mark.parametrize("d,H,Te,M,L,team", [(1024, 16, 1500, 1, 3, 32), (768, 12, 1500, 2, 2, 32), (384, 6, 1500, 4, 2, 32), (1280, 20, 1500, 1, 2, 64),
+                                              (512, 8, 700, 3, 2, 32)])
+def test_one_launch_decode_step_block_stream_matches_the_consumer_loops(native, d, H, Te, M, L, team):
+    """csrc/decode_xcd.hip: every streaming wave prefetches a STATIC sequence of ring blocks (weight tiles, cross-attention K/V) with a cursor
+    that runs ahead of the phases that consume them.  The cursor's sequence (exported for this test) must be exactly what the consumer's nested
+    loops walk: per layer qkv tiles, attn.out, cross q, cross K then V blocks of every (sequence, head, key segment) item, cross out, mlp.0,
+    mlp.2 -- tile t of a phase belongs to workgroup t % team; together the workgroups cover every tile / item exactly once."""
+    lib = native.lib()
+    SEG = 768
+    ns = -(-Te // SEG)
+    seen = {}
+    for wg in range(team):
+        buf = (ctypes.c_int * (4 * 200000))()
+        n = lib.oasr_xcd_plan_debug(d, H, Te, M, L, team, wg, buf, 200000)
+        assert 0 < n <= 200000
+        got = [tuple(buf[4 * i:4 * i + 4]) for i in range(n)]
+        want = []
+        kb_d, kb_4d = -(-(d // 64) // 4), -(-(d // 16) // 4)
+        for layer in range(L):
+            for seg, ntile, kb in ((0, 3 * d // 32, kb_d), (1, d // 32, kb_d), (2, d // 32, kb_d), (3, M * H * ns, None), (4, d // 32, kb_d),
+                                   (5, 4 * d // 32, kb_d), (6, d // 32, kb_4d)):
+                for idx, t in enumerate(range(wg, ntile, team)):
+                    if seg == 3:
+                        sg = t % ns
+                        nkeys = min(SEG, Te - sg * SEG)
+                        nb = 2 * (-(-(-(-nkeys // 32)) // 4))
+                    else:
+                        nb = kb
+                    want += [(layer, seg, idx, sub) for sub in range(nb)]
+                    seen[(layer, seg, t)] = seen.get((layer, seg, t), 0) + 1
+        assert got == want, (wg, got[:8], want[:8])
+    # coverage: every tile / item of every phase exactly once over the team
+    for layer in range(L):
+        for seg, ntile in ((0, 3 * d // 32), (1, d // 32), (2, d // 32), (3, M * H * ns), (4, d // 32), (5, 4 * d // 32), (6, d // 32)):
+            assert all(seen.get((layer, seg, t)) == 1 for t in range(ntile)), (layer, seg)
