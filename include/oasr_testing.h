@@ -19,8 +19,8 @@ int oasr_profile_gemm(int enable);
 /* experiments on the 256x256 kernel.  v < 0: defaults.  bits 0-3: schedule variant (8 = per-layout default); bits 4-5: 1 = plain
  * launches, 2 = persistent launches (next tile's prologue ahead of the epilogue); bit 6 / 7: non-temporal epilogue stores / side loads */
 int oasr_gemm_set_variant(int v);
-/* tests / A-B of the KV-cached step engine: -1 = default (up to 4 sequences on the bf16 engine: the ONE-launch engine of
- * csrc/decode_xcd.hip on the 32 CUs of one XCD; more: separate kernels), 0 = separate LayerNorm kernels, 1 = LayerNorm folded into the
+/* tests / A-B of the KV-cached step engine: -1 = default (ONE sequence on the bf16 engine: the ONE-launch engine of
+ * csrc/decode_xcd.hip on the 32 CUs of one XCD; 2-4: LayerNorm folded into the projections; more: separate kernels), 0 = separate LayerNorm kernels, 1 = LayerNorm folded into the
  * projections' operand loads for every B <= 32, 2 = one launch on one XCD, 3 / 4 = one launch with 32 / 64 workgroups spread over the
  * chip.  All bit-identical (tests/test_gpu_decode_step.py). */
 int oasr_decode_set_ln_fold(int mode);

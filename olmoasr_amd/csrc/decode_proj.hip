@@ -27,14 +27,14 @@ __device__ __forceinline__ void ln_stats(const bf16_t* x, int M, int d, ProjSmem
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = d >> 3;
   for (int row = wave; row < M; row += 4) {
-    float v[MAXC][8];
+    u32x4_t raw[MAXC];
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
       const int ch = lane + 64 * c;
-      if (ch < nchunk) unpack8(*(const u32x4_t*)(x + (long)row * d + ch * 8), v[c]);
+      if (ch < nchunk) raw[c] = *(const u32x4_t*)(x + (long)row * d + ch * 8);
     }
     float mean, rstd;
-    dec::row_stats(v, lane, nchunk, d, mean, rstd);
+    dec::row_stats(raw, lane, nchunk, d, mean, rstd);
     if (lane == 0) {
       sm.mean[row] = mean;
       sm.rstd[row] = rstd;

@@ -24,15 +24,18 @@ __device__ __forceinline__ void unpack8(const u32x4_t& p, float (&f)[8]) {
   }
 }
 
-// One wave, one row of d values held as v[c][0..7] = elements (lane + 64 c) * 8 .. + 7 (chunks past d/8 unused): mean and
-// 1/sqrt(var + eps) exactly as ln_fwd_kernel (norm.hip) computes them.
-__device__ __forceinline__ void row_stats(const float (&v)[MAXC][8], int lane, int nchunk, int d, float& mean_out, float& rstd_out) {
+// One wave, one row of d bf16 values held RAW as chunks raw[c] = elements (lane + 64 c) * 8 .. + 7 (chunks past d/8 unused): mean and
+// 1/sqrt(var + eps) exactly as ln_fwd_kernel (norm.hip) computes them.  (The values are unpacked twice instead of being kept as 32
+// floats: the unpacking is exact, and the one-launch engine has no registers to spare.)
+__device__ __forceinline__ void row_stats(const u32x4_t (&raw)[MAXC], int lane, int nchunk, int d, float& mean_out, float& rstd_out) {
   float s = 0.f;
 #pragma unroll
   for (int c = 0; c < MAXC; ++c) {
     if (lane + 64 * c < nchunk) {
+      float v[8];
+      unpack8(raw[c], v);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) s += v[c][i];
+      for (int i = 0; i < 8; ++i) s += v[i];
     }
   }
   const float mean = wave_sum(s) / (float)d;
@@ -40,9 +43,11 @@ __device__ __forceinline__ void row_stats(const float (&v)[MAXC][8], int lane, i
 #pragma unroll
   for (int c = 0; c < MAXC; ++c) {
     if (lane + 64 * c < nchunk) {
+      float v[8];
+      unpack8(raw[c], v);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const float t = v[c][i] - mean;
+        const float t = v[i] - mean;
         q += t * t;
       }
     }
@@ -100,14 +105,31 @@ __host__ __device__ __forceinline__ int n_segments(int Tk) { return (Tk + SEG_KE
 
 __device__ __forceinline__ void load_q8(const u32x4_t& q4, float (&qv)[8]) { unpack8(q4, qv); }
 
+// value of lane (lane ^ X), X in {1, 2, 4}: __shfl_xor through the DPP cross-lane path (register to register) instead of the
+// ds_bpermute hipcc emits for it (an LDS-pipe round trip per step, three dependent ones per key in score8)
+template <int X>
+__device__ __forceinline__ float xor_lane(float v) {
+  const int x = __float_as_int(v);
+  int r;
+  if (X == 1) {
+    r = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false);  // quad_perm [1, 0, 3, 2]
+  } else if (X == 2) {
+    r = __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false);  // quad_perm [2, 3, 0, 1]
+  } else {
+    r = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);  // row_shl:4 into lanes 0-3, 8-11 of every row: lane i <- lane i + 4
+    r = __builtin_amdgcn_update_dpp(r, x, 0x114, 0xF, 0xA, false);  // row_shr:4 into lanes 4-7, 12-15:           lane i <- lane i - 4
+  }
+  return __int_as_float(r);
+}
+
 // score of one key (all 8 lanes of the group return it), in the exp2 domain
 __device__ __forceinline__ float score8(const float (&qv)[8], const u32x4_t& k4) {
   float d = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) d += qv[2 * i] * bf_lo(k4[i]) + qv[2 * i + 1] * bf_hi(k4[i]);
-  d += __shfl_xor(d, 1, 64);
-  d += __shfl_xor(d, 2, 64);
-  d += __shfl_xor(d, 4, 64);
+  d += xor_lane<1>(d);
+  d += xor_lane<2>(d);
+  d += xor_lane<4>(d);
   return d * (SCALE * LOG2E);
 }
 // p = exp2(score - m) (0 for a key outside the segment): normaliser and P.V accumulation of one key

@@ -27,7 +27,8 @@ constexpr int XMAXM = 4;     // sequences this engine takes
 constexpr int XMAXL = 32;    // decoder layers
 constexpr int NSEG = 7;      // streamed segments per layer (the self-attention phase streams nothing)
 constexpr unsigned SPIN_LIMIT = 1u << 21;
-constexpr int XPART = 22;   // cross-attention partial floats per lane and batch (two batches per row: H * ns * 66 <= 128 * XPART floats = the sc | ared staging area)
+constexpr int XMAXPAIR = 40;  // (head, key segment) pairs of one sequence: H * ns <= 40 (d <= 1280)
+constexpr int XHG = 8;        // heads merged per batch of partial loads
 
 struct XLayer {  // element offsets of one decoder layer: w* into the bf16 shadow, the rest into the fp32 parameter arena / aux region
   long ln1g, ln1b, wqkv, bqkv_aux, wo, bo, lncg, lncb, wcq, bcq, wco, bco, ln2g, ln2b, w1, b1, w2, b2;
@@ -42,6 +43,9 @@ struct XArgs {
   float* part;         // cross-attention partials [M * H * ns][66]: m, l, o[64]
   unsigned* ctrl;      // [0] team barrier counter  [1] error flag  [2] epoch base  [3] XCC ids seen (bit mask)
   int d, H, Te, S_max, L, M, pos, team, stride;
+  int flags;             // experiments: bit 0 = plain (not agent-scope) activation stores, bit 2 = no sleep in the barrier poll, bit 3 = checked
+                         // instantiation, bit 4 = consume ring blocks without waiting for them, bit 5 = issue no DMA (4, 5: timing only, garbage results)
+  unsigned long long* stamps;  // optional [8 phases][8] s_memtime stamps of workgroup 0 in layer 1 (null: off)
   XLayer l0;             // decoder layer 0; layer l = l0 + l * (lstride | astride): the blocks are laid out back to back (host-checked)
   long lstride, astride;
 };
@@ -61,17 +65,21 @@ struct XGeom {
   int nkb_d, nkb_4d;  // ring blocks per wave and tile
   int cnt_qkv, cnt_d, cnt_4d, cnt_it;  // tiles of this workgroup in a phase of 3d/32, d/32, 4d/32 tiles; cross-attention items
 };
-__host__ __device__ __forceinline__ int cnt_of(int n, int wg, int team) { return wg < n ? (n - wg + team - 1) / team : 0; }
+__host__ __device__ __forceinline__ int cnt_of(int n, int wg, int team) {  // tiles t = wg, wg + team, ... < n (a short loop instead of a division)
+  int c = 0;
+  for (int t = wg; t < n; t += team) ++c;
+  return c;
+}
 __host__ __device__ __forceinline__ XGeom make_geom(int d, int H, int Te, int M, int L, int team, int wg) {
   XGeom g;
   g.d = d, g.H = H, g.Te = Te, g.M = M, g.team = team, g.wg = wg, g.L = L;
-  g.ns = (Te + dec::SEG_KEYS - 1) / dec::SEG_KEYS;
-  g.nst_d = d / 64, g.nst_4d = d / 16;
-  g.nkb_d = (g.nst_d + 3) / 4, g.nkb_4d = (g.nst_4d + 3) / 4;
-  g.cnt_qkv = cnt_of(3 * d / 32, wg, team);
-  g.cnt_d = cnt_of(d / 32, wg, team);
+  g.ns = Te > dec::SEG_KEYS ? 2 : 1;
+  g.nst_d = d >> 6, g.nst_4d = d >> 4;
+  g.nkb_d = (g.nst_d + 3) >> 2, g.nkb_4d = (g.nst_4d + 3) >> 2;
+  g.cnt_qkv = cnt_of((3 * d) >> 5, wg, team);
+  g.cnt_d = cnt_of(d >> 5, wg, team);
   g.cnt_it = cnt_of(M * H * g.ns, wg, team);
-  g.cnt_4d = cnt_of(4 * d / 32, wg, team);
+  g.cnt_4d = cnt_of((4 * d) >> 5, wg, team);
   return g;
 }
 // tiles (items for segment 3) of this workgroup in streamed segment `seg` (selects, not a table: the cursors live in SGPRs)
@@ -79,24 +87,41 @@ __host__ __device__ __forceinline__ int seg_cnt(const XGeom& g, int seg) { retur
 struct XItem {
   int b, h, sg, n, kvb;  // sequence, head, key segment, keys in it, ring blocks per K (or V) stream
 };
+// (no integer division anywhere near the cursors: hipcc expands a 32-bit division through VALU float reciprocals, whose result -- and
+// everything computed from it, i.e. the whole block bookkeeping -- then lives in VGPRs under exec-mask branches instead of SGPRs)
 __host__ __device__ __forceinline__ XItem item_of(const XGeom& g, int idx) {
   const int id = g.wg + g.team * idx;
+  const int hn = g.H * g.ns;
   XItem it;
-  it.b = id / (g.H * g.ns);
-  const int rem = id - it.b * (g.H * g.ns);
-  it.h = rem / g.ns;
-  it.sg = rem - it.h * g.ns;
+  it.b = (id >= hn ? 1 : 0) + (id >= 2 * hn ? 1 : 0) + (id >= 3 * hn ? 1 : 0);  // M <= 4 sequences
+  const int rem = id - it.b * hn;
+  it.h = g.ns == 2 ? rem >> 1 : rem;  // ns <= MAX_SEG = 2
+  it.sg = g.ns == 2 ? rem & 1 : 0;
   int n = g.Te - it.sg * dec::SEG_KEYS;
   it.n = n > dec::SEG_KEYS ? dec::SEG_KEYS : n;
-  it.kvb = ((it.n + 31) / 32 + 3) / 4;
+  it.kvb = (((it.n + 31) >> 5) + 3) >> 2;
   return it;
 }
 struct XCur {
   int layer, seg, idx, sub;
 };
+#if defined(__HIP_DEVICE_COMPILE__)
+#define XU(x) __builtin_amdgcn_readfirstlane(x)  // pin a wave-uniform value to an SGPR (hipcc's uniformity analysis gives up on the cursors)
+#else
+#define XU(x) (x)
+#endif
 __host__ __device__ __forceinline__ int nsub_of(const XGeom& g, int seg, int idx) {
   if (seg == 3) return 2 * item_of(g, idx).kvb;
   return seg == 6 ? g.nkb_4d : g.nkb_d;
+}
+// the cursor's sub already points one past the unit's last full block: roll over into the next tile / item / segment if the unit ends there
+__host__ __device__ __forceinline__ bool cur_normalise(const XGeom& g, XCur& c);
+__host__ __device__ __forceinline__ int nsub_of(const XGeom& g, int seg, int idx);
+__host__ __device__ __forceinline__ bool cur_advance_from(const XGeom& g, XCur& c) {
+  if (c.sub >= nsub_of(g, c.seg, c.idx)) c.sub = 0, ++c.idx;
+  const bool more = cur_normalise(g, c);
+  c.layer = XU(c.layer), c.seg = XU(c.seg), c.idx = XU(c.idx), c.sub = XU(c.sub);
+  return more;
 }
 // skip empty segments; returns false past the last layer
 __host__ __device__ __forceinline__ bool cur_normalise(const XGeom& g, XCur& c) {
@@ -108,7 +133,9 @@ __host__ __device__ __forceinline__ bool cur_normalise(const XGeom& g, XCur& c) 
 }
 __host__ __device__ __forceinline__ bool cur_advance(const XGeom& g, XCur& c) {
   if (++c.sub >= nsub_of(g, c.seg, c.idx)) c.sub = 0, ++c.idx;
-  return cur_normalise(g, c);
+  const bool more = cur_normalise(g, c);
+  c.layer = XU(c.layer), c.seg = XU(c.seg), c.idx = XU(c.idx), c.sub = XU(c.sub);
+  return more;
 }
 
 // ---- agent-scope data accesses (coherent across workgroups wherever they run) ---------------------------------------------------------
@@ -125,13 +152,25 @@ __device__ __forceinline__ float ldf_agent(const float* p) {
   return __uint_as_float(__hip_atomic_load((const unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 __device__ __forceinline__ void st4_agent(void* p, unsigned v) { __hip_atomic_store((unsigned*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// (experiment switch: plain stores -- they stay in this XCD's L2, which is all a team on ONE XCD needs; not valid for a spread team)
+__device__ __forceinline__ void st4_x(void* p, unsigned v, int flags) {
+  if (flags & 1) *(volatile unsigned*)p = v;
+  else st4_agent(p, v);
+}
 
 // ---- LDS-DMA of one ring block (4 x 1 KiB), issued from inline assembly (hipcc would otherwise order every later ds_read behind it with
 // s_waitcnt vmcnt(0) and drain the ring) ----------------------------------------------------------------------------------------------
-__device__ __forceinline__ void dma16(const u32x4_t rs, unsigned lds_addr, unsigned voff, unsigned soff) {
+__device__ __forceinline__ void dma16(const u32x4_t rs_in, unsigned lds_addr, unsigned voff, unsigned soff) {
+  u32x4_t rs;  // (re-pinned: a descriptor that travelled through a loop-carried struct comes back as VGPRs)
+  rs[0] = __builtin_amdgcn_readfirstlane(rs_in[0]), rs[1] = __builtin_amdgcn_readfirstlane(rs_in[1]);
+  rs[2] = 0x7fffffffu, rs[3] = 0x00020000u;
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(voff), "s"(rs),
                "s"(__builtin_amdgcn_readfirstlane(soff))
                : "memory");
+}
+// (descriptor already in SGPRs)
+__device__ __forceinline__ void dma16_s(const u32x4_t rs, unsigned lds_addr, unsigned voff, unsigned soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
 }
 __device__ __forceinline__ u32x4_t rsrc_of(const void* base) {
   const unsigned long addr = (unsigned long)base;
@@ -145,54 +184,141 @@ __device__ __forceinline__ u32x4_t rsrc_of(const void* base) {
 #define XWAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 #define XBAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-struct XStream {  // per streaming wave (all fields wave-uniform)
+struct XStream {  // per streaming wave (all fields wave-uniform, SGPR-resident)
   XCur pc;        // producer cursor: next block to issue
   bool more;      // the producer has blocks left
   int issued, consumed;
+  int islot, cslot;  // issued % XR, consumed % XR, kept incrementally
+  // the producer's current UNIT (one tile's K quarter, or one item's K or V stream): descriptor, next block's soffset and how many more
+  // FULL blocks follow with the same descriptor / lane offsets -- the per-block fast path touches nothing else
+  u32x4_t rs;
+  unsigned soff, step;
+  int left, kind;  // kind: lane-offset set 0 = weights K = d, 1 = weights K = 4d, 2 = cross K/V
+  // a weight unit spans ALL remaining tiles of this workgroup in the segment (same matrix, constant distance between its tiles):
+  int tleft, tnkb;  // blocks left in the tile being issued (incl. the next one), blocks per tile
+  unsigned jump;    // soffset step from a tile's last block to the next tile's first
 };
+// per-lane byte offsets that do not depend on the block (computed once per wave): the DMA source offsets of a FULL weight block for
+// K = d / K = 4d and of an unclamped K/V block (4 instructions each), and the LDS fragment offsets of the 4 k16 steps of a weight block
+struct XLane {
+  unsigned w_d[4], w_4d[4], kv[4], frag[4];
+};
+__device__ __forceinline__ XLane make_lane(int d, int wave, int lane) {
+  XLane v;
+  const int r8 = lane >> 3, l8 = lane & 7, row = lane & 31, kc = lane >> 5;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c16 = l8 ^ ((q * 4 + (r8 >> 1)) & 7);
+    v.w_d[q] = (unsigned)(((q * 8 + r8) * d + c16 * 8) * 2);
+    v.w_4d[q] = (unsigned)(((q * 8 + r8) * 4 * d + c16 * 8) * 2);
+    v.kv[q] = (unsigned)(((32 * q + 8 * wave + r8) * 2 * d + l8 * 8) * 2);
+    v.frag[q] = (unsigned)(row * 128 + (((2 * q + kc) ^ ((row >> 1) & 7)) << 4));
+  }
+  return v;
+}
 
-// issue the block the producer cursor points at into ring slot (issued % XR), then advance the cursor
-__device__ __forceinline__ void ring_issue(const XArgs& a, const XGeom& g, XStream& st, int wave, int lane, unsigned ring_lds) {
-  if (!st.more) return;
-  const XCur c = st.pc;
-  const XLayer ly = layer_of(a, c.layer);
-  const unsigned dst = ring_lds + (unsigned)(st.issued % XR) * SLOT;
-  const int r8 = lane >> 3, l8 = lane & 7;
+// Producer set-up at the cursor (SLOW path, once per unit and once per partial / clamped block): descriptor, soffset of the block at
+// the cursor, and the number of FULL blocks from the cursor on that share them.
+__device__ __forceinline__ void ring_setup(const XArgs& a, const XGeom& g, XStream& st, int wave) {
+  const XCur c = XCur{XU(st.pc.layer), XU(st.pc.seg), XU(st.pc.idx), XU(st.pc.sub)};
   if (c.seg == 3) {
     const XItem it = item_of(g, c.idx);
     const bool is_v = c.sub >= it.kvb;
-    const int p0 = (is_v ? c.sub - it.kvb : c.sub) * 4;  // first pass (32 keys each) of this block
+    const int j = is_v ? c.sub - it.kvb : c.sub;  // block within the K (or V) stream: 4 passes of 32 keys
     const bf16_t* ckv = a.cache + (long)c.layer * a.cache_lstride + (long)3 * a.M * a.S_max * a.d;
-    const u32x4_t rs = rsrc_of(ckv);
-    const unsigned soff = (unsigned)((((long)it.b * a.Te + (long)it.sg * dec::SEG_KEYS) * 2 * a.d + it.h * 64 + (is_v ? a.d : 0)) * 2);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      int t = 32 * (p0 + q) + 8 * wave + r8;
-      t = t < it.n ? t : it.n - 1;
-      dma16(rs, dst + q * 1024, (unsigned)(((long)t * 2 * a.d + l8 * 8) * 2), soff);
-    }
+    st.rs = rsrc_of(ckv);
+    st.soff = XU((unsigned)((((long)it.b * a.Te + (long)it.sg * dec::SEG_KEYS + 128 * j) * 2 * a.d + it.h * 64 + (is_v ? a.d : 0)) * 2));
+    st.step = XU((unsigned)(128 * 2 * a.d * 2));
+    const int nfull = it.n >> 7;  // blocks whose 128 keys all lie inside the segment
+    st.left = XU(nfull > j ? nfull - j : 0);
+    st.kind = 2;
+    st.tleft = 0x40000000, st.tnkb = 0x40000000, st.jump = st.step;
   } else {
-    const long woff = c.seg == 0 ? ly.wqkv : c.seg == 1 ? ly.wo : c.seg == 2 ? ly.wcq : c.seg == 4 ? ly.wco : c.seg == 5 ? ly.w1 : ly.w2;
+    const long woff = (c.seg == 0 ? a.l0.wqkv : c.seg == 1 ? a.l0.wo : c.seg == 2 ? a.l0.wcq : c.seg == 4 ? a.l0.wco : c.seg == 5 ? a.l0.w1 : a.l0.w2) +
+                      (long)c.layer * a.lstride;
     const int K = c.seg == 6 ? 4 * a.d : a.d;
-    const int nst = c.seg == 6 ? g.nst_4d : g.nst_d;
-    int steps = nst - c.sub * 4;
-    steps = steps > 4 ? 4 : steps;
     const int tile = g.wg + g.team * c.idx;
-    const u32x4_t rs = rsrc_of(a.wflat + woff);
-    const unsigned soff = (unsigned)((((long)tile * 32) * K + (long)wave * (K >> 2) + c.sub * 64) * 2);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      int c16 = l8 ^ ((q * 4 + (r8 >> 1)) & 7);
-      c16 = c16 < 2 * steps ? c16 : 2 * steps - 1;
-      dma16(rs, dst + q * 1024, (unsigned)(((long)(q * 8 + r8) * K + c16 * 8) * 2), soff);
+    st.rs = rsrc_of(a.wflat + woff);
+    st.soff = XU((unsigned)((((long)tile * 32) * K + (long)wave * (K >> 2) + c.sub * 64) * 2));
+    st.step = 128u;
+    const int nst = c.seg == 6 ? g.nst_4d : g.nst_d, nkb = c.seg == 6 ? g.nkb_4d : g.nkb_d;
+    st.kind = c.seg == 6 ? 1 : 0;
+    if ((nst & 3) == 0) {  // every block of every tile is full: one unit up to the end of the segment
+      st.left = XU((seg_cnt(g, c.seg) - c.idx) * nkb - c.sub);
+      st.tleft = XU(nkb - c.sub), st.tnkb = nkb;
+      st.jump = XU((unsigned)((long)g.team * 32 * K * 2 - (long)(nkb - 1) * 128));
+    } else {
+      const int nfull = nst >> 2;
+      st.left = XU(nfull > c.sub ? nfull - c.sub : 0);
+      st.tleft = 0x40000000, st.tnkb = 0x40000000, st.jump = 128u;
     }
   }
-  ++st.issued;
-  st.more = cur_advance(g, st.pc);
+}
+// issue the block the producer cursor points at into ring slot islot, then advance the cursor.  Fast path (a full block inside the
+// current unit): 4 DMA instructions with precomputed lane offsets + a handful of scalar updates.
+__device__ __forceinline__ void ring_issue(const XArgs& a, const XGeom& g, XStream& st, const XLane& lv, int wave, int lane, unsigned ring_lds) {
+  if (!st.more) return;
+  const unsigned dst = ring_lds + (unsigned)st.islot * SLOT;
+  if (st.left == 0) ring_setup(a, g, st, wave);
+  if (a.flags & 32) {  // (experiment: book-keeping only, no DMA)
+    if (st.left > 0) {
+      st.left = XU(st.left - 1);
+      if (st.tleft == 1) st.soff = XU(st.soff + st.jump), st.tleft = XU(st.tnkb), st.pc.idx = XU(st.pc.idx + 1), st.pc.sub = -1;
+      else st.soff = XU(st.soff + st.step), st.tleft = XU(st.tleft - 1);
+    }
+  } else if (st.left > 0) {
+    if (st.kind == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dma16(st.rs, dst + q * 1024, lv.w_d[q], st.soff);
+    } else if (st.kind == 1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dma16(st.rs, dst + q * 1024, lv.w_4d[q], st.soff);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dma16(st.rs, dst + q * 1024, lv.kv[q], st.soff);
+    }
+    st.left = XU(st.left - 1);
+    if (st.tleft == 1) {  // the tile's last block: on to this workgroup's next tile of the segment
+      st.soff = XU(st.soff + st.jump), st.tleft = XU(st.tnkb);
+      st.pc.idx = XU(st.pc.idx + 1), st.pc.sub = -1;
+    } else {
+      st.soff = XU(st.soff + st.step), st.tleft = XU(st.tleft - 1);
+    }
+  } else {  // a unit's last, partial (weights) or clamped (K/V) block: lanes past the end re-read the last valid piece (never used)
+    const int r8 = lane >> 3, l8 = lane & 7;
+    if (st.kind == 2) {
+      const XItem it = item_of(g, XU(st.pc.idx));
+      const int sub = XU(st.pc.sub);
+      const int last = it.n - 1 - 128 * (sub >= it.kvb ? sub - it.kvb : sub);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int t = 32 * q + 8 * wave + r8;
+        t = t < last ? t : last;
+        dma16(st.rs, dst + q * 1024, (unsigned)(((long)t * 2 * a.d + l8 * 8) * 2), st.soff);
+      }
+    } else {
+      const int K = st.kind == 1 ? 4 * a.d : a.d;
+      const int steps = (st.kind == 1 ? g.nst_4d : g.nst_d) - XU(st.pc.sub) * 4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int c16 = l8 ^ ((q * 4 + (r8 >> 1)) & 7);
+        c16 = c16 < 2 * steps ? c16 : 2 * steps - 1;
+        dma16(st.rs, dst + q * 1024, (unsigned)(((long)(q * 8 + r8) * K + c16 * 8) * 2), st.soff);
+      }
+    }
+  }
+  st.issued = XU(st.issued + 1);
+  st.islot = XU(st.islot + 1 == XR ? 0 : st.islot + 1);
+  if (st.left > 0) {
+    st.pc.sub = XU(st.pc.sub + 1);  // still inside the unit: nothing else changes
+  } else {
+    st.more = XU((int)cur_advance(g, st.pc)) != 0;  // unit (or its full part) done: the next call sets up again
+  }
 }
 // block `consumed` has landed: at most (issued - consumed - 1) younger blocks may still be in flight (loads return in order)
-__device__ __forceinline__ void ring_wait(const XStream& st) {
-  const int younger = st.issued - st.consumed - 1;
+__device__ __forceinline__ void ring_wait(const XStream& st, int flags = 0) {
+  if (flags & 16) return;  // (experiment: consume without waiting -- garbage results, pure instruction time)
+  const int younger = XU(st.issued - st.consumed - 1);
   if (younger >= 5) XWAIT_VM(20);
   else if (younger == 4) XWAIT_VM(16);
   else if (younger == 3) XWAIT_VM(12);
@@ -206,11 +332,11 @@ __device__ __forceinline__ void team_arrive(unsigned* ctrl) {
   XWAIT_VM(0);  // this workgroup's stores of the phase have been acknowledged
   if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(ctrl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void team_wait(unsigned* ctrl, unsigned target) {
+__device__ __forceinline__ void team_wait(unsigned* ctrl, unsigned target, int flags = 0) {
   if ((threadIdx.x & 63) == 0) {  // one lane polls; the wave reconverges behind it
     unsigned spins = 0;
     while ((int)(__hip_atomic_load(ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-      __builtin_amdgcn_s_sleep(1);
+      if (!(flags & 4)) __builtin_amdgcn_s_sleep(1);
       if (++spins > SPIN_LIMIT || ((spins & 63) == 0 && __hip_atomic_load(ctrl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
         __hip_atomic_fetch_or(ctrl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // a team member never arrived: poison, do not hang
         break;
@@ -219,25 +345,19 @@ __device__ __forceinline__ void team_wait(unsigned* ctrl, unsigned target) {
   }
 }
 
-struct XSmem {  // byte offsets into the dynamic LDS block
-  unsigned ring, xbuf, xs, red, sc, ared, lsum, wmax, aout, stat;
-};
-__host__ __device__ __forceinline__ XSmem smem_layout(int d, unsigned& total) {
-  XSmem s;
-  unsigned o = 0;
-  s.ring = o, o += 4 * XR * SLOT;
-  s.xs = (unsigned)(4 * d * 2 + 16);  // row stride of the activation operand (bytes): K_max = 4d, + 16 so the rows sit on different banks
-  s.xbuf = o, o += XMAXM * s.xs;
-  s.red = o, o += 2 * 4 * 16 * XMAXM * 2 * 4;
-  s.sc = o, o += dec::SEG_KEYS * 4;
-  s.ared = o, o += 32 * 64 * 4;
-  s.lsum = o, o += 32 * 4;
-  s.wmax = o, o += 4 * 4;
-  s.aout = o, o += 66 * 4 + 8;
-  s.stat = o, o += 64;
-  total = (o + 15) & ~15u;
-  return s;
-}
+// dynamic LDS block, byte offsets (compile-time: d <= XMAXD fixes the operand row stride)
+constexpr int XMAXD = 1280;
+constexpr unsigned XL_RING = 0;
+constexpr unsigned XL_XS = 4 * XMAXD * 2 + 16;  // row stride of the activation operand: K_max = 4d, + 16 so the rows sit on different banks
+constexpr unsigned XL_XBUF = XL_RING + 4 * XR * SLOT;
+constexpr unsigned XL_RED = XL_XBUF + XMAXM * XL_XS;
+constexpr unsigned XL_SC = XL_RED + 4 * 4 * 16 * XMAXM * 2 * 4;  // NRED reduction buffers
+constexpr unsigned XL_ARED = XL_SC + dec::SEG_KEYS * 4;  // (sc | ared contiguous: the cross-attention merge stages the partials there)
+constexpr unsigned XL_LSUM = XL_ARED + 32 * 64 * 4;
+constexpr unsigned XL_WMAX = XL_LSUM + 32 * 4;
+constexpr unsigned XL_AOUT = XL_WMAX + 4 * 4;
+constexpr unsigned XL_TOTAL = (XL_AOUT + 66 * 4 + 8 + 15) & ~15u;
+static_assert(XL_TOTAL <= 160 * 1024, "one-launch decode step: LDS budget");
 
 struct XGemv {  // one projection phase
   int seg;
@@ -255,37 +375,41 @@ struct XGemv {  // one projection phase
 // helper wave: activation rows of a projection phase -> LDS operand rows (bf16).  Every global load of a row is issued before the first
 // one is used: ONE round trip per row, not one per chunk.
 constexpr int XCH = 4;  // 16-byte chunks per lane and batch of a plain operand row (register budget: the kernel sits at 254 of 256 VGPRs)
-__device__ __forceinline__ void helper_operand(const XArgs& a, const XGeom& g, const XGemv& ph, char* smem, const XSmem& L, int lane) {
+__device__ __forceinline__ void helper_operand(const XArgs& a, const XGeom& g, const XGemv& ph, char* smem, int lane) {
   if (ph.merge_attn) {  // rows = merge of the cross-attention segments' partials (decode_shared.h), dimension `lane` of every head
-    float* stage = (float*)(smem + L.sc);  // (sc | ared are contiguous and idle outside the attention phases)
-    const int per_row = a.H * g.ns * 66;
+    // ONE round trip per row: lane j < H * ns fetches (m, l) of pair j, every lane its dimension of every pair's o; the (m, l) of a pair
+    // reach all lanes by a wave shuffle
+    const int npair = a.H * g.ns;  // <= 40 (decode_xcd_supports)
     for (int b = 0; b < a.M; ++b) {
-      const float* src = a.part + (long)b * per_row;
-      for (int base = 0; base < per_row; base += 64 * XPART) {  // (two round trips per row)
-        float t[XPART];
+      const float* src = a.part + (long)b * npair * 66;
+      const int jl = lane < npair ? lane : npair - 1;
+      const float m_l = ldf_agent(src + jl * 66), l_l = ldf_agent(src + jl * 66 + 1);
+      for (int h0 = 0; h0 < a.H; h0 += XHG) {  // XHG heads per batch of loads (register budget)
+        float o[XHG * dec::MAX_SEG];
 #pragma unroll
-        for (int i = 0; i < XPART; ++i)
-          if (base + lane + 64 * i < per_row) t[i] = ldf_agent(src + base + lane + 64 * i);
+        for (int j = 0; j < XHG * dec::MAX_SEG; ++j) {
+          const int pj = h0 * g.ns + j;
+          o[j] = ldf_agent(src + (pj < npair ? pj : npair - 1) * 66 + 2 + lane);  // (unconditional: one batch of loads)
+        }
 #pragma unroll
-        for (int i = 0; i < XPART; ++i)
-          if (base + lane + 64 * i < per_row) stage[base + lane + 64 * i] = t[i];
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one wave: its own LDS writes are visible to it once retired)
-      for (int h = 0; h < a.H; ++h) {
-        float m_s[dec::MAX_SEG] = {dec::NEG, dec::NEG}, l_s[dec::MAX_SEG] = {0.f, 0.f}, o_s[dec::MAX_SEG] = {0.f, 0.f};
-#pragma unroll
-        for (int sg = 0; sg < dec::MAX_SEG; ++sg) {
-          if (sg < g.ns) {
-            const float* p = stage + (h * g.ns + sg) * 66;
-            m_s[sg] = p[0], l_s[sg] = p[1], o_s[sg] = p[2 + lane];
+        for (int hh = 0; hh < XHG; ++hh) {
+          const int h = h0 + hh;
+          if (h < a.H) {
+            float m_s[dec::MAX_SEG] = {dec::NEG, dec::NEG}, l_s[dec::MAX_SEG] = {0.f, 0.f}, o_s[dec::MAX_SEG] = {0.f, 0.f};
+            if (g.ns == 2) {
+              m_s[0] = __shfl(m_l, 2 * h, 64), m_s[1] = __shfl(m_l, 2 * h + 1, 64);
+              l_s[0] = __shfl(l_l, 2 * h, 64), l_s[1] = __shfl(l_l, 2 * h + 1, 64);
+              o_s[0] = o[2 * hh], o_s[1] = o[2 * hh + 1];
+            } else {
+              m_s[0] = __shfl(m_l, h, 64), l_s[0] = __shfl(l_l, h, 64), o_s[0] = o[hh];
+            }
+            float m, lt;
+            const float val = dec::merge_segments(m_s, l_s, o_s, g.ns, m, lt);
+            const float nb = __shfl_xor(val, 1, 64);
+            if ((lane & 1) == 0) *(uint32_t*)(smem + XL_XBUF + b * XL_XS + (h * 64 + lane) * 2) = pack_bf2(val, nb);
           }
         }
-        float m, lt;
-        const float val = dec::merge_segments(m_s, l_s, o_s, g.ns, m, lt);
-        const float nb = __shfl_xor(val, 1, 64);
-        if ((lane & 1) == 0) *(uint32_t*)(smem + L.xbuf + b * L.xs + (h * 64 + lane) * 2) = pack_bf2(val, nb);
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the stage is rewritten for the next row
     }
     return;
   }
@@ -293,21 +417,17 @@ __device__ __forceinline__ void helper_operand(const XArgs& a, const XGeom& g, c
   for (int b = 0; b < a.M; ++b) {
     if (ph.ln_g) {  // K == d <= 2048: the row fits MAXC chunks per lane
       u32x4_t raw[dec::MAXC];
-      float v[dec::MAXC][8];
 #pragma unroll
       for (int c = 0; c < dec::MAXC; ++c) {
         const int ch = lane + 64 * c;
         if (ch < nchunk) raw[c] = ld16_agent(ph.xin + (long)b * ph.K + ch * 8);
       }
-#pragma unroll
-      for (int c = 0; c < dec::MAXC; ++c)
-        if (lane + 64 * c < nchunk) dec::unpack8(raw[c], v[c]);
       float mean, rstd;
-      dec::row_stats(v, lane, nchunk, ph.K, mean, rstd);
+      dec::row_stats(raw, lane, nchunk, ph.K, mean, rstd);
 #pragma unroll
       for (int c = 0; c < dec::MAXC; ++c) {
         const int ch = lane + 64 * c;
-        if (ch < nchunk) *(u32x4_t*)(smem + L.xbuf + b * L.xs + ch * 16) = dec::ln_apply8(raw[c], mean, rstd, ph.ln_g, ph.ln_b, ch * 8);
+        if (ch < nchunk) *(u32x4_t*)(smem + XL_XBUF + b * XL_XS + ch * 16) = dec::ln_apply8(raw[c], mean, rstd, ph.ln_g, ph.ln_b, ch * 8);
       }
     } else {
       for (int c0 = 0; c0 * 64 < nchunk; c0 += XCH) {  // (K = 4096: two batches)
@@ -317,13 +437,13 @@ __device__ __forceinline__ void helper_operand(const XArgs& a, const XGeom& g, c
           if (lane + 64 * (c0 + c) < nchunk) raw[c] = ld16_agent(ph.xin + (long)b * ph.K + (lane + 64 * (c0 + c)) * 8);
 #pragma unroll
         for (int c = 0; c < XCH; ++c)
-          if (lane + 64 * (c0 + c) < nchunk) *(u32x4_t*)(smem + L.xbuf + b * L.xs + (lane + 64 * (c0 + c)) * 16) = raw[c];
+          if (lane + 64 * (c0 + c) < nchunk) *(u32x4_t*)(smem + XL_XBUF + b * XL_XS + (lane + 64 * (c0 + c)) * 16) = raw[c];
       }
     }
   }
 }
 // helper wave: query rows of an attention phase -> LDS
-__device__ __forceinline__ void helper_query_rows(const XArgs& a, const bf16_t* src, long row_stride, char* smem, const XSmem& L, int lane) {
+__device__ __forceinline__ void helper_query_rows(const XArgs& a, const bf16_t* src, long row_stride, char* smem, int lane) {
   const int nchunk = a.d >> 3;
   for (int b = 0; b < a.M; ++b) {
     u32x4_t raw[dec::MAXC];
@@ -332,7 +452,7 @@ __device__ __forceinline__ void helper_query_rows(const XArgs& a, const bf16_t* 
       if (lane + 64 * c < nchunk) raw[c] = ld16_agent(src + (long)b * row_stride + (lane + 64 * c) * 8);
 #pragma unroll
     for (int c = 0; c < dec::MAXC; ++c)
-      if (lane + 64 * c < nchunk) *(u32x4_t*)(smem + L.xbuf + b * L.xs + (lane + 64 * c) * 16) = raw[c];
+      if (lane + 64 * c < nchunk) *(u32x4_t*)(smem + XL_XBUF + b * XL_XS + (lane + 64 * c) * 16) = raw[c];
   }
 }
 
@@ -351,11 +471,11 @@ __device__ __forceinline__ XEpiIn helper_epilogue_inputs(const XArgs& a, const X
   if (ph.bias) in.b0 = ph.bias[n0 + 2 * cp], in.b1 = ph.bias[n0 + 2 * cp + 1];
   return in;
 }
-__device__ __forceinline__ void helper_epilogue(const XArgs& a, const XGemv& ph, const XEpiIn& in, const char* smem, const XSmem& L, int buf, int n0,
+__device__ __forceinline__ void helper_epilogue(const XArgs& a, const XGemv& ph, const XEpiIn& in, const char* smem, int buf, int n0,
                                                 int lane) {
   const int m = lane >> 4, cp = lane & 15;
   if (m >= a.M) return;
-  const float* red = (const float*)(smem + L.red) + buf * (4 * 16 * XMAXM * 2);
+  const float* red = (const float*)(smem + XL_RED) + buf * (4 * 16 * XMAXM * 2);
   float y[2];
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
@@ -365,44 +485,139 @@ __device__ __forceinline__ void helper_epilogue(const XArgs& a, const XGemv& ph,
     const float acc = red[0 * 16 * XMAXM * 2 + idx] + red[1 * 16 * XMAXM * 2 + idx] + red[2 * 16 * XMAXM * 2 + idx] + red[3 * 16 * XMAXM * 2 + idx];
     y[e] = dec::epi_value(acc, e ? in.b1 : in.b0, ph.gelu, ph.resid != nullptr, e ? bf_hi(in.rz) : bf_lo(in.rz));
   }
-  st4_agent(ph.out + (long)m * ph.ldc + n0 + 2 * cp, pack_bf2(y[0], y[1]));
+  st4_x(ph.out + (long)m * ph.ldc + n0 + 2 * cp, pack_bf2(y[0], y[1]), a.flags);
 }
 
-// streaming waves: one projection tile = this wave's K quarter of 32 weight rows against the operand rows, through the ring
-__device__ __forceinline__ void stream_tile(const XArgs& a, const XGeom& g, XStream& st, XCur& cc, const XGemv& ph, char* smem, const XSmem& L,
-                                            unsigned ring_lds, int wave, int lane, int buf, int tile_idx) {
+// ---- fast run: `run` consecutive ring blocks during which nothing special happens on either side -- the consumer's blocks are full, the
+// producer stays inside its current unit (st.left full blocks with one descriptor / lane-offset set) and the ring is in its steady state
+// (XR blocks in flight: the block consumed and the block issued share a slot).  Per block: one counted wait, the consumer's body on the
+// slot, four DMA instructions, a handful of scalar updates -- no cursor arithmetic (the general path costs ~1.7 k cycles of
+// instruction issue per block, profiles/r05_decode_xcd_stamps_v3_instruction_bound.txt).
+__device__ __forceinline__ int fast_run_len(const XStream& st, int consumer_full_left) {
+  int run = consumer_full_left < st.left ? consumer_full_left : st.left;
+  return (run > 0 && st.more && st.issued - st.consumed == XR) ? run : 0;
+}
+template <typename F>
+__device__ __forceinline__ void fast_run(const XGeom& g, XStream& st, const XLane& lv, char* smem, unsigned ring_lds, int wave, int run, F&& body,
+                                         int flags = 0) {
+  unsigned vo[4];
+  const int kind = XU(st.kind);
+  if (kind == 0) {  // (three branches, not a select: hipcc turns the select into an indexed read of `lv` in scratch memory)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) vo[q] = lv.w_d[q];
+  } else if (kind == 1) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) vo[q] = lv.w_4d[q];
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) vo[q] = lv.kv[q];
+  }
+  u32x4_t rs;
+  rs[0] = XU(st.rs[0]), rs[1] = XU(st.rs[1]), rs[2] = 0x7fffffffu, rs[3] = 0x00020000u;
+  unsigned soff = XU(st.soff);
+  const unsigned step = XU(st.step), jump = XU(st.jump);
+  const int tnkb = XU(st.tnkb);
+  int slot_i = XU(st.cslot), tleft = XU(st.tleft), sub = XU(st.pc.sub), idx_inc = 0;
+  for (int i = 0; i < run; ++i) {
+    if (!(flags & 16)) XWAIT_VM(20);  // 4 * (XR - 1): the oldest block in flight has landed
+    body(smem + XL_RING + (wave * XR + slot_i) * SLOT, i);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the body's reads of the slot have retired: it may be re-staged
+    const unsigned slot_lds = ring_lds + (unsigned)slot_i * SLOT;
+    if (!(flags & 32)) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dma16_s(rs, slot_lds + q * 1024, vo[q], soff);
+    }
+    if (tleft == 1) {  // the tile's last block: on to this workgroup's next tile of the segment
+      soff += jump, tleft = tnkb, sub = 0, ++idx_inc;
+    } else {
+      soff += step, --tleft, ++sub;
+    }
+    slot_i = slot_i + 1 == XR ? 0 : slot_i + 1;
+  }
+  st.soff = soff;
+  st.tleft = tleft;
+  st.left = XU(st.left - run);
+  st.pc.sub = XU(sub), st.pc.idx = XU(st.pc.idx + idx_inc);
+  st.issued = XU(st.issued + run), st.consumed = XU(st.consumed + run);
+  st.cslot = st.islot = slot_i;
+  if (st.left == 0) st.more = XU((int)cur_advance_from(g, st.pc)) != 0;  // the unit's full part is done: the next issue sets up again
+}
+
+// streaming waves: the tiles of one projection phase, back to back.  A tile = this wave's K quarter of 32 weight rows against the operand
+// rows, through the ring; its 16 accumulators go to one of NRED reduction buffers.  The helper wave is met once per GROUP of NRED tiles
+// (every phase of every model up to d = 1024 is one group), not once per tile.
+constexpr int NRED = 4;
+template <bool DBG>
+__device__ __forceinline__ void stream_phase(const XArgs& a, const XGeom& g, XStream& st, XCur& cc, const XLane& lv, const XGemv& ph, char* smem,
+                                             unsigned ring_lds, int wave, int lane, int ntile) {
   const int nst = ph.seg == 6 ? g.nst_4d : g.nst_d, nkb = ph.seg == 6 ? g.nkb_4d : g.nkb_d;
+  const bool allfull = (nst & 3) == 0;
   const int row = lane & 31, kc = lane >> 5;
   const int kq0 = wave * (ph.K >> 2);
+  const char* xrow = smem + XL_XBUF + (row & (XMAXM - 1)) * XL_XS + (kq0 + kc * 8) * 2;
   f32x16_t acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const char* xrow = smem + L.xbuf + (row & (XMAXM - 1)) * L.xs + (kq0 + kc * 8) * 2;
-  for (int kb = 0; kb < nkb; ++kb) {
-    if (cc.seg != ph.seg || cc.idx != tile_idx || cc.sub != kb) __hip_atomic_fetch_or(a.ctrl + 1, 0x100u | (unsigned)ph.seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    ring_wait(st);
-    const char* slot = smem + L.ring + (wave * XR + st.consumed % XR) * SLOT;
-    int steps = nst - kb * 4;
-    steps = steps > 4 ? 4 : steps;
-    for (int s = 0; s < steps; ++s) {
-      const bf16x8_t wf = *(const bf16x8_t*)(slot + row * 128 + (((2 * s + kc) ^ ((row >> 1) & 7)) << 4));
-      const bf16x8_t xf = *(const bf16x8_t*)(xrow + (kb * 4 + s) * 32);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc, 0, 0, 0);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slot's reads have retired before it is re-staged
-    ++st.consumed;
-    cur_advance(g, cc);
-    ring_issue(a, g, st, wave, lane, ring_lds);
-  }
-  if (row < XMAXM) {
-    float* red = (float*)(smem + L.red) + buf * (4 * 16 * XMAXM * 2) + wave * (16 * XMAXM * 2);
+  int tile = 0, kb = 0;
+  auto tile_done = [&]() {  // accumulators -> reduction buffer (tile & (NRED - 1)); next tile
+    if (row < XMAXM) {
+      float* red = (float*)(smem + XL_RED) + (tile & (NRED - 1)) * (4 * 16 * XMAXM * 2) + wave * (16 * XMAXM * 2);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[(r * XMAXM + row) * 2 + kc] = acc[r];
+      for (int r = 0; r < 16; ++r) red[(r * XMAXM + row) * 2 + kc] = acc[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    kb = 0;
+    ++tile;
+  };
+  while (tile < ntile) {
+    int gend = (tile & ~(NRED - 1)) + NRED;  // end of this group of tiles
+    gend = gend < ntile ? gend : ntile;
+    const int cfull = allfull ? (gend - tile) * nkb - kb : (nst >> 2) - kb;  // full blocks ahead of the consumer before anything special
+    const int run = DBG ? 0 : fast_run_len(st, cfull);
+    if (run > 0) {
+      fast_run(g, st, lv, smem, ring_lds, wave, run, [&](const char* slot, int) {
+        bf16x8_t wf[4], xf[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          wf[q] = *(const bf16x8_t*)(slot + lv.frag[q]);
+          xf[q] = *(const bf16x8_t*)(xrow + kb * 128 + q * 32);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[q], xf[q], acc, 0, 0, 0);
+        if (++kb == nkb) tile_done();
+      }, a.flags);
+    } else {
+      if (DBG) {
+        if (cc.seg != ph.seg || cc.idx != tile || cc.sub != kb) __hip_atomic_fetch_or(a.ctrl + 1, 0x100u | (unsigned)ph.seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cur_advance(g, cc);
+      }
+      ring_wait(st, a.flags);
+      const char* slot = smem + XL_RING + (wave * XR + st.cslot) * SLOT;
+      int steps = nst - kb * 4;
+      steps = steps > 4 ? 4 : steps;
+      for (int q = 0; q < steps; ++q) {
+        const bf16x8_t wf = *(const bf16x8_t*)(slot + row * 128 + (((2 * q + kc) ^ ((row >> 1) & 7)) << 4));
+        const bf16x8_t xf = *(const bf16x8_t*)(xrow + (kb * 4 + q) * 32);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc, 0, 0, 0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slot's reads have retired before it is re-staged
+      st.consumed = XU(st.consumed + 1);
+      st.cslot = XU(st.cslot + 1 == XR ? 0 : st.cslot + 1);
+      ring_issue(a, g, st, lv, wave, lane, ring_lds);
+      if (++kb == nkb) tile_done();
+    }
+    if (kb == 0 && (tile == ntile || (tile & (NRED - 1)) == 0)) {  // a group is complete: hand its accumulators to the helper wave
+      XBAR();
+      if (tile < ntile) XBAR();  // ... and wait until it has read them before the next group overwrites the buffers
+    }
   }
 }
 
 __device__ __forceinline__ XGemv gemv_of(const XArgs& a, int layer, int ph) {
-  const XLayer ly = layer_of(a, layer);
+  XLayer ly = layer_of(a, layer);
   bf16_t* self = a.cache + (long)layer * a.cache_lstride;
   XGemv p;
   p.merge_attn = false, p.gelu = false, p.ln_g = p.ln_b = nullptr, p.resid = nullptr, p.K = a.d, p.N = a.d, p.ldc = a.d;
@@ -430,28 +645,38 @@ __device__ __forceinline__ XGemv gemv_of(const XArgs& a, int layer, int ph) {
   }
   return p;
 }
+// measurement: s_memtime of workgroup 0's helper wave (slots 0-4: phase start, barrier passed, operand / query rows in LDS, last tile stored,
+// arrived) and of its streaming wave 0 (5, 6: released, last tile handed over) in decoder layer 1
+#define XSTAMP(K)                                                                                          \
+  do {                                                                                                     \
+    if (a.stamps && wg == 0 && layer == 1 && lane == 0) a.stamps[ph * 8 + (K)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+template <bool DBG>  // DBG: the consumer checks every block against a mirror of the producer's cursor (tests; costs scalar work per block)
 __global__ __launch_bounds__(320) void decode_xcd_kernel(XArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
-  if (a.stride > 1 && (blockIdx.x % a.stride) != 0) return;
-  const int wg = blockIdx.x / a.stride;
+  if (a.stride == 8 && (blockIdx.x & 7) != 0) return;
+  const int wg = a.stride == 8 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool helper = wave == 4;
-  unsigned total;
-  const XSmem L = smem_layout(a.d, total);
-  const XGeom g = make_geom(a.d, a.H, a.Te, a.M, a.L, a.team, wg);
+  XGeom g = make_geom(a.d, a.H, a.Te, a.M, a.L, a.team, wg);
+  g.cnt_qkv = __builtin_amdgcn_readfirstlane(g.cnt_qkv), g.cnt_d = __builtin_amdgcn_readfirstlane(g.cnt_d);
+  g.cnt_4d = __builtin_amdgcn_readfirstlane(g.cnt_4d), g.cnt_it = __builtin_amdgcn_readfirstlane(g.cnt_it);
   const unsigned base = a.ctrl[2];  // epoch: the counter is never reset, every launch adds (phases x team) to it
-  const unsigned ring_lds = (unsigned)(size_t)(smem + L.ring) + (unsigned)wave * XR * SLOT;
+  const unsigned ring_lds = (unsigned)(size_t)(smem + XL_RING) + (unsigned)wave * XR * SLOT;
   unsigned gphase = 0;  // phases completed by the whole team before the current one
+  const XLane lv = make_lane(a.d, wave, lane);
 
   XStream st;
   XCur cc;  // consumer's mirror of the block sequence (a desynchronised producer is reported, not silently consumed)
-  st.pc = XCur{0, 0, 0, 0}, st.issued = st.consumed = 0;
+  st.pc = XCur{0, 0, 0, 0}, st.issued = st.consumed = 0, st.islot = st.cslot = 0;
+  st.left = 0, st.kind = 0, st.soff = 0, st.step = 0, st.rs = u32x4_t{0u, 0u, 0u, 0u};
+  st.tleft = st.tnkb = 0x40000000, st.jump = 0;
   cc = XCur{0, 0, 0, 0};
   if (!helper) {
     st.more = cur_normalise(g, st.pc);
     cur_normalise(g, cc);
-    for (int i = 0; i < XR; ++i) ring_issue(a, g, st, wave, lane, ring_lds);
+    for (int i = 0; i < XR; ++i) ring_issue(a, g, st, lv, wave, lane, ring_lds);
   } else {
     st.more = false;
     if (lane == 0) {
@@ -459,10 +684,12 @@ __global__ __launch_bounds__(320) void decode_xcd_kernel(XArgs a) {
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
       __hip_atomic_fetch_or(a.ctrl + 3, 1u << (xcc & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    for (int i = lane; i < (int)(XMAXM * L.xs / 4); i += 64) ((unsigned*)(smem + L.xbuf))[i] = 0u;  // operand rows >= M read as zeros
+    for (int i = lane; i < (int)(XMAXM * XL_XS / 4); i += 64) ((unsigned*)(smem + XL_XBUF))[i] = 0u;  // operand rows >= M read as zeros
   }
 
+#pragma unroll 1
   for (int layer = 0; layer < a.L; ++layer) {
+#pragma unroll 1
     for (int ph = 0; ph < 8; ++ph, ++gphase) {
       const unsigned target = base + gphase * (unsigned)a.team;
       if (ph == 1 || ph == 4) {
@@ -471,35 +698,40 @@ __global__ __launch_bounds__(320) void decode_xcd_kernel(XArgs a) {
         const int nitem = cross ? g.cnt_it : cnt_of(a.M * a.H, wg, a.team);
         const bf16_t* self = a.cache + (long)layer * a.cache_lstride;
         if (helper) {
-          team_wait(a.ctrl, target);
+          XSTAMP(0);
+          team_wait(a.ctrl, target, a.flags);
+          XSTAMP(1);
           // query rows -> LDS (self: the q third of cache row pos; cross: the cross query)
-          if (cross) helper_query_rows(a, a.q, a.d, smem, L, lane);
-          else helper_query_rows(a, self + (long)a.pos * 3 * a.d, (long)a.S_max * 3 * a.d, smem, L, lane);
+          if (cross) helper_query_rows(a, a.q, a.d, smem, lane);
+          else helper_query_rows(a, self + (long)a.pos * 3 * a.d, (long)a.S_max * 3 * a.d, smem, lane);
+          XSTAMP(2);
           XBAR();  // A
           for (int j = 0; j < nitem; ++j) {
             XBAR();  // 1
             XBAR();  // 2
-            XBAR();  // 3: the item's result is in L.aout
-            const float* ao = (const float*)(smem + L.aout);
+            XBAR();  // 3: the item's result is in XL_AOUT
+            const float* ao = (const float*)(smem + XL_AOUT);
             if (cross) {
               const XItem it = item_of(g, j);
               float* dst = a.part + ((long)(it.b * a.H + it.h) * g.ns + it.sg) * 66;
-              st4_agent(dst + 2 + lane, __float_as_uint(ao[2 + lane]));
-              if (lane < 2) st4_agent(dst + lane, __float_as_uint(ao[lane]));
+              st4_x(dst + 2 + lane, __float_as_uint(ao[2 + lane]), a.flags);
+              if (lane < 2) st4_x(dst + lane, __float_as_uint(ao[lane]), a.flags);
             } else {
-              const int id = wg + a.team * j, b = id / a.H, h = id - b * a.H;
+              const int id = wg + a.team * j, b = (id >= a.H ? 1 : 0) + (id >= 2 * a.H ? 1 : 0) + (id >= 3 * a.H ? 1 : 0), h = id - b * a.H;
               const float val = ao[2 + lane], nb = __shfl_xor(val, 1, 64);
-              if ((lane & 1) == 0) st4_agent(a.o + (long)b * a.d + h * 64 + lane, pack_bf2(val, nb));
+              if ((lane & 1) == 0) st4_x(a.o + (long)b * a.d + h * 64 + lane, pack_bf2(val, nb), a.flags);
             }
           }
+          XSTAMP(3);
           team_arrive(a.ctrl);
+          XSTAMP(4);
         } else {
           XBAR();  // A
-          float* sc = (float*)(smem + L.sc);
-          float(*ared)[64] = (float(*)[64])(smem + L.ared);
-          float* lsum = (float*)(smem + L.lsum);
-          float* wmax = (float*)(smem + L.wmax);
-          float* ao = (float*)(smem + L.aout);
+          float* sc = (float*)(smem + XL_SC);
+          float(*ared)[64] = (float(*)[64])(smem + XL_ARED);
+          float* lsum = (float*)(smem + XL_LSUM);
+          float* wmax = (float*)(smem + XL_WMAX);
+          float* ao = (float*)(smem + XL_AOUT);
           const int l8 = tid & 7, grp = tid >> 3;
           for (int j = 0; j < nitem; ++j) {
             int b, h, n;
@@ -509,19 +741,36 @@ __global__ __launch_bounds__(320) void decode_xcd_kernel(XArgs a) {
               b = it.b, h = it.h, n = it.n;
             } else {
               const int id = wg + a.team * j;
-              b = id / a.H, h = id - b * a.H, n = a.pos + 1;
+              b = (id >= a.H ? 1 : 0) + (id >= 2 * a.H ? 1 : 0) + (id >= 3 * a.H ? 1 : 0), h = id - b * a.H, n = a.pos + 1;
             }
             float qv[8];
-            dec::load_q8(*(const u32x4_t*)(smem + L.xbuf + b * L.xs + (h * 64 + l8 * 8) * 2), qv);
+            dec::load_q8(*(const u32x4_t*)(smem + XL_XBUF + b * XL_XS + (h * 64 + l8 * 8) * 2), qv);
             float mx = dec::NEG, l = 0.f, o[8];
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) o[jj] = 0.f;
             if (cross) {
               // K blocks, then V blocks, of this wave's keys (t == 8 wave + (lane >> 3) mod 32) through the ring
-              for (int kb = 0; kb < it.kvb; ++kb) {
-                if (cc.seg != 3 || cc.idx != j || cc.sub != kb) __hip_atomic_fetch_or(a.ctrl + 1, 0x103u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ring_wait(st);
-                const char* slot = smem + L.ring + (wave * XR + st.consumed % XR) * SLOT;
+              for (int kb = 0; kb < it.kvb;) {
+                const int run = DBG ? 0 : fast_run_len(st, (n >> 7) - kb);  // blocks whose 128 keys all lie inside the segment
+                if (run > 0) {
+                  fast_run(g, st, lv, smem, ring_lds, wave, run, [&](const char* slot, int i) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                      const int t = 32 * ((kb + i) * 4 + q) + grp;
+                      const float s2 = dec::score8(qv, *(const u32x4_t*)(slot + q * 1024 + lane * 16));
+                      if (l8 == 0) sc[t] = s2;
+                      mx = fmaxf(mx, s2);
+                    }
+                  }, a.flags);
+                  kb += run;
+                  continue;
+                }
+                if (DBG) {
+                  if (cc.seg != 3 || cc.idx != j || cc.sub != kb) __hip_atomic_fetch_or(a.ctrl + 1, 0x103u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  cur_advance(g, cc);
+                }
+                ring_wait(st, a.flags);
+                const char* slot = smem + XL_RING + (wave * XR + st.cslot) * SLOT;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                   const int t = 32 * (kb * 4 + q) + grp;
@@ -532,9 +781,10 @@ __global__ __launch_bounds__(320) void decode_xcd_kernel(XArgs a) {
                   }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                ++st.consumed;
-                cur_advance(g, cc);
-                ring_issue(a, g, st, wave, lane, ring_lds);
+                st.consumed = XU(st.consumed + 1);
+                st.cslot = XU(st.cslot + 1 == XR ? 0 : st.cslot + 1);
+                ring_issue(a, g, st, lv, wave, lane, ring_lds);
+                ++kb;
               }
             } else {
               // self-attention: <= S_max cached keys, q | k | v rows of this sequence (agent-scope: row pos was written in this launch)
@@ -562,19 +812,35 @@ __global__ __launch_bounds__(320) void decode_xcd_kernel(XArgs a) {
             XBAR();  // 1
             const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
             if (cross) {
-              for (int kb = 0; kb < it.kvb; ++kb) {
-                if (cc.seg != 3 || cc.idx != j || cc.sub != it.kvb + kb) __hip_atomic_fetch_or(a.ctrl + 1, 0x113u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ring_wait(st);
-                const char* slot = smem + L.ring + (wave * XR + st.consumed % XR) * SLOT;
+              for (int kb = 0; kb < it.kvb;) {
+                const int run = DBG ? 0 : fast_run_len(st, (n >> 7) - kb);
+                if (run > 0) {
+                  fast_run(g, st, lv, smem, ring_lds, wave, run, [&](const char* slot, int i) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                      const int t = 32 * ((kb + i) * 4 + q) + grp;
+                      dec::accum_pv(__builtin_amdgcn_exp2f(sc[t] - m), *(const u32x4_t*)(slot + q * 1024 + lane * 16), l, o);
+                    }
+                  }, a.flags);
+                  kb += run;
+                  continue;
+                }
+                if (DBG) {
+                  if (cc.seg != 3 || cc.idx != j || cc.sub != it.kvb + kb) __hip_atomic_fetch_or(a.ctrl + 1, 0x113u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  cur_advance(g, cc);
+                }
+                ring_wait(st, a.flags);
+                const char* slot = smem + XL_RING + (wave * XR + st.cslot) * SLOT;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                   const int t = 32 * (kb * 4 + q) + grp;
                   dec::accum_pv(t < n ? __builtin_amdgcn_exp2f(sc[t] - m) : 0.f, *(const u32x4_t*)(slot + q * 1024 + lane * 16), l, o);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                ++st.consumed;
-                cur_advance(g, cc);
-                ring_issue(a, g, st, wave, lane, ring_lds);
+                st.consumed = XU(st.consumed + 1);
+                st.cslot = XU(st.cslot + 1 == XR ? 0 : st.cslot + 1);
+                ring_issue(a, g, st, lv, wave, lane, ring_lds);
+                ++kb;
               }
             } else {
               const bf16_t* vp = self + (long)b * a.S_max * 3 * a.d + 2 * a.d + h * 64 + l8 * 8;
@@ -616,22 +882,32 @@ __global__ __launch_bounds__(320) void decode_xcd_kernel(XArgs a) {
         const XGemv p = gemv_of(a, layer, ph);
         const int ntile = seg_cnt(g, p.seg);
         if (helper) {
-          team_wait(a.ctrl, target);
-          if (ntile > 0) helper_operand(a, g, p, smem, L, lane);
+          XSTAMP(0);
+          team_wait(a.ctrl, target, a.flags);
+          XSTAMP(1);
+          if (ntile > 0) helper_operand(a, g, p, smem, lane);
+          XSTAMP(2);
           XBAR();  // A: operand rows ready
-          for (int i = 0; i < ntile; ++i) {
-            const int n0 = (wg + a.team * i) * 32;
-            const XEpiIn in = helper_epilogue_inputs(a, p, n0, lane);
-            XBAR();  // B_i: the tile's four K-quarter accumulators are in red[i & 1]
-            helper_epilogue(a, p, in, smem, L, i & 1, n0, lane);
+          for (int i0 = 0; i0 < ntile; i0 += NRED) {  // groups of NRED tiles (stream_phase)
+            const int i1 = i0 + NRED < ntile ? i0 + NRED : ntile;
+            XEpiIn in[NRED];
+#pragma unroll
+            for (int k = 0; k < NRED; ++k)
+              if (i0 + k < i1) in[k] = helper_epilogue_inputs(a, p, (wg + a.team * (i0 + k)) * 32, lane);
+            XBAR();  // B: the group's accumulators are in the reduction buffers
+#pragma unroll
+            for (int k = 0; k < NRED; ++k)
+              if (i0 + k < i1) helper_epilogue(a, p, in[k], smem, k, (wg + a.team * (i0 + k)) * 32, lane);
+            if (i1 < ntile) XBAR();  // buffers free again
           }
+          XSTAMP(3);
           team_arrive(a.ctrl);
+          XSTAMP(4);
         } else {
           XBAR();  // A
-          for (int i = 0; i < ntile; ++i) {
-            stream_tile(a, g, st, cc, p, smem, L, ring_lds, wave, lane, i & 1, i);
-            XBAR();  // B_i
-          }
+          if (wave == 0) XSTAMP(5);
+          stream_phase<DBG>(a, g, st, cc, lv, p, smem, ring_lds, wave, lane, ntile);
+          if (wave == 0) XSTAMP(6);
         }
       }
     }
@@ -650,10 +926,8 @@ __global__ __launch_bounds__(320) void decode_xcd_kernel(XArgs a) {
 size_t decode_xcd_part_floats(int M, int H, int Te) { return (size_t)M * H * dec::n_segments(Te) * 66; }
 
 bool decode_xcd_supports(int d, int H, int Te, int S_max, int L, int M) {
-  unsigned total;
-  smem_layout(d, total);
-  return M >= 1 && M <= XMAXM && L >= 1 && L <= XMAXL && d % 64 == 0 && d == H * 64 && d <= 2048 && total <= 160 * 1024 && S_max <= dec::SEG_KEYS &&
-         Te <= dec::MAX_SEG * dec::SEG_KEYS && Te >= 1 && H * dec::n_segments(Te) * 66 <= 128 * XPART && 128 * XPART <= dec::SEG_KEYS + 32 * 64;
+  return M >= 1 && M <= XMAXM && L >= 1 && L <= XMAXL && d % 64 == 0 && d == H * 64 && d <= XMAXD && S_max <= dec::SEG_KEYS &&
+         Te <= dec::MAX_SEG * dec::SEG_KEYS && Te >= 1 && H * dec::n_segments(Te) <= XMAXPAIR;
 }
 
 // Debug / CPU test: the block sequence (seg, idx, sub) of workgroup `wg` as the kernel's cursors generate it
@@ -678,16 +952,22 @@ int launch_decode_xcd(const DecodeXcdArgs& h, hipStream_t s) {
   a.wflat = h.wflat, a.params = h.params, a.aux = h.aux, a.cache = h.cache, a.cache_lstride = h.cache_lstride;
   a.x = h.x, a.x2 = h.x2, a.x3 = h.x3, a.q = h.q, a.o = h.o, a.hg = h.hg, a.part = h.part, a.ctrl = h.ctrl;
   a.d = h.d, a.H = h.H, a.Te = h.Te, a.S_max = h.S_max, a.L = h.L, a.M = h.M, a.pos = h.pos, a.team = h.team, a.stride = h.stride;
+  a.flags = h.flags, a.stamps = (unsigned long long*)h.stamps;
   {
     const int64_t* o = h.layer_offsets;  // layer 0
     a.l0 = XLayer{o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], o[8], o[9], o[10], o[11], o[12], o[13], o[14], o[15], o[16], o[17]};
     a.lstride = h.lstride, a.astride = h.astride;
   }
-  unsigned lds;
-  smem_layout(h.d, lds);
+  const unsigned lds = XL_TOTAL;
   static LdsAttrOnce attr;
-  { const int rc_ = ensure_dynamic_lds(attr, (const void*)decode_xcd_kernel, (int)lds); if (rc_) return rc_; }
-  hipLaunchKernelGGL(decode_xcd_kernel, dim3(h.team * h.stride), dim3(320), lds, s, a);
+  static LdsAttrOnce attr_dbg;
+  if (h.flags & 8) {  // checked instantiation (tests)
+    { const int rc_ = ensure_dynamic_lds(attr_dbg, (const void*)decode_xcd_kernel<true>, (int)lds); if (rc_) return rc_; }
+    hipLaunchKernelGGL(decode_xcd_kernel<true>, dim3(h.team * h.stride), dim3(320), lds, s, a);
+  } else {
+    { const int rc_ = ensure_dynamic_lds(attr, (const void*)decode_xcd_kernel<false>, (int)lds); if (rc_) return rc_; }
+    hipLaunchKernelGGL(decode_xcd_kernel<false>, dim3(h.team * h.stride), dim3(320), lds, s, a);
+  }
   OASR_LAUNCH_CHECK();
   return OASR_OK;
 }

@@ -948,8 +948,8 @@ unsigned* kv_ctrl(const oasr_ctx* c, void* cache, int B) {  // 256 bytes behind 
   const size_t per_layer = ((size_t)3 * B * c->S_max * c->d + (size_t)B * c->Te * 2 * c->d) * (c->f32 ? 4 : 2);
   return (unsigned*)((char*)cache + per_layer * c->L_dec);
 }
-// A/B and test switch of the step engine: -1 = default (B <= 4 on the bf16 engine: the one-launch engine of decode_xcd.hip, team = the 32
-// CUs of one XCD; larger batches: separate kernels), 0 = separate LayerNorm kernels, 1 = LayerNorm folded into the projections' operand
+// A/B and test switch of the step engine: -1 = default (ONE sequence on the bf16 engine: the one-launch engine of decode_xcd.hip, team = the 32
+// CUs of one XCD; 2-4 sequences: LayerNorm folded into the projections; more: separate kernels), 0 = separate LayerNorm kernels, 1 = LayerNorm folded into the projections' operand
 // loads (the round-2/3 default for B <= 4) for every B <= 32, 2 = one launch on one XCD, 3 = one launch, 32 workgroups spread over the
 // chip, 4 = the same with 64.  All bit-identical (tests/test_gpu_decode_step.py).
 int g_decode_ln_fold = -1;
@@ -970,7 +970,7 @@ extern "C" size_t oasr_decode_step_workspace_bytes(const oasr_ctx* c, int B) {
   if (!c || B <= 0) return 0;
   // x, ln, q, o, x2 (5 * B*d) + u, hg (2 * B*4d) + logits (B*Vp) bf16 + stats
   return ((size_t)B * c->d * 6 + (size_t)B * 8 * c->d + (size_t)B * c->Vp + 9 * 32) * (c->f32 ? 4 : 2) + (size_t)B * c->H * 8 + (size_t)B * 16 + 8192 +
-         (B <= 4 ? decode_xcd_part_floats(B, c->H, c->Te) * 4 + 256 : 0);
+         (B <= 4 ? decode_xcd_part_floats(B, c->H, c->Te) * 4 + 256 + 512 : 0);
 }
 
 template <typename T>
@@ -1029,7 +1029,9 @@ static int oasr_decode_step_impl(oasr_ctx* c, const int64_t* tokens_last, int B,
     folded = d % 64 == 0 && d <= 2048 && g_decode_ln_fold != 0 && (B <= 4 || (g_decode_ln_fold == 1 && B <= 32));
     // one launch for the whole decoder stack (decode_xcd.hip): the default for a handful of sequences
     const int mode = g_decode_ln_fold;
-    if ((mode == -1 || mode >= 2) && !c->xcd_offsets.empty() && decode_xcd_supports(d, c->H, c->Te, S_max, c->L_dec, B)) {
+    // (default: ONE sequence -- the timestamp-mode transcribe loop; measured 1.99 vs 2.44 ms per token at medium, level at small, slower from
+    // B = 2 on where the multi-launch kernels spread over the whole chip: profiles/r05_decode_xcd_probe_v5.txt.  Modes 2-4 force it up to B = 4.)
+    if (((mode == -1 && B == 1) || mode >= 2) && !c->xcd_offsets.empty() && decode_xcd_supports(d, c->H, c->Te, S_max, c->L_dec, B)) {
       DecodeXcdArgs xa;
       xa.wflat = c->template Wt<bf16_t>(0);
       xa.params = c->params;
@@ -1042,6 +1044,14 @@ static int oasr_decode_step_impl(oasr_ctx* c, const int64_t* tokens_last, int B,
       xa.d = d, xa.H = c->H, xa.Te = c->Te, xa.S_max = S_max, xa.L = c->L_dec, xa.M = B, xa.pos = pos;
       xa.team = mode == 4 ? 64 : 32;
       xa.stride = (mode == 3 || mode == 4) ? 1 : 8;
+      {  // measurement hooks (scripts/decode_xcd_probe.py; inert without OASR_TESTING_HOOKS=1): experiment flags, in-kernel stamps in the workspace tail
+        static const int xflags = [] {
+          const char *h = getenv("OASR_TESTING_HOOKS"), *e = getenv("OASR_XCD_FLAGS");
+          return (h && h[0] == '1' && e) ? atoi(e) : 0;
+        }();
+        xa.flags = xflags & 0xff;
+        xa.stamps = (xflags & 0x100) ? (void*)((char*)workspace + workspace_bytes - 512) : nullptr;
+      }
       xa.layer_offsets = c->xcd_offsets.data();
       xa.lstride = c->xcd_lstride, xa.astride = c->xcd_astride;
       RC(launch_decode_xcd(xa, st));

@@ -164,6 +164,8 @@ struct DecodeXcdArgs {
   float* part;          // decode_xcd_part_floats() floats
   unsigned* ctrl;       // 4 words, zeroed once per cache (oasr_decode_begin): barrier counter, error flag, epoch base, XCC mask
   int d, H, Te, S_max, L, M, pos;
+  int flags;            // experiments (decode_xcd.hip::XArgs::flags), 0 in production
+  void* stamps;         // optional 512-byte device buffer for in-kernel cycle stamps (measurement), or null
   int team, stride;     // `team` workgroups; stride 8 = one per CU of ONE XCD (grid 8 x team, blockIdx % 8 == 0), 1 = spread over the chip
   const int64_t* layer_offsets;   // HOST: [18] element offsets of decoder layer 0 in decode_xcd.hip::XLayer order
   long lstride, astride;          // layer l = layer 0 + l * lstride (arena / shadow elements), + l * astride for the aux entry

@@ -50,6 +50,15 @@ def main():
         same = "" if ref is None else f"  logits == mode {modes[0]}: {bool(torch.equal(ref, last))} (max |d| {float((ref - last).abs().max()):.3g})"
         if ref is None:
             ref = last.clone()
+        if mode >= 2 and (int(os.environ.get("OASR_XCD_FLAGS", "0")) & 0x100):
+            t = st["ws"][-512:].view(torch.int64).view(8, 8).cpu().tolist()
+            names = ["qkv", "self-attn", "attn.out", "cross q", "cross-attn", "cross out", "mlp.0", "mlp.2"]
+            print("   in-kernel s_memtime stamps, workgroup 0, decoder layer 1 (ticks; helper: wait | operand | tiles+epilogue | arrive ; streaming wave 0: released->done):")
+            for p_, r in enumerate(t):
+                nxt = t[p_ + 1][0] if p_ < 7 else None
+                print(f"     {names[p_]:10s} wait {r[1] - r[0]:6d}  operand {r[2] - r[1]:6d}  tiles {r[3] - r[2]:6d}  arrive {r[4] - r[3]:6d}  | stream {r[6] - r[5] if r[6] and r[5] else 0:6d}"
+                      f"  | phase total {(nxt - r[0]) if nxt else r[4] - r[0]:6d}")
+            print(f"     layer total {t[7][4] - t[0][0]} ticks")
         print(f"{variant} B={B} pos={pos} mode {mode} [{NAMES[mode]}]: {ms:.3f} ms/step = {dbytes / ms / 1e6:.0f} GB/s = {dbytes / ms / 1e6 / 8000:.3f} of 8 TB/s; "
               f"ctrl (counter, flag, epoch, xcc mask) = {ctrl[0]} {ctrl[1]:#x} {ctrl[2]} {ctrl[3]:#x}{same}", flush=True)
     N.lib().oasr_decode_set_ln_fold(-1)

@@ -7,13 +7,13 @@
 #   4. rocprofv3 --pmc GRBM_GUI_ACTIVE         -> effective shader clock per kernel under the step's load (scripts/pmc_clock.py)
 # Counter passes never carry --kernel-trace/--stats-unrelated trace domains (gpurun refuses pmc + sys/hip/hsa tracing).
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
-BENCH="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile"
-BENCH1="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile"
+BENCH="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --ab-steps 0"
+BENCH1="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --ab-steps 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
 f=$(find $OUT/trace -name "*kernel_trace.csv" | head -1)
 [ -n "$f" ] && python scripts/rocprof_summary.py "$f" > $OUT/${TAG}_bench_default_kernel_stats.txt
