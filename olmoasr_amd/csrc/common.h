@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 typedef uint16_t bf16_t;  // raw bf16 bits; all arithmetic goes through float
@@ -40,6 +41,14 @@ void oasr_set_error(const char* fmt, ...);
   } while (0)
 
 #define OASR_LAUNCH_CHECK() OASR_CHECK_HIP(hipGetLastError())
+
+// Experiment / A-B switches read from the environment (OASR_PP_*, OASR_GEMM_*, OASR_LOGMEL, OASR_PROF_SHAPES, OASR_XCD_FLAGS) are part of the
+// measurement tooling, not of the product: like the setters of include/oasr_testing.h they are INERT unless the process opted in with
+// OASR_TESTING_HOOKS=1 (scripts/ and tests/ do), so a production process cannot be steered through its environment.
+static inline const char* oasr_experiment_env(const char* name) {
+  const char* h = getenv("OASR_TESTING_HOOKS");
+  return (h && h[0] == '1') ? getenv(name) : nullptr;
+}
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel: a process that touches a second GPU must set
 // it there too.  One of these per launch site (a function-local static); setting it again is harmless, so two host threads racing on

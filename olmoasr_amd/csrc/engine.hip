@@ -1046,8 +1046,8 @@ static int oasr_decode_step_impl(oasr_ctx* c, const int64_t* tokens_last, int B,
       xa.stride = (mode == 3 || mode == 4) ? 1 : 8;
       {  // measurement hooks (scripts/decode_xcd_probe.py; inert without OASR_TESTING_HOOKS=1): experiment flags, in-kernel stamps in the workspace tail
         static const int xflags = [] {
-          const char *h = getenv("OASR_TESTING_HOOKS"), *e = getenv("OASR_XCD_FLAGS");
-          return (h && h[0] == '1' && e) ? atoi(e) : 0;
+          const char* e = oasr_experiment_env("OASR_XCD_FLAGS");
+          return e ? atoi(e) : 0;
         }();
         xa.flags = xflags & 0xff;
         xa.stamps = (xflags & 0x100) ? (void*)((char*)workspace + workspace_bytes - 512) : nullptr;

@@ -1281,7 +1281,7 @@ int launch_pp_variant(const GemmArgs& a, hipStream_t stream) {
     return n >= 8 ? n : 8;
   }();
   static const int env_persist = [] {
-    const char* e = getenv("OASR_PP_PERSISTENT");
+    const char* e = oasr_experiment_env("OASR_PP_PERSISTENT");
     return e ? atoi(e) : -1;
   }();
   GemmArgs pa = a;
@@ -1289,7 +1289,7 @@ int launch_pp_variant(const GemmArgs& a, hipStream_t stream) {
   // (experiment: OASR_PP_PERSIST_GELU=1 launches only the GELU-epilogue shapes persistent -- mlp.0 forward and the dgrad through GELU',
   // whose 12.7 k-cycle epilogues are the largest fixed cost per tile, profiles/r03_gemm_tile_stamps.txt)
   static const int env_persist_gelu = [] {
-    const char* e = getenv("OASR_PP_PERSIST_GELU");
+    const char* e = oasr_experiment_env("OASR_PP_PERSIST_GELU");
     return e ? atoi(e) : 0;
   }();
   int want = g_pp_persistent >= 0 ? g_pp_persistent : env_persist;
@@ -1329,7 +1329,7 @@ int launch_pp_cfg(const GemmArgs& a, hipStream_t stream) {
   // whose B fragments come through ds_read_b64_tr_b16.  The fused-colsum dgrad keeps four pinned 8-MFMA sections (2), which won
   // the whole-step A/B for it.  (NT at K = 4096 is 2 % faster on 2; not worth a second instantiation per layout.)
   static const int env_var = [] {
-    const char* e = getenv("OASR_PP_VARIANT");  // experiments: force one variant for a whole process
+    const char* e = oasr_experiment_env("OASR_PP_VARIANT");  // experiments: force one variant for a whole process
     return e ? atoi(e) : -1;
   }();
   const int forced = g_pp_dma_in_mma >= 0 ? g_pp_dma_in_mma : env_var;
@@ -1384,7 +1384,7 @@ int launch_fast_t(const GemmArgs& a, hipStream_t stream) {
   // problem has under half a wave of 256x256 tiles; split-K / atomic outputs (wgrad) -> 256x128 with 3 workgroups per
   // CU, whose co-resident workgroups hide the atomic epilogues.  OASR_GEMM_GEOM=1|2|3 overrides (experiments).
   static const int env_geom = [] {
-    const char* e = getenv("OASR_GEMM_GEOM");
+    const char* e = oasr_experiment_env("OASR_GEMM_GEOM");
     return e ? atoi(e) : 0;
   }();
   const int geom = g_fast_geometry ? g_fast_geometry : env_geom;
@@ -1495,7 +1495,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   OASR_REQUIRE(a.out || a.out_f32 || a.out_pre, "gemm: no output");
   OASR_REQUIRE(!a.colsum || (a.out && (a.N % 8) == 0 && a.split_k == 1), "gemm: colsum needs a bf16 `out`, N % 8 == 0, split_k == 1");
   static const int env_gm = [] {
-    const char* e = getenv("OASR_GEMM_GM");
+    const char* e = oasr_experiment_env("OASR_GEMM_GM");
     return e ? atoi(e) : 0;
   }();
   if (a.raster_gm == 0 && env_gm > 0) {
@@ -1552,7 +1552,7 @@ int gemm_profile_collect(double ms[4], double flops[4], long count[4], char* by_
     ms[k] += t;
     flops[k] += g_prof.recs[i].flops;
     count[k] += 1;
-    static const bool by_shape = getenv("OASR_PROF_SHAPES") != nullptr;  // experiments: one line per (symbol, shape, epilogue)
+    static const bool by_shape = oasr_experiment_env("OASR_PROF_SHAPES") != nullptr;  // experiments: one line per (symbol, shape, epilogue)
     std::string key = g_prof.recs[i].name;
     if (by_shape) {
       char sfx[96];

@@ -616,7 +616,7 @@ static int log_mel_impl(const void* pcm, int pcm_dtype, int B, int n_samples, fl
   unsigned* clipmax = (unsigned*)workspace;
   OASR_CHECK_HIP(hipMemsetAsync(clipmax, 0, sizeof(unsigned) * B, stream));
   static const bool use_mfma_dft = [] {
-    const char* e = getenv("OASR_LOGMEL");  // "mfma": the dense folded DFT on the fp32 matrix pipe (round 1-2 kernel; A/B and cross-check)
+    const char* e = oasr_experiment_env("OASR_LOGMEL");  // "mfma": the dense folded DFT on the fp32 matrix pipe (round 1-2 kernel; A/B and cross-check)
     return e && strcmp(e, "mfma") == 0;
   }();
   const long per_clip = (long)NMEL * n_frames;

@@ -1,4 +1,5 @@
 # same-box A/B of the whole step under forced ping-pong GEMM variants (OASR_PP_VARIANT)
+export OASR_TESTING_HOOKS=1  # the OASR_PP_* switches are inert without it (csrc/common.h::oasr_experiment_env)
 for v in 0 2 7 -1 0 -1; do
   if [ "$v" = "-1" ]; then unset OASR_PP_VARIANT; else export OASR_PP_VARIANT=$v; fi
   python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
