@@ -169,8 +169,13 @@ __device__ __forceinline__ void dma16(const u32x4_t rs_in, unsigned lds_addr, un
                : "memory");
 }
 // (descriptor already in SGPRs)
-__device__ __forceinline__ void dma16_s(const u32x4_t rs, unsigned lds_addr, unsigned voff, unsigned soff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
+__device__ __forceinline__ void dma16_s(const u32x4_t rs_in, unsigned lds_addr, unsigned voff, unsigned soff) {
+  u32x4_t rs;
+  rs[0] = __builtin_amdgcn_readfirstlane(rs_in[0]), rs[1] = __builtin_amdgcn_readfirstlane(rs_in[1]);
+  rs[2] = 0x7fffffffu, rs[3] = 0x00020000u;
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(voff), "s"(rs),
+               "s"(__builtin_amdgcn_readfirstlane(soff))
+               : "memory");
 }
 __device__ __forceinline__ u32x4_t rsrc_of(const void* base) {
   const unsigned long addr = (unsigned long)base;
@@ -184,136 +189,139 @@ __device__ __forceinline__ u32x4_t rsrc_of(const void* base) {
 #define XWAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 #define XBAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+// ---- the producer: a table of UNITS per wave ------------------------------------------------------------------------------------------
+// A unit = a run of ring blocks that share one descriptor and one set of per-lane offsets: all tiles of one projection segment that belong
+// to this workgroup (consecutive tiles lie a constant distance apart), the full blocks of one item's K (or V) stream, or the one clamped
+// block that ends a stream.  The units of decoder layer 0 are listed ONCE per launch by walking the cursor (the CPU-tested sequence) and
+// kept in a wave-private LDS table; layer l adds l x (layer stride) to the soffset.  Issuing a block is then: 4 DMA instructions, three
+// scalar updates, and -- at a unit's end -- one 16-byte LDS read.  (Versions 1-5 advanced the cursor per block: ~2 k cycles of single-wave
+// instruction issue at every unit boundary, profiles/r05_decode_xcd_stamps_v5.txt.)
+constexpr int XTABN = 32;  // units per layer and wave (6 projection segments + 4 per cross-attention item, <= 5 items)
 struct XStream {  // per streaming wave (all fields wave-uniform, SGPR-resident)
-  XCur pc;        // producer cursor: next block to issue
   bool more;      // the producer has blocks left
   int issued, consumed;
   int islot, cslot;  // issued % XR, consumed % XR, kept incrementally
-  // the producer's current UNIT (one tile's K quarter, or one item's K or V stream): descriptor, next block's soffset and how many more
-  // FULL blocks follow with the same descriptor / lane offsets -- the per-block fast path touches nothing else
-  u32x4_t rs;
-  unsigned soff, step;
-  int left, kind;  // kind: lane-offset set 0 = weights K = d, 1 = weights K = 4d, 2 = cross K/V
-  // a weight unit spans ALL remaining tiles of this workgroup in the segment (same matrix, constant distance between its tiles):
-  int tleft, tnkb;  // blocks left in the tile being issued (incl. the next one), blocks per tile
-  unsigned jump;    // soffset step from a tile's last block to the next tile's first
+  int u, nunits, layer;  // current unit, units per layer, layer of the block to issue next
+  unsigned soff, jump;   // soffset of the next block; step from a tile's last block to this workgroup's next tile (weights)
+  int left, kind;        // blocks left in the unit; lane-offset set: 0 weights K = d, 1 weights K = 4d, 2 cross K/V, 3 cross K/V last (clamped) block
+  int tleft, tnkb;       // blocks left in the tile being issued (incl. the next one), blocks per tile
 };
-// per-lane byte offsets that do not depend on the block (computed once per wave): the DMA source offsets of a FULL weight block for
-// K = d / K = 4d and of an unclamped K/V block (4 instructions each), and the LDS fragment offsets of the 4 k16 steps of a weight block
+// per-lane byte offsets that do not depend on the block (computed once per wave): the DMA source offsets of a weight block for K = d / K = 4d,
+// of a K/V block, of the clamped last K/V block of the partial key segment, and the LDS fragment offsets of the 4 k16 steps of a weight block
 struct XLane {
-  unsigned w_d[4], w_4d[4], kv[4], frag[4];
+  unsigned w_d[4], w_4d[4], kv[4], kvc[4], frag[4];
 };
-__device__ __forceinline__ XLane make_lane(int d, int wave, int lane) {
+__device__ __forceinline__ XLane make_lane(int d, int Te, int wave, int lane) {
   XLane v;
   const int r8 = lane >> 3, l8 = lane & 7, row = lane & 31, kc = lane >> 5;
+  const int n_p = Te - (Te > dec::SEG_KEYS ? dec::SEG_KEYS : 0);  // keys of the last (possibly partial) segment
+  const int last = n_p - 1 - 128 * ((n_p - 1) >> 7);              // last valid key of its last block, relative to that block
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int c16 = l8 ^ ((q * 4 + (r8 >> 1)) & 7);
     v.w_d[q] = (unsigned)(((q * 8 + r8) * d + c16 * 8) * 2);
     v.w_4d[q] = (unsigned)(((q * 8 + r8) * 4 * d + c16 * 8) * 2);
-    v.kv[q] = (unsigned)(((32 * q + 8 * wave + r8) * 2 * d + l8 * 8) * 2);
+    const int t = 32 * q + 8 * wave + r8;
+    v.kv[q] = (unsigned)((t * 2 * d + l8 * 8) * 2);
+    v.kvc[q] = (unsigned)(((t < last ? t : last) * 2 * d + l8 * 8) * 2);  // keys past the segment's end re-read its last key (never used)
     v.frag[q] = (unsigned)(row * 128 + (((2 * q + kc) ^ ((row >> 1) & 7)) << 4));
   }
   return v;
 }
 
-// Producer set-up at the cursor (SLOW path, once per unit and once per partial / clamped block): descriptor, soffset of the block at
-// the cursor, and the number of FULL blocks from the cursor on that share them.
-__device__ __forceinline__ void ring_setup(const XArgs& a, const XGeom& g, XStream& st, int wave) {
-  const XCur c = XCur{XU(st.pc.layer), XU(st.pc.seg), XU(st.pc.idx), XU(st.pc.sub)};
-  if (c.seg == 3) {
-    const XItem it = item_of(g, c.idx);
-    const bool is_v = c.sub >= it.kvb;
-    const int j = is_v ? c.sub - it.kvb : c.sub;  // block within the K (or V) stream: 4 passes of 32 keys
-    const bf16_t* ckv = a.cache + (long)c.layer * a.cache_lstride + (long)3 * a.M * a.S_max * a.d;
-    st.rs = rsrc_of(ckv);
-    st.soff = XU((unsigned)((((long)it.b * a.Te + (long)it.sg * dec::SEG_KEYS + 128 * j) * 2 * a.d + it.h * 64 + (is_v ? a.d : 0)) * 2));
-    st.step = XU((unsigned)(128 * 2 * a.d * 2));
-    const int nfull = it.n >> 7;  // blocks whose 128 keys all lie inside the segment
-    st.left = XU(nfull > j ? nfull - j : 0);
-    st.kind = 2;
-    st.tleft = 0x40000000, st.tnkb = 0x40000000, st.jump = st.step;
-  } else {
-    const long woff = (c.seg == 0 ? a.l0.wqkv : c.seg == 1 ? a.l0.wo : c.seg == 2 ? a.l0.wcq : c.seg == 4 ? a.l0.wco : c.seg == 5 ? a.l0.w1 : a.l0.w2) +
-                      (long)c.layer * a.lstride;
-    const int K = c.seg == 6 ? 4 * a.d : a.d;
-    const int tile = g.wg + g.team * c.idx;
-    st.rs = rsrc_of(a.wflat + woff);
-    st.soff = XU((unsigned)((((long)tile * 32) * K + (long)wave * (K >> 2) + c.sub * 64) * 2));
-    st.step = 128u;
-    const int nst = c.seg == 6 ? g.nst_4d : g.nst_d, nkb = c.seg == 6 ? g.nkb_4d : g.nkb_d;
-    st.kind = c.seg == 6 ? 1 : 0;
-    if ((nst & 3) == 0) {  // every block of every tile is full: one unit up to the end of the segment
-      st.left = XU((seg_cnt(g, c.seg) - c.idx) * nkb - c.sub);
-      st.tleft = XU(nkb - c.sub), st.tnkb = nkb;
-      st.jump = XU((unsigned)((long)g.team * 32 * K * 2 - (long)(nkb - 1) * 128));
+// List the units of decoder layer 0 for this wave into its LDS table (4 words each: soffset, blocks, kind | blocks per tile << 8, tile jump);
+// returns their number.  Runs once per launch; walks the same cursor functions the CPU test pins.
+__device__ __forceinline__ int build_units(const XArgs& a, const XGeom& g, int wave, int lane, unsigned* tab) {
+  XCur c{0, 0, 0, 0};
+  bool more = cur_normalise(g, c);
+  int n = 0;
+  while (more && c.layer == 0 && n < XTABN) {
+    unsigned soff, jump = 0;
+    int nblk, kind, tnkb = 0x400000;
+    if (c.seg == 3) {
+      const XItem it = item_of(g, c.idx);
+      const bool is_v = c.sub >= it.kvb;
+      const int j = is_v ? c.sub - it.kvb : c.sub;
+      soff = (unsigned)((((long)it.b * a.Te + (long)it.sg * dec::SEG_KEYS + 128 * j) * 2 * a.d + it.h * 64 + (is_v ? a.d : 0)) * 2);
+      const int nfull = it.n >> 7;
+      if (nfull > j) nblk = nfull - j, kind = 2;
+      else nblk = 1, kind = 3;
+      c.sub += nblk;
+      more = cur_advance_from(g, c);
     } else {
-      const int nfull = nst >> 2;
-      st.left = XU(nfull > c.sub ? nfull - c.sub : 0);
-      st.tleft = 0x40000000, st.tnkb = 0x40000000, st.jump = 128u;
+      const long woff = c.seg == 0 ? a.l0.wqkv : c.seg == 1 ? a.l0.wo : c.seg == 2 ? a.l0.wcq : c.seg == 4 ? a.l0.wco : c.seg == 5 ? a.l0.w1 : a.l0.w2;
+      const int K = c.seg == 6 ? 4 * a.d : a.d, nkb = c.seg == 6 ? g.nkb_4d : g.nkb_d;
+      const int tile = g.wg + g.team * c.idx;
+      soff = (unsigned)((unsigned long)((woff + ((long)tile * 32) * K + (long)wave * (K >> 2)) * 2));  // relative to the arena's bf16 shadow
+      nblk = (seg_cnt(g, c.seg) - c.idx) * nkb, kind = c.seg == 6 ? 1 : 0, tnkb = nkb;
+      jump = (unsigned)((long)g.team * 32 * K * 2 - (long)(nkb - 1) * 128);
+      c.idx = seg_cnt(g, c.seg), c.sub = 0;
+      more = cur_normalise(g, c);
     }
+    if (lane == 0) {
+      tab[4 * n] = soff, tab[4 * n + 1] = (unsigned)nblk, tab[4 * n + 2] = (unsigned)kind | ((unsigned)tnkb << 8), tab[4 * n + 3] = jump;
+    }
+    ++n;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (read back by this wave only)
+  return XU(n);
+}
+// load unit st.u of layer st.layer into the producer state
+__device__ __forceinline__ void unit_load(const XArgs& a, XStream& st, const unsigned* tab) {
+  const u32x4_t e = *(const u32x4_t*)(tab + 4 * st.u);
+  const int kind = XU(e[2] & 0xffu);
+  const long stride = kind >= 2 ? a.cache_lstride : a.lstride;
+  st.soff = XU(e[0] + (unsigned)((long)st.layer * stride * 2));
+  st.left = XU(e[1]);
+  st.kind = kind;
+  st.tnkb = XU(e[2] >> 8);
+  st.tleft = st.tnkb;
+  st.jump = XU(e[3]);
+}
+// after a block has been issued: next block of the unit, next tile, or next unit / layer
+__device__ __forceinline__ void unit_advance(const XArgs& a, XStream& st, const unsigned* tab) {
+  st.left = XU(st.left - 1);
+  if (st.left == 0) {
+    st.u = XU(st.u + 1);
+    if (st.u == st.nunits) st.u = 0, st.layer = XU(st.layer + 1);
+    if (st.layer == a.L) st.more = false;
+    else unit_load(a, st, tab);
+  } else if (st.tleft == 1) {
+    st.soff = XU(st.soff + st.jump), st.tleft = st.tnkb;  // the tile's last block: on to this workgroup's next tile of the segment
+  } else {
+    st.soff = XU(st.soff + (st.kind >= 2 ? (unsigned)(128 * 2 * a.d * 2) : 128u)), st.tleft = XU(st.tleft - 1);
   }
 }
-// issue the block the producer cursor points at into ring slot islot, then advance the cursor.  Fast path (a full block inside the
-// current unit): 4 DMA instructions with precomputed lane offsets + a handful of scalar updates.
-__device__ __forceinline__ void ring_issue(const XArgs& a, const XGeom& g, XStream& st, const XLane& lv, int wave, int lane, unsigned ring_lds) {
-  if (!st.more) return;
-  const unsigned dst = ring_lds + (unsigned)st.islot * SLOT;
-  if (st.left == 0) ring_setup(a, g, st, wave);
-  if (a.flags & 32) {  // (experiment: book-keeping only, no DMA)
-    if (st.left > 0) {
-      st.left = XU(st.left - 1);
-      if (st.tleft == 1) st.soff = XU(st.soff + st.jump), st.tleft = XU(st.tnkb), st.pc.idx = XU(st.pc.idx + 1), st.pc.sub = -1;
-      else st.soff = XU(st.soff + st.step), st.tleft = XU(st.tleft - 1);
-    }
-  } else if (st.left > 0) {
-    if (st.kind == 0) {
+// the four DMA instructions of one block
+__device__ __forceinline__ void issue_block(const XStream& st, const XLane& lv, const u32x4_t rs_w, const u32x4_t rs_kv, unsigned dst) {
+  const int kind = XU(st.kind);
+  const unsigned soff = XU(st.soff);
+  if (kind == 0) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) dma16(st.rs, dst + q * 1024, lv.w_d[q], st.soff);
-    } else if (st.kind == 1) {
+    for (int q = 0; q < 4; ++q) dma16_s(rs_w, dst + q * 1024, lv.w_d[q], soff);
+  } else if (kind == 1) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) dma16(st.rs, dst + q * 1024, lv.w_4d[q], st.soff);
-    } else {
+    for (int q = 0; q < 4; ++q) dma16_s(rs_w, dst + q * 1024, lv.w_4d[q], soff);
+  } else if (kind == 2) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) dma16(st.rs, dst + q * 1024, lv.kv[q], st.soff);
-    }
-    st.left = XU(st.left - 1);
-    if (st.tleft == 1) {  // the tile's last block: on to this workgroup's next tile of the segment
-      st.soff = XU(st.soff + st.jump), st.tleft = XU(st.tnkb);
-      st.pc.idx = XU(st.pc.idx + 1), st.pc.sub = -1;
-    } else {
-      st.soff = XU(st.soff + st.step), st.tleft = XU(st.tleft - 1);
-    }
-  } else {  // a unit's last, partial (weights) or clamped (K/V) block: lanes past the end re-read the last valid piece (never used)
-    const int r8 = lane >> 3, l8 = lane & 7;
-    if (st.kind == 2) {
-      const XItem it = item_of(g, XU(st.pc.idx));
-      const int sub = XU(st.pc.sub);
-      const int last = it.n - 1 - 128 * (sub >= it.kvb ? sub - it.kvb : sub);
+    for (int q = 0; q < 4; ++q) dma16_s(rs_kv, dst + q * 1024, lv.kv[q], soff);
+  } else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        int t = 32 * q + 8 * wave + r8;
-        t = t < last ? t : last;
-        dma16(st.rs, dst + q * 1024, (unsigned)(((long)t * 2 * a.d + l8 * 8) * 2), st.soff);
-      }
-    } else {
-      const int K = st.kind == 1 ? 4 * a.d : a.d;
-      const int steps = (st.kind == 1 ? g.nst_4d : g.nst_d) - XU(st.pc.sub) * 4;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        int c16 = l8 ^ ((q * 4 + (r8 >> 1)) & 7);
-        c16 = c16 < 2 * steps ? c16 : 2 * steps - 1;
-        dma16(st.rs, dst + q * 1024, (unsigned)(((long)(q * 8 + r8) * K + c16 * 8) * 2), st.soff);
-      }
-    }
+    for (int q = 0; q < 4; ++q) dma16_s(rs_kv, dst + q * 1024, lv.kvc[q], soff);
   }
+}
+struct XProd {  // launch constants of the producer
+  u32x4_t rs_w, rs_kv;  // descriptors: the bf16 shadow of the parameter arena; layer 0's cross K/V
+  const unsigned* tab;  // this wave's unit table (LDS)
+  unsigned ring_lds;    // LDS byte address of this wave's ring
+};
+// issue the next block into ring slot islot and advance
+__device__ __forceinline__ void ring_issue(const XArgs& a, XStream& st, const XLane& lv, const XProd& pr) {
+  if (!st.more) return;
+  if (!(a.flags & 32)) issue_block(st, lv, pr.rs_w, pr.rs_kv, pr.ring_lds + (unsigned)st.islot * SLOT);
   st.issued = XU(st.issued + 1);
   st.islot = XU(st.islot + 1 == XR ? 0 : st.islot + 1);
-  if (st.left > 0) {
-    st.pc.sub = XU(st.pc.sub + 1);  // still inside the unit: nothing else changes
-  } else {
-    st.more = XU((int)cur_advance(g, st.pc)) != 0;  // unit (or its full part) done: the next call sets up again
-  }
+  unit_advance(a, st, pr.tab);
 }
 // block `consumed` has landed: at most (issued - consumed - 1) younger blocks may still be in flight (loads return in order)
 __device__ __forceinline__ void ring_wait(const XStream& st, int flags = 0) {
@@ -356,7 +364,8 @@ constexpr unsigned XL_ARED = XL_SC + dec::SEG_KEYS * 4;  // (sc | ared contiguou
 constexpr unsigned XL_LSUM = XL_ARED + 32 * 64 * 4;
 constexpr unsigned XL_WMAX = XL_LSUM + 32 * 4;
 constexpr unsigned XL_AOUT = XL_WMAX + 4 * 4;
-constexpr unsigned XL_TOTAL = (XL_AOUT + 66 * 4 + 8 + 15) & ~15u;
+constexpr unsigned XL_TAB = (XL_AOUT + 66 * 4 + 8 + 15) & ~15u;  // 4 waves x XTABN units x 16 bytes
+constexpr unsigned XL_TOTAL = XL_TAB + 4 * XTABN * 16;
 static_assert(XL_TOTAL <= 160 * 1024, "one-launch decode step: LDS budget");
 
 struct XGemv {  // one projection phase
@@ -494,53 +503,29 @@ __device__ __forceinline__ void helper_epilogue(const XArgs& a, const XGemv& ph,
 // slot, four DMA instructions, a handful of scalar updates -- no cursor arithmetic (the general path costs ~1.7 k cycles of
 // instruction issue per block, profiles/r05_decode_xcd_stamps_v3_instruction_bound.txt).
 __device__ __forceinline__ int fast_run_len(const XStream& st, int consumer_full_left) {
-  int run = consumer_full_left < st.left ? consumer_full_left : st.left;
-  return (run > 0 && st.more && st.issued - st.consumed == XR) ? run : 0;
+  return (consumer_full_left > 0 && st.more && st.issued - st.consumed == XR) ? consumer_full_left : 0;
 }
 template <typename F>
-__device__ __forceinline__ void fast_run(const XGeom& g, XStream& st, const XLane& lv, char* smem, unsigned ring_lds, int wave, int run, F&& body,
-                                         int flags = 0) {
-  unsigned vo[4];
-  const int kind = XU(st.kind);
-  if (kind == 0) {  // (three branches, not a select: hipcc turns the select into an indexed read of `lv` in scratch memory)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) vo[q] = lv.w_d[q];
-  } else if (kind == 1) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) vo[q] = lv.w_4d[q];
-  } else {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) vo[q] = lv.kv[q];
-  }
-  u32x4_t rs;
-  rs[0] = XU(st.rs[0]), rs[1] = XU(st.rs[1]), rs[2] = 0x7fffffffu, rs[3] = 0x00020000u;
-  unsigned soff = XU(st.soff);
-  const unsigned step = XU(st.step), jump = XU(st.jump);
-  const int tnkb = XU(st.tnkb);
-  int slot_i = XU(st.cslot), tleft = XU(st.tleft), sub = XU(st.pc.sub), idx_inc = 0;
-  for (int i = 0; i < run; ++i) {
-    if (!(flags & 16)) XWAIT_VM(20);  // 4 * (XR - 1): the oldest block in flight has landed
-    body(smem + XL_RING + (wave * XR + slot_i) * SLOT, i);
+__device__ __forceinline__ void fast_run(const XArgs& a, XStream& st, const XLane& lv, const XProd& pr, char* smem, int wave, int run, F&& body) {
+  int i = 0;
+  for (; i < run && st.more; ++i) {
+    if (!(a.flags & 16)) XWAIT_VM(20);  // 4 * (XR - 1): the oldest block in flight has landed
+    body(smem + XL_RING + (wave * XR + st.cslot) * SLOT, i);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the body's reads of the slot have retired: it may be re-staged
-    const unsigned slot_lds = ring_lds + (unsigned)slot_i * SLOT;
-    if (!(flags & 32)) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) dma16_s(rs, slot_lds + q * 1024, vo[q], soff);
-    }
-    if (tleft == 1) {  // the tile's last block: on to this workgroup's next tile of the segment
-      soff += jump, tleft = tnkb, sub = 0, ++idx_inc;
-    } else {
-      soff += step, --tleft, ++sub;
-    }
-    slot_i = slot_i + 1 == XR ? 0 : slot_i + 1;
+    if (!(a.flags & 32)) issue_block(st, lv, pr.rs_w, pr.rs_kv, pr.ring_lds + (unsigned)st.cslot * SLOT);  // (steady state: islot == cslot)
+    st.cslot = XU(st.cslot + 1 == XR ? 0 : st.cslot + 1);
+    unit_advance(a, st, pr.tab);
   }
-  st.soff = soff;
-  st.tleft = tleft;
-  st.left = XU(st.left - run);
-  st.pc.sub = XU(sub), st.pc.idx = XU(st.pc.idx + idx_inc);
-  st.issued = XU(st.issued + run), st.consumed = XU(st.consumed + run);
-  st.cslot = st.islot = slot_i;
-  if (st.left == 0) st.more = XU((int)cur_advance_from(g, st.pc)) != 0;  // the unit's full part is done: the next issue sets up again
+  st.islot = st.cslot;
+  st.issued = XU(st.issued + i), st.consumed = XU(st.consumed + i);
+  // the producer ran dry inside the run (the step's last blocks): the rest of the run is consumed without issuing
+  for (; i < run; ++i) {
+    ring_wait(st, a.flags);
+    body(smem + XL_RING + (wave * XR + st.cslot) * SLOT, i);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    st.consumed = XU(st.consumed + 1);
+    st.cslot = XU(st.cslot + 1 == XR ? 0 : st.cslot + 1);
+  }
 }
 
 // streaming waves: the tiles of one projection phase, back to back.  A tile = this wave's K quarter of 32 weight rows against the operand
@@ -548,8 +533,8 @@ __device__ __forceinline__ void fast_run(const XGeom& g, XStream& st, const XLan
 // (every phase of every model up to d = 1024 is one group), not once per tile.
 constexpr int NRED = 4;
 template <bool DBG>
-__device__ __forceinline__ void stream_phase(const XArgs& a, const XGeom& g, XStream& st, XCur& cc, const XLane& lv, const XGemv& ph, char* smem,
-                                             unsigned ring_lds, int wave, int lane, int ntile) {
+__device__ __forceinline__ void stream_phase(const XArgs& a, const XGeom& g, XStream& st, XCur& cc, const XLane& lv, const XProd& pr, const XGemv& ph,
+                                             char* smem, int wave, int lane, int ntile) {
   const int nst = ph.seg == 6 ? g.nst_4d : g.nst_d, nkb = ph.seg == 6 ? g.nkb_4d : g.nkb_d;
   const bool allfull = (nst & 3) == 0;
   const int row = lane & 31, kc = lane >> 5;
@@ -576,7 +561,7 @@ __device__ __forceinline__ void stream_phase(const XArgs& a, const XGeom& g, XSt
     const int cfull = allfull ? (gend - tile) * nkb - kb : (nst >> 2) - kb;  // full blocks ahead of the consumer before anything special
     const int run = DBG ? 0 : fast_run_len(st, cfull);
     if (run > 0) {
-      fast_run(g, st, lv, smem, ring_lds, wave, run, [&](const char* slot, int) {
+      fast_run(a, st, lv, pr, smem, wave, run, [&](const char* slot, int) {
         bf16x8_t wf[4], xf[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -588,7 +573,7 @@ __device__ __forceinline__ void stream_phase(const XArgs& a, const XGeom& g, XSt
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[q], xf[q], acc, 0, 0, 0);
         if (++kb == nkb) tile_done();
-      }, a.flags);
+      });
     } else {
       if (DBG) {
         if (cc.seg != ph.seg || cc.idx != tile || cc.sub != kb) __hip_atomic_fetch_or(a.ctrl + 1, 0x100u | (unsigned)ph.seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -606,7 +591,7 @@ __device__ __forceinline__ void stream_phase(const XArgs& a, const XGeom& g, XSt
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slot's reads have retired before it is re-staged
       st.consumed = XU(st.consumed + 1);
       st.cslot = XU(st.cslot + 1 == XR ? 0 : st.cslot + 1);
-      ring_issue(a, g, st, lv, wave, lane, ring_lds);
+      ring_issue(a, st, lv, pr);
       if (++kb == nkb) tile_done();
     }
     if (kb == 0 && (tile == ntile || (tile & (NRED - 1)) == 0)) {  // a group is complete: hand its accumulators to the helper wave
@@ -665,18 +650,25 @@ __global__ __launch_bounds__(320) void decode_xcd_kernel(XArgs a) {
   const unsigned base = a.ctrl[2];  // epoch: the counter is never reset, every launch adds (phases x team) to it
   const unsigned ring_lds = (unsigned)(size_t)(smem + XL_RING) + (unsigned)wave * XR * SLOT;
   unsigned gphase = 0;  // phases completed by the whole team before the current one
-  const XLane lv = make_lane(a.d, wave, lane);
+  const XLane lv = make_lane(a.d, a.Te, wave, lane);
 
   XStream st;
-  XCur cc;  // consumer's mirror of the block sequence (a desynchronised producer is reported, not silently consumed)
-  st.pc = XCur{0, 0, 0, 0}, st.issued = st.consumed = 0, st.islot = st.cslot = 0;
-  st.left = 0, st.kind = 0, st.soff = 0, st.step = 0, st.rs = u32x4_t{0u, 0u, 0u, 0u};
-  st.tleft = st.tnkb = 0x40000000, st.jump = 0;
+  XCur cc;  // consumer's mirror of the block sequence (checked instantiation: a desynchronised producer is reported, not silently consumed)
+  st.issued = st.consumed = 0, st.islot = st.cslot = 0;
+  st.u = 0, st.nunits = 0, st.layer = 0, st.soff = 0, st.jump = 0, st.left = 0, st.kind = 0, st.tleft = st.tnkb = 0x400000;
   cc = XCur{0, 0, 0, 0};
+  XProd pr;
+  pr.tab = (const unsigned*)(smem + XL_TAB) + (wave & 3) * (XTABN * 4);
+  pr.ring_lds = ring_lds;
+  pr.rs_w = rsrc_of(a.wflat);
+  pr.rs_kv = rsrc_of(a.cache + (long)3 * a.M * a.S_max * a.d);
   if (!helper) {
-    st.more = cur_normalise(g, st.pc);
+    st.nunits = build_units(a, g, wave, lane, (unsigned*)(smem + XL_TAB) + wave * (XTABN * 4));
+    st.more = st.nunits > 0 && st.nunits < XTABN;  // (a full table means the walk was cut short: never the case for a supported shape)
+    if (st.nunits >= XTABN && lane == 0) __hip_atomic_fetch_or(a.ctrl + 1, 0x200u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (st.more) unit_load(a, st, pr.tab);
     cur_normalise(g, cc);
-    for (int i = 0; i < XR; ++i) ring_issue(a, g, st, lv, wave, lane, ring_lds);
+    for (int i = 0; i < XR; ++i) ring_issue(a, st, lv, pr);
   } else {
     st.more = false;
     if (lane == 0) {
@@ -753,7 +745,7 @@ __global__ __launch_bounds__(320) void decode_xcd_kernel(XArgs a) {
               for (int kb = 0; kb < it.kvb;) {
                 const int run = DBG ? 0 : fast_run_len(st, (n >> 7) - kb);  // blocks whose 128 keys all lie inside the segment
                 if (run > 0) {
-                  fast_run(g, st, lv, smem, ring_lds, wave, run, [&](const char* slot, int i) {
+                  fast_run(a, st, lv, pr, smem, wave, run, [&](const char* slot, int i) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                       const int t = 32 * ((kb + i) * 4 + q) + grp;
@@ -761,7 +753,7 @@ __global__ __launch_bounds__(320) void decode_xcd_kernel(XArgs a) {
                       if (l8 == 0) sc[t] = s2;
                       mx = fmaxf(mx, s2);
                     }
-                  }, a.flags);
+                  });
                   kb += run;
                   continue;
                 }
@@ -783,7 +775,7 @@ __global__ __launch_bounds__(320) void decode_xcd_kernel(XArgs a) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 st.consumed = XU(st.consumed + 1);
                 st.cslot = XU(st.cslot + 1 == XR ? 0 : st.cslot + 1);
-                ring_issue(a, g, st, lv, wave, lane, ring_lds);
+                ring_issue(a, st, lv, pr);
                 ++kb;
               }
             } else {
@@ -815,13 +807,13 @@ __global__ __launch_bounds__(320) void decode_xcd_kernel(XArgs a) {
               for (int kb = 0; kb < it.kvb;) {
                 const int run = DBG ? 0 : fast_run_len(st, (n >> 7) - kb);
                 if (run > 0) {
-                  fast_run(g, st, lv, smem, ring_lds, wave, run, [&](const char* slot, int i) {
+                  fast_run(a, st, lv, pr, smem, wave, run, [&](const char* slot, int i) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                       const int t = 32 * ((kb + i) * 4 + q) + grp;
                       dec::accum_pv(__builtin_amdgcn_exp2f(sc[t] - m), *(const u32x4_t*)(slot + q * 1024 + lane * 16), l, o);
                     }
-                  }, a.flags);
+                  });
                   kb += run;
                   continue;
                 }
@@ -839,7 +831,7 @@ __global__ __launch_bounds__(320) void decode_xcd_kernel(XArgs a) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 st.consumed = XU(st.consumed + 1);
                 st.cslot = XU(st.cslot + 1 == XR ? 0 : st.cslot + 1);
-                ring_issue(a, g, st, lv, wave, lane, ring_lds);
+                ring_issue(a, st, lv, pr);
                 ++kb;
               }
             } else {
@@ -906,7 +898,7 @@ __global__ __launch_bounds__(320) void decode_xcd_kernel(XArgs a) {
         } else {
           XBAR();  // A
           if (wave == 0) XSTAMP(5);
-          stream_phase<DBG>(a, g, st, cc, lv, p, smem, ring_lds, wave, lane, ntile);
+          stream_phase<DBG>(a, g, st, cc, lv, pr, p, smem, wave, lane, ntile);
           if (wave == 0) XSTAMP(6);
         }
       }
@@ -926,7 +918,8 @@ __global__ __launch_bounds__(320) void decode_xcd_kernel(XArgs a) {
 size_t decode_xcd_part_floats(int M, int H, int Te) { return (size_t)M * H * dec::n_segments(Te) * 66; }
 
 bool decode_xcd_supports(int d, int H, int Te, int S_max, int L, int M) {
-  return M >= 1 && M <= XMAXM && L >= 1 && L <= XMAXL && d % 64 == 0 && d == H * 64 && d <= XMAXD && S_max <= dec::SEG_KEYS &&
+  // (d % 256: a wave's K quarter is whole 64-element ring blocks)
+  return M >= 1 && M <= XMAXM && L >= 1 && L <= XMAXL && d % 256 == 0 && d == H * 64 && d <= XMAXD && S_max <= dec::SEG_KEYS &&
          Te <= dec::MAX_SEG * dec::SEG_KEYS && Te >= 1 && H * dec::n_segments(Te) <= XMAXPAIR;
 }
 
