@@ -231,7 +231,12 @@ __device__ __forceinline__ XLane make_lane(int d, int Te, int wave, int lane) {
 
 // List the units of decoder layer 0 for this wave into its LDS table (4 words each: soffset, blocks, kind | blocks per tile << 8, tile jump);
 // returns their number.  Runs once per launch; walks the same cursor functions the CPU test pins.
-__device__ __forceinline__ int build_units(const XArgs& a, const XGeom& g, int wave, int lane, unsigned* tab) {
+struct XBuild {  // what the unit walk needs, BY VALUE (a reference to the kernel arguments would pull them out of SGPRs into scratch memory)
+  int d, H, Te, M, L, team, wg;
+  long w[6];  // layer 0 weight offsets by streamed segment: qkv, attn.out, cross q, (3 unused), cross out, mlp.0, mlp.2 -> indices 0,1,2,3,4,5
+};
+__device__ __attribute__((noinline)) int build_units(XBuild p, int wave, int lane, unsigned* tab) {
+  const XGeom g = make_geom(p.d, p.H, p.Te, p.M, p.L, p.team, p.wg);
   XCur c{0, 0, 0, 0};
   bool more = cur_normalise(g, c);
   int n = 0;
@@ -242,15 +247,15 @@ __device__ __forceinline__ int build_units(const XArgs& a, const XGeom& g, int w
       const XItem it = item_of(g, c.idx);
       const bool is_v = c.sub >= it.kvb;
       const int j = is_v ? c.sub - it.kvb : c.sub;
-      soff = (unsigned)((((long)it.b * a.Te + (long)it.sg * dec::SEG_KEYS + 128 * j) * 2 * a.d + it.h * 64 + (is_v ? a.d : 0)) * 2);
+      soff = (unsigned)((((long)it.b * p.Te + (long)it.sg * dec::SEG_KEYS + 128 * j) * 2 * p.d + it.h * 64 + (is_v ? p.d : 0)) * 2);
       const int nfull = it.n >> 7;
       if (nfull > j) nblk = nfull - j, kind = 2;
       else nblk = 1, kind = 3;
       c.sub += nblk;
       more = cur_advance_from(g, c);
     } else {
-      const long woff = c.seg == 0 ? a.l0.wqkv : c.seg == 1 ? a.l0.wo : c.seg == 2 ? a.l0.wcq : c.seg == 4 ? a.l0.wco : c.seg == 5 ? a.l0.w1 : a.l0.w2;
-      const int K = c.seg == 6 ? 4 * a.d : a.d, nkb = c.seg == 6 ? g.nkb_4d : g.nkb_d;
+      const long woff = p.w[c.seg < 3 ? c.seg : c.seg - 1];
+      const int K = c.seg == 6 ? 4 * p.d : p.d, nkb = c.seg == 6 ? g.nkb_4d : g.nkb_d;
       const int tile = g.wg + g.team * c.idx;
       soff = (unsigned)((unsigned long)((woff + ((long)tile * 32) * K + (long)wave * (K >> 2)) * 2));  // relative to the arena's bf16 shadow
       nblk = (seg_cnt(g, c.seg) - c.idx) * nkb, kind = c.seg == 6 ? 1 : 0, tnkb = nkb;
@@ -264,7 +269,7 @@ __device__ __forceinline__ int build_units(const XArgs& a, const XGeom& g, int w
     ++n;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (read back by this wave only)
-  return XU(n);
+  return n;
 }
 // load unit st.u of layer st.layer into the producer state
 __device__ __forceinline__ void unit_load(const XArgs& a, XStream& st, const unsigned* tab) {
@@ -318,14 +323,13 @@ struct XProd {  // launch constants of the producer
 // issue the next block into ring slot islot and advance
 __device__ __forceinline__ void ring_issue(const XArgs& a, XStream& st, const XLane& lv, const XProd& pr) {
   if (!st.more) return;
-  if (!(a.flags & 32)) issue_block(st, lv, pr.rs_w, pr.rs_kv, pr.ring_lds + (unsigned)st.islot * SLOT);
+  issue_block(st, lv, pr.rs_w, pr.rs_kv, pr.ring_lds + (unsigned)st.islot * SLOT);
   st.issued = XU(st.issued + 1);
   st.islot = XU(st.islot + 1 == XR ? 0 : st.islot + 1);
   unit_advance(a, st, pr.tab);
 }
 // block `consumed` has landed: at most (issued - consumed - 1) younger blocks may still be in flight (loads return in order)
-__device__ __forceinline__ void ring_wait(const XStream& st, int flags = 0) {
-  if (flags & 16) return;  // (experiment: consume without waiting -- garbage results, pure instruction time)
+__device__ __forceinline__ void ring_wait(const XStream& st, int = 0) {
   const int younger = XU(st.issued - st.consumed - 1);
   if (younger >= 5) XWAIT_VM(20);
   else if (younger == 4) XWAIT_VM(16);
@@ -381,6 +385,8 @@ struct XGemv {  // one projection phase
   long ldc;
 };
 
+__device__ __forceinline__ float rdlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
 // helper wave: activation rows of a projection phase -> LDS operand rows (bf16).  Every global load of a row is issued before the first
 // one is used: ONE round trip per row, not one per chunk.
 constexpr int XCH = 4;  // 16-byte chunks per lane and batch of a plain operand row (register budget: the kernel sits at 254 of 256 VGPRs)
@@ -405,16 +411,17 @@ __device__ __forceinline__ void helper_operand(const XArgs& a, const XGeom& g, c
           const int h = h0 + hh;
           if (h < a.H) {
             float m_s[dec::MAX_SEG] = {dec::NEG, dec::NEG}, l_s[dec::MAX_SEG] = {0.f, 0.f}, o_s[dec::MAX_SEG] = {0.f, 0.f};
+            // (m, l) of a pair sit in lane `pair` of m_l / l_l: v_readlane (a scalar broadcast), not a ds_bpermute round trip
             if (g.ns == 2) {
-              m_s[0] = __shfl(m_l, 2 * h, 64), m_s[1] = __shfl(m_l, 2 * h + 1, 64);
-              l_s[0] = __shfl(l_l, 2 * h, 64), l_s[1] = __shfl(l_l, 2 * h + 1, 64);
+              m_s[0] = rdlane(m_l, 2 * h), m_s[1] = rdlane(m_l, 2 * h + 1);
+              l_s[0] = rdlane(l_l, 2 * h), l_s[1] = rdlane(l_l, 2 * h + 1);
               o_s[0] = o[2 * hh], o_s[1] = o[2 * hh + 1];
             } else {
-              m_s[0] = __shfl(m_l, h, 64), l_s[0] = __shfl(l_l, h, 64), o_s[0] = o[hh];
+              m_s[0] = rdlane(m_l, h), l_s[0] = rdlane(l_l, h), o_s[0] = o[hh];
             }
             float m, lt;
             const float val = dec::merge_segments(m_s, l_s, o_s, g.ns, m, lt);
-            const float nb = __shfl_xor(val, 1, 64);
+            const float nb = dec::xor_lane<1>(val);
             if ((lane & 1) == 0) *(uint32_t*)(smem + XL_XBUF + b * XL_XS + (h * 64 + lane) * 2) = pack_bf2(val, nb);
           }
         }
@@ -509,10 +516,10 @@ template <typename F>
 __device__ __forceinline__ void fast_run(const XArgs& a, XStream& st, const XLane& lv, const XProd& pr, char* smem, int wave, int run, F&& body) {
   int i = 0;
   for (; i < run && st.more; ++i) {
-    if (!(a.flags & 16)) XWAIT_VM(20);  // 4 * (XR - 1): the oldest block in flight has landed
+    XWAIT_VM(20);  // 4 * (XR - 1): the oldest block in flight has landed
     body(smem + XL_RING + (wave * XR + st.cslot) * SLOT, i);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the body's reads of the slot have retired: it may be re-staged
-    if (!(a.flags & 32)) issue_block(st, lv, pr.rs_w, pr.rs_kv, pr.ring_lds + (unsigned)st.cslot * SLOT);  // (steady state: islot == cslot)
+    issue_block(st, lv, pr.rs_w, pr.rs_kv, pr.ring_lds + (unsigned)st.cslot * SLOT);  // (steady state: islot == cslot)
     st.cslot = XU(st.cslot + 1 == XR ? 0 : st.cslot + 1);
     unit_advance(a, st, pr.tab);
   }
@@ -663,7 +670,12 @@ __global__ __launch_bounds__(320) void decode_xcd_kernel(XArgs a) {
   pr.rs_w = rsrc_of(a.wflat);
   pr.rs_kv = rsrc_of(a.cache + (long)3 * a.M * a.S_max * a.d);
   if (!helper) {
-    st.nunits = build_units(a, g, wave, lane, (unsigned*)(smem + XL_TAB) + wave * (XTABN * 4));
+    {
+      XBuild bp;
+      bp.d = a.d, bp.H = a.H, bp.Te = a.Te, bp.M = a.M, bp.L = a.L, bp.team = a.team, bp.wg = wg;
+      bp.w[0] = a.l0.wqkv, bp.w[1] = a.l0.wo, bp.w[2] = a.l0.wcq, bp.w[3] = a.l0.wco, bp.w[4] = a.l0.w1, bp.w[5] = a.l0.w2;
+      st.nunits = XU(build_units(bp, wave, lane, (unsigned*)(smem + XL_TAB) + wave * (XTABN * 4)));
+    }
     st.more = st.nunits > 0 && st.nunits < XTABN;  // (a full table means the walk was cut short: never the case for a supported shape)
     if (st.nunits >= XTABN && lane == 0) __hip_atomic_fetch_or(a.ctrl + 1, 0x200u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (st.more) unit_load(a, st, pr.tab);
@@ -710,7 +722,7 @@ __global__ __launch_bounds__(320) void decode_xcd_kernel(XArgs a) {
               if (lane < 2) st4_x(dst + lane, __float_as_uint(ao[lane]), a.flags);
             } else {
               const int id = wg + a.team * j, b = (id >= a.H ? 1 : 0) + (id >= 2 * a.H ? 1 : 0) + (id >= 3 * a.H ? 1 : 0), h = id - b * a.H;
-              const float val = ao[2 + lane], nb = __shfl_xor(val, 1, 64);
+              const float val = ao[2 + lane], nb = dec::xor_lane<1>(val);
               if ((lane & 1) == 0) st4_x(a.o + (long)b * a.d + h * 64 + lane, pack_bf2(val, nb), a.flags);
             }
           }
