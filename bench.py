@@ -296,7 +296,7 @@ def hbm_kernel_rooflines(net, dims, mb, dev):
     line("decode_step(B=1)", timed(dstep, reps=20), dbytes,
          f"one KV-cached decoder step of this model at position {S_pos}: bf16 decoder weights + tied logits matrix once, cross K/V [{dims.n_audio_ctx}, {2 * d}] x {L_dec} layers, self K/V so far; "
          f"round 5: ONE persistent launch for the decoder stack (csrc/decode_xcd.hip: a team of 32 CUs, weights / cross K/V prefetched through wave-private LDS rings, "
-         f"{8 * L_dec} team barriers) + embedding + logits launches; issue-bound at ~900 cycles per 4 KB ring block (profiles/r05_decode_xcd_stamps_v5_issue_bound.txt); "
+         f"{8 * L_dec} team barriers) + embedding + logits launches; issue-bound at ~1.1 k cycles per 4 KB ring block (profiles/r05_decode_xcd_stamps_v8.txt, r05_decode_xcd_stamps_v5_issue_bound.txt); "
          f"the multi-launch step it replaces: ~{8 * L_dec + 2} dependent launches")
     del state, xa
     n = net.flat_params.numel()

@@ -1029,8 +1029,8 @@ static int oasr_decode_step_impl(oasr_ctx* c, const int64_t* tokens_last, int B,
     folded = d % 64 == 0 && d <= 2048 && g_decode_ln_fold != 0 && (B <= 4 || (g_decode_ln_fold == 1 && B <= 32));
     // one launch for the whole decoder stack (decode_xcd.hip): the default for a handful of sequences
     const int mode = g_decode_ln_fold;
-    // (default: ONE sequence -- the timestamp-mode transcribe loop; measured 1.99 vs 2.44 ms per token at medium, level at small, slower from
-    // B = 2 on where the multi-launch kernels spread over the whole chip: profiles/r05_decode_xcd_probe_v5.txt.  Modes 2-4 force it up to B = 4.)
+    // (default: ONE sequence -- the timestamp-mode transcribe loop; measured 1.75 vs 2.44 ms per token at medium, 0.85 vs 0.94 at small; at small B = 4
+    // the multi-launch kernels, which spread over the whole chip, win: profiles/r05_decode_xcd_probe_v8.txt.  Modes 2-4 force it up to B = 4.)
     if (((mode == -1 && B == 1) || mode >= 2) && !c->xcd_offsets.empty() && decode_xcd_supports(d, c->H, c->Te, S_max, c->L_dec, B)) {
       DecodeXcdArgs xa;
       xa.wflat = c->template Wt<bf16_t>(0);
