@@ -104,13 +104,19 @@ int oasr_decode_logits(oasr_ctx*, const int64_t* tokens, const void* xa, const i
 /* Cached greedy decoding = the reference's install_kv_cache_hooks (model.py:925-964 / inf_model.py:422-453) + one
  * TextDecoder step per token.  kv_cache: oasr_kv_cache_bytes(B) bytes, caller owned, valid for one 30 s window batch.
  * decode_begin computes the cross-attention K/V of every layer from xa (bf16 [B, n_audio_ctx, d]); decode_step consumes
- * the token at position `pos` of each sequence (tokens_last i64 [B]) and returns f32 logits [B, rows] for position pos+1. */
+ * the token at position `pos` of each sequence (tokens_last i64 [B]) and returns f32 logits [B, rows] for position pos+1.
+ * Engines (all bit-identical, csrc/decode_shared.h): ONE sequence on the bf16 engine -> one persistent launch for the whole decoder
+ * stack (csrc/decode_xcd.hip: a team of 32 CUs, weights and cross K/V prefetched through LDS rings); 2-4 sequences -> LayerNorm folded
+ * into the projections' operand loads; more -> separate kernels.  The one-launch engine keeps four control words in the cache's last
+ * 256 bytes (zeroed by decode_begin): a team member that never reaches a barrier poisons a flag instead of hanging, and
+ * oasr_decode_check reports it as OASR_ESTATE. */
 size_t oasr_kv_cache_bytes(const oasr_ctx*, int B);
 size_t oasr_decode_step_workspace_bytes(const oasr_ctx*, int B);
 int oasr_decode_begin(oasr_ctx*, const void* xa, int B, void* kv_cache, void* stream);
 int oasr_decode_step(oasr_ctx*, const int64_t* tokens_last, int B, int pos, void* kv_cache, float* logits_out, void* workspace,
                      size_t workspace_bytes, void* stream);
-/* Synchronises the stream: call once per decoded window, where the caller reads the tokens back. */
+/* Synchronises the stream and checks the one-launch engine's error flag: call once per decoded window, where the caller reads the
+ * tokens back. */
 int oasr_decode_check(oasr_ctx*, int B, void* kv_cache, void* stream);
 
 /* One micro-step of train() (train_timestamps.py:1440-1454): forward, CE(ignore_index=pad)/accum, backward.
