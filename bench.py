@@ -451,7 +451,7 @@ def main():
     if ddp_path:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world, pg_options=ddp.rccl_options())  # "nccl" is RCCL on ROCm
 
     dims = VARIANT_TO_DIMS[args.variant]
     net = OLMoASR(dims, device=dev, seed=0)

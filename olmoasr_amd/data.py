@@ -174,7 +174,8 @@ class ShardLoader:
                        ty=torch.full((self.B, N_TEXT_CTX), PAD_ID, dtype=torch.int64, **pin), tl=torch.zeros(self.B, dtype=torch.int32, **pin))
                   for _ in range(n_slot)]
         self.d = [{k: torch.empty_like(v, device=self.device) for k, v in slot.items()} for slot in self.h] if self.cuda else self.h
-        self.copy_stream = torch.cuda.Stream(self.device) if self.cuda else None
+        # (high priority: a default-priority stream may share the compute stream's hardware queue on ROCm and run behind it -- see ddp.GradReducer)
+        self.copy_stream = torch.cuda.Stream(self.device, priority=-1) if self.cuda else None
         self.uploaded = [None] * n_slot   # event: the slot's H2D has completed (host slot reusable, device slot readable)
         self.consumed = [None] * n_slot   # event on the consumer's stream: the device slot may be overwritten
         self.pending = []                 # [slot, futures, upload issued?, rows]

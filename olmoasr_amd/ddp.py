@@ -72,7 +72,11 @@ class GradReducer:
         # 1/world): the buckets come back as the MEAN -- ReduceOp.AVG inside the collective on RCCL (no extra pass over the
         # gradients at all), SUM followed by a per-bucket scale on the communication stream elsewhere (gloo has no AVG).
         self.mean_scale: Optional[float] = None
-        self.comm_stream = torch.cuda.Stream(flat_grads.device) if self.cuda else None
+        # HIGH-PRIORITY stream: on ROCm a default-priority stream may share its hardware queue with the compute stream -- its commands
+        # then run in submission order behind the whole backward and nothing overlaps (measured at world 1: first bucket started 0.01 ms
+        # AFTER the end of the backward, `comm_lead_ms` in bench.py's `ddp` block, profiles/r05_ddp_overlap.txt); a stream of another
+        # priority gets a queue of its own, and the short RCCL kernels are scheduled ahead of the GEMMs that fill the chip
+        self.comm_stream = torch.cuda.Stream(flat_grads.device, priority=-1) if self.cuda else None
         self.events = None
         if self.cuda:
             # torch creates the underlying HIP event lazily at the first record(); the engine needs the raw handles
@@ -202,6 +206,15 @@ class DistributedDataParallel(torch.nn.Module):
             finally:
                 self.require_backward_grad_sync = old
         return ctx()
+
+
+def rccl_options():
+    """``pg_options`` for ``init_process_group("nccl", ...)``: RCCL's kernels go to a HIGH-PRIORITY stream (a hardware queue of their own,
+    scheduled ahead of the GEMMs that fill the chip) -- same reason as ``GradReducer.comm_stream``.  None where the build has no NCCL backend."""
+    try:
+        return dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+    except Exception:  # pragma: no cover
+        return None
 
 
 def broadcast_parameters(flat_params: torch.Tensor, src: int = 0, group: Optional[dist.ProcessGroup] = None):

@@ -352,7 +352,7 @@ def main(argv=None):
         if force_dist:  # the single-rank rehearsal needs no launcher: loopback rendezvous on a port of its own
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 400))
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world_size)  # RCCL over xGMI
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world_size, pg_options=ddp.rccl_options())  # RCCL over xGMI
 
     betas = tuple(args.betas)
     dims = VARIANT_TO_DIMS[args.model_variant]
