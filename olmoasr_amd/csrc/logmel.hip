@@ -197,16 +197,13 @@ __global__ __launch_bounds__(256) void logmel_main(const PCM* __restrict__ pcm, 
 // lanes of a half-wave run the same butterfly on different frames -- no divergence, table reads are broadcasts, and every LDS
 // row stride (162 floats of samples, 201 complex / 201 floats per frame) is odd in its access width: conflict-free.  fp32 throughout
 // (twiddles rounded once from double): |error| ~ 1e-7 of the frame's amplitude, same as the k-ordered fmaf chains of the MFMA form.
-constexpr int XT = 32;                        // frames per workgroup
-constexpr int XNS = XT * HOP + (NFFT - HOP);  // 5360 samples
+// (frames per workgroup: template parameter T of logmel_fft, 16 by default)
 constexpr int XROW = 201;                     // per-frame row length (complex for Z, float for the power spectrum)
-constexpr int XR0 = XNS + 2 * (XNS / HOP + 1);  // region 0 (floats): the staged samples (pairs stay 8-byte aligned: +2 per hop)
 // constant tables, resident in LDS: W200 (200 complex) | hann[0..200] (+3 pad) | W400 (201 complex) | mel: (first bin, first weight) x 81 | weights
 // (the power spectrum overwrites the Z rows in place -- each thread holds its 26 values across a barrier -- so samples + Z + tables
 // fit 80 KiB: two workgroups per CU)
 constexpr int XTAB_A = 400 + 204, XTAB_P = 402, XTAB_M_MAX = 604;
 constexpr int XTAB_OFF_P = XTAB_A, XTAB_OFF_M = XTAB_A + XTAB_P, XTAB = XTAB_A + XTAB_P + XTAB_M_MAX;
-constexpr int XLDS_FLOATS = ((XR0 + 3) & ~3) + 2 * XT * XROW + XTAB;
 
 struct cf {
   float x, y;
@@ -251,36 +248,42 @@ __device__ __forceinline__ void dft5(cf x0, cf x1, cf x2, cf x3, cf x4, cf (&y)[
 }
 __device__ __forceinline__ int xsamp_addr(int s) { return s + 2 * (s / HOP); }  // 162 floats between frames: 81 8-byte slots (odd)
 
-template <typename PCM>
-__global__ __launch_bounds__(256, 2) void logmel_fft(const PCM* __restrict__ pcm, int n_samples, int n_frames,
+// T = frames per workgroup (32: lane = frame over a half wave, 8 item groups, two workgroups per CU; 16: 16 item groups, 43 KiB of LDS,
+// three workgroups per CU -- half the serial work per thread in the sample / unpack / mel stages and 12 instead of 8 waves per CU to hide the
+// LDS round trips this kernel is bound by, profiles/r03_logmel_fft.txt)
+template <typename PCM, int T>
+__global__ __launch_bounds__(256, T == 32 ? 2 : 3) void logmel_fft(const PCM* __restrict__ pcm, int n_samples, int n_frames,
                                                      const float* __restrict__ tab,  // [XTAB]: the three stage tables
                                                      int mel_words,                  // words of the mel table (162 + non-zeros)
                                                      int max_span,                   // taps of the widest filter
                                                      float* __restrict__ out, unsigned* __restrict__ clipmax) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NG = 256 / T;                    // item groups: thread (f = tid % T, j0 = tid / T)
+  constexpr int TNS = T * HOP + (NFFT - HOP);    // samples of T frames
+  constexpr int TR0 = TNS + 2 * (TNS / HOP + 1);
   float* samp = smem;                       // region 0: samples
-  cf* cb = (cf*)(smem + ((XR0 + 3) & ~3));  // [XT][XROW] complex: A, then Z, then (as floats, same row stride) the power spectrum
+  cf* cb = (cf*)(smem + ((TR0 + 3) & ~3));  // [T][XROW] complex: A, then Z, then (as floats, same row stride) the power spectrum
   float* pw = (float*)cb;
-  float* tw = smem + ((XR0 + 3) & ~3) + 2 * XT * XROW;
+  float* tw = smem + ((TR0 + 3) & ~3) + 2 * T * XROW;
   const cf* tw200 = (const cf*)tw;
   const float* win = tw + 400;
   const cf* tw400 = (const cf*)(tw + XTAB_OFF_P);
   // 1-D grid, XCD-contiguous: neighbouring frame blocks of a clip run on the same XCD at the same time, so the 128-byte row
   // segments they write (row pitch 12000 B: never line aligned) meet in ONE L2 and leave it as whole lines, and the 240 samples
   // two neighbours share are fetched once
-  const int nblk = (n_frames + XT - 1) / XT;
+  const int nblk = (n_frames + T - 1) / T;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int b = bid / nblk, f0 = (bid - b * nblk) * XT, tid = threadIdx.x;
-  const int f = tid & 31, j0 = tid >> 5;  // lane = frame, 8 items per pass
+  const int b = bid / nblk, f0 = (bid - b * nblk) * T, tid = threadIdx.x;
+  const int f = tid & (T - 1), j0 = tid / T;  // lane = frame, NG items per pass
   const PCM* clip = pcm + (long)b * n_samples;
 
   for (int i = tid; i < (XTAB_OFF_M + mel_words + 3) / 4; i += 256) ((f32x4_t*)tw)[i] = ((const f32x4_t*)tab)[i];  // (XTAB floats allocated)
   // ---- samples of these 32 frames (reflect padding of torch.stft(center=True) at the clip's ends)
   const long s_begin = (long)f0 * HOP - NFFT / 2;
-  const bool interior = s_begin >= 0 && s_begin + XNS <= n_samples && ((size_t)(clip + s_begin) & 15) == 0;
+  const bool interior = s_begin >= 0 && s_begin + TNS <= n_samples && ((size_t)(clip + s_begin) & 15) == 0;
   if (interior) {  // (wave-uniform) 16-byte loads; a vector never straddles a hop boundary (160 % 8 == 0), so its floats stay adjacent
     constexpr int PER = 16 / (int)sizeof(PCM);  // 8 int16 / 4 float samples per load
-    for (int v = tid; v < XNS / PER; v += 256) {
+    for (int v = tid; v < TNS / PER; v += 256) {
       const u32x4_t raw = *(const u32x4_t*)(clip + s_begin + (long)v * PER);
       float* dst = samp + xsamp_addr(v * PER);
       if (sizeof(PCM) == 2) {
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void logmel_fft(const PCM* __restrict__ pcm
       }
     }
   } else {
-    for (int s = tid; s < XNS; s += 256) {
+    for (int s = tid; s < TNS; s += 256) {
       long idx = s_begin + s;
       if (idx < 0) idx = -idx;
       if (idx >= n_samples) idx = 2L * (n_samples - 1) - idx;
@@ -307,8 +310,8 @@ __global__ __launch_bounds__(256, 2) void logmel_fft(const PCM* __restrict__ pcm
 
   // ---- stage A
 #pragma unroll 1
-  for (int it = 0; it < 4; ++it) {
-    const int n2 = it * 8 + j0;
+  for (int it = 0; it < (25 + NG - 1) / NG; ++it) {
+    const int n2 = it * NG + j0;
     if (n2 < 25) {
       cf v[8];
 #pragma unroll
@@ -327,30 +330,35 @@ __global__ __launch_bounds__(256, 2) void logmel_fft(const PCM* __restrict__ pcm
   }
   __syncthreads();
 
-  // ---- stage B: k1 = j0
+  // ---- stage B: k1 = j0 (the groups past 7 idle here when NG = 16)
   {
-    const int k1 = j0;
+    const int k1 = j0 & 7;
+    const bool act = j0 < 8;
     cf a[25];
     const cf* src = cb + f * XROW + k1 * 25;
+    if (act) {
 #pragma unroll
-    for (int i = 0; i < 25; ++i) a[i] = src[i];
-    __syncthreads();  // every thread holds its inputs: the rows can be overwritten in natural order
-    cf bm[5][5];      // [b][c]
-#pragma unroll
-    for (int bb = 0; bb < 5; ++bb) {
-      cf y[5];
-      dft5(a[bb], a[5 + bb], a[10 + bb], a[15 + bb], a[20 + bb], y);
-      bm[bb][0] = y[0];
-#pragma unroll
-      for (int c = 1; c < 5; ++c) bm[bb][c] = bb == 0 ? y[c] : cmul(y[c], tw200[8 * bb * c]);  // W25^(b c) = W200^(8 b c)
+      for (int i = 0; i < 25; ++i) a[i] = src[i];
     }
-    cf* dst = cb + f * XROW + k1;
+    __syncthreads();  // every thread holds its inputs: the rows can be overwritten in natural order
+    if (act) {
+      cf bm[5][5];  // [b][c]
 #pragma unroll
-    for (int c = 0; c < 5; ++c) {
-      cf y[5];
-      dft5(bm[0][c], bm[1][c], bm[2][c], bm[3][c], bm[4][c], y);
+      for (int bb = 0; bb < 5; ++bb) {
+        cf y[5];
+        dft5(a[bb], a[5 + bb], a[10 + bb], a[15 + bb], a[20 + bb], y);
+        bm[bb][0] = y[0];
 #pragma unroll
-      for (int e = 0; e < 5; ++e) dst[8 * (c + 5 * e)] = y[e];
+        for (int c = 1; c < 5; ++c) bm[bb][c] = bb == 0 ? y[c] : cmul(y[c], tw200[8 * bb * c]);  // W25^(b c) = W200^(8 b c)
+      }
+      cf* dst = cb + f * XROW + k1;
+#pragma unroll
+      for (int c = 0; c < 5; ++c) {
+        cf y[5];
+        dft5(bm[0][c], bm[1][c], bm[2][c], bm[3][c], bm[4][c], y);
+#pragma unroll
+        for (int e = 0; e < 5; ++e) dst[8 * (c + 5 * e)] = y[e];
+      }
     }
   }
   __syncthreads();
@@ -358,10 +366,11 @@ __global__ __launch_bounds__(256, 2) void logmel_fft(const PCM* __restrict__ pcm
   // ---- unpack + power: every thread first computes its 26 bins of frame f into registers, then (behind a barrier: all reads of
   // the Z rows are done) writes them over the row, as floats
   {
-    float pv[26];
+    constexpr int NU = (201 + NG - 1) / NG;
+    float pv[NU];
 #pragma unroll
-    for (int it = 0; it < 26; ++it) {
-      const int k = it * 8 + j0;
+    for (int it = 0; it < NU; ++it) {
+      const int k = it * NG + j0;
       pv[it] = 0.f;
       if (k <= 200) {
         const cf zk = cb[f * XROW + (k == 200 ? 0 : k)];
@@ -374,8 +383,8 @@ __global__ __launch_bounds__(256, 2) void logmel_fft(const PCM* __restrict__ pcm
     }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < 26; ++it) {
-      const int k = it * 8 + j0;
+    for (int it = 0; it < NU; ++it) {
+      const int k = it * NG + j0;
       if (k <= 200) pw[f * (2 * XROW) + k] = pv[it];
     }
   }
@@ -389,22 +398,24 @@ __global__ __launch_bounds__(256, 2) void logmel_fft(const PCM* __restrict__ pcm
   {
     // this thread's 10 filters (m = 8 it + j0) advance together, one tap per step: 10 independent LDS-read + fma chains in flight
     // instead of one serial chain per filter (each step is two LDS round trips; the filters have 2..14 taps)
-    int lo[10], p0[10], cnt[10];
-    float acc[10];
+    constexpr int NF = NMEL / NG, NH = (NF + 1) / 2;  // filters per thread (m = NG it + j0); they advance in pairs (a, a + NH)
+    int lo[NF], p0[NF], cnt[NF];
+    float acc[NF];
 #pragma unroll
-    for (int it = 0; it < 10; ++it) {
-      const int m = it * 8 + j0;
+    for (int it = 0; it < NF; ++it) {
+      const int m = it * NG + j0;
       lo[it] = mel_idx[2 * m];
       p0[it] = mel_idx[2 * m + 1];
       cnt[it] = mel_idx[2 * m + 3] - p0[it];
       acc[it] = 0.f;
     }
     const float* prow = pw + f * (2 * XROW);
-    // filters it and it + 5 advance together (two independent chains); the step count of a pair is the widest filter any lane of
-    // the wave holds for it (filter width grows with the index: ~44 steps in all instead of 10 x the global maximum)
+    // filters a and a + NH advance together (two independent chains); the step count of a pair is the widest filter any lane of
+    // the wave holds for it (filter width grows with the index)
 #pragma unroll
-    for (int a = 0; a < 5; ++a) {
-      int n = cnt[a] > cnt[a + 5] ? cnt[a] : cnt[a + 5];
+    for (int a = 0; a < NH; ++a) {
+      const int a2 = a + NH < NF ? a + NH : a;  // (odd NF: the last one runs alone)
+      int n = cnt[a] > cnt[a2] ? cnt[a] : cnt[a2];
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) n = max(n, __shfl_xor(n, o, 64));
       n = __builtin_amdgcn_readfirstlane(n);
@@ -414,21 +425,21 @@ __global__ __launch_bounds__(256, 2) void logmel_fft(const PCM* __restrict__ pcm
         for (int u = 0; u < 4; ++u) {
           x0[u] = prow[lo[a] + i + u];
           w0[u] = mel_val[p0[a] + i + u];
-          x1[u] = prow[lo[a + 5] + i + u];
-          w1[u] = mel_val[p0[a + 5] + i + u];
+          x1[u] = prow[lo[a2] + i + u];
+          w1[u] = mel_val[p0[a2] + i + u];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           acc[a] = (i + u < cnt[a]) ? fmaf(x0[u], w0[u], acc[a]) : acc[a];
-          acc[a + 5] = (i + u < cnt[a + 5]) ? fmaf(x1[u], w1[u], acc[a + 5]) : acc[a + 5];
+          if (a2 != a) acc[a2] = (i + u < cnt[a2]) ? fmaf(x1[u], w1[u], acc[a2]) : acc[a2];
         }
       }
     }
     if (t < n_frames) {
 #pragma unroll
-      for (int it = 0; it < 10; ++it) {
+      for (int it = 0; it < NF; ++it) {
         const float v = log10f(fmaxf(acc[it], 1e-10f));
-        out[((long)b * NMEL + it * 8 + j0) * n_frames + t] = v;
+        out[((long)b * NMEL + it * NG + j0) * n_frames + t] = v;
         vmax = fmaxf(vmax, v);
       }
     }
@@ -622,18 +633,29 @@ static int log_mel_impl(const void* pcm, int pcm_dtype, int B, int n_samples, fl
   const long per_clip = (long)NMEL * n_frames;
   const dim3 g2((unsigned)((per_clip / 4 + 255) / 256 > 64 ? 64 : (per_clip / 4 + 255) / 256 + 1), B);
   if (!use_mfma_dft) {
-    const size_t xlds = sizeof(float) * XLDS_FLOATS;
-    const dim3 xgrid((unsigned)(cdiv(n_frames, XT) * B));
-    static LdsAttrOnce attr16, attr32;
+    static const int frames_per_wg = [] {  // A/B: OASR_LOGMEL=fft32 is the round-3/4 geometry
+      const char* e = oasr_experiment_env("OASR_LOGMEL");
+      return (e && strcmp(e, "fft32") == 0) ? 32 : 16;
+    }();
+    auto lds_floats = [](int T) { const int tns = T * HOP + (NFFT - HOP); const int r0 = tns + 2 * (tns / HOP + 1); return ((r0 + 3) & ~3) + 2 * T * XROW + XTAB; };
+    const size_t xlds = sizeof(float) * lds_floats(frames_per_wg);
+    const dim3 xgrid((unsigned)(cdiv(n_frames, frames_per_wg) * B));
+    static LdsAttrOnce attr16_32, attr32_32, attr16_16, attr32_16;
+#define OASR_LOGMEL_LAUNCH(PCM_T, TT, ATTR)                                                                                       \
+  do {                                                                                                                          \
+    const int rc_ = ensure_dynamic_lds(ATTR, (const void*)logmel_fft<PCM_T, TT>, (int)xlds);                                    \
+    if (rc_) return rc_;                                                                                                        \
+    hipLaunchKernelGGL((logmel_fft<PCM_T, TT>), xgrid, dim3(256), xlds, stream, (const PCM_T*)pcm, n_samples, n_frames, t->fft_tab, \
+                       t->mel_words, t->mel_span, mel, clipmax);                                                                \
+  } while (0)
     if (pcm_dtype == 1) {
-      { const int rc_ = ensure_dynamic_lds(attr16, (const void*)logmel_fft<int16_t>, (int)xlds); if (rc_) return rc_; }
-      hipLaunchKernelGGL(logmel_fft<int16_t>, xgrid, dim3(256), xlds, stream, (const int16_t*)pcm, n_samples, n_frames, t->fft_tab,
-                         t->mel_words, t->mel_span, mel, clipmax);
+      if (frames_per_wg == 32) OASR_LOGMEL_LAUNCH(int16_t, 32, attr16_32);
+      else OASR_LOGMEL_LAUNCH(int16_t, 16, attr16_16);
     } else {
-      { const int rc_ = ensure_dynamic_lds(attr32, (const void*)logmel_fft<float>, (int)xlds); if (rc_) return rc_; }
-      hipLaunchKernelGGL(logmel_fft<float>, xgrid, dim3(256), xlds, stream, (const float*)pcm, n_samples, n_frames, t->fft_tab, t->mel_words,
-                         t->mel_span, mel, clipmax);
+      if (frames_per_wg == 32) OASR_LOGMEL_LAUNCH(float, 32, attr32_32);
+      else OASR_LOGMEL_LAUNCH(float, 16, attr32_16);
     }
+#undef OASR_LOGMEL_LAUNCH
     OASR_LAUNCH_CHECK();
     if (clip_max_out) hipLaunchKernelGGL(logmel_clipmax_kernel, dim3(cdiv(B, 256)), dim3(256), 0, stream, clipmax, clip_max_out, B);
     else hipLaunchKernelGGL(logmel_finalize, g2, dim3(256), 0, stream, mel, clipmax, per_clip);
