@@ -659,7 +659,11 @@ def main():
                        "free_hbm_gib": round(free_gib, 2), "workspace_gib": round(ws_gib(mb), 2), "hbm_margin_gib": args.hbm_margin_gib,
                        "parallelism": f"dp{world}" + (f" ({head_algo} gradient exchange, {args.bucket_mb:g} MiB buckets)" if world > 1 else ""),
                        "optimizer": "AdamW fused (unscale+clip+step), loss scale 65536",
-                       "step_mode": head_mode, "decoder_positions": shape_txt},
+                       "step_mode": head_mode, "decoder_positions": shape_txt,
+                       # span steps: which GEMMs run on the engine's lowest-priority side streams (csrc/engine.hip Runner::side_mode; bit 0: the decoder
+                       # backward's weight gradients over the active rows, bit 2: the cross-attention key|value gradients).  Their HIP-event / rocprof
+                       # durations are begin-to-end spans that include waiting for compute units: by_symbol sums overlap in wall time
+                       "side_streams": int(N.lib().oasr_span_side_streams()) if head_mode != "plain" else 0},
             # per-step spread of the timed region on rank 0 (HIP events between the steps): a 1 % kernel change vs box noise
             "per_step_ms": spread(per_step_ms),
             # the same process timed the other step modes right after the headline (a few steps each): what the headline's shape buys

@@ -2,7 +2,7 @@
  * the drop-in surface: nothing on the training / decoding path calls them.  Users: bench.py (live GEMM roofline), tests/
  * (kernel-path forcing, hardware-behaviour probes that pin what the kernels rely on), scripts/ (A/B experiments).
  * The setters that change process-wide kernel selection (oasr_gemm_set_variant / _set_stagger / _force_general,
- * oasr_attention_set_pingpong, oasr_decode_set_ln_fold) are INERT unless the process opts in with OASR_TESTING_HOOKS=1 in its
+ * oasr_attention_set_pingpong, oasr_decode_set_ln_fold, oasr_span_set_side_streams) are INERT unless the process opts in with OASR_TESTING_HOOKS=1 in its
  * environment: without it they return OASR_ESTATE and change nothing, so a production process cannot be steered through them. */
 #ifndef OASR_TESTING_H
 #define OASR_TESTING_H
@@ -24,6 +24,13 @@ int oasr_gemm_set_variant(int v);
  * projections' operand loads for every B <= 32, 2 = one launch on one XCD, 3 / 4 = one launch with 32 / 64 workgroups spread over the
  * chip.  All bit-identical (tests/test_gpu_decode_step.py). */
 int oasr_decode_set_ln_fold(int mode);
+/* tests / A-B: side streams of the supervised-span step (oasr_train_fwd_bwd_span; csrc/engine.hip: Runner::side_mode).  Bit 0: the decoder
+ * backward's weight gradients over the R active rows, bit 2: the cross-attention key|value weight gradient and d(xa) -- run on lowest-priority
+ * streams beside the data-gradient chain; bit 1: the key|value projections of the decoder forward likewise; bit 3: without segment events leave
+ * the key|value gradients in flight across blocks.  -1 = the library default.  Gradients differ by fp32 atomic order only
+ * (tests/test_gpu_span.py).  The getter returns the mode in effect. */
+int oasr_span_set_side_streams(int mode);
+int oasr_span_side_streams(void);
 /* tests (CPU): the static block stream of workgroup `wg` of the one-launch step engine as its cursors generate it: out[4 i ..] = layer,
  * segment (0 qkv, 1 attn.out, 2 cross q, 3 cross K/V, 4 cross out, 5 mlp.0, 6 mlp.2), tile / item ordinal, block; returns the count. */
 int oasr_xcd_plan_debug(int d, int H, int Te, int M, int L, int team, int wg, int* out, int max_blocks);

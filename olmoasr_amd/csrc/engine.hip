@@ -40,6 +40,12 @@ struct Segment {
 
 }  // namespace
 
+// Runner::side_mode of the span step.  5 = the decoder backward's R-row weight gradients + the cross-attention key|value gradients on the side
+// streams: -0.7 % of the step (same-box A/B, profiles/r05_side_streams.txt).  7 (+ the forward's key|value projections) measures -1.4 %, and is not
+// the default because those 48 launches share the dominant forward kernel's symbol: as low-priority filler their begin-to-end spans include
+// waiting for compute units, which would turn that kernel's per-launch statistics (bench.py `roofline`, rocprofv3 --stats) into something else.
+constexpr int SIDE_STREAMS_DEFAULT = 5;
+
 struct oasr_ctx {
   oasr_dims dims;
   int d, H, L_enc, L_dec, Te, T1, S_max, V, Vp;  // V = n_vocab+1 rows (train model), Vp = padded to 128
@@ -58,6 +64,26 @@ struct oasr_ctx {
   int f32 = 0;  // compute_dtype: 0 = bf16 production kernels, 1 = fp32 validation kernels (fp32ref.hip)
   std::vector<int64_t> xcd_offsets;  // decoder layer 0's 18 tensor offsets in decode_xcd.hip::XLayer order (empty: irregular layout, engine off)
   int64_t xcd_lstride = 0, xcd_astride = 0;  // layer l = layer 0 + l * stride
+  // Side stream of the span step's decoder backward (Runner::wgrad_side): created on first use, lowest priority, so its weight-gradient
+  // workgroups fill the compute units the main stream's launches leave idle
+  struct Side {
+    hipStream_t stream = nullptr;  // the R-row weight gradients of the decoder backward
+    hipStream_t big = nullptr;     // the encoder-sized GEMMs of the cross-attention key|value side (forward projection, its two gradients)
+    hipEvent_t fork[4] = {nullptr, nullptr, nullptr, nullptr}, join[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> kv_ready;  // [L_dec]: layer i's key|value projection has been written (forward)
+    unsigned nf = 0, nj = 0;
+  };
+  mutable Side side;
+  ~oasr_ctx() {
+    for (hipEvent_t e : side.fork)
+      if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : side.join)
+      if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : side.kv_ready)
+      if (e) (void)hipEventDestroy(e);
+    if (side.stream) (void)hipStreamDestroy(side.stream);
+    if (side.big) (void)hipStreamDestroy(side.big);
+  }
   // compute copy of the weight at arena offset `off`: the bf16 shadow, or -- fp32 validation -- the master weights themselves
   template <typename T>
   const T* Wt(int64_t off) const;
@@ -393,6 +419,71 @@ struct Runner {
     }
     return launch_gemm(g, st);
   }
+  // ---- side stream (decoder backward of a span step) ----------------------------------------------------------------------------
+  // The decoder-side GEMMs of a span step run over R ~ 18.7k rows: 292 tiles of 256 x 256 for an N = 1024 output = 1.14 rounds over the 256
+  // CUs, the second round 14 % full.  A weight gradient and the data gradient launched after it are independent (both read dy), so the
+  // weight gradients go to a second, lowest-priority stream whose workgroups take the CUs the main stream's tails leave idle; the main
+  // stream waits for them (join_side) before the LayerNorm backward that ends each section of block_bwd -- the next kernel that may
+  // overwrite something a weight gradient reads -- so the per-block events (DDP buckets) still mean "this block's gradients are complete".
+  // The encoder-sized GEMMs of the cross-attention key|value side (the projection of xa in the forward -- it depends on the encoder output
+  // only, so all L_dec of them are issued when the decoder starts; its weight gradient and d(xa) in the backward) run on a second side
+  // stream the same way: short workgroups by the thousand, the filler for every tail of the decoder's own launches.
+  struct OnStream {  // launches of this scope go to `to`
+    hipStream_t& ref;
+    hipStream_t keep;
+    OnStream(hipStream_t& r, hipStream_t to) : ref(r), keep(r) { ref = to; }
+    ~OnStream() { ref = keep; }
+  };
+  int side_mode = 0;  // bit 0: R-row weight gradients, bit 1: forward key|value projections, bit 2: backward key|value gradients
+  bool side_pending = false, big_pending = false;
+  int side_begin(int mode) {
+    oasr_ctx::Side& sd = c->side;
+    if (!sd.stream) {
+      int least = 0, greatest = 0;
+      OASR_CHECK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      OASR_CHECK_HIP(hipStreamCreateWithPriority(&sd.stream, hipStreamNonBlocking, least));
+      OASR_CHECK_HIP(hipStreamCreateWithPriority(&sd.big, hipStreamNonBlocking, least));
+      for (hipEvent_t& e : sd.fork) OASR_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      for (hipEvent_t& e : sd.join) OASR_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      sd.kv_ready.assign((size_t)c->L_dec, nullptr);
+      for (hipEvent_t& e : sd.kv_ready) OASR_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    side_mode = mode;
+    return OASR_OK;
+  }
+  // everything launched on `st` so far happens before whatever is launched on `to` next
+  int fork_to(hipStream_t to) {
+    oasr_ctx::Side& sd = c->side;
+    hipEvent_t e = sd.fork[sd.nf++ & 3];
+    OASR_CHECK_HIP(hipEventRecord(e, st));
+    OASR_CHECK_HIP(hipStreamWaitEvent(to, e, 0));
+    return OASR_OK;
+  }
+  int join_from(hipStream_t from) {
+    oasr_ctx::Side& sd = c->side;
+    hipEvent_t e = sd.join[sd.nj++ & 3];
+    OASR_CHECK_HIP(hipEventRecord(e, from));
+    OASR_CHECK_HIP(hipStreamWaitEvent(st, e, 0));
+    return OASR_OK;
+  }
+  int wgrad_side(const T* dy, long ldy, long M, int N, const View& x, int K, float* dW, long ldw) {
+    if (!(side_mode & 1)) return wgrad(dy, ldy, M, N, x, K, dW, ldw);
+    RC(fork_to(c->side.stream));
+    OnStream on(st, c->side.stream);
+    side_pending = true;
+    return wgrad(dy, ldy, M, N, x, K, dW, ldw);
+  }
+  int join_side() {
+    if (!side_pending) return OASR_OK;
+    side_pending = false;
+    return join_from(c->side.stream);
+  }
+  int join_big() {
+    if (!big_pending) return OASR_OK;
+    big_pending = false;
+    return join_from(c->side.big);
+  }
+
   int attn_args(Attn& a, const AttnSave& s, bool cross, long Tq, long Tk, bool causal) {
     const int d = c->d;
     memset(&a, 0, sizeof(a));
@@ -430,7 +521,11 @@ struct Runner {
     return OASR_OK;
   }
 
-  int block_fwd(const BlockP& bp, BlockSave& s, const T* x_in, long M, long Tq, const T* xa, bool causal) {
+  int kv_proj(const BlockP& bp, BlockSave& s, const T* xa) {
+    const int d = c->d;
+    return linear(xa, (long)B * c->Te, d, c->template Wt<T>(bp.cattn.kw), 2 * d, c->aux(bp.cattn.fused_bias) + d, 0, nullptr, s.ca.kv, nullptr);
+  }
+  int block_fwd(const BlockP& bp, BlockSave& s, const T* x_in, long M, long Tq, const T* xa, bool causal, hipEvent_t kv_ready = nullptr) {
     const int d = c->d;
     s.x_in = const_cast<T*>(x_in);
     RC(launch_layernorm_fwd(x_in, c->P(bp.attn_ln_w), c->P(bp.attn_ln_b), s.sa.ln, s.sa.mean, s.sa.rstd, M, d, st));
@@ -443,7 +538,10 @@ struct Runner {
     if (bp.cross) {
       RC(launch_layernorm_fwd(xm, c->P(bp.cln_w), c->P(bp.cln_b), s.ca.ln, s.ca.mean, s.ca.rstd, M, d, st));
       RC(linear(s.ca.ln, M, d, c->template Wt<T>(bp.cattn.qw), d, c->P(bp.cattn.qb), 0, nullptr, s.ca.qkv, nullptr));
-      RC(linear(xa, (long)B * c->Te, d, c->template Wt<T>(bp.cattn.kw), 2 * d, c->aux(bp.cattn.fused_bias) + d, 0, nullptr, s.ca.kv, nullptr));
+      if (kv_ready)  // (decoder_fwd issued this layer's key|value projection on the side stream)
+        OASR_CHECK_HIP(hipStreamWaitEvent(st, kv_ready, 0));
+      else
+        RC(kv_proj(bp, s, xa));
       attn_args(a, s.ca, true, Tq, c->Te, false);
       RC(launch_attention_fwd(a, st));
       RC(linear(s.ca.o, M, d, c->template Wt<T>(bp.cattn.ow), d, c->P(bp.cattn.ob), 0, xm, s.x_mid2, nullptr));
@@ -537,9 +635,18 @@ struct Runner {
     const int d = c->d;
     const long Md = dec_rows_fwd ? dec_rows_fwd : (long)B * S;  // token rows the row-wise kernels run over
     RC(launch_embedding_fwd(tokens, c->P(c->tok_emb), c->P(c->dec_pos), p.dx0, B, S, d, c->V, st, dec_rows));
+    const bool kv_side = (side_mode & 2) && train;  // (training plan: every layer has its own key|value buffer)
+    if (kv_side) {
+      RC(fork_to(c->side.big));  // p.xa is complete
+      OnStream on(st, c->side.big);
+      for (int i = 0; i < c->L_dec; ++i) {
+        RC(kv_proj(c->dec[i], p.dec[i], p.xa));
+        OASR_CHECK_HIP(hipEventRecord(c->side.kv_ready[i], st));
+      }
+    }
     const T* x = p.dx0;
     for (int i = 0; i < c->L_dec; ++i) {
-      RC(block_fwd(c->dec[i], p.dec[i], x, Md, S, p.xa, true));
+      RC(block_fwd(c->dec[i], p.dec[i], x, Md, S, p.xa, true, kv_side ? c->side.kv_ready[i] : nullptr));
       x = p.dec[i].x_out;
     }
     RC(launch_layernorm_fwd(x, c->P(c->dec_ln_w), c->P(c->dec_ln_b), p.lnf, p.mean_f, p.rstd_f, Md, d, st));
@@ -573,10 +680,11 @@ struct Runner {
     const int d = c->d;
     const T* xm = bp.cross ? s.x_mid2 : s.x_mid;
     // ---- MLP -----------------------------------------------------------------------------------------------
-    RC(wgrad(dx_out, d, M, d, plain_view(s.hg, 4 * d), 4 * d, c->G(bp.w2), 4 * d));
+    RC(wgrad_side(dx_out, d, M, d, plain_view(s.hg, 4 * d), 4 * d, c->G(bp.w2), 4 * d));
     RC(dgrad(dx_out, M, d, c->template Wt<T>(bp.w2), 4 * d, s.u, nullptr, p.gu, c->G(bp.b1), true));  // s.u = GELU'(u); + fused mlp.0.bias gradient
-    RC(wgrad(p.gu, 4 * d, M, 4 * d, plain_view(s.ln2, d), d, c->G(bp.w1), d));
+    RC(wgrad_side(p.gu, 4 * d, M, 4 * d, plain_view(s.ln2, d), d, c->G(bp.w1), d));
     RC(dgrad(p.gu, M, 4 * d, c->template Wt<T>(bp.w1), d, nullptr, nullptr, p.gln));
+    RC(join_side());
     RC(launch_layernorm_bwd(p.gln, xm, c->P(bp.mlp_ln_w), s.mean2, s.rstd2, dx_out, scratch_a, c->G(bp.mlp_ln_w), c->G(bp.mlp_ln_b),
                             c->G(bp.cross ? bp.cattn.ob : bp.attn.ob), M, d, st));
     const T* dx = scratch_a;
@@ -584,7 +692,7 @@ struct Runner {
     // ---- cross attention ---------------------------------------------------------------------------------------
     if (bp.cross) {
       const long Mkv = (long)B * c->Te;
-      RC(wgrad(dx, d, M, d, plain_view(s.ca.o, d), d, c->G(bp.cattn.ow), d));
+      RC(wgrad_side(dx, d, M, d, plain_view(s.ca.o, d), d, c->G(bp.cattn.ow), d));
       RC(dgrad(dx, M, d, c->template Wt<T>(bp.cattn.ow), d, nullptr, nullptr, p.go));
       Attn a;
       attn_args(a, s.ca, true, Tq, c->Te, false);
@@ -601,12 +709,22 @@ struct Runner {
       // it are not even written)
       a.qtile_flags = dec_span ? nullptr : p.qtile_flags;
       a.q_span = dec_span;
+      RC(join_big());  // (the previous layer's key|value gradients still read p.gkv)
       RC(launch_attention_bwd(a, st));
-      RC(wgrad(p.gq, d, M, d, plain_view(s.ca.ln, d), d, c->G(bp.cattn.qw), d));
-      RC(wgrad(p.gkv, 2 * d, Mkv, 2 * d, plain_view(p.xa, d), d, c->G(bp.cattn.kw), d));
-      // d(xa) accumulates over the decoder layers (bf16, like autograd's accumulation into xa.grad)
-      RC(dgrad(p.gkv, Mkv, 2 * d, c->template Wt<T>(bp.cattn.kw), d, nullptr, first_cross ? nullptr : p.gxa, p.gxa));
+      RC(wgrad_side(p.gq, d, M, d, plain_view(s.ca.ln, d), d, c->G(bp.cattn.qw), d));
+      {
+        const bool big = (side_mode & 4) != 0;
+        if (big) {
+          RC(fork_to(c->side.big));
+          big_pending = true;
+        }
+        OnStream on(st, big ? c->side.big : st);
+        RC(wgrad(p.gkv, 2 * d, Mkv, 2 * d, plain_view(p.xa, d), d, c->G(bp.cattn.kw), d));
+        // d(xa) accumulates over the decoder layers (bf16, like autograd's accumulation into xa.grad)
+        RC(dgrad(p.gkv, Mkv, 2 * d, c->template Wt<T>(bp.cattn.kw), d, nullptr, first_cross ? nullptr : p.gxa, p.gxa));
+      }
       RC(dgrad(p.gq, M, d, c->template Wt<T>(bp.cattn.qw), d, nullptr, nullptr, p.gln));
+      RC(join_side());
       RC(launch_layernorm_bwd(p.gln, s.x_mid, c->P(bp.cln_w), s.ca.mean, s.ca.rstd, dx, nxt, c->G(bp.cln_w), c->G(bp.cln_b),
                               c->G(bp.attn.ob), M, d, st));
       const T* t = dx;
@@ -614,7 +732,7 @@ struct Runner {
       nxt = const_cast<T*>(t);
     }
     // ---- self attention ----------------------------------------------------------------------------------------
-    RC(wgrad(dx, d, M, d, plain_view(s.sa.o, d), d, c->G(bp.attn.ow), d));
+    RC(wgrad_side(dx, d, M, d, plain_view(s.sa.o, d), d, c->G(bp.attn.ow), d));
     RC(dgrad(dx, M, d, c->template Wt<T>(bp.attn.ow), d, nullptr, nullptr, p.go));
     Attn a;
     attn_args(a, s.sa, false, Tq, Tq, causal);
@@ -629,8 +747,9 @@ struct Runner {
     a.qtile_flags = (causal && !dec_span) ? p.qtile_flags : nullptr;  // (decoder blocks only: an encoder block's d_o has no zero rows)
     a.q_span = causal ? dec_span : nullptr;
     RC(launch_attention_bwd(a, st));
-    RC(wgrad(p.gqkv, 3 * d, M, 3 * d, plain_view(s.sa.ln, d), d, c->G(bp.attn.qw), d));
+    RC(wgrad_side(p.gqkv, 3 * d, M, 3 * d, plain_view(s.sa.ln, d), d, c->G(bp.attn.qw), d));
     RC(dgrad(p.gqkv, M, 3 * d, c->template Wt<T>(bp.attn.qw), d, nullptr, nullptr, p.gln));
+    RC(join_side());
     RC(launch_layernorm_bwd(p.gln, s.x_in, c->P(bp.attn_ln_w), s.sa.mean, s.sa.rstd, dx, nxt, c->G(bp.attn_ln_w), c->G(bp.attn_ln_b),
                             dsum_next, M, d, st));
     *dx_in = nxt;
@@ -954,6 +1073,26 @@ unsigned* kv_ctrl(const oasr_ctx* c, void* cache, int B) {  // 256 bytes behind 
 // chip, 4 = the same with 64.  All bit-identical (tests/test_gpu_decode_step.py).
 int g_decode_ln_fold = -1;
 }  // namespace
+// Side streams of the supervised-span step (Runner::side_mode): the setter is a testing hook, OASR_SIDE_STREAMS an experiment switch
+static int g_side_streams = -1;
+static int span_side_streams() {
+  if (g_side_streams >= 0) return g_side_streams;
+  static const int env = [] {
+    const char* e = oasr_experiment_env("OASR_SIDE_STREAMS");
+    return e ? atoi(e) : -1;
+  }();
+  return env >= 0 ? (env & 15) : SIDE_STREAMS_DEFAULT;
+}
+extern "C" int oasr_span_side_streams(void) { return span_side_streams(); }
+extern "C" int oasr_span_set_side_streams(int mode) {
+  const char* e = getenv("OASR_TESTING_HOOKS");
+  if (!(e && e[0] == '1')) {
+    oasr_set_error("oasr_span_set_side_streams: testing hook called without OASR_TESTING_HOOKS=1 (include/oasr_testing.h)");
+    return OASR_ESTATE;
+  }
+  g_side_streams = mode < 0 ? -1 : (mode & 15);
+  return OASR_OK;
+}
 extern "C" int oasr_decode_set_ln_fold(int mode) {
   {  // a testing hook (include/oasr_testing.h): inert without OASR_TESTING_HOOKS=1
     const char* e = getenv("OASR_TESTING_HOOKS");
@@ -1216,8 +1355,14 @@ static int train_backward(oasr_ctx* c, typename Engine<T>::Runner& r, typename E
     const T* dx_in = nullptr;
     RC(r.block_bwd(c->dec[i], p.dec[i], p, dx, sa, sb, Md, S, true, i == c->L_dec - 1, i > 0 ? c->G(c->dec[i - 1].b2) : nullptr, &dx_in));
     dx = dx_in;
+    // the block's event says "every gradient of this block is complete" (the DDP reducer sends the bucket on it): that includes the
+    // key|value weight gradient on the side stream (bit 3, experiments without events: leave it in flight until the next block needs p.gkv)
+    if (ev || !(r.side_mode & 8)) RC(r.join_big());
     RC(r.record(ev, seg++));
   }
+  RC(r.join_side());
+  RC(r.join_big());
+  r.side_mode = 0;  // (the encoder's 192k-row GEMMs fill the chip on their own)
   RC(launch_embedding_bwd(tokens, dx, c->G(c->tok_emb), c->G(c->dec_pos), B, S, d, PAD_ID, c->V, st, r.dec_rows, r.dec_span));
   RC(r.record(ev, seg++));  // decoder.positional_embedding
   RC(r.record(ev, seg++));  // token embedding (arena tail)
@@ -1362,6 +1507,7 @@ static int oasr_train_fwd_bwd_span_impl(oasr_ctx* c, const float* mel, const int
   r.dec_rows_bwd = R;
   r.dec_rows_fwd = forward_rows == OASR_SPAN_FORWARD_ACTIVE ? R : 0;
   r.mel_clip_max = mel_clip_max;
+  if (const int mode = span_side_streams()) RC(r.side_begin(mode));
   // ---------------- forward (every position, unless the caller opted out of the padded ones) ----------------
   RC(r.encoder_fwd(p, mel));
   RC(r.decoder_fwd(p, tokens));

@@ -211,6 +211,52 @@ def test_span_step_equals_plain_step(variant, B, dtype):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("variant,B,dtype", [("tiny", 6, "bfloat16"), ("base", 9, "bfloat16"), ("tiny", 4, "float32")])
+def test_span_step_side_streams_change_nothing_but_the_summation_order(variant, B, dtype, monkeypatch):
+    """The span step's side streams (csrc/engine.hip Runner::side_mode: weight gradients over the active rows, the cross-attention
+    key|value projections and their gradients on lowest-priority streams beside the main chain) against the single-stream step:
+    same loss (the forward's arithmetic does not change), gradients equal up to the order of the fp32 atomics --
+    with and without per-segment events (the events force the key|value gradients' join at every block: the DDP path), twice in a
+    row on the same workspace (a missing join would let step 2 overwrite what step 1's side work still reads)."""
+    from olmoasr_amd import _native as N
+    from olmoasr_amd import ops
+    from olmoasr_amd.config.model_dims import VARIANT_TO_DIMS
+    from olmoasr_amd.model import OLMoASR
+    from olmoasr_amd.synth import synth_samples
+    monkeypatch.setenv("OASR_TESTING_HOOKS", "1")
+    net = OLMoASR(VARIANT_TO_DIMS[variant], device=DEV, seed=0, compute_dtype=dtype)
+    pcm, ti, ty, tl = synth_samples(list(range(40, 40 + B)), DEV)
+    mel = ops.log_mel(pcm)
+    lib = N.lib()
+    try:
+        results = {}
+        for mode in (0, 1, 7, 15):
+            N.check(lib.oasr_span_set_side_streams(mode), "side streams")
+            assert lib.oasr_span_side_streams() == mode
+            for with_events in (False, True):
+                ev = None
+                if with_events:
+                    ev = [torch.cuda.Event() for _ in net.grad_segments()]
+                    for e in ev:
+                        e.record()
+                for rep in range(2):
+                    net.zero_grad()
+                    loss, _ = net.loss_and_backward(mel, ti, ty, tl, loss_scale=1024.0, span=True, segment_events=ev)
+                torch.cuda.synchronize()
+                results[(mode, with_events)] = (float(loss), net.flat_grads.clone())
+        l0, g0 = results[(0, False)]
+        for key, (l, g) in results.items():
+            rel = _rel(g, g0)
+            print(f"   side streams {key} ({variant}, B={B}, {dtype}): loss {l:.7f} vs {l0:.7f}, grads rel-L2 {rel:.2e}")
+            assert abs(l - l0) <= 1e-6 * abs(l0), (key, l, l0)
+            assert rel <= 1e-5, (key, rel)
+            assert bool(torch.isfinite(g).all())
+    finally:
+        lib.oasr_span_set_side_streams(-1)
+    del net
+    torch.cuda.empty_cache()
+
+
 def test_span_step_rejects_bad_spans_and_falls_back():
     from olmoasr_amd import _native as N
     from olmoasr_amd import ops

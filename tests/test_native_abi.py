@@ -172,11 +172,12 @@ def test_testing_hooks_are_inert_without_the_opt_in(native, monkeypatch):
     lib = native.lib()
     monkeypatch.delenv("OASR_TESTING_HOOKS", raising=False)
     for fn, args in ((lib.oasr_gemm_force_general, (1,)), (lib.oasr_attention_set_pingpong, (0,)), (lib.oasr_gemm_set_stagger, (1, 2)),
-                     (lib.oasr_gemm_set_variant, (1,)), (lib.oasr_decode_set_ln_fold, (0,))):
+                     (lib.oasr_gemm_set_variant, (1,)), (lib.oasr_decode_set_ln_fold, (0,)), (lib.oasr_span_set_side_streams, (0,))):
         assert fn(*args) != 0
         assert b"OASR_TESTING_HOOKS" in lib.oasr_last_error()
     monkeypatch.setenv("OASR_TESTING_HOOKS", "1")
     assert lib.oasr_gemm_force_general(0) == 0 and lib.oasr_attention_set_pingpong(1) == 0 and lib.oasr_decode_set_ln_fold(-1) == 0
+    assert lib.oasr_span_set_side_streams(-1) == 0 and 0 <= lib.oasr_span_side_streams() <= 15
 
 
 def test_a_library_of_another_abi_generation_is_refused_before_any_symbol_is_declared(native, tmp_path, monkeypatch):
