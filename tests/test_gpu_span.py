@@ -236,7 +236,7 @@ def test_span_step_side_streams_change_nothing_but_the_summation_order(variant, 
             for with_events in (False, True):
                 ev = None
                 if with_events:
-                    ev = [torch.cuda.Event() for _ in net.grad_segments()]
+                    ev = [torch.cuda.Event() for _ in net.grad_segments]
                     for e in ev:
                         e.record()
                 for rep in range(2):
@@ -249,7 +249,7 @@ def test_span_step_side_streams_change_nothing_but_the_summation_order(variant, 
             rel = _rel(g, g0)
             print(f"   side streams {key} ({variant}, B={B}, {dtype}): loss {l:.7f} vs {l0:.7f}, grads rel-L2 {rel:.2e}")
             assert abs(l - l0) <= 1e-6 * abs(l0), (key, l, l0)
-            assert rel <= 1e-5, (key, rel)
+            assert rel <= 1e-6, (key, rel)  # measured 4-6e-8: the spread between two runs of the single-stream step itself
             assert bool(torch.isfinite(g).all())
     finally:
         lib.oasr_span_set_side_streams(-1)
