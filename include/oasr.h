@@ -145,7 +145,11 @@ int oasr_train_fwd_bwd_s(oasr_ctx*, const float* mel, const int64_t* tokens, con
 #define OASR_SPAN_FORWARD_ALL 0    /* the reference's shape: the decoder's forward covers all n_text_ctx positions */
 #define OASR_SPAN_FORWARD_ACTIVE 1 /* opt-in: the forward leaves the positions past the span out too -- their logits exist in the reference
                                     * (model.py:768-770 over the padded context) but nothing reads them: loss and gradients unchanged */
-/* mel_clip_max: NULL (mel is finished log-mel, as everywhere else), or device f32 [B] with mel = oasr_log_mel_raw's output. */
+/* mel_clip_max: NULL (mel is finished log-mel, as everywhere else), or device f32 [B] with mel = oasr_log_mel_raw's output.
+ * Streams: asynchronous on `stream` like everything else.  Part of the decoder's backward (weight-gradient GEMMs) runs on two lowest-priority
+ * streams the context owns (created on the first call, destroyed by oasr_destroy), forked from and joined back into `stream` with events inside
+ * the call: when the call returns, everything it enqueued is ordered before whatever the caller enqueues on `stream` next, and each
+ * seg_events[i] still means "every gradient of segment i is complete". */
 int oasr_train_fwd_bwd_span(oasr_ctx*, const float* mel, const int64_t* tokens, const int64_t* targets, const int32_t* text_len,
                             const int32_t* span_host, int forward_rows, const float* mel_clip_max, int B, float loss_scale, float inv_accum,
                             float* loss_out, int accumulate_loss, void** seg_events, void* workspace, size_t workspace_bytes, void* stream);
