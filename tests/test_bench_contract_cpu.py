@@ -52,3 +52,5 @@ def test_committed_bench_line_has_the_contract_fields_and_consistent_arithmetic(
     assert rows["plain"][0] == rows["plain"][1] == rows["span-backward"][0] == 256 * 448 and rows["span-forward"][0] == rows["span-forward"][1] == rows["span-backward"][1]
     c = j["config"]
     assert c["micro_batch"] == 128 and c["micro_batch_auto_reduced"] is False and c["workspace_gib"] + c["hbm_margin_gib"] <= c["free_hbm_gib"]
+    # the final binary runs the span step with its side streams (weight gradients beside the data-gradient chain): the line says which
+    assert c.get("side_streams") == 5
