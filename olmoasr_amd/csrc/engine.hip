@@ -40,11 +40,12 @@ struct Segment {
 
 }  // namespace
 
-// Runner::side_mode of the span step.  5 = the decoder backward's R-row weight gradients + the cross-attention key|value gradients on the side
-// streams: -0.7 % of the step (same-box A/B, profiles/r05_side_streams.txt).  7 (+ the forward's key|value projections) measures -1.4 %, and is not
-// the default because those 48 launches share the dominant forward kernel's symbol: as low-priority filler their begin-to-end spans include
-// waiting for compute units, which would turn that kernel's per-launch statistics (bench.py `roofline`, rocprofv3 --stats) into something else.
-constexpr int SIDE_STREAMS_DEFAULT = 5;
+// Runner::side_mode of the span step.  7 = the decoder backward's R-row weight gradients, the cross-attention key|value gradients AND the
+// forward's key|value projections on the lowest-priority side streams: -1.4..-1.55 % of the step against no side streams, -0.7 % against mode 5
+// (same-box A/Bs, profiles/r05_side_streams.txt; round 6 re-measured: profiles/r06_side_streams.txt).  The 48 forward projections share the
+// dominant forward kernel's symbol; as filler their begin-to-end spans are queueing times, so the GEMM launch statistics carry the lane a
+// launch ran on (gemm_profile_lane, set by Runner::OnStream) and bench.py's `roofline` / scripts/rocprof_summary.py price main-stream launches only.
+constexpr int SIDE_STREAMS_DEFAULT = 7;
 
 struct oasr_ctx {
   oasr_dims dims;
@@ -431,8 +432,12 @@ struct Runner {
   struct OnStream {  // launches of this scope go to `to`
     hipStream_t& ref;
     hipStream_t keep;
-    OnStream(hipStream_t& r, hipStream_t to) : ref(r), keep(r) { ref = to; }
-    ~OnStream() { ref = keep; }
+    int lane;  // (bench.py's per-launch GEMM statistics keep side-stream spans -- queueing times -- apart from main-stream kernel times)
+    OnStream(hipStream_t& r, hipStream_t to) : ref(r), keep(r), lane(gemm_profile_lane(to != r ? 1 : -1)) { ref = to; }
+    ~OnStream() {
+      ref = keep;
+      gemm_profile_lane(lane);
+    }
   };
   int side_mode = 0;  // bit 0: R-row weight gradients, bit 1: forward key|value projections, bit 2: backward key|value gradients
   bool side_pending = false, big_pending = false;

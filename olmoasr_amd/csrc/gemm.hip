@@ -42,8 +42,18 @@ struct GemmProfile {
     double flops;
     const char* name;  // kernel symbol as rocprofv3 prints it (template arguments included)
     int M = 0, N = 0, K = 0, epi = 0;  // shape + epilogue summary (bit 0 bias, 1 residual, 2 GELU, 3 GELU' input, 4 colsum, 5 atomic/split-K)
+    int lane = 0;                      // 0 = the caller's stream, 1 = a lowest-priority side stream of the span step (gemm_profile_lane)
   };
   std::vector<Rec> recs;
+  int lane = 0;
+  // A side-stream launch is low-priority filler: its begin-to-end span (HIP events and rocprofv3 alike) includes the time it waits for
+  // compute units behind the main stream's workgroups, so it is a queueing time, not a kernel time.  Records carry the lane they were
+  // launched on and gemm_profile_collect() reports the lanes apart ("symbol [side]"): the roofline of a symbol is that of its main-stream
+  // launches only (profiles/r05_side_streams.txt: mixing them turned 0.40 into 0.33 while the step got faster).
+  void push(Rec r) {
+    r.lane = lane;
+    recs.push_back(r);
+  }
 };
 GemmProfile g_prof;
 bool g_force_general = false;
@@ -1251,7 +1261,7 @@ int launch_fast_cfg(const GemmArgs& a, hipStream_t stream) {
     auto tf = [](bool b) { return b ? "true" : "false"; };
     static const std::string name = std::string("oasr_gemm_fast_kernel<") + tf(TA) + ", " + tf(TB) + ", " + std::to_string(FBN) + ", " +
                                     std::to_string(NWN) + ", " + std::to_string(NSTAGE) + ", " + tf(SWAP) + ", " + tf(CSUM) + ">";
-    g_prof.recs.push_back({(TA ? 2 : 0) + (TB ? 1 : 0), 2.0 * (double)a.M * (double)a.N * (double)a.K, name.c_str(), a.M, a.N, a.K,
+    g_prof.push({(TA ? 2 : 0) + (TB ? 1 : 0), 2.0 * (double)a.M * (double)a.N * (double)a.K, name.c_str(), a.M, a.N, a.K,
                            (a.bias ? 1 : 0) | (a.resid ? 2 : 0) | (a.act ? 4 : 0) | (a.dgelu_u ? 8 : 0) | (a.colsum ? 16 : 0) | (a.atomic ? 32 : 0)});
     OASR_CHECK_HIP(hipEventRecord(e0, stream));
   }
@@ -1309,7 +1319,7 @@ int launch_pp_variant(const GemmArgs& a, hipStream_t stream) {
     auto tf = [](bool b) { return b ? "true" : "false"; };
     static const std::string name = std::string("oasr_gemm_pp_kernel<") + tf(TA) + ", " + tf(TB) + ", " + tf(SWAP) + ", " + tf(CSUM) +
                                     ", " + std::to_string(DMA) + ">";
-    g_prof.recs.push_back({(TA ? 2 : 0) + (TB ? 1 : 0), 2.0 * (double)a.M * (double)a.N * (double)a.K, name.c_str(), a.M, a.N, a.K,
+    g_prof.push({(TA ? 2 : 0) + (TB ? 1 : 0), 2.0 * (double)a.M * (double)a.N * (double)a.K, name.c_str(), a.M, a.N, a.K,
                            (a.bias ? 1 : 0) | (a.resid ? 2 : 0) | (a.act ? 4 : 0) | (a.dgelu_u ? 8 : 0) | (a.colsum ? 16 : 0) | (a.atomic ? 32 : 0)});
     OASR_CHECK_HIP(hipEventRecord(e0, stream));
   }
@@ -1365,7 +1375,7 @@ int launch_skinny(const GemmArgs& a, hipStream_t stream) {
     }
     e0 = g_prof.events[2 * idx];
     e1 = g_prof.events[2 * idx + 1];
-    g_prof.recs.push_back({0, 2.0 * (double)a.M * (double)a.N * (double)a.K, a.M <= 32 ? "gemm_skinny_kernel<1>" : "gemm_skinny_kernel<2>"});
+    g_prof.push({0, 2.0 * (double)a.M * (double)a.N * (double)a.K, a.M <= 32 ? "gemm_skinny_kernel<1>" : "gemm_skinny_kernel<2>"});
     OASR_CHECK_HIP(hipEventRecord(e0, stream));
   }
   if (a.M <= 32)
@@ -1441,7 +1451,7 @@ int launch_t(const GemmArgs& a, hipStream_t stream) {
     const double kk = a.A.rpb ? (double)(a.ta ? a.K : a.A.kvalid) : (double)a.K;
     const double nn = (a.B.rpb && a.tb) ? (double)a.B.kvalid : (double)a.N;
     static const std::string name = std::string("gemm_kernel<") + (TA ? "true" : "false") + ", " + (TB ? "true" : "false") + ">";
-    g_prof.recs.push_back({(TA ? 2 : 0) + (TB ? 1 : 0), 2.0 * (double)a.M * nn * kk, name.c_str()});
+    g_prof.push({(TA ? 2 : 0) + (TB ? 1 : 0), 2.0 * (double)a.M * nn * kk, name.c_str()});
     OASR_CHECK_HIP(hipEventRecord(e0, stream));
   }
   hipLaunchKernelGGL((gemm_kernel<TA, TB>), grid, dim3(256), lds, stream, a);
@@ -1529,6 +1539,11 @@ void gemm_profile_enable(int on) {
   g_prof.on = on != 0;
   if (on) g_prof.recs.clear();
 }
+int gemm_profile_lane(int lane) {
+  const int old = g_prof.lane;
+  if (lane >= 0) g_prof.lane = lane;  // (negative: query only)
+  return old;
+}
 
 // Sums elapsed ms / algorithmic flops / launch count per operand layout (index = 2*ta + tb) and, as text
 // "symbol\tlaunches\tms\tflops\n", per kernel symbol (so bench.py can be checked against rocprofv3's per-kernel
@@ -1549,11 +1564,14 @@ int gemm_profile_collect(double ms[4], double flops[4], long count[4], char* by_
     float t = 0.f;
     OASR_CHECK_HIP(hipEventElapsedTime(&t, g_prof.events[2 * i], g_prof.events[2 * i + 1]));
     const int k = g_prof.recs[i].kind;
-    ms[k] += t;
-    flops[k] += g_prof.recs[i].flops;
-    count[k] += 1;
+    if (!g_prof.recs[i].lane) {  // per-layout totals: main-stream launches only (side-stream spans are queueing times)
+      ms[k] += t;
+      flops[k] += g_prof.recs[i].flops;
+      count[k] += 1;
+    }
     static const bool by_shape = oasr_experiment_env("OASR_PROF_SHAPES") != nullptr;  // experiments: one line per (symbol, shape, epilogue)
     std::string key = g_prof.recs[i].name;
+    if (g_prof.recs[i].lane) key += " [side]";
     if (by_shape) {
       char sfx[96];
       snprintf(sfx, sizeof(sfx), " M=%d N=%d K=%d epi=%d", g_prof.recs[i].M, g_prof.recs[i].N, g_prof.recs[i].K, g_prof.recs[i].epi);

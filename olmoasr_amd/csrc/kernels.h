@@ -75,6 +75,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream);
 int launch_gemm(const GemmArgsF& a, hipStream_t stream);  // fp32 validation kernel: any shape / view, split_k ignored
 // bench-only: time every GEMM launch with HIP events on its stream; collect() sums per variant (2*ta+tb)
 void gemm_profile_enable(int on);
+int gemm_profile_lane(int lane);  // tag the following launches' profile records (0 = main stream, 1 = side stream); returns the old tag
 void gemm_force_general(int on);  // tests: disable the direct-to-LDS fast path
 void gemm_set_variant(int dma_in_mma);  // experiments: ping-pong kernel issues its DMA pieces between the MFMAs
 void gemm_set_stagger(int sleeps, int phases);  // experiments: first-wave phase stagger of the ping-pong kernel

@@ -14,10 +14,11 @@ int16 -- loader threads ``np.load`` into PINNED ring slots zero-padded exactly a
 one asynchronous H2D per micro-batch on a copy stream (0.96 MB per clip instead of the reference's 0.96 MB fp32 mel + 0.8 MB
 mask), the mel on the GPU.  The [448, 448] float mask never exists: ``text_len`` (its first -inf column) is what the kernels take.
 
-Text: the whisper tokenizer (tiktoken vocabulary) and ``olmoasr.utils.TranscriptReader`` (webvtt) are not available offline, so the
-tokenisation itself is a plug: ``text_fn(sample_dict) -> (tokens, timestamp_mode, norm_end)`` = what ``preprocess_text`` computes
-before the shift/pad.  The default reads a pre-tokenised ``"tokens"`` field; INTEGRATION.md shows the reference's own
-``AudioTextDataset.preprocess_text`` wired in as ``text_fn`` where whisper / olmoasr.utils are importable.
+Text: the whisper tokenizer (tiktoken vocabulary) is not available offline, so the tokenizer is a plug.  ``olmoasr_amd/text_layout.py``
+is ``AudioTextDataset.preprocess_text`` itself (WebVTT ``seg_content`` -> the four token layouts, the reference's coin, the > 30 s rules;
+pinned bit-exactly against the reference's own file running, tests/test_token_layout_ref_cpu.py): ``text_fn =
+text_layout.reference_text_fn(tokenizer)`` with any object that has whisper's tokenizer attributes.  The default ``text_fn`` reads a
+pre-tokenised ``"tokens"`` field (what the offline synthetic shards carry).
 """
 import glob
 import gzip

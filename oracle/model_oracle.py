@@ -383,6 +383,76 @@ def pad_sample(tokens, n_text_ctx=448):
     return text_input, text_y, L - 1
 
 
+NO_SPEECH = 50361  # <|nospeech|> of the English-only vocabulary (tokenizer.no_speech; the scripted tokenizer of the a18 pin uses it too)
+
+
+def ms_of(timestamp) -> int:
+    """olmoasr/utils.py:31-47 (convert_to_milliseconds) for "HH:MM:SS.mmm" strings; ints pass through."""
+    if not isinstance(timestamp, str):
+        return int(timestamp)
+    h, m, s, ms = map(float, timestamp.replace(".", ":").split(":"))
+    return int(h * 3600000 + m * 60000 + s * 1000 + ms)
+
+
+def process_empty_transcript(encode, norm_end: int, only_no_ts_mode, rand):
+    """AudioTextDataset._process_empty_transcript, train_timestamps.py:345-393."""
+    nxt = TIMESTAMP_BEGIN + (30000 // 20 if norm_end > 30000 else norm_end // 20)
+    if norm_end >= 30000:
+        return [SOT, NO_TIMESTAMPS, NO_SPEECH, EOT]
+    if only_no_ts_mode is True:
+        return [SOT, NO_TIMESTAMPS] + list(encode("")) + [EOT]
+    if rand() >= 0.5:
+        return [SOT, TIMESTAMP_BEGIN] + list(encode("")) + [nxt, nxt, EOT]
+    return [SOT, NO_TIMESTAMPS] + list(encode("")) + [EOT]
+
+
+def process_non_empty_transcript(transcript, encode, norm_end: int, ts_mode, only_no_ts_mode, rand):
+    """AudioTextDataset._process_non_empty_transcript, train_timestamps.py:395-460, on top of build_token_sequence():
+    transcript = [((start, end), text)] in file order (the items of TranscriptReader's dict)."""
+    transcript = list(transcript)
+    if norm_end > 30000:
+        if len(transcript) > 1:
+            transcript = transcript[:-1]
+            norm_end = transcript[-1][0][1]  # (a "HH:MM:SS.mmm" STRING from here on, as in the reference)
+        only_no_ts_mode = True
+    segs = [(ms_of(a), ms_of(b), list(encode(" " + text.strip()))) for (a, b), text in transcript]
+    want_ts = False
+    if only_no_ts_mode is not True:
+        if rand() >= 0.5:
+            want_ts = ts_mode is True
+    tokens, timestamp_mode = build_token_sequence(segs, norm_end if want_ts else 0, want_ts)
+    return tokens, timestamp_mode, norm_end
+
+
+def preprocess_text(transcript, encode, norm_end, ts_mode, only_no_ts_mode, rand, n_text_ctx=448):
+    """AudioTextDataset.preprocess_text, train_timestamps.py:238-343, after the transcript has been parsed: returns
+    (text_input [448], text_y [448], text_len = first -inf column of the padding mask, timestamp_mode, norm_end)."""
+    timestamp_mode = False
+    norm_end = ms_of(norm_end)
+    if not transcript:
+        tokens = process_empty_transcript(encode, norm_end, only_no_ts_mode, rand)
+        if only_no_ts_mode is False and norm_end < 30000:
+            if rand() >= 0.5:
+                timestamp_mode = True
+    else:
+        tokens, timestamp_mode, norm_end = process_non_empty_transcript(transcript, encode, norm_end, ts_mode, only_no_ts_mode, rand)
+    text_input, text_y, text_len = pad_sample(tokens, n_text_ctx)
+    return text_input, text_y, text_len, timestamp_mode, norm_end
+
+
+def sched_rule(train_steps: int, world_size: int, train_batch_size: int, eff_batch_size: int):
+    """prepare_sched, train_timestamps.py:739-783: (accumulation_steps, warmup_steps, lr factor as a function of the step)."""
+    import math
+    accum = 1 if eff_batch_size <= world_size * train_batch_size else eff_batch_size // (world_size * train_batch_size)
+    warmup = math.ceil(0.002 * train_steps)
+
+    def factor(step: int) -> float:
+        if step < warmup:
+            return float(step) / float(max(1, warmup))
+        return max(0.0, float(train_steps - step) / float(max(1, train_steps - warmup)))
+    return accum, warmup, factor
+
+
 def synthetic_sample(index: int, n_text_ctx=448, timestamps: bool = False):
     """Deterministic (audio int16 [480000], text_input i64 [448], text_y i64 [448], text_len).
     timestamps=True: the same audio and text body cut into 1-4 transcript segments whose boundaries are multiples of
