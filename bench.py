@@ -603,10 +603,15 @@ def main():
                 name, n, t, f = line.split("\t")
                 sym[name] = {"launches": int(n), "ms": float(t), "flops": float(f)}
         # launches made on the span step's lowest-priority side streams are reported apart ("symbol [side]", csrc/gemm.hip GemmProfile::lane):
-        # their begin-to-end spans are queueing times, so the dominant kernel and its roofline are taken over main-stream launches only
-        main_sym = {k: v for k, v in sym.items() if not k.endswith(" [side]")}
+        # their begin-to-end spans are queueing times.  Main-stream launches of the decoder phases, which share the chip with that filler
+        # ("symbol [shared]"), give up compute units to it and run longer for it.  The dominant kernel and its roofline are taken over the
+        # launches that have the chip to themselves; every row is in by_symbol, and main_stream_all gives the symbol's whole main-stream average
+        main_sym = {k: v for k, v in sym.items() if not k.endswith("]")}
         dom = max(main_sym, key=lambda k: main_sym[k]["ms"])
         dsym = main_sym[dom]
+        shared = sym.get(dom + " [shared]")
+        main_all = {"launches": dsym["launches"] + (shared["launches"] if shared else 0), "ms": dsym["ms"] + (shared["ms"] if shared else 0.0),
+                    "flops": dsym["flops"] + (shared["flops"] if shared else 0.0)}
         achieved = dsym["flops"] / dsym["ms"] / 1e9
         traffic = traffic_src = None
         if args.traffic_json and os.path.exists(args.traffic_json):  # HBM bytes per launch from the PMC passes (profiles/)
@@ -623,7 +628,11 @@ def main():
                 "by_symbol": {k: {"launches": v["launches"], "avg_us": round(1000.0 * v["ms"] / v["launches"], 2),
                                   "tflops": round(v["flops"] / v["ms"] / 1e9, 1)} for k, v in sorted(sym.items(), key=lambda kv: -kv[1]["ms"])},
                 "by_symbol_note": "'[side]' = launches on the span step's lowest-priority side streams: begin-to-end spans that include waiting for "
-                                  "compute units (queueing times, overlapping the main stream in wall time); every other row, `kernel` and `frac` are main-stream launches",
+                                  "compute units (queueing times, overlapping the main stream in wall time); '[shared]' = main-stream launches of the decoder "
+                                  "phases, running beside that filler; `kernel` / `frac` / `avg_launch_us` = the symbol's launches with the chip to themselves",
+                "main_stream_all": {"launches": main_all["launches"], "avg_us": round(1000.0 * main_all["ms"] / main_all["launches"], 2),
+                                    "tflops": round(main_all["flops"] / main_all["ms"] / 1e9, 1),
+                                    "frac": round(main_all["flops"] / main_all["ms"] / 1e9 / PEAK_BF16_TFLOPS, 4)},
                 "by_layout_tflops": {layouts[k]: round(fl[k] / ms[k] / 1e9, 1) for k in range(4) if cnt[k]},
                 "gemm_ms_per_step": round(sum(ms), 2)}
         # where the board actually was during the profiled step (live hwmon sample).  Reference points that were NOT measured in this

@@ -22,6 +22,7 @@ extern "C" {
 #define OASR_EINVAL (-1)
 #define OASR_EHIP (-2)
 #define OASR_ESTATE (-3)
+#define OASR_ERETRY (-4) /* oasr_decode_check: the window's steps must be enqueued again (the context changed engines; see there) */
 
 typedef struct oasr_ctx oasr_ctx;
 
@@ -34,7 +35,7 @@ typedef struct oasr_dims {
 const char* oasr_last_error(void);
 /* ABI version: 100 * major + minor.  Structs passed by pointer (oasr_attn_args, oasr_gemm_args) only grow at the end and only with a
  * major bump; olmoasr_amd/_native.py refuses to drive a library whose version differs from OASR_ABI_VERSION. */
-#define OASR_ABI_VERSION 200
+#define OASR_ABI_VERSION 210
 int oasr_version(void);
 
 /* ---- log-mel front end: whisper.audio.log_mel_spectrogram as called at train_timestamps.py:196,214 and
@@ -108,15 +109,18 @@ int oasr_decode_logits(oasr_ctx*, const int64_t* tokens, const void* xa, const i
  * Engines (all bit-identical, csrc/decode_shared.h): ONE sequence on the bf16 engine -> one persistent launch for the whole decoder
  * stack (csrc/decode_xcd.hip: a team of 32 CUs, weights and cross K/V prefetched through LDS rings); 2-4 sequences -> LayerNorm folded
  * into the projections' operand loads; more -> separate kernels.  The one-launch engine keeps four control words in the cache's last
- * 256 bytes (zeroed by decode_begin): a team member that never reaches a barrier poisons a flag instead of hanging, and
- * oasr_decode_check reports it as OASR_ESTATE. */
+ * 256 bytes (zeroed by decode_begin; the cache is oasr_kv_cache_bytes(B) bytes INCLUDING that tail -- ABI 210; a caller that re-packs
+ * a cache, e.g. the beam re-gather of whisper's rearrange_kv_cache, zeroes the tail of the new buffer).  The team needs its 32 workgroups
+ * resident at once, i.e. the device to itself: a team member that never reaches a barrier (a second decoder on the device, a CU mask)
+ * poisons a flag instead of hanging; oasr_decode_check then clears it, switches the CONTEXT to the multi-launch engine for good and
+ * returns OASR_ERETRY: the caller decodes the window again. */
 size_t oasr_kv_cache_bytes(const oasr_ctx*, int B);
 size_t oasr_decode_step_workspace_bytes(const oasr_ctx*, int B);
 int oasr_decode_begin(oasr_ctx*, const void* xa, int B, void* kv_cache, void* stream);
 int oasr_decode_step(oasr_ctx*, const int64_t* tokens_last, int B, int pos, void* kv_cache, float* logits_out, void* workspace,
                      size_t workspace_bytes, void* stream);
 /* Synchronises the stream and checks the one-launch engine's error flag: call once per decoded window, where the caller reads the
- * tokens back. */
+ * tokens back.  OASR_OK, or OASR_ERETRY (see above: enqueue the window's begin / steps again; at most once per context). */
 int oasr_decode_check(oasr_ctx*, int B, void* kv_cache, void* stream);
 
 /* One micro-step of train() (train_timestamps.py:1440-1454): forward, CE(ignore_index=pad)/accum, backward.

@@ -44,7 +44,7 @@ class AttnArgs(C.Structure):
                 ("q_rows", C.c_void_p), ("k_rows", C.c_void_p), ("q_span", C.c_void_p)]
 
 
-ABI_VERSION = 200  # include/oasr.h: OASR_ABI_VERSION
+ABI_VERSION = 210  # include/oasr.h: OASR_ABI_VERSION (210: KV cache carries a 256-byte control tail, OASR_ERETRY from oasr_decode_check)
 ROWTAB = 16        # include/oasr.h: OASR_ROWTAB (entries per sample of a chunk-row table)
 
 
@@ -157,6 +157,9 @@ def lib():
 def enable_testing_hooks():
     """Opt this process in to the kernel-selection setters of include/oasr_testing.h (they are inert otherwise)."""
     os.environ["OASR_TESTING_HOOKS"] = "1"
+
+
+ERETRY = -4  # include/oasr.h: OASR_ERETRY
 
 
 def check(rc, what=""):

@@ -20,6 +20,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
 #define OASR_EINVAL (-1)
 #define OASR_EHIP (-2)
 #define OASR_ESTATE (-3)
+#define OASR_ERETRY (-4)
 
 void oasr_set_error(const char* fmt, ...);
 

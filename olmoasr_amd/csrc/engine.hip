@@ -75,6 +75,9 @@ struct oasr_ctx {
     unsigned nf = 0, nj = 0;
   };
   mutable Side side;
+  // set by oasr_decode_check when the one-launch decoder step (decode_xcd.hip) reported a poisoned team barrier: its 32 workgroups must be
+  // resident at once, which a shared / CU-masked device does not guarantee.  From then on this context decodes on the multi-launch engine.
+  bool xcd_disabled = false;
   ~oasr_ctx() {
     for (hipEvent_t e : side.fork)
       if (e) (void)hipEventDestroy(e);
@@ -444,14 +447,29 @@ struct Runner {
   int side_begin(int mode) {
     oasr_ctx::Side& sd = c->side;
     if (!sd.stream) {
-      int least = 0, greatest = 0;
-      OASR_CHECK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-      OASR_CHECK_HIP(hipStreamCreateWithPriority(&sd.stream, hipStreamNonBlocking, least));
-      OASR_CHECK_HIP(hipStreamCreateWithPriority(&sd.big, hipStreamNonBlocking, least));
-      for (hipEvent_t& e : sd.fork) OASR_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-      for (hipEvent_t& e : sd.join) OASR_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-      sd.kv_ready.assign((size_t)c->L_dec, nullptr);
-      for (hipEvent_t& e : sd.kv_ready) OASR_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      // built into a local and published only when every call has succeeded: a failure half way must not leave a non-null stream
+      // beside null events for the next step to trip over (whatever was created is destroyed again)
+      oasr_ctx::Side nw;
+      nw.kv_ready.assign((size_t)c->L_dec, nullptr);
+      auto build = [&]() -> int {
+        int least = 0, greatest = 0;
+        OASR_CHECK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        OASR_CHECK_HIP(hipStreamCreateWithPriority(&nw.stream, hipStreamNonBlocking, least));
+        OASR_CHECK_HIP(hipStreamCreateWithPriority(&nw.big, hipStreamNonBlocking, least));
+        for (hipEvent_t& e : nw.fork) OASR_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (hipEvent_t& e : nw.join) OASR_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (hipEvent_t& e : nw.kv_ready) OASR_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        return OASR_OK;
+      };
+      if (const int rc = build()) {
+        for (hipEvent_t e : nw.fork) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : nw.join) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : nw.kv_ready) if (e) (void)hipEventDestroy(e);
+        if (nw.stream) (void)hipStreamDestroy(nw.stream);
+        if (nw.big) (void)hipStreamDestroy(nw.big);
+        return rc;
+      }
+      sd = nw;
     }
     side_mode = mode;
     return OASR_OK;
@@ -641,6 +659,8 @@ struct Runner {
     const long Md = dec_rows_fwd ? dec_rows_fwd : (long)B * S;  // token rows the row-wise kernels run over
     RC(launch_embedding_fwd(tokens, c->P(c->tok_emb), c->P(c->dec_pos), p.dx0, B, S, d, c->V, st, dec_rows));
     const bool kv_side = (side_mode & 2) && train;  // (training plan: every layer has its own key|value buffer)
+    // launch statistics: from here until the backward's last join the main stream shares the chip with side-stream filler (lane 2, "[shared]")
+    if (side_mode && train) gemm_profile_lane(2);
     if (kv_side) {
       RC(fork_to(c->side.big));  // p.xa is complete
       OnStream on(st, c->side.big);
@@ -1175,7 +1195,7 @@ static int oasr_decode_step_impl(oasr_ctx* c, const int64_t* tokens_last, int B,
     const int mode = g_decode_ln_fold;
     // (default: ONE sequence -- the timestamp-mode transcribe loop; measured 1.75 vs 2.44 ms per token at medium, 0.85 vs 0.94 at small; at small B = 4
     // the multi-launch kernels, which spread over the whole chip, win: profiles/r05_decode_xcd_probe_v8.txt.  Modes 2-4 force it up to B = 4.)
-    if (((mode == -1 && B == 1) || mode >= 2) && !c->xcd_offsets.empty() && decode_xcd_supports(d, c->H, c->Te, S_max, c->L_dec, B)) {
+    if (((mode == -1 && B == 1) || mode >= 2) && !c->xcd_disabled && !c->xcd_offsets.empty() && decode_xcd_supports(d, c->H, c->Te, S_max, c->L_dec, B)) {
       DecodeXcdArgs xa;
       xa.wflat = c->template Wt<bf16_t>(0);
       xa.params = c->params;
@@ -1296,9 +1316,17 @@ extern "C" int oasr_decode_check(oasr_ctx* c, int B, void* kv_cache, void* strea
   unsigned ctrl[4] = {0, 0, 0, 0};  // the one-launch step engine's control words: a poisoned team barrier / a desynchronised stream is an error
   OASR_CHECK_HIP(hipMemcpy(ctrl, kv_ctrl(c, kv_cache, B), sizeof(ctrl), hipMemcpyDeviceToHost));
   if (ctrl[1] != 0) {
-    oasr_set_error("oasr_decode_check: the one-launch decoder step reported 0x%x (1 = a team member never reached a barrier, 0x1xx = block stream "
-                   "out of step); XCC mask 0x%x", ctrl[1], ctrl[3]);
-    return OASR_ESTATE;
+    // The one-launch engine needs its whole team (32 workgroups x ~160 KB of LDS on one XCD) resident at once; a second decoder on the same
+    // device, or a CU-masked / partitioned device, can leave part of a team queued behind the rest, and the bounded spin then poisons the
+    // barrier instead of hanging.  Nothing is wrong with the cache's K/V rows written before that step, but the window's tokens are: the
+    // context falls back to the multi-launch engine for good, the control words are cleared, and the caller re-decodes the window
+    // (olmoasr_amd.decoding.decode does; OASR_ERETRY says "same call again").
+    c->xcd_disabled = true;
+    OASR_CHECK_HIP(hipMemset(kv_ctrl(c, kv_cache, B), 0, 256));
+    oasr_set_error("oasr_decode_check: the one-launch decoder step reported 0x%x (1 = a team member never reached a barrier -- is the device "
+                   "shared or CU-masked? --, 0x1xx = block stream out of step); XCC mask 0x%x.  The one-launch engine is now disabled for this "
+                   "context; decode the window again (it will run on the multi-launch engine)", ctrl[1], ctrl[3]);
+    return OASR_ERETRY;
   }
   return OASR_OK;
 }
@@ -1368,6 +1396,7 @@ static int train_backward(oasr_ctx* c, typename Engine<T>::Runner& r, typename E
   RC(r.join_side());
   RC(r.join_big());
   r.side_mode = 0;  // (the encoder's 192k-row GEMMs fill the chip on their own)
+  gemm_profile_lane(0);
   RC(launch_embedding_bwd(tokens, dx, c->G(c->tok_emb), c->G(c->dec_pos), B, S, d, PAD_ID, c->V, st, r.dec_rows, r.dec_span));
   RC(r.record(ev, seg++));  // decoder.positional_embedding
   RC(r.record(ev, seg++));  // token embedding (arena tail)

@@ -42,14 +42,16 @@ struct GemmProfile {
     double flops;
     const char* name;  // kernel symbol as rocprofv3 prints it (template arguments included)
     int M = 0, N = 0, K = 0, epi = 0;  // shape + epilogue summary (bit 0 bias, 1 residual, 2 GELU, 3 GELU' input, 4 colsum, 5 atomic/split-K)
-    int lane = 0;                      // 0 = the caller's stream, 1 = a lowest-priority side stream of the span step (gemm_profile_lane)
+    int lane = 0;                      // 0 = the caller's stream with the chip to itself, 1 = a lowest-priority side stream of the span step,
+                                       // 2 = the caller's stream while side-stream filler is in flight (gemm_profile_lane)
   };
   std::vector<Rec> recs;
   int lane = 0;
   // A side-stream launch is low-priority filler: its begin-to-end span (HIP events and rocprofv3 alike) includes the time it waits for
   // compute units behind the main stream's workgroups, so it is a queueing time, not a kernel time.  Records carry the lane they were
-  // launched on and gemm_profile_collect() reports the lanes apart ("symbol [side]"): the roofline of a symbol is that of its main-stream
-  // launches only (profiles/r05_side_streams.txt: mixing them turned 0.40 into 0.33 while the step got faster).
+  // launched on and gemm_profile_collect() reports the lanes apart ("symbol [side]"; "symbol [shared]" = main-stream launches of the decoder
+  // phases, which give up compute units to that filler and run longer for it): the roofline of a symbol is that of the launches that have
+  // the chip to themselves (profiles/r05_side_streams.txt: mixing them turned 0.40 into 0.33 while the step got faster).
   void push(Rec r) {
     r.lane = lane;
     recs.push_back(r);
@@ -1564,14 +1566,14 @@ int gemm_profile_collect(double ms[4], double flops[4], long count[4], char* by_
     float t = 0.f;
     OASR_CHECK_HIP(hipEventElapsedTime(&t, g_prof.events[2 * i], g_prof.events[2 * i + 1]));
     const int k = g_prof.recs[i].kind;
-    if (!g_prof.recs[i].lane) {  // per-layout totals: main-stream launches only (side-stream spans are queueing times)
+    if (g_prof.recs[i].lane != 1) {  // per-layout totals: main-stream launches only (side-stream spans are queueing times)
       ms[k] += t;
       flops[k] += g_prof.recs[i].flops;
       count[k] += 1;
     }
     static const bool by_shape = oasr_experiment_env("OASR_PROF_SHAPES") != nullptr;  // experiments: one line per (symbol, shape, epilogue)
     std::string key = g_prof.recs[i].name;
-    if (g_prof.recs[i].lane) key += " [side]";
+    if (g_prof.recs[i].lane) key += g_prof.recs[i].lane == 1 ? " [side]" : " [shared]";
     if (by_shape) {
       char sfx[96];
       snprintf(sfx, sizeof(sfx), " M=%d N=%d K=%d epi=%d", g_prof.recs[i].M, g_prof.recs[i].N, g_prof.recs[i].K, g_prof.recs[i].epi);

@@ -169,6 +169,18 @@ def decode(model, mel: torch.Tensor, options: Optional[DecodingOptions] = None, 
     """``mel``: [80, 3000] or [n, 80, 3000] windows (or already-encoded audio features).  Returns DecodingResult / list.
     With a ``tokenizer`` (see ``resolve_tokenizer``) the results carry ``text`` and ``compression_ratio`` exactly as
     whisper.decoding.DecodingTask.run fills them: text = tokenizer.decode(tokens without timestamps).strip()."""
+    out = _decode(model, mel, options, tokenizer, kwargs)
+    if out is _RETRY:  # oasr_decode_check switched the context to the multi-launch step engine (model.kv_cache_check): same window again
+        out = _decode(model, mel, options, tokenizer, kwargs)
+        if out is _RETRY:
+            raise RuntimeError("decode: the step engine asked for a second retry of one window")
+    return out
+
+
+_RETRY = object()
+
+
+def _decode(model, mel, options, tokenizer, kwargs):
     if options is None:
         options = DecodingOptions(**kwargs)
     elif kwargs:
@@ -313,8 +325,8 @@ def decode(model, mel: torch.Tensor, options: Optional[DecodingOptions] = None, 
         return max(cands, key=score)
 
     results = []
-    if state is not None:
-        model.kv_cache_check(state)
+    if state is not None and not model.kv_cache_check(state):
+        return _RETRY
     tok_cpu, sums = tokens.cpu(), sum_logprobs.cpu()
     for a in range(n_audio):
         if beam:

@@ -20,6 +20,8 @@ import math
 from typing import Optional
 
 import numpy as np
+import warnings
+
 import torch
 from torch import Tensor, nn
 
@@ -125,6 +127,7 @@ class _EngineKV:
         lib = N.lib()
         cache = torch.empty(lib.oasr_kv_cache_bytes(m._ctx, Bn), dtype=torch.uint8, device=flat.device)
         cache[: (n_self + n_cross) // B * Bn * L * esz].view(m._act_dtype).copy_(torch.cat(parts, 1).reshape(-1))
+        cache[-256:].zero_()  # the one-launch step engine's control words (include/oasr.h, "Cached greedy decoding"): only decode_begin zeroes them
         ws = torch.empty(lib.oasr_decode_step_workspace_bytes(m._ctx, Bn), dtype=torch.uint8, device=flat.device)
         return _EngineKV(m, {"cache": cache, "ws": ws, "B": Bn, "pos": self.state["pos"]})
 
@@ -709,10 +712,18 @@ class OLMoASR(nn.Module):
             rows = flat[layer, :n_self].view(B, self.dims.n_text_ctx, 3 * d)[:, :pos, d:]
             rows.copy_(rows.index_select(0, idx))
 
-    def kv_cache_check(self, state) -> None:
-        """Synchronises the stream (oasr_decode_check); call once per decoded window, before reading the tokens back."""
+    def kv_cache_check(self, state) -> bool:
+        """Synchronises the stream (oasr_decode_check); call once per decoded window, before reading the tokens back.  False: the
+        one-launch step engine could not keep its team resident (a shared or CU-masked device) and the context has switched to the
+        multi-launch engine -- the window's tokens are void and the caller decodes it again (``decoding.decode`` does)."""
         with torch.cuda.device(state["cache"].device):
-            N.check(N.lib().oasr_decode_check(self._ctx, state["B"], N.ptr(state["cache"]), N.stream_ptr()), "oasr_decode_check")
+            rc = N.lib().oasr_decode_check(self._ctx, state["B"], N.ptr(state["cache"]), N.stream_ptr())
+        if rc == N.ERETRY:
+            msg = N.lib().oasr_last_error()
+            warnings.warn(f"decode window repeated: {msg.decode() if msg else 'oasr_decode_check asked for a retry'}")
+            return False
+        N.check(rc, "oasr_decode_check")
+        return True
 
     def install_kv_cache_hooks(self, cache: Optional[dict] = None):
         """olmoasr/model.py:925-964.  The reference hooks every key/value Linear and keeps their outputs in a dict; here the

@@ -95,3 +95,76 @@ def test_decode_through_every_step_engine(tiny_case):
             N.lib().oasr_decode_set_ln_fold(-1)
         for a, b in zip(r_f, r_m):
             assert a.tokens == b.tokens and abs(a.avg_logprob - b.avg_logprob) < 1e-6
+
+
+def test_reindexed_cache_steps_on_the_one_launch_engine(tiny_case):
+    """whisper's rearrange_kv_cache path (``cache[module][source_indices]``, model._EngineKV.__getitem__) builds a NEW cache buffer: its
+    256-byte control tail (barrier counter, error flag, epoch base, XCC mask) must start zeroed like decode_begin leaves it -- a re-indexed
+    one-sequence cache continues on the one-launch engine bit-identically to the original, and the window's check stays clean."""
+    from olmoasr_amd import _native as N
+    from olmoasr_amd.model import OLMoASR, _EngineKV
+    from oracle import model_oracle as mo
+    dims = mo.Dims(80, 1500, 512, 8, 1, 51864, 448, 512, 8, 2)
+    net = OLMoASR(_dims(dims), device=DEV, seed=4, inference=True)
+    mel = tiny_case["mel"].to(DEV)
+    xa = net.embed_audio(mel)  # two sequences
+    toks = torch.randint(0, 50000, (2, 8), generator=torch.Generator().manual_seed(2)).to(DEV)
+    toks[:, 0] = 50257
+    N.lib().oasr_decode_set_ln_fold(2)
+    try:
+        st = net.kv_cache_begin(xa)
+        for p in range(4):
+            net.kv_cache_step(st, toks[:, p])
+        # garbage where a fresh torch.empty could have it: the allocator hands this block out again for the re-indexed cache
+        junk = torch.full((N.lib().oasr_kv_cache_bytes(net._ctx, 1),), 0xA5, dtype=torch.uint8, device=DEV)
+        del junk
+        one = _EngineKV(net, st)[[1]].state  # sequence 1 alone: B = 1
+        assert one["B"] == 1 and int(one["cache"][-256:].to(torch.int32).sum()) == 0
+        ref = [net.kv_cache_step(st, toks[:, p])[1] for p in range(4, 8)]
+        got = [net.kv_cache_step(one, toks[1:, p])[0] for p in range(4, 8)]
+        assert net.kv_cache_check(one) is True and net.kv_cache_check(st) is True
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b)
+    finally:
+        N.lib().oasr_decode_set_ln_fold(-1)
+
+
+def test_poisoned_one_launch_engine_falls_back_to_the_multi_launch_engine(tiny_case):
+    """A team of the one-launch engine that cannot be resident at once (shared / CU-masked device) poisons its barrier flag instead of
+    hanging.  oasr_decode_check then returns OASR_ERETRY once, clears the flag and disables the one-launch engine for the CONTEXT;
+    ``decode`` repeats the window and returns the tokens of the multi-launch engine."""
+    import warnings
+    from olmoasr_amd.decoding import DecodingOptions, decode
+    from olmoasr_amd.model import OLMoASR
+    from oracle import model_oracle as mo
+    dims = mo.Dims(80, 1500, 512, 8, 1, 51864, 448, 512, 8, 2)
+    net = OLMoASR(_dims(dims), device=DEV, seed=9, inference=True)
+    mel = tiny_case["mel"][:1].to(DEV)
+    opts = DecodingOptions(sample_len=6, use_kv_cache=True, without_timestamps=True)
+    clean = decode(net, mel, opts)
+    xa = net.embed_audio(mel)
+    st = net.kv_cache_begin(xa)
+    net.kv_cache_step(st, torch.tensor([50257], device=DEV))
+    st["cache"][-256:].view(torch.int32)[1] = 1  # what a timed-out team barrier writes
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert net.kv_cache_check(st) is False
+    assert w and "multi-launch" in str(w[0].message)
+    assert int(st["cache"][-256:].view(torch.int32)[1]) == 0 and net.kv_cache_check(st) is True  # flag cleared, context switched
+    again = decode(net, mel, opts)  # multi-launch engine now (bit-identical engines)
+    assert again[0].tokens == clean[0].tokens and abs(again[0].avg_logprob - clean[0].avg_logprob) < 1e-6
+    # decode() itself repeats a window whose check asks for it
+    net2 = OLMoASR(_dims(dims), device=DEV, seed=9, inference=True)
+    calls = {"n": 0}
+    real = net2.kv_cache_check
+
+    def poison_first(state):
+        calls["n"] += 1
+        if calls["n"] == 1:
+            state["cache"][-256:].view(torch.int32)[1] = 1
+        return real(state)
+    net2.kv_cache_check = poison_first
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        r = decode(net2, mel, opts)
+    assert calls["n"] == 2 and r[0].tokens == clean[0].tokens
