@@ -34,6 +34,9 @@ int oasr_span_side_streams(void);
 /* tests (CPU): the static block stream of workgroup `wg` of the one-launch step engine as its cursors generate it: out[4 i ..] = layer,
  * segment (0 qkv, 1 attn.out, 2 cross q, 3 cross K/V, 4 cross out, 5 mlp.0, 6 mlp.2), tile / item ordinal, block; returns the count. */
 int oasr_xcd_plan_debug(int d, int H, int Te, int M, int L, int team, int wg, int* out, int max_blocks);
+/* tests (CPU): 1 when every 32-bit buffer offset of a one-launch step stays below 2 GiB (layer0 = the 18 element offsets of decoder layer 0
+ * in csrc/decode_xcd.hip::XLayer order, strides in elements), 0 when the engine must take the multi-launch step instead. */
+int oasr_xcd_offsets_ok_debug(const int64_t* layer0, long long lstride, long long cache_lstride, int d, int Te, int L, int M);
 /* tests / A-B: 1 (default) = the unmasked attention cases (encoder self-, cross-attention) run the 8-wave ping-pong kernels,
  * 0 = the general (maskable) kernels run everything.  Same results up to accumulation order (tests/test_gpu_ops.py). */
 int oasr_attention_set_pingpong(int on);

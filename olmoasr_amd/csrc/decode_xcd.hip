@@ -935,6 +935,28 @@ bool decode_xcd_supports(int d, int H, int Te, int S_max, int L, int M) {
          Te <= dec::MAX_SEG * dec::SEG_KEYS && Te >= 1 && H * dec::n_segments(Te) <= XMAXPAIR;
 }
 
+// The ring DMA addresses everything through raw buffer descriptors with 32-bit byte offsets from the start of the bf16 weight shadow and
+// from layer 0's cross K/V rows (rsrc_of / dma16: num_records 0x7fffffff): an offset at or past 2 GiB would read zeros without any error.
+// True when the furthest byte any block of this launch can address stays below that (weights: OLMoASR-large ends at ~1.7 GB because the
+// decoder sits at the start of the arena); the engine takes the multi-launch step otherwise.
+bool decode_xcd_offsets_ok(const int64_t* layer0, long lstride, long cache_lstride, int d, int Te, int L, int M) {
+  const long kLimit = (1L << 31) - (1L << 20);  // 1 MiB of slack for the per-lane part of an address
+  long w_end = 0;
+  const int wsel[6] = {2, 4, 8, 10, 14, 16};  // XLayer: wqkv, wo, wcq, wco, w1, w2
+  const long wsize[6] = {3L * d * d, (long)d * d, (long)d * d, (long)d * d, 4L * d * d, 4L * d * d};
+  for (int k = 0; k < 6; ++k) {
+    if (layer0[wsel[k]] < 0) return false;
+    const long e = layer0[wsel[k]] + (long)(L - 1) * lstride + wsize[k];
+    w_end = e > w_end ? e : w_end;
+  }
+  const long kv_end = (long)(L - 1) * cache_lstride + (long)M * Te * 2 * d;  // from layer 0's cross K/V rows
+  return lstride >= 0 && cache_lstride >= 0 && w_end * 2 < kLimit && kv_end * 2 < kLimit;
+}
+
+extern "C" int oasr_xcd_offsets_ok_debug(const int64_t* layer0, long long lstride, long long cache_lstride, int d, int Te, int L, int M) {
+  return decode_xcd_offsets_ok(layer0, (long)lstride, (long)cache_lstride, d, Te, L, M) ? 1 : 0;
+}
+
 // Debug / CPU test: the block sequence (seg, idx, sub) of workgroup `wg` as the kernel's cursors generate it
 extern "C" int oasr_xcd_plan_debug(int d, int H, int Te, int M, int L, int team, int wg, int* out, int max_blocks) {
   const XGeom g = make_geom(d, H, Te, M, L, team, wg);
@@ -953,6 +975,8 @@ int launch_decode_xcd(const DecodeXcdArgs& h, hipStream_t s) {
   OASR_REQUIRE(decode_xcd_supports(h.d, h.H, h.Te, h.S_max, h.L, h.M), "decode_xcd: unsupported shape (d=%d H=%d Te=%d S=%d L=%d M=%d)", h.d, h.H,
                h.Te, h.S_max, h.L, h.M);
   OASR_REQUIRE(h.team >= 1 && h.team <= 256 && (h.stride == 1 || h.stride == 8) && h.pos >= 0 && h.pos < h.S_max, "decode_xcd: bad launch shape");
+  OASR_REQUIRE(decode_xcd_offsets_ok(h.layer_offsets, h.lstride, h.cache_lstride, h.d, h.Te, h.L, h.M),
+               "decode_xcd: a weight / cross K/V byte offset reaches 2 GiB (32-bit buffer offsets); use the multi-launch step");
   XArgs a;
   a.wflat = h.wflat, a.params = h.params, a.aux = h.aux, a.cache = h.cache, a.cache_lstride = h.cache_lstride;
   a.x = h.x, a.x2 = h.x2, a.x3 = h.x3, a.q = h.q, a.o = h.o, a.hg = h.hg, a.part = h.part, a.ctrl = h.ctrl;

@@ -1195,7 +1195,8 @@ static int oasr_decode_step_impl(oasr_ctx* c, const int64_t* tokens_last, int B,
     const int mode = g_decode_ln_fold;
     // (default: ONE sequence -- the timestamp-mode transcribe loop; measured 1.75 vs 2.44 ms per token at medium, 0.85 vs 0.94 at small; at small B = 4
     // the multi-launch kernels, which spread over the whole chip, win: profiles/r05_decode_xcd_probe_v8.txt.  Modes 2-4 force it up to B = 4.)
-    if (((mode == -1 && B == 1) || mode >= 2) && !c->xcd_disabled && !c->xcd_offsets.empty() && decode_xcd_supports(d, c->H, c->Te, S_max, c->L_dec, B)) {
+    if (((mode == -1 && B == 1) || mode >= 2) && !c->xcd_disabled && !c->xcd_offsets.empty() && decode_xcd_supports(d, c->H, c->Te, S_max, c->L_dec, B) &&
+        decode_xcd_offsets_ok(c->xcd_offsets.data(), c->xcd_lstride, (long)3 * B * S_max * d + (long)B * c->Te * 2 * d, d, c->Te, c->L_dec, B)) {
       DecodeXcdArgs xa;
       xa.wflat = c->template Wt<bf16_t>(0);
       xa.params = c->params;

@@ -173,6 +173,8 @@ struct DecodeXcdArgs {
 };
 int launch_decode_xcd(const DecodeXcdArgs& a, hipStream_t s);
 bool decode_xcd_supports(int d, int H, int Te, int S_max, int L, int M);
+// every 32-bit buffer offset of the launch stays below 2 GiB (else: the multi-launch step)
+bool decode_xcd_offsets_ok(const int64_t* layer0, long lstride, long cache_lstride, int d, int Te, int L, int M);
 size_t decode_xcd_part_floats(int M, int H, int Te);
 
 // ---- elementwise / reductions -------------------------------------------------------------------------

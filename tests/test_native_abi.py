@@ -232,3 +232,27 @@ def test_one_launch_decode_step_block_stream_matches_the_consumer_loops(native, 
     for layer in range(L):
         for seg, ntile in ((0, 3 * d // 32), (1, d // 32), (2, d // 32), (3, M * H * ns), (4, d // 32), (5, 4 * d // 32), (6, d // 32)):
             assert all(seen.get((layer, seg, t)) == 1 for t in range(ntile)), (layer, seg)
+
+
+def test_one_launch_decode_refuses_layouts_past_the_32_bit_buffer_offsets(native):
+    """csrc/decode_xcd.hip addresses weights and cross K/V through raw buffer descriptors with 32-bit byte offsets: the host-side guard
+    (decode_xcd_offsets_ok) accepts the real layouts -- OLMoASR-large's decoder ends at ~1.7 GB of bf16 shadow -- and sends anything
+    that would reach 2 GiB to the multi-launch step instead of reading zeros."""
+    lib = native.lib()
+
+    def layer0(d):  # a decoder layer as the arena lays it out: LayerNorm / bias vectors between the matrices (element offsets)
+        off, o = 0, []
+        for n in (d, d, 3 * d * d, 0, d * d, d, d, d, d * d, d, d * d, d, d, d, 4 * d * d, 4 * d, 4 * d * d, d):
+            o.append(off)
+            off += n
+        return (ctypes.c_int64 * 18)(*o), off + 2 * d * d + d  # (+ the cross key | value weights, which only decode_begin reads)
+    for name, d, L in (("tiny", 384, 4), ("small", 768, 12), ("medium", 1024, 24), ("large", 1280, 32)):
+        o, per_layer = layer0(d)
+        kv = 3 * 448 * d + 1500 * 2 * d
+        assert lib.oasr_xcd_offsets_ok_debug(o, per_layer, kv, d, 1500, L, 1) == 1, name
+    o, per_layer = layer0(1280)
+    assert per_layer * 2 * 32 < 2**31 < per_layer * 2 * 41  # (L = 41 still fits: the last layer ends before its cross key | value weights)
+    assert lib.oasr_xcd_offsets_ok_debug(o, per_layer, 3 * 448 * 1280 + 1500 * 2 * 1280, 1280, 1500, 42, 1) == 0  # weights past 2 GiB
+    assert lib.oasr_xcd_offsets_ok_debug(o, per_layer, 2**29, 1280, 1500, 4, 1) == 0                               # K/V layer stride past 2 GiB
+    shifted = (ctypes.c_int64 * 18)(*[x + 2**30 for x in o])                                                       # decoder not at the arena start
+    assert lib.oasr_xcd_offsets_ok_debug(shifted, per_layer, 3 * 448 * 1280 + 1500 * 2 * 1280, 1280, 1500, 32, 1) == 0
