@@ -66,8 +66,8 @@ def gen_inf_ckpt(checkpoint: dict) -> dict:
 def load_model(name: str, device: Optional[Union[str, torch.device]] = None, download_root: Optional[str] = None,
                inference: bool = False, in_memory: bool = False):
     from .model import OLMoASR
-    if device is None:
-        device = "cuda"
+    if device is None:  # olmoasr/__init__.py:127-128 (the native model itself refuses a CPU device, loudly: there is no CPU fallback)
+        device = "cuda" if torch.cuda.is_available() else "cpu"
     if name in MODEL2LINK:
         root = Path(download_root).expanduser() if download_root else Path.home() / ".cache" / "olmoasr"
         path = root / f"OLMoASR-{name}.pt"
@@ -82,9 +82,16 @@ def load_model(name: str, device: Optional[Union[str, torch.device]] = None, dow
                 raise RuntimeError(f"{path} not found and downloading {MODEL2LINK[name]} failed: {e}") from e
     elif os.path.isfile(name):
         path = Path(name)
+    else:  # olmoasr/__init__.py:135-138
+        raise ValueError(f"Model '{name}' not found. Available models: {list(MODEL2LINK.keys())}")
+    if in_memory:  # olmoasr/__init__.py:141-151: the file is read into host memory first, torch.load parses the bytes
+        import io
+        with open(path, "rb") as f:
+            blob = f.read()
+        checkpoint = load_checkpoint(io.BytesIO(blob))
+        del blob
     else:
-        raise RuntimeError(f"Model {name} not found; available models = {list(MODEL2LINK)}")
-    checkpoint = load_checkpoint(path)
+        checkpoint = load_checkpoint(path)
     dims = dims_of(checkpoint["dims"])
     sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in checkpoint["model_state_dict"].items()}
     rows = sd["decoder.token_embedding.weight"].shape[0]

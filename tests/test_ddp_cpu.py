@@ -390,3 +390,60 @@ def test_bench_self_launches_ranks_without_torchrun():
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, capture_output=True,
                            text=True, timeout=300)
         assert r.returncode != 0 and "needs 2 devices" in r.stderr and "AssertionError" not in r.stderr, r.stderr[-2000:]
+
+
+# ---- world 4 and 8 under gloo (round 6: the node the scaling bench runs on has 8 ranks; no such node is available to the builder) -----------
+@pytest.mark.parametrize("world", [4, 8])
+def test_grad_reducer_world4_and_8_gloo(world):
+    """The world-2 worker at the world sizes of the scaling bench: allreduce buckets in completion order, algo="direct" (reduce-scatter +
+    all-gather in place on the arena slice) on buckets of 333 and 667 elements -- neither divisible by 4 or 8, so every rank's slice has a
+    ragged tail --, parameter broadcast and the DistributedSampler partition."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(r, "ok") for r in range(world)], res
+
+
+def test_shard_range_tiles_the_arena_for_every_world_size():
+    from olmoasr_amd import zero
+    for n in (4, 8, 1003 * 4 + 4, 762_321_920 // 4 * 4, 37 * 4):  # (4 * k: the arena is padded to whole float4s)
+        for world in (1, 2, 3, 4, 8):
+            rs = [zero.shard_range(n, r, world) for r in range(world)]
+            assert rs[0][0] == 0 and all(rs[i][0] + rs[i][1] == rs[i + 1][0] for i in range(world - 1)) and rs[-1][0] + rs[-1][1] == n
+            assert all(off % 4 == 0 and ln % 4 == 0 for off, ln in rs) and all(ln >= 0 for _, ln in rs)
+            assert max(ln for _, ln in rs[:-1] or [(0, 0)]) <= rs[-1][1] or world == 1  # the last rank takes the rest
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_zero1_sharded_step_world4_and_8(world):
+    """ZeRO-1 at the scaling bench's world sizes: n = 4016 elements is not a multiple of world * 4 (the last rank's range is longer), two
+    consecutive steps (the sharded moments carry over), every rank ends with the parameters of ONE replicated AdamW on the mean gradient."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_zero_worker, args=(r, world, port, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for pr in procs:
+        pr.join(60)
+    assert all(r[1] == "ok" for r in res), [r[1] for r in res if r[1] != "ok"][:1]
+    n = 1003 * 4 + 4
+    p = torch.randn(n, generator=torch.Generator().manual_seed(0))
+    ref = _TorchRangeBackend(p, torch.zeros(n))
+    m, v = torch.zeros(n), torch.zeros(n)
+    for step, base in ((1, 10), (2, 20)):
+        ref.g = sum(torch.randn(n, generator=torch.Generator().manual_seed(base + r)) * 1024.0 for r in range(world))
+        ref.step(0, n, m, v, ref.sumsq(0, n), step=step, lr=1e-2, inv_loss_scale=1.0 / (1024.0 * world), max_grad_norm=1.0, betas=(0.9, 0.98), eps=1e-6,
+                 weight_decay=0.1)
+        for rank, _, outs, off, ln in res:
+            got = torch.from_numpy(outs[step - 1][0])
+            assert torch.allclose(got, p, atol=2e-6, rtol=0), (step, rank, float((got - p).abs().max()))
+    offs = [(r[3], r[4]) for r in res]
+    assert offs[0][0] == 0 and all(offs[i][0] + offs[i][1] == offs[i + 1][0] for i in range(world - 1)) and offs[-1][0] + offs[-1][1] == n

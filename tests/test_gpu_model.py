@@ -322,6 +322,9 @@ def test_inference_model_decode_and_transcribe(tmp_path, tiny_case):
     assert net.inference and net.decoder.token_embedding.weight.shape[0] == 51864
     net_t = olmoasr_amd.load_model(str(p_train), device=DEV)  # DDP-prefixed training checkpoint
     assert net_t.decoder.token_embedding.weight.shape[0] == 51865
+    net_m = olmoasr_amd.load_model(str(p_inf), inference=True, in_memory=True)  # device=None -> "cuda" here; the file parsed from host memory
+    assert net_m.device.type == "cuda" and all(torch.equal(a, b) for a, b in zip(net_m.state_dict().values(), net.state_dict().values()))
+    del net_m
     c = tiny_case
     mel = c["mel"].to(DEV)
     # logits(tokens, embed_audio(mel)) == forward(mel, tokens); inference head == training head on the shared rows

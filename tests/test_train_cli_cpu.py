@@ -150,5 +150,5 @@ def test_load_model_by_name_without_network_fails_loudly_and_leaves_no_partial_f
     with pytest.raises(RuntimeError, match="OLMoASR-tiny.en.pt"):
         hub.load_model("tiny", device="cpu", download_root=str(tmp_path))
     assert not list(tmp_path.glob("*.pt"))
-    with pytest.raises(RuntimeError, match="available models"):
+    with pytest.raises(ValueError, match="Available models"):  # the reference's exception type and wording (olmoasr/__init__.py:135-138)
         hub.load_model("no-such-model", device="cpu")
