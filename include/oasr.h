@@ -217,6 +217,13 @@ typedef struct oasr_attn_args {
 size_t oasr_sizeof_attn_args(void);
 int oasr_attention_fwd(const oasr_attn_args*, void* stream);
 int oasr_attention_bwd(const oasr_attn_args*, void* stream);
+/* The score matrix on request = `qk` of MultiHeadAttention.qkv_attention (olmoasr/model.py:347-442, returned by forward :327,:345 on the
+ * manual path; inf_model.py:172-196): scores f32 [B, H, Tq, Tk] = (q * 64^-1/4) . (k * 64^-1/4), pre-softmax, with -inf where the
+ * reference's additive mask puts it (causal: j > i; key padding: j >= kv_len[b]).  Reads q, k, their strides, kv_len, B, H, Tq, Tk, causal
+ * of the argument block; dtype = OASR_DTYPE_BF16 / OASR_DTYPE_F32 of the operands.  The training and decoding kernels never form this
+ * matrix; word-level timestamp alignment (whisper.timing.find_alignment, called from olmoasr/transcribe.py:410-419) reads it from the
+ * cross-attention of the upper decoder layers. */
+int oasr_attention_scores(const oasr_attn_args*, int dtype, float* scores, void* stream);
 int oasr_cross_entropy(void* logits_bf16, int64_t ld, int V, const int64_t* targets, int64_t rows, int64_t ignore, float gscale,
                        int32_t* n_valid_dev, float* row_loss, float* loss_out, int write_grad, void* stream);
 int oasr_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);

@@ -96,6 +96,7 @@ def _declare(lib):
         "oasr_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp]),
         "oasr_attention_fwd": (i32, [C.POINTER(AttnArgs), vp]),
         "oasr_attention_bwd": (i32, [C.POINTER(AttnArgs), vp]),
+        "oasr_attention_scores": (i32, [C.POINTER(AttnArgs), i32, vp, vp]),
         "oasr_cross_entropy": (i32, [vp, i64, i32, vp, i64, i64, f32, vp, vp, vp, i32, vp]),
         "oasr_cast_f32_bf16": (i32, [vp, vp, i64, vp]),
         "oasr_pick_tokens": (i32, [vp, i64, i32, i64, vp, vp, vp, vp, vp]),

@@ -158,6 +158,19 @@ extern "C" int oasr_attention_bwd(const oasr_attn_args* a, void* stream) {
   OASR_REQUIRE(a, "oasr_attention_bwd: null args");
   return launch_attention_bwd(to_attn(a), (hipStream_t)stream);
 }
+extern "C" int oasr_attention_scores(const oasr_attn_args* a, int dtype, float* scores, void* stream) {
+  OASR_REQUIRE(a && scores, "oasr_attention_scores: null args");
+  OASR_REQUIRE(dtype == OASR_DTYPE_BF16 || dtype == OASR_DTYPE_F32, "oasr_attention_scores: dtype %d (0 = bf16 operands, 1 = fp32 operands)", dtype);
+  if (dtype == OASR_DTYPE_BF16) return launch_attention_scores(to_attn(a), scores, (hipStream_t)stream);
+  AttnArgsF f;
+  memset(&f, 0, sizeof(f));
+  f.q = (const float*)a->q, f.k = (const float*)a->k;
+  f.ldq = a->ldq, f.ldk = a->ldk, f.bsq = a->bsq, f.bsk = a->bsk;
+  f.kv_len = a->kv_len;
+  f.B = a->B, f.H = a->H, f.Tq = a->Tq, f.Tk = a->Tk, f.causal = a->causal;
+  f.q_rows = a->q_rows, f.k_rows = a->k_rows;
+  return launch_attention_scores(f, scores, (hipStream_t)stream);
+}
 
 extern "C" int oasr_test_span_tables(const int32_t* span_host, int B, int S, const int64_t* targets, int32_t* rows_out, int32_t* span_out,
                                      int64_t* targets_rows_out, int64_t* active_rows_out, void* stream) {

@@ -146,9 +146,12 @@ typedef AttnArgsT<bf16_t> AttnArgs;
 typedef AttnArgsT<float> AttnArgsF;
 int launch_attention_fwd(const AttnArgs& a, hipStream_t s);
 int launch_attention_bwd(const AttnArgs& a, hipStream_t s);
+// qk of MultiHeadAttention.qkv_attention (model.py:347-442): fp32 pre-softmax scaled scores [B, H, Tq, Tk], masked entries -inf (scores.hip)
+int launch_attention_scores(const AttnArgs& a, float* out, hipStream_t s);
 void attention_set_pingpong(int on);  // testing hook: 0 = general kernels for the unmasked case too
 int launch_attention_fwd(const AttnArgsF& a, hipStream_t s);  // fp32 validation kernels (o_lo unused: O is fp32)
 int launch_attention_bwd(const AttnArgsF& a, hipStream_t s);
+int launch_attention_scores(const AttnArgsF& a, float* out, hipStream_t s);
 
 // ---- LayerNorm-folded decode projection (decode_proj.hip) ------------------------------------------------
 int launch_decode_proj(const bf16_t* x, int M, int K, const bf16_t* W, int N, const float* ln_g, const float* ln_b, const float* bias,

@@ -266,11 +266,19 @@ class MultiHeadAttention(_ParamModule):
         self.value = Linear(n_state, n_state)
         self.out = Linear(n_state, n_state)
 
+    # ``qk`` on request for calls the reference answers with None (its SDPA branch, model.py:328-340): set on an instance -- or on the class --
+    # by code that wants to look at the attention scores of mask-free calls, i.e. the cross-attention that word-level timestamp alignment
+    # reads (olmoasr_amd/timing.py; whisper.timing.find_alignment hooks ``block.cross_attn`` and takes ``outs[-1]``).
+    return_qk = False
+
     def forward(self, x: Tensor, xa: Optional[Tensor] = None, mask: Optional[Tensor] = None, kv_cache: Optional[dict] = None,
                 verbose: bool = False):
-        """(out, qk) of reference model.py:266-345, head_dim 64.  ``qk`` is always None: the flash kernels never form the score
-        matrix (its only consumer is word-level timestamp alignment, out of scope here).  ``kv_cache`` dicts belong to
-        ``TextDecoder.forward`` (the engine owns the cache); a per-module cache is refused."""
+        """(out, qk) of reference model.py:266-345, head_dim 64.  ``qk`` follows the reference: the fp32 pre-softmax score matrix
+        [B, H, Tq, Tk] (``qkv_attention``, :347-442: (q * 64^-1/4) @ (k * 64^-1/4)^T + mask) when the call takes the reference's manual
+        path -- a 2-D mask, i.e. the eval loop's causal decoder self-attention (:316-327) --, None on its SDPA path (3-D padding masks and
+        mask-free calls) unless ``return_qk`` asks for it.  The attention output itself always comes from the flash kernels, which never
+        form the matrix; ``qk`` is computed by its own kernel (csrc/scores.hip, ``oasr_attention_scores``) only when it is returned.
+        ``kv_cache`` dicts belong to ``TextDecoder.forward`` (the engine owns the cache); a per-module cache is refused."""
         from . import ops
         if kv_cache is not None:
             raise N.NativeError("MultiHeadAttention.forward(kv_cache=...): the KV cache lives in the engine -- drive it through "
@@ -285,7 +293,10 @@ class MultiHeadAttention(_ParamModule):
         k = self.key._apply(src).view(B, Tk, H, 64)
         v = self.value._apply(src).view(B, Tk, H, 64)
         o, _ = ops.attention_fwd(q, k, v, kv_len, causal)
-        return self.out._apply(o).to(x.dtype), None
+        qk = None
+        if (mask is not None and mask.dim() == 2) or self.return_qk:
+            qk = ops.attention_scores(q, k, kv_len, causal)
+        return self.out._apply(o).to(x.dtype), qk
 
 
 class _Sequential(nn.Module):

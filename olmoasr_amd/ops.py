@@ -87,6 +87,23 @@ def attention_fwd(q, k, v, kv_len=None, causal=False, want_o_lo=False):
     return (o, lse, o_lo) if want_o_lo else (o, lse)
 
 
+def attention_scores(q, k, kv_len=None, causal=False):
+    """``qk`` of the reference's manual attention path (MultiHeadAttention.qkv_attention, olmoasr/model.py:347-442): q [B,Tq,H,64],
+    k [B,Tk,H,64] (bf16 or fp32, any token/batch strides) -> fp32 [B, H, Tq, Tk] pre-softmax scaled scores, -inf where masked."""
+    B, Tq, H, _ = q.shape
+    Tk = k.shape[1]
+    assert q.dtype == k.dtype and q.dtype in (BF, torch.float32)
+    assert q.stride(3) == 1 and q.stride(2) == 64 and k.stride(3) == 1 and k.stride(2) == 64
+    out = torch.empty(B, H, Tq, Tk, device=q.device, dtype=torch.float32)
+    a = N.AttnArgs()
+    a.q, a.k = q.data_ptr(), k.data_ptr()
+    a.ldq, a.ldk, a.bsq, a.bsk = q.stride(1), k.stride(1), q.stride(0), k.stride(0)
+    a.kv_len = kv_len.data_ptr() if kv_len is not None else None
+    a.B, a.H, a.Tq, a.Tk, a.causal = B, H, Tq, Tk, int(causal)
+    N.check(N.lib().oasr_attention_scores(C.byref(a), 0 if q.dtype == BF else 1, N.ptr(out), N.stream_ptr()), "attention_scores")
+    return out
+
+
 def attention_bwd(q, k, v, o, lse, d_o, kv_len=None, causal=False, o_lo=None, dq_colsum=None, dv_colsum=None, qtile_flags=None):
     """qtile_flags: optional int32 [B, H, ceil(Tq/64)] workspace -- all-zero 64-query tiles of d_o are recorded and skipped (bit-identical)."""
     B, Tq, H, _ = q.shape

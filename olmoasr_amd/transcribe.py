@@ -6,8 +6,10 @@ reference takes its tokenizer from the un-vendored openai-whisper package (:167-
 ``text`` of each segment and of the result, the ``compression_ratio_threshold`` fallback (:213-217: "too repetitive" -> next
 temperature), the "instantaneous or no text" rule on the decoded string (:494-499), ``initial_prompt`` (:258-264), ``verbose``
 printing (:488-492).  Without one the same loop runs at TOKEN level: ``text`` is None, the compression-ratio test is skipped and a
-segment counts as empty when it holds no token below eot.  ``word_timestamps`` / ``hallucination_silence_threshold`` need the
-cross-attention weights (never formed by the flash kernels) and are refused with a warning either way:
+segment counts as empty when it holds no token below eot.  ``word_timestamps`` (:409-424) runs ``olmoasr_amd.timing.add_word_timestamps``
+-- cross-attention scores on request + DTW, the published algorithm of the ``whisper.timing`` function the reference imports -- and
+``hallucination_silence_threshold`` (:426-486) the reference's own skipping rules on the words it returns; both need a tokenizer (words
+are a property of the text).  With the reference's model class the option cannot work (its cross-attention returns ``qk = None``):
 
   * whole-file log-mel once with ``padding=N_SAMPLES`` (:148), ``content_frames = n_frames - 3000`` (:149)
   * ``clip_timestamps`` -> seek clips (:177-186); window = ``mel[:, seek : seek + segment_size]`` with
@@ -33,6 +35,33 @@ import torch
 
 from .audio import FRAMES_PER_SECOND, HOP_LENGTH, N_FRAMES, N_SAMPLES, SAMPLE_RATE, log_mel_spectrogram, pad_or_trim
 from .decoding import EOT, TIMESTAMP_BEGIN, DecodingOptions, DecodingResult, decode, resolve_tokenizer
+from .timing import add_word_timestamps
+
+PUNCTUATION = "\"'“¿([{-\"'.。,，!！?？:：”)]}、"  # (:188)
+
+
+def get_end(segments: List[dict]) -> Optional[float]:
+    """whisper.utils.get_end: the end of the last word of the last segment that has words, else the last segment's own end."""
+    return next((w["end"] for s in reversed(segments) for w in reversed(s["words"])), segments[-1]["end"] if segments else None)
+
+
+def word_anomaly_score(word: dict) -> float:
+    """(:323-333) anomalous words are improbable, very short or very long"""
+    probability, duration = word.get("probability", 0.0), word["end"] - word["start"]
+    return (1.0 if probability < 0.15 else 0.0) + ((0.133 - duration) * 15 if duration < 0.133 else 0.0) + (duration - 2.0 if duration > 2.0 else 0.0)
+
+
+def is_segment_anomaly(segment: Optional[dict]) -> bool:
+    """(:335-342) over the first eight non-punctuation words"""
+    if segment is None or not segment["words"]:
+        return False
+    words = [w for w in segment["words"] if w["word"] not in PUNCTUATION][:8]
+    score = sum(word_anomaly_score(w) for w in words)
+    return score >= 3 or score + 0.01 >= len(words)
+
+
+def next_words_segment(segments: List[dict]) -> Optional[dict]:
+    return next((s for s in segments if s["words"]), None)
 
 
 def format_timestamp(seconds: float) -> str:
@@ -50,18 +79,19 @@ def transcribe(model, audio, *, verbose: Optional[bool] = None,
                compression_ratio_threshold: Optional[float] = 2.4, logprob_threshold: Optional[float] = -1.0,
                no_speech_threshold: Optional[float] = 0.6, condition_on_previous_text: bool = True,
                initial_prompt: Optional[str] = None, carry_initial_prompt: bool = False, word_timestamps: bool = False,
-               prepend_punctuations: str = "", append_punctuations: str = "", clip_timestamps: Union[str, Sequence[float]] = "0",
+               prepend_punctuations: str = "\"'“¿([{-", append_punctuations: str = "\"'.。,，!！?？:：”)]}、",
+               clip_timestamps: Union[str, Sequence[float]] = "0",
                hallucination_silence_threshold: Optional[float] = None, batch_windows: int = 16, tokenizer=None, **decode_options):
     if isinstance(audio, str):
         from .audio import load_audio
         audio = load_audio(audio)
-    if word_timestamps or hallucination_silence_threshold is not None:
-        warnings.warn("word_timestamps / hallucination_silence_threshold need the cross-attention weights, which the flash kernels never "
-                      "form (olmoasr/model.py:331-340 returns qk only on the non-SDPA path): ignored")
+    if hallucination_silence_threshold is not None and not word_timestamps:  # (the reference's CLI says the same, :575; the loop reads it under word_timestamps only, :409-428)
+        warnings.warn("hallucination_silence_threshold is ignored without word_timestamps")
     if not torch.is_tensor(audio):
         audio = torch.from_numpy(np.ascontiguousarray(audio))
     mel = log_mel_spectrogram(audio, model.dims.n_mels, padding=N_SAMPLES, device=model.device)  # [80, content + 3000]
     content_frames = mel.shape[-1] - N_FRAMES
+    content_duration = float(content_frames * HOP_LENGTH / SAMPLE_RATE)
     if decode_options.get("language", None) is None:
         decode_options["language"] = "en"  # not model.is_multilingual (:152-154)
     if isinstance(clip_timestamps, str):
@@ -76,6 +106,11 @@ def transcribe(model, audio, *, verbose: Optional[bool] = None,
     tokenizer = resolve_tokenizer(model, tokenizer, decode_options["language"], decode_options.get("task", "transcribe"))  # (:167-172)
     if tokenizer is None and initial_prompt is not None:
         warnings.warn("initial_prompt needs a tokenizer (tokenizer=...): ignored")
+    if word_timestamps and tokenizer is None:
+        raise ValueError("word_timestamps=True needs a tokenizer (tokenizer=...): words are a property of the decoded text "
+                         "(tokenizer.split_to_word_tokens); whisper's own is used where the package is installed")
+    if word_timestamps and decode_options.get("task", "transcribe") == "translate":  # (:174-175)
+        warnings.warn("Word-level timestamps on translations may not be reliable.")
     initial_prompt_tokens: List[int] = []
     if tokenizer is not None and initial_prompt is not None:  # (:258-264; the prompt conditioning itself is commented out in the reference)
         initial_prompt_tokens = list(tokenizer.encode(" " + initial_prompt.strip()))
@@ -118,7 +153,8 @@ def transcribe(model, audio, *, verbose: Optional[bool] = None,
 
     all_tokens: List[int] = list(initial_prompt_tokens)
     all_segments: List[dict] = []
-    independent = bool(decode_options.get("without_timestamps", False))
+    independent = bool(decode_options.get("without_timestamps", False)) and not word_timestamps  # (word timing moves the seek)
+    last_speech_timestamp = 0.0
     clip_idx = 0
     seek = seek_clips[clip_idx][0]
     pending: List[Tuple[int, int, DecodingResult]] = []  # (seek, segment_size, result) decoded ahead (independent windows only)
@@ -144,6 +180,7 @@ def transcribe(model, audio, *, verbose: Optional[bool] = None,
             pending = [(s, sz, r) for s, (_, sz), r in zip(ahead, wins, res)]
             _, segment_size, result = pending.pop(0)
         time_offset = float(seek * HOP_LENGTH / SAMPLE_RATE)
+        window_end_time = float((seek + N_FRAMES) * HOP_LENGTH / SAMPLE_RATE)
         segment_duration = segment_size * HOP_LENGTH / SAMPLE_RATE
         tokens = list(result.tokens)
 
@@ -155,6 +192,7 @@ def transcribe(model, audio, *, verbose: Optional[bool] = None,
                 seek += segment_size
                 continue
 
+        previous_seek = seek
         current_segments: List[dict] = []
 
         def new_segment(*, start: float, end: float, toks: List[int]):
@@ -188,6 +226,52 @@ def transcribe(model, audio, *, verbose: Optional[bool] = None,
             current_segments.append(new_segment(start=time_offset, end=time_offset + duration, toks=tokens))
             seek += segment_size
 
+        if word_timestamps:  # (:409-486)
+            add_word_timestamps(segments=current_segments, model=model, tokenizer=tokenizer, mel=window(previous_seek, seek_clip_end)[0],
+                                num_frames=segment_size, prepend_punctuations=prepend_punctuations, append_punctuations=append_punctuations,
+                                last_speech_timestamp=last_speech_timestamp)
+            if not single_timestamp_ending:  # resume right after the last word instead of at the last closed timestamp
+                last_word_end = get_end(current_segments)
+                if last_word_end is not None and last_word_end > time_offset:
+                    seek = round(last_word_end * FRAMES_PER_SECOND)
+            if hallucination_silence_threshold is not None:  # skip silence before possible hallucinations
+                threshold = hallucination_silence_threshold
+                if not single_timestamp_ending:
+                    last_word_end = get_end(current_segments)
+                    if last_word_end is not None and last_word_end > time_offset:
+                        remaining_duration = window_end_time - last_word_end
+                        seek = round(last_word_end * FRAMES_PER_SECOND) if remaining_duration > threshold else previous_seek + segment_size
+                # if the first segment might be a hallucination, skip the leading silence
+                first_segment = next_words_segment(current_segments)
+                if first_segment is not None and is_segment_anomaly(first_segment):
+                    gap = first_segment["start"] - time_offset
+                    if gap > threshold:
+                        seek = previous_seek + round(gap * FRAMES_PER_SECOND)
+                        continue
+                # skip silence before any possible hallucination that is surrounded by silence or more hallucinations
+                hal_last_end = last_speech_timestamp
+                for si in range(len(current_segments)):
+                    segment = current_segments[si]
+                    if not segment["words"]:
+                        continue
+                    if is_segment_anomaly(segment):
+                        next_segment = next_words_segment(current_segments[si + 1:])
+                        hal_next_start = next_segment["words"][0]["start"] if next_segment is not None else time_offset + segment_duration
+                        silence_before = (segment["start"] - hal_last_end > threshold or segment["start"] < threshold
+                                          or segment["start"] - time_offset < 2.0)
+                        silence_after = (hal_next_start - segment["end"] > threshold or is_segment_anomaly(next_segment)
+                                         or window_end_time - segment["end"] < 2.0)
+                        if silence_before and silence_after:
+                            seek = round(max(time_offset + 1, segment["start"]) * FRAMES_PER_SECOND)
+                            if content_duration - segment["end"] < threshold:
+                                seek = content_frames
+                            current_segments[si:] = []
+                            break
+                    hal_last_end = segment["end"]
+            last_word_end = get_end(current_segments)
+            if last_word_end is not None:
+                last_speech_timestamp = last_word_end
+
         if verbose and tokenizer is not None:  # (:488-492)
             for seg in current_segments:
                 print(f"[{format_timestamp(seg['start'])} --> {format_timestamp(seg['end'])}] {seg['text']}")
@@ -197,6 +281,7 @@ def transcribe(model, audio, *, verbose: Optional[bool] = None,
             empty = seg["text"].strip() == "" if tokenizer is not None else not any(t < EOT for t in seg["tokens"])
             if seg["start"] == seg["end"] or empty:
                 seg["tokens"] = []
+                seg["words"] = []
                 if tokenizer is not None:
                     seg["text"] = ""
         all_segments.extend({"id": i, **seg} for i, seg in enumerate(current_segments, start=len(all_segments)))

@@ -221,16 +221,59 @@ def decode(sd, dims, mel: torch.Tensor, opt: Options) -> List[Result]:
     return out
 
 
+PUNCTUATION = "\"'“¿([{-\"'.。,，!！?？:：”)]}、"  # olmoasr/transcribe.py:188
+
+
+def get_end(segments):
+    """whisper.utils.get_end (third party, imported at olmoasr/transcribe.py:28): end of the last word of the last segment that has any,
+    else the end of the last segment, else None."""
+    for s in reversed(segments):
+        for w in reversed(s["words"]):
+            return w["end"]
+    return segments[-1]["end"] if segments else None
+
+
+def word_anomaly_score(word) -> float:  # olmoasr/transcribe.py:323-333
+    probability = word.get("probability", 0.0)
+    duration = word["end"] - word["start"]
+    score = 0.0
+    if probability < 0.15:
+        score += 1.0
+    if duration < 0.133:
+        score += (0.133 - duration) * 15
+    if duration > 2.0:
+        score += duration - 2.0
+    return score
+
+
+def is_segment_anomaly(segment) -> bool:  # olmoasr/transcribe.py:335-342
+    if segment is None or not segment["words"]:
+        return False
+    words = [w for w in segment["words"] if w["word"] not in PUNCTUATION]
+    words = words[:8]
+    score = sum(word_anomaly_score(w) for w in words)
+    return score >= 3 or score + 0.01 >= len(words)
+
+
+def next_words_segment(segments):  # olmoasr/transcribe.py:344-345
+    return next((s for s in segments if s["words"]), None)
+
+
 def transcribe(sd, dims, mel_padded: torch.Tensor, *, temperature=(0.0, 0.2, 0.4, 0.6, 0.8, 1.0), logprob_threshold: Optional[float] = -1.0,
                no_speech_threshold: Optional[float] = 0.6, clip_timestamps: Sequence[float] = (0.0,), tokenizer=None,
-               compression_ratio_threshold: Optional[float] = 2.4, initial_prompt: Optional[str] = None, **decode_kw) -> dict:
+               compression_ratio_threshold: Optional[float] = 2.4, initial_prompt: Optional[str] = None, word_timestamps: bool = False,
+               add_word_timestamps=None, hallucination_silence_threshold: Optional[float] = None,
+               prepend_punctuations: str = "\"'“¿([{-", append_punctuations: str = "\"'.。,，!！?？:：”)]}、", **decode_kw) -> dict:
     """olmoasr/transcribe.py:147-517.  ``mel_padded`` = log_mel_spectrogram(audio, padding=N_SAMPLES) [80, content_frames + 3000]
     (:148).  With ``tokenizer`` (decode / encode; the reference's comes from the un-vendored whisper package, :167-172) the text steps
     run too: the compression-ratio fallback (:213-217, on the ``compression_ratio`` the decode result carries), segment / result text
     (:266-279, :519-523), the empty-text rule (:494-499), initial_prompt (:258-264).  Without one: token level, the compression test
-    skipped.  word_timestamps / hallucination_silence_threshold are outside; prompt conditioning is commented out in the reference
-    (:297-302)."""
+    skipped.  ``word_timestamps`` (:409-486): ``add_word_timestamps`` is the callable the reference imports from whisper.timing (here a
+    parameter: the pin scripts it), followed by the seek-to-last-word rule and the ``hallucination_silence_threshold`` skipping rules.
+    Prompt conditioning is commented out in the reference (:297-302)."""
     content_frames = mel_padded.shape[-1] - N_FRAMES
+    content_duration = float(content_frames * HOP_LENGTH / SAMPLE_RATE)
+    last_speech_timestamp = 0.0
     seek_points = [round(ts * FRAMES_PER_SECOND) for ts in clip_timestamps] or [0]
     if len(seek_points) % 2 == 1:
         seek_points.append(content_frames)
@@ -275,6 +318,7 @@ def transcribe(sd, dims, mel_padded: torch.Tensor, *, temperature=(0.0, 0.2, 0.4
             continue
         seeks.append(seek)
         time_offset = seek * HOP_LENGTH / SAMPLE_RATE
+        window_end_time = float((seek + N_FRAMES) * HOP_LENGTH / SAMPLE_RATE)
         segment_size = min(N_FRAMES, content_frames - seek, clip_end - seek)
         seg = mel_padded[:, seek:seek + segment_size]
         segment_duration = segment_size * HOP_LENGTH / SAMPLE_RATE
@@ -288,6 +332,7 @@ def transcribe(sd, dims, mel_padded: torch.Tensor, *, temperature=(0.0, 0.2, 0.4
             if should_skip:
                 seek += segment_size
                 continue
+        previous_seek = seek
         current = []
 
         def new_segment(start, end, toks):
@@ -321,10 +366,64 @@ def transcribe(sd, dims, mel_padded: torch.Tensor, *, temperature=(0.0, 0.2, 0.4
                 duration = (stamps[-1] - TIMESTAMP_BEGIN) * time_precision
             current.append(new_segment(time_offset, time_offset + duration, tokens))
             seek += segment_size
+        if word_timestamps:  # (:409-486)
+            add_word_timestamps(segments=current, model=None, tokenizer=tokenizer, mel=seg, num_frames=segment_size,
+                                prepend_punctuations=prepend_punctuations, append_punctuations=append_punctuations,
+                                last_speech_timestamp=last_speech_timestamp)
+            if not single_timestamp_ending:
+                last_word_end = get_end(current)
+                if last_word_end is not None and last_word_end > time_offset:
+                    seek = round(last_word_end * FRAMES_PER_SECOND)
+            skip_window = False
+            if hallucination_silence_threshold is not None:
+                threshold = hallucination_silence_threshold
+                if not single_timestamp_ending:
+                    last_word_end = get_end(current)
+                    if last_word_end is not None and last_word_end > time_offset:
+                        remaining_duration = window_end_time - last_word_end
+                        if remaining_duration > threshold:
+                            seek = round(last_word_end * FRAMES_PER_SECOND)
+                        else:
+                            seek = previous_seek + segment_size
+                first_segment = next_words_segment(current)
+                if first_segment is not None and is_segment_anomaly(first_segment):
+                    gap = first_segment["start"] - time_offset
+                    if gap > threshold:
+                        seek = previous_seek + round(gap * FRAMES_PER_SECOND)
+                        skip_window = True
+                if not skip_window:
+                    hal_last_end = last_speech_timestamp
+                    for si in range(len(current)):
+                        segment = current[si]
+                        if not segment["words"]:
+                            continue
+                        if is_segment_anomaly(segment):
+                            next_segment = next_words_segment(current[si + 1:])
+                            if next_segment is not None:
+                                hal_next_start = next_segment["words"][0]["start"]
+                            else:
+                                hal_next_start = time_offset + segment_duration
+                            silence_before = (segment["start"] - hal_last_end > threshold or segment["start"] < threshold
+                                              or segment["start"] - time_offset < 2.0)
+                            silence_after = (hal_next_start - segment["end"] > threshold or is_segment_anomaly(next_segment)
+                                             or window_end_time - segment["end"] < 2.0)
+                            if silence_before and silence_after:
+                                seek = round(max(time_offset + 1, segment["start"]) * FRAMES_PER_SECOND)
+                                if content_duration - segment["end"] < threshold:
+                                    seek = content_frames
+                                current[si:] = []
+                                break
+                        hal_last_end = segment["end"]
+            if skip_window:
+                continue  # (:441-443: the window is decoded again from after the leading silence)
+            last_word_end = get_end(current)
+            if last_word_end is not None:
+                last_speech_timestamp = last_word_end
         for s in current:  # "instantaneous or does not contain text" (:494-499); without a tokenizer text == tokens below eot
             empty = s["text"].strip() == "" if tokenizer is not None else not any(t < EOT for t in s["tokens"])
             if s["start"] == s["end"] or empty:
                 s["tokens"] = []
+                s["words"] = []
                 if tokenizer is not None:
                     s["text"] = ""
         base_id = len(all_segments)  # ids continue across windows (:501-508); evaluated before the list grows

@@ -1,7 +1,8 @@
 """Writes tests/golden/transcribe_ref.json: outputs of the UNMODIFIED reference ``olmoasr/transcribe.py`` (run through
 oracle/ref_transcribe_harness.py in the build container) on (a) the 40 scripted-decode cases of
 ``ref_transcribe_harness.scripted_cases()`` (token level) and the 24 of ``scripted_cr_cases()`` (with a tokenizer: texts,
-compression-ratio fallback, initial_prompt) and (b) a real tiny model with the timestamp bonus, 41 s of the seeded generator's
+compression-ratio fallback, initial_prompt), the 36 of ``scripted_words_cases()`` (word_timestamps / hallucination_silence_threshold with a
+scripted ``add_word_timestamps``) and (b) a real tiny model with the timestamp bonus, 41 s of the seeded generator's
 audio.  ``python -m oracle.gen_transcribe_golden``.  TEST INFRASTRUCTURE ONLY; the fixture travels to the GPU box, the reference
 does not."""
 import json
@@ -33,13 +34,17 @@ def model_case():
 
 def main():
     torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
-    out = {"scripted": [], "scripted_cr": [], "model": None}
+    out = {"scripted": [], "scripted_cr": [], "scripted_words": [], "model": None}
     for c in H.scripted_cases():
         ref = H.run_reference(H.scripted_decode(c["seed"]), H.index_mel(c["content_frames"]), **dict(c["kw"]))
         out["scripted"].append(H.comparable(ref))
     for c in H.scripted_cr_cases():  # with a tokenizer: compression-ratio fallback, segment / result text, initial_prompt
         ref = H.run_reference(H.scripted_decode_cr(c["seed"]), H.index_mel(c["content_frames"]), **dict(c["kw"]))
         out["scripted_cr"].append(H.comparable(ref, text=True))
+    for c in H.scripted_words_cases():  # word_timestamps=True (+ hallucination_silence_threshold): scripted add_word_timestamps on both sides
+        ref = H.run_reference(H.scripted_decode_cr(c["seed"]), H.index_mel(c["content_frames"]), add_word_timestamps=H.scripted_words(c["seed"]),
+                              **dict(c["kw"]))
+        out["scripted_words"].append(H.comparable(ref, text=True, words=True))
     sd, dims, mel_padded, bias, kw = model_case()
     out["model"] = H.comparable(H.run_reference(H.model_decode(sd, dims, bias), mel_padded, **kw))
     with open(OUT, "w") as f:

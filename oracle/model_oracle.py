@@ -164,6 +164,50 @@ def attention(q, k, v, n_head, mask, cfg):
     return o.permute(0, 2, 1, 3).reshape(B, N, D)
 
 
+def qkv_attention(q, k, v, n_head, mask=None):
+    """MultiHeadAttention.qkv_attention, model.py:347-442 (inf_model.py:172-196): the manual path, returning (wv, qk) with
+    qk = (q * d_head^-1/4) @ (k * d_head^-1/4)^T (+ mask), .float(), PRE-softmax -- the tensor ``forward`` hands back as its second
+    output (:327, :345) and whisper.timing reads from the cross-attention."""
+    B, N, D = q.shape
+    M = k.shape[1]
+    scale = (D // n_head) ** -0.25
+    qh = q.view(B, N, n_head, -1).permute(0, 2, 1, 3) * scale
+    kh = k.view(B, M, n_head, -1).permute(0, 2, 3, 1) * scale
+    vh = v.view(B, M, n_head, -1).permute(0, 2, 1, 3)
+    qk = qh @ kh
+    if mask is not None:
+        qk = qk + (mask[:N, :M] if mask.dim() == 2 else mask.unsqueeze(1))
+    qk = qk.float()
+    w = torch.softmax(qk, dim=-1).to(q.dtype)
+    return (w @ vh).permute(0, 2, 1, 3).flatten(start_dim=2), qk.detach()
+
+
+def cross_attention_scores(sd, dims: Dims, tokens, xa, layers, autocast_bf16=False):
+    """{layer: qk [B, H, S, n_audio_ctx]} of the decoder's CROSS-attention for a teacher-forced token sequence: the tensors whisper.timing's
+    forward hooks on ``block.cross_attn`` collect (``outs[-1]``) when the manual attention path is active -- a walk of TextDecoder.forward
+    (model.py:688-775) block by block with qkv_attention() in place of the cross-attention's SDPA call."""
+    cfg = _Cfg(autocast_bf16)
+    S = tokens.shape[-1]
+    x = (sd["decoder.token_embedding.weight"][tokens] + sd["decoder.positional_embedding"][:S]).to(xa.dtype)
+    causal = torch.full((dims.n_text_ctx, dims.n_text_ctx), float("-inf")).triu_(1)[:S, :S]
+    out = {}
+    for i in range(dims.n_text_layer):
+        pre = f"decoder.blocks.{i}"
+        x = x + mha(sd, pre + ".attn", layer_norm(x, sd[pre + ".attn_ln.weight"], sd[pre + ".attn_ln.bias"]), None, causal, dims.n_text_head, cfg)
+        h = layer_norm(x, sd[pre + ".cross_attn_ln.weight"], sd[pre + ".cross_attn_ln.bias"])
+        q = linear(h, sd[pre + ".cross_attn.query.weight"], sd[pre + ".cross_attn.query.bias"], cfg)
+        k = linear(xa, sd[pre + ".cross_attn.key.weight"], None, cfg)
+        v = linear(xa, sd[pre + ".cross_attn.value.weight"], sd[pre + ".cross_attn.value.bias"], cfg)
+        wv, qk = qkv_attention(q.float(), k.float(), v.float(), dims.n_text_head)
+        if i in layers:
+            out[i] = qk
+        x = x + linear(wv.to(q.dtype), sd[pre + ".cross_attn.out.weight"], sd[pre + ".cross_attn.out.bias"], cfg)
+        h = layer_norm(x, sd[pre + ".mlp_ln.weight"], sd[pre + ".mlp_ln.bias"])
+        h = gelu(linear(h, sd[pre + ".mlp.0.weight"], sd[pre + ".mlp.0.bias"], cfg))
+        x = x + linear(h, sd[pre + ".mlp.2.weight"], sd[pre + ".mlp.2.bias"], cfg)
+    return out
+
+
 def mha(sd, prefix, x, xa, mask, n_head, cfg):
     """model.py:266-345."""
     q = linear(x, sd[prefix + ".query.weight"], sd[prefix + ".query.bias"], cfg)

@@ -115,6 +115,61 @@ def scripted_decode_cr(seed: int) -> Callable:
     return decode
 
 
+def scripted_words(seed: int) -> Callable:
+    """A scripted stand-in for ``whisper.timing.add_word_timestamps`` (keyword signature of the call at olmoasr/transcribe.py:410-419),
+    supplied to BOTH sides of the word-timestamp pin: a pure function of what it is handed -- the window (read back from the mel), the
+    segment's seek / start / token count, ``num_frames`` and ``last_speech_timestamp`` (so a wrong value of any of them changes the
+    words) -- that fills ``segment["words"]`` with plausible, anomalous (very short / very long / improbable), late-starting or no
+    words, punctuation-only words included, and -- like the real function -- moves the segment's own start / end onto its words."""
+    def add_word_timestamps(*, segments, model, tokenizer, mel, num_frames, prepend_punctuations, append_punctuations, last_speech_timestamp,
+                            **kwargs):
+        assert prepend_punctuations == "\"'“¿([{-" and append_punctuations == "\"'.。,，!！?？:：”)]}、"
+        if len(segments) == 0:
+            return
+        window = int(mel[0, 0].item()) - 1
+        assert window == segments[0]["seek"], (window, segments[0]["seek"])
+        for si, seg in enumerate(segments):
+            text_tokens = [t for t in seg["tokens"] if t < do.EOT]
+            rng = random.Random(hash((880002, seed, window, si, len(text_tokens), round(seg["start"] * 100), int(num_frames),
+                                      round(last_speech_timestamp * 100))) & 0xFFFFFFFF)
+            kind = rng.choice(["normal", "normal", "normal", "anomalous", "none", "late", "late", "tail"])
+            words = []
+            if text_tokens and kind != "none":
+                t = seg["start"] + (rng.choice([0.5, 3.0, 6.5]) if kind == "late" else rng.choice([0.0, 0.02, 0.1]))
+                for tok in text_tokens[:12]:
+                    if kind == "anomalous":
+                        dur, prob = rng.choice([0.02, 0.05, 0.1, 2.5, 4.0]), rng.choice([0.05, 0.1, 0.5])
+                    else:
+                        dur, prob = rng.choice([0.14, 0.2, 0.3, 0.46, 0.8]), rng.choice([0.3, 0.6, 0.9, 0.99])
+                    word = str(tok) if rng.random() > 0.15 else rng.choice([".", ",", "?"])
+                    words.append(dict(word=word, start=round(t, 2), end=round(t + dur, 2), probability=prob))
+                    t += dur + rng.choice([0.0, 0.0, 0.04, 0.3, 1.2])
+                if kind == "tail":  # the last word runs far past the segment
+                    words[-1]["end"] = round(words[-1]["end"] + rng.choice([2.0, 6.0]), 2)
+                if rng.random() < 0.8:
+                    seg["start"], seg["end"] = words[0]["start"], words[-1]["end"]
+            seg["words"] = words
+    return add_word_timestamps
+
+
+def scripted_words_cases() -> List[dict]:
+    """Cases of the fixture's "scripted_words" list: transcribe(word_timestamps=True) with and without hallucination_silence_threshold."""
+    cases = []
+    for seed in range(36):
+        rng = random.Random(9000 + seed)
+        kw: dict = dict(temperature=rng.choice([(0.0, 0.2, 0.4, 0.6, 0.8, 1.0), (0.0, 0.4), 0.0]), logprob_threshold=rng.choice([-1.0, -1.0, None]),
+                        no_speech_threshold=rng.choice([0.6, None]), compression_ratio_threshold=rng.choice([2.4, None]), word_timestamps=True,
+                        hallucination_silence_threshold=rng.choice([None, 0.5, 2.0, 2.0, 5.0]))
+        content = rng.choice([2999, 3001, 9000, 12345, 20000])
+        if rng.random() < 0.25:
+            pts = sorted(rng.sample(range(0, content // 100), rng.choice([1, 2, 3])))
+            kw["clip_timestamps"] = [float(p) for p in pts]
+        if rng.random() < 0.15:
+            kw["without_timestamps"] = True
+        cases.append(dict(seed=seed, content_frames=content, kw=kw))
+    return cases
+
+
 def model_decode(sd, dims, logit_bias: Optional[torch.Tensor] = None) -> Callable:
     def decode(segment: torch.Tensor, temperature: float, kw: dict) -> do.Result:
         kw = {k: v for k, v in kw.items() if k in do.Options.__dataclass_fields__}
@@ -131,7 +186,8 @@ def run_oracle(decode: Callable, mel_padded: torch.Tensor, **kw) -> dict:
         passed = {k: v for k, v in fields.items() if k in shim.kw}  # only what transcribe() forwarded
         return [decode(seg[0], opt.temperature, passed)]
     tkw = {k: kw.pop(k) for k in list(kw) if k in ("temperature", "logprob_threshold", "no_speech_threshold", "clip_timestamps", "tokenizer",
-                                                   "compression_ratio_threshold", "initial_prompt")}
+                                                   "compression_ratio_threshold", "initial_prompt", "word_timestamps", "add_word_timestamps",
+                                                   "hallucination_silence_threshold")}
     shim.kw = dict(kw)
     do.decode = shim
     try:
@@ -163,6 +219,10 @@ def run_reference(decode: Callable, mel_padded: torch.Tensor, **kw) -> dict:
     rt.pad_or_trim = lambda x, length: F.pad(x, (0, length - x.shape[-1])) if x.shape[-1] < length else x[..., :length]
     rt.get_tokenizer = lambda *a, **k: Tok()
     rt.DecodingOptions = Opt
+    words = kw.pop("add_word_timestamps", None)
+    if words is not None:  # the two whisper names the word-timestamp section calls (:410, :422)
+        rt.add_word_timestamps = words
+        rt.get_end = do.get_end
     if "clip_timestamps" in kw:
         kw["clip_timestamps"] = list(kw["clip_timestamps"])
     kw.pop("tokenizer", None)  # (the reference builds its own through get_tokenizer, patched above)
@@ -172,11 +232,12 @@ def run_reference(decode: Callable, mel_padded: torch.Tensor, **kw) -> dict:
     return {"segments": out["segments"], "tokens": toks, "text": out["text"]}
 
 
-def comparable(out: dict, text: bool = False) -> dict:
+def comparable(out: dict, text: bool = False, words: bool = False) -> dict:
     """The fields both sides define, JSON-ready.  ``text``: also the text-level fields (runs with a tokenizer)."""
     keys = ("id", "seek", "start", "end", "tokens", "temperature", "avg_logprob", "no_speech_prob") + (("text", "compression_ratio") if text else ())
     res = {"tokens": [int(t) for t in out["tokens"]],
-           "segments": [{k: ([int(t) for t in s[k]] if k == "tokens" else s[k]) for k in keys} for s in out["segments"]]}
+           "segments": [{**{k: ([int(t) for t in s[k]] if k == "tokens" else s[k]) for k in keys}, **({"words": s["words"]} if words else {})}
+                        for s in out["segments"]]}
     if text:
         res["text"] = out["text"]
     return res

@@ -113,3 +113,26 @@ def test_oracle_vs_live_reference(ora, tiny_case):
     with torch.no_grad():
         ref = net(c["mel"], c["tokens"], pm)
     assert (ref - ora["logits"]).abs().max().item() < 5e-5
+
+
+@pytest.mark.skipif(not ref_import.available(), reason="/root/reference not mounted (build container only)")
+def test_oracle_qkv_attention_equals_the_reference_manual_path_live():
+    """row a8: ``qk`` as the reference's MultiHeadAttention returns it -- the manual path (a 2-D mask, model.py:316-327, 347-442) hands back
+    the fp32 pre-softmax scores, the SDPA path (no mask / a 3-D mask) None.  oracle.model_oracle.qkv_attention is that path, bit for bit."""
+    model, _, _ = ref_import.load()
+    torch.manual_seed(0)
+    m = model.MultiHeadAttention(128, 2)
+    x, xa = torch.randn(2, 7, 128), torch.randn(2, 11, 128)
+    mask = torch.full((9, 9), float("-inf")).triu_(1)[:7, :7]
+    with torch.no_grad():
+        out, qk = m(x, mask=mask)
+        wv, qk_o = mo.qkv_attention(m.query(x), m.key(x), m.value(x), 2, mask)
+        assert qk.dtype == torch.float32 and qk.shape == (2, 2, 7, 7) and torch.equal(qk, qk_o) and torch.equal(m.out(wv), out)
+        assert m(x)[1] is None and m(x, xa)[1] is None and m(x, mask=torch.zeros(2, 7, 7))[1] is None  # SDPA path: no scores
+        # cross-attention scores of a whole decoder, the tensor word-timestamp alignment needs, through the oracle's block walk
+        dims = mo.Dims(80, 1500, 128, 2, 1, 51864, 448, 128, 2, 2)
+        sd = mo.init_state_dict(dims, seed=3)
+        toks = torch.tensor([[50257, 50362, 5, 6, 7, 50256]])
+        xa2 = torch.randn(1, 1500, 128)
+        got = mo.cross_attention_scores(sd, dims, toks, xa2, [1])
+        assert set(got) == {1} and got[1].shape == (1, 2, 6, 1500) and torch.isfinite(got[1]).all()

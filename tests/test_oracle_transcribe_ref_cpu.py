@@ -29,10 +29,12 @@ def golden(golden_dir):
         return json.load(f)
 
 
-def _eq(got, want, what, text=False):
+def _eq(got, want, what, text=False, words=False):
     assert got["tokens"] == want["tokens"], what
     assert len(got["segments"]) == len(want["segments"]), what
     for a, b in zip(got["segments"], want["segments"]):
+        if words:
+            assert a["words"] == b["words"], (what, a["id"], a["words"][:3], b["words"][:3])
         for k in ("id", "seek", "tokens", "temperature") + (("text",) if text else ()):
             assert a[k] == b[k], (what, k, a, b)
         for k in ("start", "end", "avg_logprob", "no_speech_prob") + (("compression_ratio",) if text else ()):
@@ -79,6 +81,28 @@ def test_oracle_transcribe_with_tokenizer_equals_reference_fixture(golden):
     assert cr_decides >= 8 and prompts >= 3 and fallback >= 8, (cr_decides, prompts, fallback)
 
 
+def test_oracle_transcribe_word_timestamps_equals_reference_fixture(golden):
+    """transcribe(word_timestamps=True[, hallucination_silence_threshold=...]) (:409-486): the seek-to-last-word rule, the three silence /
+    hallucination skipping rules, ``last_speech_timestamp`` and the ``words`` of cleared segments, with ``add_word_timestamps`` (third party,
+    whisper.timing) scripted identically on both sides."""
+    cases = H.scripted_words_cases()
+    assert len(cases) == len(golden["scripted_words"]) == 36
+    hal_decides = word_seek = with_words = dropped = 0
+    for c, want in zip(cases, golden["scripted_words"]):
+        dec, mel, words = H.scripted_decode_cr(c["seed"]), H.index_mel(c["content_frames"]), H.scripted_words(c["seed"])
+        got = H.comparable(H.run_oracle(dec, mel, tokenizer=H.Tok(), add_word_timestamps=words, **dict(c["kw"])), text=True, words=True)
+        _eq(got, want, f"scripted_words case {c['seed']} {c['kw']}", text=True, words=True)
+        plain = H.comparable(H.run_oracle(dec, mel, tokenizer=H.Tok(), **{**c["kw"], "word_timestamps": False, "hallucination_silence_threshold": None}), text=True)
+        word_seek += [s["seek"] for s in plain["segments"]] != [s["seek"] for s in got["segments"]]
+        if c["kw"]["hallucination_silence_threshold"] is not None:
+            no_hal = H.comparable(H.run_oracle(dec, mel, tokenizer=H.Tok(), add_word_timestamps=words, **{**c["kw"], "hallucination_silence_threshold": None}),
+                                  text=True, words=True)
+            hal_decides += no_hal != got
+            dropped += len(no_hal["segments"]) != len(got["segments"])
+        with_words += any(s["words"] for s in got["segments"])
+    assert hal_decides >= 8 and word_seek >= 15 and with_words >= 25 and dropped >= 5, (hal_decides, word_seek, with_words, dropped)
+
+
 def test_oracle_transcribe_equals_reference_fixture_real_model(golden):
     from oracle.gen_transcribe_golden import model_case
     torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
@@ -98,6 +122,11 @@ def test_oracle_transcribe_equals_reference_live():
         dec, mel = H.scripted_decode_cr(c["seed"]), H.index_mel(c["content_frames"])
         _eq(H.comparable(H.run_oracle(dec, mel, tokenizer=H.Tok(), **dict(c["kw"])), text=True),
             H.comparable(H.run_reference(dec, mel, **dict(c["kw"])), text=True), f"live, with tokenizer {c}", text=True)
+    for c in H.scripted_words_cases():
+        dec, mel, words = H.scripted_decode_cr(c["seed"]), H.index_mel(c["content_frames"]), H.scripted_words(c["seed"])
+        _eq(H.comparable(H.run_oracle(dec, mel, tokenizer=H.Tok(), add_word_timestamps=words, **dict(c["kw"])), text=True, words=True),
+            H.comparable(H.run_reference(dec, mel, add_word_timestamps=words, **dict(c["kw"])), text=True, words=True),
+            f"live, word timestamps {c}", text=True, words=True)
 
 
 def test_product_seek_loop_equals_reference_fixture(golden, monkeypatch):
@@ -142,6 +171,25 @@ def test_product_seek_loop_with_tokenizer_equals_reference_fixture(golden, monke
         for bw in (1, 4):
             out = T.transcribe(model, H.index_mel(c["content_frames"]), batch_windows=bw, tokenizer=H.Tok(), **dict(c["kw"]))
             _eq(H.comparable(out, text=True), want, f"product loop with tokenizer, case {c['seed']}, batch_windows {bw}", text=True)
+
+
+def test_product_seek_loop_word_timestamps_equals_reference_fixture(golden, monkeypatch):
+    """olmoasr_amd/transcribe.py with word_timestamps / hallucination_silence_threshold against what the reference's own transcribe()
+    produced with the same scripted decode results and the same scripted add_word_timestamps (fixture "scripted_words")."""
+    from olmoasr_amd import transcribe as T
+    model = types.SimpleNamespace(dims=types.SimpleNamespace(n_mels=80, n_audio_ctx=1500, n_text_ctx=448), device="cpu")
+    monkeypatch.setattr(T, "log_mel_spectrogram", lambda audio, n_mels=80, padding=0, device=None: audio)
+    for c, want in zip(H.scripted_words_cases(), golden["scripted_words"]):
+        monkeypatch.setattr(T, "decode", _fake_decode(T, H.scripted_decode_cr(c["seed"])))
+        monkeypatch.setattr(T, "add_word_timestamps", H.scripted_words(c["seed"]))
+        kw = dict(c["kw"])
+        if "clip_timestamps" in kw:
+            kw["clip_timestamps"] = ",".join(str(x) for x in kw["clip_timestamps"])
+        out = T.transcribe(model, H.index_mel(c["content_frames"]), batch_windows=4, tokenizer=H.Tok(), **kw)
+        _eq(H.comparable(out, text=True, words=True), want, f"product loop, word timestamps, case {c['seed']}", text=True, words=True)
+    with pytest.raises(ValueError, match="tokenizer"):
+        monkeypatch.setattr(T, "resolve_tokenizer", lambda model, tokenizer=None, *a, **k: tokenizer)
+        T.transcribe(model, H.index_mel(3000), word_timestamps=True)
 
 
 def test_decode_fills_text_and_compression_ratio_like_whisper():
