@@ -58,6 +58,15 @@ class GradReducer:
         # on the compute stream, first bucket started / last bucket done on the communication stream -- read back by comm_report()
         self.timing = bool(timing) and flat_grads.is_cuda
         self._tev = None
+        # Overlap self-check in training (timing=False): every `overlap_check_every`-th reduce() records the same three events and the NEXT
+        # reduce() reads them (they have long completed: no synchronisation).  The exchange overlaps the backward only because the
+        # communication stream has a hardware queue of its own (see comm_stream below) -- an empirical property of the runtime; if a driver
+        # or torch update ever folds the two streams into one queue again, the first bucket starts AFTER the backward has ended
+        # (comm_lead_ms <= 0) and every step silently pays the whole exchange.  Warned about once, loudly.
+        self.overlap_check_every = 64
+        self._n_reduce = 0
+        self._pending_check = None
+        self._warned_no_overlap = False
         self.algo = algo
         self.flat = flat_grads
         self.force = force  # run the collectives even at world_size 1 (single-GPU test of the event/stream path)
@@ -128,8 +137,12 @@ class GradReducer:
         main = torch.cuda.current_stream(self.flat.device)
         if not use_events:
             self.comm_stream.wait_stream(main)
+        self._n_reduce += 1
+        self._check_overlap_sample()
+        sample = (not self.timing and use_events and len(self.buckets) > 1 and self.overlap_check_every > 0
+                  and self._n_reduce >= 2 and (self._n_reduce - 2) % self.overlap_check_every == 0)  # (never the first step: warm-up)
         tev = None
-        if self.timing:
+        if self.timing or sample:
             tev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
             tev[0].record(main)  # every kernel of the backward has been enqueued in front of this
         with torch.cuda.stream(self.comm_stream):
@@ -141,8 +154,23 @@ class GradReducer:
                 self._sum_bucket(self.flat[off:off + n])
             if tev is not None:
                 tev[2].record(self.comm_stream)
-        self._tev = tev
+        if sample:
+            self._pending_check = tev
+        else:
+            self._tev = tev
         main.wait_stream(self.comm_stream)
+
+    def _check_overlap_sample(self):
+        tev, self._pending_check = self._pending_check, None
+        if tev is None or self._warned_no_overlap or not tev[2].query():
+            return
+        lead = tev[1].elapsed_time(tev[0])  # first bucket started -> end of the backward
+        if lead <= 0.0:
+            self._warned_no_overlap = True
+            import warnings
+            warnings.warn(f"GradReducer: the gradient exchange did not overlap the backward (first bucket started {-lead:.2f} ms AFTER the "
+                          f"backward ended; exchange {tev[1].elapsed_time(tev[2]):.2f} ms fully exposed per step).  The communication stream "
+                          "no longer has a hardware queue of its own -- see GradReducer.comm_stream / ddp.rccl_options()")
 
     def comm_report(self) -> dict:
         """Of the most recent ``reduce()`` (``timing=True``; synchronises on its last event):

@@ -295,6 +295,23 @@ def test_bucketed_reducer_events_single_gpu(native_tiny, tiny_case):
         assert rel < 1e-3, rel
         for off, n, _ in red.buckets:
             assert float(g_red[off:off + n].abs().sum()) > 0.0
+        # the run-time overlap self-check (every overlap_check_every-th reduce() samples the three events, the next one reads them): silent
+        # while the first bucket starts before the backward ends; warns ONCE when the exchange is queued behind the backward -- provoked
+        # here by waiting for the whole backward before reduce(), which is what a communication stream without its own queue amounts to
+        import warnings
+        red.overlap_check_every = 1  # sample every reduce() from the second on
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            for k in range(3):
+                net.zero_grad()
+                net.loss_and_backward(*args, segment_events=red.segment_events())
+                if k >= 1:
+                    torch.cuda.synchronize()  # the backward has ENDED before the first bucket can start
+                red.reduce()
+                torch.cuda.synchronize()
+            red.reduce()  # reads the last sample
+        msgs = [str(x.message) for x in w if "did not overlap" in str(x.message)]
+        assert len(msgs) == 1 and "fully exposed" in msgs[0], msgs
     finally:
         if own_pg:
             dist.destroy_process_group()

@@ -66,7 +66,11 @@ def test_attention_and_block_forwards_equal_the_oracle(tiny_case, kind):
             mask = mo.build_padding_mask(torch.tensor([17, 201]), T) + mask
     x = torch.randn(2, T, d, generator=g)
     out, qk = blk.attn(x.to(DEV), mask=None if mask is None else mask.to(DEV))
-    assert qk is None and out.shape == x.shape
+    assert out.shape == x.shape
+    if kind == "decoder-causal":  # a 2-D mask is the reference's manual path: qk = the fp32 pre-softmax scores (model.py:316-327, 347-442)
+        assert qk.dtype == torch.float32 and qk.shape == (2, H, T, T) and bool(torch.isinf(qk[0, 0, 0, 1:]).all()) and bool(torch.isfinite(qk[..., 0]).all())
+    else:                         # mask-free / 3-D mask: its SDPA path returns None
+        assert qk is None
     ref = mo.mha(sd, prefix + ".attn", x, None, mask, H, cfg)
     _close(out, ref, 2e-2, "self-attention")
     if cross:

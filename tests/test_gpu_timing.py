@@ -129,8 +129,12 @@ def test_transcribe_with_word_timestamps_runs_end_to_end(tiny_case):
     net = OLMoASR(_dims(dims), device=DEV, seed=0)
     net.load_state_dict(sd)
     pcm = tiny_case["pcm"][0].float() / 32768.0
-    out = net.transcribe(pcm, tokenizer=WordTok(), word_timestamps=True, hallucination_silence_threshold=2.0, temperature=0.0,
-                         logprob_threshold=None, no_speech_threshold=None, compression_ratio_threshold=None, sample_len=12)
+    kw = dict(tokenizer=WordTok(), word_timestamps=True, temperature=0.0, logprob_threshold=None, no_speech_threshold=None,
+              compression_ratio_threshold=None, sample_len=12)
+    # (a random-weight model's words are improbable: with the hallucination rules on, its segments may all be dropped -- only that it runs)
+    hal = net.transcribe(pcm, hallucination_silence_threshold=2.0, **kw)
+    assert isinstance(hal["segments"], list) and all("words" in s for s in hal["segments"])
+    out = net.transcribe(pcm, **kw)
     assert out["segments"]
     seen = 0
     for s in out["segments"]:
