@@ -455,6 +455,8 @@ __global__ __launch_bounds__(256, T == 32 ? 2 : 3) void logmel_fft(const PCM* __
   }
 }
 
+#include "logmel_quad.h"
+
 __global__ __launch_bounds__(256) void logmel_finalize(float* __restrict__ mel, const unsigned* __restrict__ clipmax,
                                                        long per_clip) {
   const int b = blockIdx.y;
@@ -476,6 +478,7 @@ struct MelTables {
   float* basis = nullptr;    // [208][416] (folded)
   float* melfilt = nullptr;  // [208][80]
   float* fft_tab = nullptr;  // [XTAB] stage tables of the FFT kernel (twiddles, window, sparse mel filters)
+  float* quad_tab = nullptr; // [QTAB] per-lane tables of the quad-lane kernel (logmel_quad.h)
   int mel_words = 0;         // used words of its mel table
   int mel_span = 0;          // taps of the widest filter
   int device = -1;
@@ -577,6 +580,41 @@ static int ensure_tables(int device, MelTables** t_out) {
       OASR_CHECK_HIP(hipMalloc((void**)&t.fft_tab, sizeof(float) * XTAB));
       OASR_CHECK_HIP(hipMemcpy(t.fft_tab, ft.data(), sizeof(float) * XTAB, hipMemcpyHostToDevice));
     }
+    {  // quad-lane kernel tables: lane l of a quad holds k1 = {0, 2, 1, 3}[l] (bit-reversed) after the cross-lane radix-4
+      const int K1[4] = {0, 2, 1, 3};
+      std::vector<float> qt((size_t)QTAB, 0.f);
+      for (int s = 0; s < NFFT; ++s) qt[(size_t)QTAB_WIN + s] = (float)(0.5 - 0.5 * cos(2.0 * PI * s / NFFT));
+      for (int m = 0; m < 50; ++m)
+        for (int l = 0; l < 4; ++l) {
+          const int e200 = (m * K1[l]) % 200, e400 = K1[l] + 4 * m;  // W200^(m k1); W400^(k1 + 4 k2) with k2 = m
+          qt[(size_t)QTAB_TW200 + 2 * (4 * m + l)] = (float)cos(2.0 * PI * e200 / 200.0);
+          qt[(size_t)QTAB_TW200 + 2 * (4 * m + l) + 1] = (float)(-sin(2.0 * PI * e200 / 200.0));
+          qt[(size_t)QTAB_TW400 + 2 * (4 * m + l)] = (float)cos(2.0 * PI * e400 / 400.0);
+          qt[(size_t)QTAB_TW400 + 2 * (4 * m + l) + 1] = (float)(-sin(2.0 * PI * e400 / 400.0));
+        }
+      oasr_mel_filterbank(fb);
+      for (int m = 0; m < NMEL; ++m) {
+        int lo = NFREQ, hi = -1;
+        for (int f = 0; f < NFREQ; ++f)
+          if (fb[m * NFREQ + f] != 0.f) {
+            lo = f < lo ? f : lo;
+            hi = f;
+          }
+        // the compile-time slot structure (logmel_quad_tables.h, generated from the same formulas) must describe THIS filterbank
+        if (hi < lo || lo / 4 != QMEL_K2LO[m] || hi / 4 - lo / 4 + 1 != QMEL_NSLOT[m] || hi > 199) {
+          oasr_set_error("log-mel: filter %d spans bins %d..%d, logmel_quad_tables.h says k2 %d + %d: regenerate (scripts/gen_logmel_quad_tables.py)",
+                         m, lo, hi, QMEL_K2LO[m], QMEL_NSLOT[m]);
+          return OASR_ESTATE;
+        }
+        for (int sl = 0; sl < QMEL_NSLOT[m]; ++sl)
+          for (int l = 0; l < 4; ++l) {
+            const int k = K1[l] + 4 * (QMEL_K2LO[m] + sl);
+            qt[(size_t)QTAB_MEL + 4 * (QMEL_OFF[m] + sl) + l] = k <= 199 ? 0.25f * fb[m * NFREQ + k] : 0.f;  // (P holds 4 |X|^2)
+          }
+      }
+      OASR_CHECK_HIP(hipMalloc((void**)&t.quad_tab, sizeof(float) * QTAB));
+      OASR_CHECK_HIP(hipMemcpy(t.quad_tab, qt.data(), sizeof(float) * QTAB, hipMemcpyHostToDevice));
+    }
     OASR_CHECK_HIP(hipMalloc((void**)&t.basis, sizeof(float) * NK * NB));
     OASR_CHECK_HIP(hipMalloc((void**)&t.melfilt, sizeof(float) * NBH * NMEL));
     OASR_CHECK_HIP(hipMemcpy(t.basis, hb, sizeof(float) * NK * NB, hipMemcpyHostToDevice));
@@ -632,6 +670,27 @@ static int log_mel_impl(const void* pcm, int pcm_dtype, int B, int n_samples, fl
   }();
   const long per_clip = (long)NMEL * n_frames;
   const dim3 g2((unsigned)((per_clip / 4 + 255) / 256 > 64 ? 64 : (per_clip / 4 + 255) / 256 + 1), B);
+  static const bool use_lds_fft = [] {  // "fft" / "fft32": the round-3/5 LDS FFT kernel (A/B and cross-check); default: the quad-lane register kernel
+    const char* e = oasr_experiment_env("OASR_LOGMEL");
+    return e && (strcmp(e, "fft") == 0 || strcmp(e, "fft32") == 0);
+  }();
+  if (!use_mfma_dft && !use_lds_fft) {
+    const size_t qlds = pcm_dtype == 1 ? quad_lds_bytes<int16_t>() : quad_lds_bytes<float>();
+    const dim3 qgrid((unsigned)(cdiv(n_frames, QT) * B));
+    static LdsAttrOnce qattr16, qattr32;
+    if (pcm_dtype == 1) {
+      { const int rc_ = ensure_dynamic_lds(qattr16, (const void*)logmel_quad<int16_t>, (int)qlds); if (rc_) return rc_; }
+      hipLaunchKernelGGL(logmel_quad<int16_t>, qgrid, dim3(256), qlds, stream, (const int16_t*)pcm, n_samples, n_frames, t->quad_tab, mel, clipmax);
+    } else {
+      { const int rc_ = ensure_dynamic_lds(qattr32, (const void*)logmel_quad<float>, (int)qlds); if (rc_) return rc_; }
+      hipLaunchKernelGGL(logmel_quad<float>, qgrid, dim3(256), qlds, stream, (const float*)pcm, n_samples, n_frames, t->quad_tab, mel, clipmax);
+    }
+    OASR_LAUNCH_CHECK();
+    if (clip_max_out) hipLaunchKernelGGL(logmel_clipmax_kernel, dim3(cdiv(B, 256)), dim3(256), 0, stream, clipmax, clip_max_out, B);
+    else hipLaunchKernelGGL(logmel_finalize, g2, dim3(256), 0, stream, mel, clipmax, per_clip);
+    OASR_LAUNCH_CHECK();
+    return OASR_OK;
+  }
   if (!use_mfma_dft) {
     static const int frames_per_wg = [] {  // A/B: OASR_LOGMEL=fft32 is the round-3/4 geometry
       const char* e = oasr_experiment_env("OASR_LOGMEL");

@@ -31,6 +31,7 @@ def main():
             (f"M={M} qkv   N=3072 K=1024 bias", lambda x=x, w=w, bias=bias, out=out, M=M: ops.gemm(x[:, :d], w[:3 * d, :d], M, 3 * d, d, bias=bias[:3 * d], out=out[:, :3 * d]), 2.0 * M * 3 * d * d),
             (f"M={M} proj  N=1024 K=1024 bias+resid", lambda x=x, w=w, bias=bias, out=out, resid=resid, M=M: ops.gemm(x[:, :d], w[:d, :d], M, d, d, bias=bias[:d], resid=resid, out=out[:, :d]), 2.0 * M * d * d),
             (f"M={M} mlp1  N=4096 K=1024 gelu", lambda x=x, w=w, bias=bias, out=out, pre=pre, M=M: ops.gemm(x[:, :d], w[:, :d], M, 4 * d, d, bias=bias, act=1, out=out, out_pre=pre), 2.0 * M * 4 * d * d),
+            (f"M={M} mlp1  N=4096 K=1024 gelu+gelu' (training)", lambda x=x, w=w, bias=bias, out=out, pre=pre, M=M: ops.gemm(x[:, :d], w[:, :d], M, 4 * d, d, bias=bias, act=2, out=out, out_pre=pre), 2.0 * M * 4 * d * d),
             (f"M={M} mlp2  N=1024 K=4096 bias+resid", lambda x=x, w=w, bias=bias, out=out, resid=resid, M=M: ops.gemm(x, w[:d], M, d, 4 * d, bias=bias[:d], resid=resid, out=out[:, :d]), 2.0 * M * 4 * d * d),
             (f"M={M} dgrad N=1024 K=1024", lambda x=x, w=w, out=out, M=M: ops.gemm(x[:, :d], w[:d, :d], M, d, d, tb=True, out=out[:, :d]), 2.0 * M * d * d),
             (f"M={M} dgrad N=1024 K=3072", lambda x=x, w=w, out=out, M=M: ops.gemm(x[:, :3 * d], w[:3 * d, :d], M, d, 3 * d, tb=True, out=out[:, :d]), 2.0 * M * 3 * d * d),
@@ -52,9 +53,9 @@ def main():
                 if r:
                     res.setdefault((name, c), []).append(ev[0].elapsed_time(ev[1]) / 3)
     N.lib().oasr_gemm_force_general(0)
-    print(f"{'shape':44s} " + " ".join(f"code{c}: med/min ms (TF/s med)" for c in codes))
+    print(f"{'shape':52s} " + " ".join(f"code{c}: med/min ms (TF/s med)" for c in codes))
     for name, fn, flops in shapes:
-        row = f"{name:44s} "
+        row = f"{name:52s} "
         for c in codes:
             v = res[(name, c)]
             med = statistics.median(v)
