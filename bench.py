@@ -269,7 +269,7 @@ def hbm_kernel_rooflines(net, dims, mb, dev):
          f"[{rows}, {d}]: dy, x, dres in, dx out (+ stats)")
     del x, y, dy
     pcm = torch.zeros(mb, 480000, dtype=torch.int16, device=dev).random_(-3000, 3000)
-    line("logmel_fft (floor fused into the encoder's transpose)", timed(lambda: ops.log_mel(pcm, finalize=False)), mb * 1.92e6,
+    line("logmel_fft (round 6: the quad-lane register kernel logmel_quad; floor fused into the encoder's transpose)", timed(lambda: ops.log_mel(pcm, finalize=False)), mb * 1.92e6,
          f"{mb} clips: int16 PCM in + fp32 [80,3000] log10 mel power + per-clip maximum out (what the timed step runs)")
     line("logmel_fft+finalize (whisper.audio.log_mel_spectrogram's own output)", timed(lambda: ops.log_mel(pcm)), mb * 1.92e6,
          f"{mb} clips: the same + the in-place floor / scale pass (3.84 MB per clip actually move)")
@@ -402,7 +402,8 @@ def main():
     ap.add_argument("--hbm-margin-gib", type=float, default=16.0,
                     help="HBM left free beside the saved-activation workspace when the micro-batch is chosen: transient tensors of a step "
                          "(< 1 GiB) + RCCL's channel buffers at N > 1 (~1-2 GiB); one world-independent number so N = 1 and N = 8 pick the same micro-batch")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r05_hbm_traffic.json"),
+    ap.add_argument("--traffic-json", default=next((p for p in (os.path.join(ROOT, "profiles", f) for f in ("r06_hbm_traffic.json", "r05_hbm_traffic.json"))
+                                                    if os.path.exists(p)), os.path.join(ROOT, "profiles", "r06_hbm_traffic.json")),
                     help="per-symbol HBM bytes per launch from the rocprofv3 PMC passes (scripts/pmc_traffic.py)")
     ap.add_argument("--bucket-mb", type=float, default=128.0)
     ap.add_argument("--reducer", default="allreduce", choices=["allreduce", "direct", "both"],
