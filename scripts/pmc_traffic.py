@@ -38,8 +38,12 @@ def main():
         wr = w[k] * 1024 / max(nw[k], 1)
         out[k] = {"launches": launches, "fetch_bytes_per_launch_x2_corrected": round(rd), "write_bytes_per_launch": round(wr),
                   "hbm_bytes_per_launch": round(rd + wr)}
+    import datetime
+    out["_meta"] = {"collected": datetime.datetime.now(datetime.timezone.utc).strftime("%Y-%m-%d %H:%M UTC"),
+                    "what": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (separate) of `python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile "
+                            "--ab-steps 0`; reads x 2 (gfx950 correction, MI355X_MICROARCH.md), bytes = counter x 1024; side-stream and main-stream launches of a symbol are averaged together"}
     json.dump(out, open(sys.argv[3], "w"), indent=1)
-    for k, v in list(out.items())[:12]:
+    for k, v in [kv for kv in out.items() if kv[0] != "_meta"][:12]:
         print(f"{k[:80]:80s} {v['hbm_bytes_per_launch'] / 1e6:10.2f} MB/launch (rd {v['fetch_bytes_per_launch_x2_corrected'] / 1e6:.2f} wr {v['write_bytes_per_launch'] / 1e6:.2f})")
 
 

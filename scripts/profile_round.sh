@@ -7,7 +7,7 @@
 #   4. rocprofv3 --pmc GRBM_GUI_ACTIVE         -> effective shader clock per kernel under the step's load (scripts/pmc_clock.py)
 # Counter passes never carry --kernel-trace/--stats-unrelated trace domains (gpurun refuses pmc + sys/hip/hsa tracing).
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd "$(dirname "$0")/.." || exit 1
@@ -17,6 +17,7 @@ BENCH1="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --ab
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
 f=$(find $OUT/trace -name "*kernel_trace.csv" | head -1)
 [ -n "$f" ] && python scripts/rocprof_summary.py "$f" > $OUT/${TAG}_bench_default_kernel_stats.txt
+[ -n "$f" ] && python scripts/rocprof_summary.py "$f" --by-queue > $OUT/${TAG}_bench_default_kernel_stats_by_queue.txt
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o pmc -- $BENCH1 > $OUT/pmc_$c.log 2>&1
 done

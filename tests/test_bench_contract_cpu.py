@@ -62,3 +62,33 @@ def test_committed_bench_line_has_the_contract_fields_and_consistent_arithmetic(
         assert not r["kernel"].endswith("]") and any(k.endswith("[side]") for k in r["by_symbol"]) and any(k.endswith("[shared]") for k in r["by_symbol"])
         ma = r["main_stream_all"]
         assert ma["launches"] > r["launches_per_step"] and 0 < ma["frac"] <= r["frac"] + 0.02
+
+
+def test_cpu_baseline_times_the_unmodified_reference_where_it_is_mounted():
+    """bench.py's `cpu_baseline` leg: kind "reference" (the reference's own module through the training lines) where /root/reference is
+    readable -- the build container --, kind "port" (the oracle restatement) on the GPU box; the same loss either way."""
+    import importlib.util
+    import sys
+    import pytest
+    import torch
+    from oracle import model_oracle as mo
+    from oracle import ref_import
+    spec = importlib.util.spec_from_file_location("oasr_bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        spec.loader.exec_module(bench)
+    finally:
+        sys.argv = argv
+    sd = mo.init_state_dict(mo.VARIANTS["tiny"], seed=0)
+    threads = torch.get_num_threads()
+    try:
+        blk, loss, logits = bench.cpu_baseline("tiny", sd, budget_s=1.0)
+    finally:
+        torch.set_num_threads(threads)
+    assert blk["kind"] == ("reference" if ref_import.available() else "port") and blk["value"] > 0 and blk["cores"] >= 1
+    pcm, ti, ty, tl = mo.synthetic_batch([0])
+    from oracle import mel_oracle as me
+    import numpy as np
+    want, _, _ = mo.loss_and_grads(sd, mo.VARIANTS["tiny"], torch.from_numpy(me.log_mel_batch(pcm.numpy(), dtype=np.float32)), ti, ty, tl)
+    assert abs(loss - float(want)) < 1e-4 and logits.shape[-1] == 51865
