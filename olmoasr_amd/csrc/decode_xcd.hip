@@ -941,16 +941,17 @@ bool decode_xcd_supports(int d, int H, int Te, int S_max, int L, int M) {
 // decoder sits at the start of the arena); the engine takes the multi-launch step otherwise.
 bool decode_xcd_offsets_ok(const int64_t* layer0, long lstride, long cache_lstride, int d, int Te, int L, int M) {
   const long kLimit = (1L << 31) - (1L << 20);  // 1 MiB of slack for the per-lane part of an address
-  long w_end = 0;
   const int wsel[6] = {2, 4, 8, 10, 14, 16};  // XLayer: wqkv, wo, wcq, wco, w1, w2
   const long wsize[6] = {3L * d * d, (long)d * d, (long)d * d, (long)d * d, 4L * d * d, 4L * d * d};
+  // layer l = layer 0 + l * lstride; the arena keeps the decoder blocks in gradient-completion order (last block first), so the stride
+  // is NEGATIVE in the product's layout: both ends of the walk are checked
+  const long span = (long)(L - 1) * lstride;
   for (int k = 0; k < 6; ++k) {
-    if (layer0[wsel[k]] < 0) return false;
-    const long e = layer0[wsel[k]] + (long)(L - 1) * lstride + wsize[k];
-    w_end = e > w_end ? e : w_end;
+    const long first = layer0[wsel[k]] + (span < 0 ? span : 0), last = layer0[wsel[k]] + (span > 0 ? span : 0) + wsize[k];
+    if (first < 0 || last * 2 >= kLimit) return false;
   }
   const long kv_end = (long)(L - 1) * cache_lstride + (long)M * Te * 2 * d;  // from layer 0's cross K/V rows
-  return lstride >= 0 && cache_lstride >= 0 && w_end * 2 < kLimit && kv_end * 2 < kLimit;
+  return cache_lstride >= 0 && kv_end * 2 < kLimit;
 }
 
 extern "C" int oasr_xcd_offsets_ok_debug(const int64_t* layer0, long long lstride, long long cache_lstride, int d, int Te, int L, int M) {

@@ -11,7 +11,7 @@ from olmoasr_amd import _native as N  # noqa: E402
 from olmoasr_amd.config.model_dims import VARIANT_TO_DIMS  # noqa: E402
 from olmoasr_amd.model import OLMoASR  # noqa: E402
 
-NAMES = {0: "separate LayerNorm kernels", 1: "multi-launch, LayerNorm folded (round 2-4 default for B <= 4)", 2: "ONE launch, 32 CUs of one XCD",
+NAMES = {-1: "library default", 0: "separate LayerNorm kernels", 1: "multi-launch, LayerNorm folded (round 2-4 default for B <= 4)", 2: "ONE launch, 32 CUs of one XCD",
          3: "ONE launch, 32 workgroups spread over the chip", 4: "ONE launch, 64 workgroups spread over the chip"}
 
 

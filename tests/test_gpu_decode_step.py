@@ -168,3 +168,24 @@ def test_poisoned_one_launch_engine_falls_back_to_the_multi_launch_engine(tiny_c
         warnings.simplefilter("ignore")
         r = decode(net2, mel, opts)
     assert calls["n"] == 2 and r[0].tokens == clean[0].tokens
+
+
+@pytest.mark.parametrize("width,heads,layers", [(768, 12, 3), (1024, 16, 2)])
+def test_default_engine_for_one_sequence_is_the_one_launch_engine(tiny_case, width, heads, layers):
+    """All step engines are bit-identical, so a default that silently falls back to the multi-launch kernels passes every parity test --
+    and costs 10-30 % per token (it happened: a host-side guard rejected the product's own arena layout, whose decoder blocks are stored
+    last-first, i.e. with a negative layer stride).  The one-launch engine leaves a trace: its team barrier counter in the cache's tail."""
+    from olmoasr_amd.model import OLMoASR
+    from oracle import model_oracle as mo
+    dims = mo.Dims(80, 1500, width, heads, 1, 51864, 448, width, heads, layers)
+    net = OLMoASR(_dims(dims), device=DEV, seed=2, inference=True)
+    xa = net.embed_audio(tiny_case["mel"][:1].to(DEV))
+    st = net.kv_cache_begin(xa)
+    for p in range(3):
+        net.kv_cache_step(st, torch.tensor([50257 + p], device=DEV))
+    assert net.kv_cache_check(st) is True
+    counter = int(st["cache"][-256:].view(torch.int32)[0])
+    assert counter >= 3 * 8 * layers, f"team barrier counter {counter}: the one-launch engine did not run"
+    two = net.kv_cache_begin(xa.repeat(2, 1, 1))  # two sequences: the multi-launch kernels by default (they spread over the chip)
+    net.kv_cache_step(two, torch.tensor([50257, 50257], device=DEV))
+    assert net.kv_cache_check(two) is True and int(two["cache"][-256:].view(torch.int32)[0]) == 0

@@ -256,3 +256,9 @@ def test_one_launch_decode_refuses_layouts_past_the_32_bit_buffer_offsets(native
     assert lib.oasr_xcd_offsets_ok_debug(o, per_layer, 2**29, 1280, 1500, 4, 1) == 0                               # K/V layer stride past 2 GiB
     shifted = (ctypes.c_int64 * 18)(*[x + 2**30 for x in o])                                                       # decoder not at the arena start
     assert lib.oasr_xcd_offsets_ok_debug(shifted, per_layer, 3 * 448 * 1280 + 1500 * 2 * 1280, 1280, 1500, 32, 1) == 0
+    # the PRODUCT's arena keeps the decoder blocks last-first (gradient-completion order): layer 0 sits highest and the layer stride is negative
+    for name, d, L in (("small", 768, 12), ("medium", 1024, 24), ("large", 1280, 32)):
+        o, per_layer = layer0(d)
+        top = (ctypes.c_int64 * 18)(*[x + (L - 1) * per_layer for x in o])
+        assert lib.oasr_xcd_offsets_ok_debug(top, -per_layer, 3 * 448 * d + 1500 * 2 * d, d, 1500, L, 1) == 1, name
+        assert lib.oasr_xcd_offsets_ok_debug(o, -per_layer, 3 * 448 * d + 1500 * 2 * d, d, 1500, L, 1) == 0, name  # would walk below the arena
