@@ -587,8 +587,9 @@ static int ensure_tables(int device, MelTables** t_out) {
       for (int m = 0; m < 50; ++m)
         for (int l = 0; l < 4; ++l) {
           const int e200 = (m * K1[l]) % 200, e400 = K1[l] + 4 * m;  // W200^(m k1); W400^(k1 + 4 k2) with k2 = m
-          qt[(size_t)QTAB_TW200 + 2 * (4 * m + l)] = (float)cos(2.0 * PI * e200 / 200.0);
-          qt[(size_t)QTAB_TW200 + 2 * (4 * m + l) + 1] = (float)(-sin(2.0 * PI * e200 / 200.0));
+          const double sgn = (l == 1 || l == 2) ? -1.0 : 1.0;       // sg1 sg2 of lane l: the sign its one-instruction butterflies leave (logmel_quad.h)
+          qt[(size_t)QTAB_TW200 + 2 * (4 * m + l)] = (float)(sgn * cos(2.0 * PI * e200 / 200.0));
+          qt[(size_t)QTAB_TW200 + 2 * (4 * m + l) + 1] = (float)(-sgn * sin(2.0 * PI * e200 / 200.0));
           qt[(size_t)QTAB_TW400 + 2 * (4 * m + l)] = (float)cos(2.0 * PI * e400 / 400.0);
           qt[(size_t)QTAB_TW400 + 2 * (4 * m + l) + 1] = (float)(-sin(2.0 * PI * e400 / 400.0));
         }

@@ -42,6 +42,20 @@ __device__ __forceinline__ float qperm(float v) {
 template <int CTRL>
 __device__ __forceinline__ cf qperm(cf v) { return cf{qperm<CTRL>(v.x), qperm<CTRL>(v.y)}; }
 
+// acc + quad_perm(x) * c in ONE instruction (v_fmac_f32_dpp: a DPP instruction issues in ~4.2 cycles whatever it computes, so the exchange and
+// the butterfly's add cost what the exchange alone did; hipcc's DPP combiner does not form it from fmaf(mov_dpp(x), c, acc)).  Inline asm: the
+// VALU-write -> DPP-read hazard (2 wait states, cdna_hip_programming.md 5.7 item 2) is padded inside the string -- x usually comes straight out of
+// the multiply in front.  x and acc may be the same value: every lane reads before any lane writes.
+template <int CTRL>
+__device__ __forceinline__ float fmac_qperm(float acc, float x, float c) {
+  static_assert(CTRL == DPP_XOR1 || CTRL == DPP_XOR2, "spelled-out controls only");
+  if constexpr (CTRL == DPP_XOR1)
+    asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(x), "v"(c));
+  else
+    asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(x), "v"(c));
+  return acc;
+}
+
 // Per-lane selects as BIT selects on an all-ones / all-zeros mask register (v_bfi_b32): 195 fewer VALU instructions per lane than the
 // v_cmp-free ternaries compile to (sign flips fold into v_xor), same speed (profiles/r06_logmel_quad.txt).  The masks pass through an
 // empty asm so that the compiler cannot turn the and / or back into a select.
@@ -172,6 +186,7 @@ __global__ __launch_bounds__(256, QUAD_WAVES) void logmel_quad(const PCM* __rest
   // per-lane constants of the cross-lane radix-4
   const float sg1 = (l & 2) ? -1.f : 1.f;  // x + / - its xor-2 partner
   const float sg2 = (l & 1) ? -1.f : 1.f;  // r + / - its xor-1 partner
+  const float sg12 = sg1 * sg2;            // what the one-instruction butterflies leave on the result (folded into the W200 rows; applied to m = 0 here)
   const unsigned rot = lane_mask(l == 3);  // lane 3 carries (x1 - x3): times -i before the second exchange
   const unsigned m_self = lane_mask(l == 0), m_odd = lane_mask(l & 1), m_hi = lane_mask(l & 2);
 
@@ -196,12 +211,11 @@ __global__ __launch_bounds__(256, QUAD_WAVES) void logmel_quad(const PCM* __rest
       static_for<0, 2>([&](auto hc) {
         constexpr int m = 2 * j + decltype(hc)::value;
         const cf zz = z[decltype(hc)::value];
-        const cf p2 = qperm<DPP_XOR2>(zz);
-        const cf u = cf{fmaf(sg1, zz.x, p2.x), fmaf(sg1, zz.y, p2.y)};
+        // u' = z + sg1 P2(z) = sg1 u;  r' = rot(u') = sg1 r;  y' = r' + sg2 P1(r') = sg1 sg2 y: the lane's sign sg1 sg2 rides in its twiddle row
+        const cf u = cf{fmac_qperm<DPP_XOR2>(zz.x, zz.x, sg1), fmac_qperm<DPP_XOR2>(zz.y, zz.y, sg1)};
         const cf r = cf{bsel(rot, u.y, u.x), bsel(rot, fneg(u.x), u.y)};
-        const cf p1 = qperm<DPP_XOR1>(r);
-        const cf y = cf{fmaf(sg2, r.x, p1.x), fmaf(sg2, r.y, p1.y)};
-        if constexpr (m == 0) v[m] = y;
+        const cf y = cf{fmac_qperm<DPP_XOR1>(r.x, r.x, sg2), fmac_qperm<DPP_XOR1>(r.y, r.y, sg2)};
+        if constexpr (m == 0) v[m] = cf{y.x * sg12, y.y * sg12};
         else v[m] = cmul(y, t200[4 * m]);
       });
     });
