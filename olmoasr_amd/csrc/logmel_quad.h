@@ -97,6 +97,9 @@ __device__ __forceinline__ void dft25(const cf (&x)[25], cf (&out)[25]) {
 #ifndef QUAD_WAVES
 #define QUAD_WAVES 3
 #endif
+#ifndef QUAD_ABLATE
+#define QUAD_ABLATE 0  // timing experiments only (results garbage): bit 0 no cross-lane radix-4, 1 no 50-point FFT, 2 no unpack, 3 no mel reduction / pick
+#endif
 #ifndef QUAD_STAGE16
 #define QUAD_STAGE16 0  // 1: int16 PCM stays int16 in LDS (21 KB instead of 42: five workgroups per CU) and every lane converts its own 100 samples
 #endif
@@ -211,6 +214,10 @@ __global__ __launch_bounds__(256, QUAD_WAVES) void logmel_quad(const PCM* __rest
       static_for<0, 2>([&](auto hc) {
         constexpr int m = 2 * j + decltype(hc)::value;
         const cf zz = z[decltype(hc)::value];
+        if constexpr (QUAD_ABLATE & 1) {
+          v[m] = zz;
+          return;
+        }
         // u' = z + sg1 P2(z) = sg1 u;  r' = rot(u') = sg1 r;  y' = r' + sg2 P1(r') = sg1 sg2 y: the lane's sign sg1 sg2 rides in its twiddle row
         const cf u = cf{fmac_qperm<DPP_XOR2>(zz.x, zz.x, sg1), fmac_qperm<DPP_XOR2>(zz.y, zz.y, sg1)};
         const cf r = cf{bsel(rot, u.y, u.x), bsel(rot, fneg(u.x), u.y)};
@@ -224,7 +231,9 @@ __global__ __launch_bounds__(256, QUAD_WAVES) void logmel_quad(const PCM* __rest
   __builtin_amdgcn_sched_barrier(0);  // (phase fences: the scheduler otherwise hoists the next phase's table reads over this one and spills)
   // ---- stage 2: 50-point FFT over m in registers -> z[k2] = Z[k1(l) + 4 k2]
   cf z[50];
-  {
+  if constexpr (QUAD_ABLATE & 2) {
+    static_for<0, 50>([&](auto kc) { z[decltype(kc)::value] = v[decltype(kc)::value]; });
+  } else {
     cf t0[25], t1[25], g0[25], g1[25];
     static_for<0, 25>([&](auto bc) {
       constexpr int bb = decltype(bc)::value;
@@ -256,6 +265,10 @@ __global__ __launch_bounds__(256, QUAD_WAVES) void logmel_quad(const PCM* __rest
     auto bin = [&](auto kc) {
       constexpr int k2 = decltype(kc)::value;
       const cf own = z[k2];
+      if constexpr (QUAD_ABLATE & 4) {
+        P[k2] = own.x * own.x + own.y * own.y;
+        return;
+      }
       const cf pa = z[(50 - k2) % 50];
       const cf pb = qperm<DPP_SWAP23>(z[49 - k2]);
       const cf part = cf{bsel(m_self, pa.x, pb.x), bsel(m_self, pa.y, pb.y)};  // Z[200 - k]; its conjugate is (c, -d)
@@ -291,11 +304,13 @@ __global__ __launch_bounds__(256, QUAD_WAVES) void logmel_quad(const PCM* __rest
         constexpr int lo = QMEL_K2LO[m], ns = QMEL_NSLOT[m], off = QMEL_OFF[m];
         float a = mw[4 * off] * P[lo];
         static_for<1, ns>([&](auto sc) { a = fmaf(mw[4 * (off + decltype(sc)::value)], P[lo + decltype(sc)::value], a); });
-        a += qperm<DPP_XOR1>(a);
-        a += qperm<DPP_XOR2>(a);
+        if constexpr (!(QUAD_ABLATE & 8)) {
+          a += qperm<DPP_XOR1>(a);
+          a += qperm<DPP_XOR2>(a);
+        }
         s4[decltype(ic)::value] = a;
       });
-      const float mine = bsel(m_hi, bsel(m_odd, s4[3], s4[2]), bsel(m_odd, s4[1], s4[0]));
+      const float mine = (QUAD_ABLATE & 8) ? (s4[0] + s4[1]) + (s4[2] + s4[3]) : bsel(m_hi, bsel(m_odd, s4[3], s4[2]), bsel(m_odd, s4[1], s4[0]));
       // log10 = log2 * log10(2) on the hardware log2 (v_log_f32, ~1 ulp; the argument is a normal number >= 1e-10): libm's log10f spends a dozen
       // VALU on denormal scaling and a correction step this kernel has no use for (20 values per lane)
       val[j] = __builtin_amdgcn_logf(fmaxf(mine, 1e-10f)) * 0.30102999566398120f;
