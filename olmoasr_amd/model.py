@@ -767,6 +767,22 @@ class OLMoASR(nn.Module):
         from .transcribe import transcribe as _transcribe
         return _transcribe(self, audio, **kwargs)
 
+    # Word-level timestamp alignment (olmoasr_amd/timing.py) averages the cross-attention of these (layer, head) pairs.  None = whisper's
+    # default when a checkpoint names none: every head of the upper half of the decoder (the reference's load_model would call
+    # set_alignment_heads for a checkpoint that carries a mask, olmoasr/__init__.py:145, 163-164; none of the published ones does).
+    alignment_heads = None
+
+    def set_alignment_heads(self, dump) -> None:
+        """``dump``: a bool [n_text_layer, n_text_head] tensor / array, or whisper's serialised form (base85 of a gzip'd bool array)."""
+        if isinstance(dump, (bytes, str)):
+            import base64
+            import gzip
+            raw = gzip.decompress(base64.b85decode(dump))
+            mask = torch.from_numpy(np.frombuffer(raw, dtype=bool).copy())
+        else:
+            mask = torch.as_tensor(np.asarray(dump)).to(torch.bool)
+        self.alignment_heads = mask.reshape(self.dims.n_text_layer, self.dims.n_text_head).to_sparse()
+
     @property
     def device(self):
         return self._flat.device

@@ -125,3 +125,17 @@ def test_alignment_heads_default_is_the_upper_half_of_the_decoder():
     mask[1, 2] = mask[3, 0] = True
     m.alignment_heads = mask.to_sparse()
     assert T.alignment_heads(m) == [(1, 2), (3, 0)]
+
+
+def test_set_alignment_heads_accepts_a_mask_or_whispers_serialised_form():
+    import base64
+    import gzip
+    import types
+    from olmoasr_amd.model import OLMoASR
+    m = types.SimpleNamespace(dims=types.SimpleNamespace(n_text_layer=4, n_text_head=6), alignment_heads=None)
+    mask = np.zeros((4, 6), dtype=bool)
+    mask[2, 1] = mask[3, 5] = True
+    OLMoASR.set_alignment_heads(m, mask)
+    assert T.alignment_heads(m) == [(2, 1), (3, 5)]
+    OLMoASR.set_alignment_heads(m, base64.b85encode(gzip.compress(mask.tobytes())))
+    assert T.alignment_heads(m) == [(2, 1), (3, 5)]
