@@ -35,7 +35,7 @@ typedef struct oasr_dims {
 const char* oasr_last_error(void);
 /* ABI version: 100 * major + minor.  Structs passed by pointer (oasr_attn_args, oasr_gemm_args) only grow at the end and only with a
  * major bump; olmoasr_amd/_native.py refuses to drive a library whose version differs from OASR_ABI_VERSION. */
-#define OASR_ABI_VERSION 210
+#define OASR_ABI_VERSION 211
 int oasr_version(void);
 
 /* ---- log-mel front end: whisper.audio.log_mel_spectrogram as called at train_timestamps.py:196,214 and
@@ -106,14 +106,17 @@ int oasr_decode_logits(oasr_ctx*, const int64_t* tokens, const void* xa, const i
  * TextDecoder step per token.  kv_cache: oasr_kv_cache_bytes(B) bytes, caller owned, valid for one 30 s window batch.
  * decode_begin computes the cross-attention K/V of every layer from xa (bf16 [B, n_audio_ctx, d]); decode_step consumes
  * the token at position `pos` of each sequence (tokens_last i64 [B]) and returns f32 logits [B, rows] for position pos+1.
- * Engines (all bit-identical, csrc/decode_shared.h): ONE sequence on the bf16 engine -> one persistent launch for the whole decoder
- * stack (csrc/decode_xcd.hip: a team of 32 CUs, weights and cross K/V prefetched through LDS rings); 2-4 sequences -> LayerNorm folded
- * into the projections' operand loads; more -> separate kernels.  The one-launch engine keeps four control words in the cache's last
- * 256 bytes (zeroed by decode_begin; the cache is oasr_kv_cache_bytes(B) bytes INCLUDING that tail -- ABI 210; a caller that re-packs
- * a cache, e.g. the beam re-gather of whisper's rearrange_kv_cache, zeroes the tail of the new buffer).  The team needs its 32 workgroups
- * resident at once, i.e. the device to itself: a team member that never reaches a barrier (a second decoder on the device, a CU mask)
+ * Engines (one arithmetic, csrc/decode_shared.h): ONE sequence on the bf16 engine -> one persistent launch for the whole decoder stack
+ * on every CU of the device (csrc/decode_wide.hip: a few weight rows per workgroup, rows exchanged through per-workgroup phase flags;
+ * agrees with the other engines to the fp32 rounding of a differently ordered K sum); where that engine does not apply, the one-XCD team
+ * of csrc/decode_xcd.hip; 2-4 sequences -> LayerNorm folded into the projections' operand loads; more -> separate kernels (these three
+ * are bit-identical).  The one-launch engines keep their control words and phase flags in the cache's last OASR_KV_TAIL_BYTES bytes
+ * (zeroed by decode_begin; the cache is oasr_kv_cache_bytes(B) bytes INCLUDING that tail -- ABI 211; a caller that re-packs a cache,
+ * e.g. the beam re-gather of whisper's rearrange_kv_cache, zeroes the tail of the new buffer).  A one-launch engine needs all of its
+ * workgroups resident at once, i.e. the device to itself: a workgroup that never arrives (a second decoder on the device, a CU mask)
  * poisons a flag instead of hanging; oasr_decode_check then clears it, switches the CONTEXT to the multi-launch engine for good and
  * returns OASR_ERETRY: the caller decodes the window again. */
+#define OASR_KV_TAIL_BYTES 2048
 size_t oasr_kv_cache_bytes(const oasr_ctx*, int B);
 size_t oasr_decode_step_workspace_bytes(const oasr_ctx*, int B);
 int oasr_decode_begin(oasr_ctx*, const void* xa, int B, void* kv_cache, void* stream);

@@ -44,7 +44,8 @@ class AttnArgs(C.Structure):
                 ("q_rows", C.c_void_p), ("k_rows", C.c_void_p), ("q_span", C.c_void_p)]
 
 
-ABI_VERSION = 210  # include/oasr.h: OASR_ABI_VERSION (210: KV cache carries a 256-byte control tail, OASR_ERETRY from oasr_decode_check)
+ABI_VERSION = 211  # include/oasr.h: OASR_ABI_VERSION (211: the KV cache's control tail is OASR_KV_TAIL_BYTES; 210: OASR_ERETRY from oasr_decode_check)
+KV_TAIL_BYTES = 2048  # include/oasr.h: OASR_KV_TAIL_BYTES
 ROWTAB = 16        # include/oasr.h: OASR_ROWTAB (entries per sample of a chunk-row table)
 
 

@@ -1,0 +1,609 @@
+// Chip-wide one-launch KV-cached decoder step for ONE sequence on gfx950 -- TextDecoder.forward for one new token, olmoasr/model.py:786-817
+// with the kv_cache hooks of :925-964 (inference twin: olmoasr/inf_model.py:150-196, 320-362).
+//
+// Why a second one-launch engine: decode_xcd.hip keeps its team on ONE XCD (32 CUs) so that its barrier is an L2-local counter, and a team of
+// 32 CUs is issue-bound at ~1.2 TB/s (profiles/r05_decode_xcd_stamps_v5_issue_bound.txt) -- about what one XCD's fabric port delivers anyway.
+// A token at medium moves 960 MB, so that engine cannot go below ~0.8 ms of streaming however cheap its barriers are.  Spreading the SAME
+// engine over the chip does not help (profiles/r05_decode_xcd_probe_v6.txt: 1.87 ms): its 32-row MFMA tiles give an N = d projection only 32
+// workgroups' worth of work.  What the measurements ask for is the opposite trade: ALL 256 CUs, a few weight rows each, so that the
+// streaming time all but disappears (115 KB per workgroup and layer) and a token costs (phases) x (one exchange across the chip).
+//   * Work split: a projection's N output rows are dealt out in contiguous runs of R = 2 ceil(N / (2 nwg)) rows per workgroup (4 of mlp.2's
+//     1024 at medium, 16 of mlp.0's 4096).  A (row, 512-element K span) pair is a UNIT = one 16-byte load per lane; a workgroup's units are dealt
+//     round-robin to its 8 waves (1-4 units per wave and phase at medium).  One row against one token is a dot product: plain fp32 FMAs on
+//     the unpacked bf16 pairs, no MFMA (at M = 1 an MFMA tile is 31/32 padding) -- 24 VALU instructions per unit.
+//   * The weights of the NEXT projection phase are requested into registers (<= 8 x 16 bytes per lane) as soon as the current phase's
+//     products are done: they are in flight while the workgroup publishes its rows and waits for everybody else's.
+//   * Exchange: no counter.  Every workgroup owns one 32-bit flag = the number of the last phase it has completed (epoch-based, never
+//     reset); a consumer polls the 1 KB flag array with ONE 16-byte agent-scope load per lane and goes on when every flag has reached the
+//     phase before its own.  Rows travel through agent-scope (sc1) stores and loads only, so nothing depends on which XCD a workgroup is on.
+//     A workgroup without work in a phase does not poll at all.
+//   * Attention: self-attention = one workgroup per head (<= 448 cached keys: 7 per 8-lane group, K and V rows requested together);
+//     cross-attention = one workgroup per (head, quarter of the 1500 keys) whose K / V rows -- static data -- are requested BEFORE the poll;
+//     the four partials (m, l, o[64]) of a head are merged by the consumer phase's operand stage (decode_shared.h's segment merge).
+// Arithmetic: fp32 accumulation, bf16 rounding at the same points as the multi-launch step (decode_shared.h: LayerNorm output, Linear output,
+// GELU input, residual sum, P before it multiplies V); the K reduction order differs (512-element spans, summed in order), so results agree
+// with the other engines to fp32 rounding of the accumulation, not to the last bit (tests/test_gpu_decode_step.py states the tolerance).
+#include "decode_shared.h"
+
+namespace {
+
+#ifndef DW_WT
+#define DW_WT 576
+#endif
+constexpr int WT = DW_WT;  // threads per workgroup
+constexpr int WW = WT / 64;
+constexpr int WC = WW - 1;  // compute waves 1 .. WW-1; wave 0 is the helper: poll, operand row, epilogue, stores, flag -- it requests no weights, so nothing slow sits in front of its polls
+constexpr int WNG = WT / 8;  // 8-lane groups (attention: one key per group and step)
+constexpr int WMAXU = 64 / WC;  // units per compute wave and phase (64 units per workgroup at most)
+constexpr int WNS = 4;    // cross-attention key segments per head
+constexpr int WSK = (448 + WNG - 1) / WNG;  // self-attention keys per 8-lane group: S_max <= 448
+constexpr int WCK = (384 + WNG - 1) / WNG;  // cross-attention keys per group and segment: ceil(Te / 4) <= 384
+constexpr int WMAXD = 1280;
+constexpr int WLNC = 3;    // 16-byte chunks per lane of a LayerNorm row: d <= 1536
+constexpr int WMAXL = 32;
+constexpr int WMAXWG = 256;
+constexpr unsigned WSPIN = 1u << 20;
+
+#define WWAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+struct WLayer {  // element offsets of one decoder layer (the order of DecodeXcdArgs::layer_offsets)
+  long ln1g, ln1b, wqkv, bqkv_aux, wo, bo, lncg, lncb, wcq, bcq, wco, bco, ln2g, ln2b, w1, b1, w2, b2;
+};
+struct WArgs {
+  const bf16_t* wflat;
+  const float* params;
+  const float* aux;
+  bf16_t* cache;
+  long cache_lstride;
+  bf16_t *x, *x2, *x3, *q, *o, *hg;
+  float* part;      // [H * WNS][66]: m, l, o[64]
+  unsigned* ctrl;   // [1] error flag  [3] XCC ids seen  [4] epoch base of this engine
+  unsigned* flagv;  // [nwg] last completed phase (epoch-based)
+  int d, H, Te, S_max, L, pos, nwg, flags;
+  unsigned long long* stamps;
+  WLayer l0;
+  long lstride, astride;
+};
+__device__ __forceinline__ WLayer layer_of(const WArgs& a, int l) {
+  WLayer y = a.l0;
+  const long s = (long)l * a.lstride;
+  y.ln1g += s, y.ln1b += s, y.wqkv += s, y.wo += s, y.bo += s, y.lncg += s, y.lncb += s, y.wcq += s, y.bcq += s, y.wco += s, y.bco += s;
+  y.ln2g += s, y.ln2b += s, y.w1 += s, y.b1 += s, y.w2 += s, y.b2 += s;
+  y.bqkv_aux += (long)l * a.astride;
+  return y;
+}
+
+// ---- agent-scope accesses --------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32x4_t ld16_agent(const void* p) {
+  const uint64_t a = __hip_atomic_load((const uint64_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint64_t b = __hip_atomic_load((const uint64_t*)((const char*)p + 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  u32x4_t r;
+  r[0] = (unsigned)a, r[1] = (unsigned)(a >> 32), r[2] = (unsigned)b, r[3] = (unsigned)(b >> 32);
+  return r;
+}
+__device__ __forceinline__ u32x4_t ld16_agent_off(const void* sbase, unsigned off) { return ld16_agent((const char*)sbase + (size_t)off); }
+__device__ __forceinline__ unsigned ld4_agent(const void* p) { return __hip_atomic_load((const unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ldf_agent(const float* p) { return __uint_as_float(ld4_agent(p)); }
+__device__ __forceinline__ void st4_agent(void* p, unsigned v) { __hip_atomic_store((unsigned*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// ---- wave reductions on the DPP path (register to register: ~10 instructions; __shfl_xor is six dependent ds_bpermute round trips, ~700 cycles
+// per sum where a phase has ~4000 to spend).  All 64 lanes must be active.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float rdl(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ float wsum(float v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm [1, 0, 3, 2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2, 3, 0, 1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror: every lane holds its 16-lane row's sum
+  return (rdl(v, 0) + rdl(v, 16)) + (rdl(v, 32) + rdl(v, 48));
+}
+__device__ __forceinline__ float wmaxf(float v) {
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  v = fmaxf(v, dpp_mov<0x140>(v));
+  return fmaxf(fmaxf(rdl(v, 0), rdl(v, 16)), fmaxf(rdl(v, 32), rdl(v, 48)));
+}
+// mean and 1 / sqrt(var + eps) of one row held as chunks raw[c] = elements (lane + 64 c) * 8 .. + 7 (two passes, as ln_fwd_kernel)
+__device__ __forceinline__ void row_stats_w(const u32x4_t (&raw)[dec::MAXC], int lane, int nchunk, int d, float& mean_out, float& rstd_out) {
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < dec::MAXC; ++c)
+    if (lane + 64 * c < nchunk) {
+      float v[8];
+      dec::unpack8(raw[c], v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += v[i];
+    }
+  const float mean = wsum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < dec::MAXC; ++c)
+    if (lane + 64 * c < nchunk) {
+      float v[8];
+      dec::unpack8(raw[c], v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float t = v[i] - mean;
+        q += t * t;
+      }
+    }
+  mean_out = mean;
+  rstd_out = rsqrtf(wsum(q) / (float)d + 1e-5f);
+}
+
+// wave 0: every workgroup has completed phase `target` (or the wait gave up and poisoned the launch)
+__device__ __forceinline__ void wide_wait(const WArgs& a, unsigned target, int lane) {
+  unsigned spins = 0;
+  for (;;) {
+    bool ok = true;
+    if (lane * 4 < a.nwg) {  // (nwg is a multiple of 4, the flag array 16-byte aligned)
+      const u32x4_t f = ld16_agent(a.flagv + lane * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ok = ok && (int)(f[i] - target) >= 0;
+    }
+    if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+    if (!(a.flags & 4)) __builtin_amdgcn_s_sleep(1);
+    if (++spins > WSPIN || ((spins & 63) == 0 && ld4_agent(a.ctrl + 1) != 0)) {
+      if (lane == 0) __hip_atomic_fetch_or(a.ctrl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // somebody never arrived: poison, do not hang
+      break;
+    }
+  }
+}
+
+struct WGemv {  // one projection phase
+  const bf16_t* w;  // [N][K]
+  int K, N, R;
+  const bf16_t* xin;
+  const float *ln_g, *ln_b;
+  bool merge;
+  const float* bias;
+  bool gelu;
+  const bf16_t* resid;
+  bf16_t* out;
+};
+__device__ __forceinline__ WGemv gemv_of(const WArgs& a, int layer, int ph) {
+  const WLayer ly = layer_of(a, layer);
+  WGemv p;
+  p.merge = false, p.gelu = false, p.ln_g = p.ln_b = nullptr, p.resid = nullptr, p.K = a.d, p.N = a.d, p.xin = nullptr;
+  switch (ph) {
+    case 0:  // attn_ln -> q | k | v of position pos, straight into the cache row
+      p.w = a.wflat + ly.wqkv, p.xin = a.x, p.N = 3 * a.d, p.ln_g = a.params + ly.ln1g, p.ln_b = a.params + ly.ln1b, p.bias = a.aux + ly.bqkv_aux;
+      p.out = a.cache + (long)layer * a.cache_lstride + (long)a.pos * 3 * a.d;
+      break;
+    case 2:  // self-attention output projection + residual
+      p.w = a.wflat + ly.wo, p.xin = a.o, p.bias = a.params + ly.bo, p.resid = a.x, p.out = a.x2;
+      break;
+    case 3:  // cross_attn_ln -> cross query
+      p.w = a.wflat + ly.wcq, p.xin = a.x2, p.ln_g = a.params + ly.lncg, p.ln_b = a.params + ly.lncb, p.bias = a.params + ly.bcq, p.out = a.q;
+      break;
+    case 5:  // cross-attention output projection + residual (operand = merged segment partials)
+      p.w = a.wflat + ly.wco, p.merge = true, p.bias = a.params + ly.bco, p.resid = a.x2, p.out = a.x3;
+      break;
+    case 6:  // mlp_ln -> mlp.0 + GELU
+      p.w = a.wflat + ly.w1, p.xin = a.x3, p.N = 4 * a.d, p.ln_g = a.params + ly.ln2g, p.ln_b = a.params + ly.ln2b, p.bias = a.params + ly.b1, p.gelu = true;
+      p.out = a.hg;
+      break;
+    default:  // 7: mlp.2 + residual
+      p.w = a.wflat + ly.w2, p.xin = a.hg, p.K = 4 * a.d, p.bias = a.params + ly.b2, p.resid = a.x3, p.out = a.x;
+      break;
+  }
+  p.R = 2 * ((p.N + 2 * a.nwg - 1) / (2 * a.nwg));
+  return p;
+}
+
+// this wave's weight chunks of a projection phase -> registers (unit u = wave + 8 i: row u / J of the workgroup's run, K span u % J)
+// Units (row r of the workgroup's run, 512-element K span j), numbered u = r J + j, are dealt to the compute waves in contiguous runs of
+// upw = ceil(U / WC): one division per wave and phase, then (r, j) by stepping.
+struct WUnits {
+  int U, upw, u0, r0, j0, J, KC;
+};
+__device__ __forceinline__ WUnits units_of(const WGemv& p, int wg, int wave) {
+  WUnits q;
+  q.KC = p.K >> 3, q.J = (q.KC + 63) >> 6;
+  int rows = p.N - wg * p.R;
+  rows = rows < 0 ? 0 : (rows > p.R ? p.R : rows);
+  q.U = rows * q.J;
+  q.upw = (q.U + WC - 1) / WC;  // (WC is a compile-time constant)
+  q.u0 = (wave - 1) * q.upw;
+  q.r0 = q.u0 / q.J, q.j0 = q.u0 - q.r0 * q.J;
+  return q;
+}
+__device__ __forceinline__ void request_units(const WGemv& p, int wg, int wave, int lane, u32x4_t (&wreg)[WMAXU]) {
+  if (wave == 0) return;
+  const WUnits q = units_of(p, wg, wave);
+  const bf16_t* row = p.w + (long)(wg * p.R + q.r0) * p.K;
+  int j = q.j0;
+#pragma unroll
+  for (int i = 0; i < WMAXU; ++i) {
+    const int c = j * 64 + lane;
+    if (i < q.upw && q.u0 + i < q.U && c < q.KC) wreg[i] = __builtin_nontemporal_load((const u32x4_t*)(row + (long)c * 8));  // (else: never read)
+    if (++j == q.J) j = 0, row += p.K;
+  }
+}
+// a FRESH (undefined) value: registers that are assigned under a condition inside the layer loop would otherwise carry their previous contents
+// around the loop as far as the register allocator can tell (measured: the two attention phases' K / V rows were live at the same time)
+template <typename V>
+__device__ __forceinline__ void fresh(V& v) {
+  asm volatile("" : "=v"(v));
+}
+// the registers of a phase's weights hold nothing any more (request_units assigns them under conditions: without this the OLD values stay live
+// across the attention phases as far as the register allocator can tell)
+__device__ __forceinline__ void kill_units(u32x4_t (&wreg)[WMAXU]) {
+#pragma unroll
+  for (int i = 0; i < WMAXU; ++i) asm volatile("" : "=v"(wreg[i]));
+}
+__device__ __forceinline__ float dot8(const u32x4_t& w, const u32x4_t& x) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s += bf_lo(w[i]) * bf_lo(x[i]) + bf_hi(w[i]) * bf_hi(x[i]);
+  return s;
+}
+__device__ __forceinline__ float rdlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ float merge_w(const float (&m_s)[WNS], const float (&l_s)[WNS], const float (&o_s)[WNS]) {
+  float m = m_s[0];
+#pragma unroll
+  for (int s = 1; s < WNS; ++s) m = fmaxf(m, m_s[s]);
+  float L = 0.f, O = 0.f;
+#pragma unroll
+  for (int s = 0; s < WNS; ++s) {
+    const float w = __builtin_amdgcn_exp2f(m_s[s] - m);
+    L += l_s[s] * w;
+    O += o_s[s] * w;
+  }
+  return L > 0.f ? O / L : 0.f;
+}
+
+#define WSTAMP(K)                                                                                                \
+  do {                                                                                                           \
+    if (a.stamps && wg == 0 && layer == 1 && tid == 0) a.stamps[ph * 8 + (K)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+
+__global__ __launch_bounds__(WT) void decode_wide_kernel(WArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned short xs[4 * WMAXD];  // the operand row (bf16)
+  __shared__ float psum[64];
+  __shared__ float ared[WNG][64];
+  __shared__ float lsum[WNG];
+  __shared__ float wmax[WW];
+  const unsigned base = a.ctrl[4];
+  if (threadIdx.x == 0) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    __hip_atomic_fetch_or(a.ctrl + 3, 1u << (xcc & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  u32x4_t wreg[WMAXU];
+  request_units(gemv_of(a, 0, 0), blockIdx.x, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), threadIdx.x & 63, wreg);
+  unsigned gp = 0;  // phases before the current one
+#pragma unroll 1
+  for (int layer = 0; layer < a.L; ++layer) {
+    const bf16_t* self = a.cache + (long)layer * a.cache_lstride;
+    const bf16_t* cross = self + (long)3 * a.S_max * a.d;
+#pragma unroll 1
+    for (int ph = 0; ph < 8; ++ph, ++gp) {
+      const unsigned target = base + gp;  // every workgroup has completed the phase before this one
+      // (thread and workgroup ids re-materialised per phase: otherwise every address that depends on them only is hoisted out of the layer
+      // loop and spilled -- 130 VGPRs' worth)
+      int tid = threadIdx.x, wg = blockIdx.x;
+      asm volatile("" : "+v"(tid), "+s"(wg));
+      const int lane = tid & 63, l8 = tid & 7, grp = tid >> 3;
+      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+      if (ph == 1) {
+        // ---------------- self-attention: one workgroup per head ----------------
+        if (wg < a.H) {
+          const int h = wg, n = a.pos + 1;
+          WSTAMP(0);
+          if (wave == 0) wide_wait(a, target, lane);
+          __syncthreads();
+          WSTAMP(1);
+          const u32x4_t q4 = ld16_agent(self + (long)a.pos * 3 * a.d + h * 64 + l8 * 8);
+          const bf16_t* kb = self + a.d + h * 64;  // (uniform bases + one 32-bit offset per key: K and V rows share it)
+          const bf16_t* vb = kb + a.d;
+          u32x4_t k4[WSK], v4[WSK];
+#pragma unroll
+          for (int u = 0; u < WSK; ++u) {
+            fresh(k4[u]), fresh(v4[u]);
+            const int t = grp + WNG * u;
+            if (WNG * u < n) {  // (wave-uniform; keys of this launch and of earlier ones alike: row pos was written a phase ago)
+              const unsigned off = (unsigned)(((t < n ? t : n - 1) * 3 * a.d + l8 * 8) * 2);
+              k4[u] = ld16_agent_off(kb, off), v4[u] = ld16_agent_off(vb, off);
+            }
+          }
+          float qv[8];
+          dec::load_q8(q4, qv);
+          float s2[WSK], mx = dec::NEG;
+#pragma unroll
+          for (int u = 0; u < WSK; ++u) {
+            s2[u] = dec::NEG;
+            if (WNG * u < n) {
+              const float s = dec::score8(qv, k4[u]);
+              if (grp + WNG * u < n) s2[u] = s, mx = fmaxf(mx, s);
+            }
+          }
+          mx = wmaxf(mx);
+          if (lane == 0) wmax[wave] = mx;
+          __syncthreads();
+          float m = wmax[0];
+#pragma unroll
+          for (int w = 1; w < WW; ++w) m = fmaxf(m, wmax[w]);
+          float l = 0.f, o[8];
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) o[jj] = 0.f;
+#pragma unroll
+          for (int u = 0; u < WSK; ++u)
+            if (WNG * u < n) dec::accum_pv(grp + WNG * u < n ? __builtin_amdgcn_exp2f(s2[u] - m) : 0.f, v4[u], l, o);
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) ared[grp][l8 * 8 + jj] = o[jj];
+          if (l8 == 0) lsum[grp] = l;
+          __syncthreads();
+          if (tid < 64) {
+            float acc = 0.f, lt = 0.f;
+#pragma unroll 8
+            for (int g = 0; g < WNG; ++g) acc += ared[g][tid], lt += lsum[g];
+            const float val = lt > 0.f ? acc / lt : 0.f, nb = dec::xor_lane<1>(val);
+            if ((lane & 1) == 0) st4_agent(a.o + h * 64 + lane, pack_bf2(val, nb));
+            WWAIT_VM0();
+          }
+          WSTAMP(2);
+        }
+      } else if (ph == 4) {
+        // ---------------- cross-attention: one workgroup per (head, key segment) ----------------
+        if (wg < a.H * WNS) {
+          const int h = wg >> 2, sg = wg & 3;
+          const int SL = (a.Te + WNS - 1) / WNS;
+          const int t0 = sg * SL;
+          int n = a.Te - t0;
+          n = n > SL ? SL : (n < 0 ? 0 : n);
+          // the segment's K / V rows do not depend on the token: requested before the poll
+          const bf16_t* kb = cross + (long)t0 * 2 * a.d + h * 64;
+          const bf16_t* vb = kb + a.d;
+          u32x4_t k4[WCK], v4[WCK];
+#pragma unroll
+          for (int u = 0; u < WCK; ++u) {
+            fresh(k4[u]), fresh(v4[u]);
+            const int t = grp + WNG * u;
+            if (WNG * u < n) {
+              const size_t off = (size_t)(unsigned)(((t < n ? t : n - 1) * 2 * a.d + l8 * 8) * 2);
+              k4[u] = __builtin_nontemporal_load((const u32x4_t*)((const char*)kb + off));
+              v4[u] = __builtin_nontemporal_load((const u32x4_t*)((const char*)vb + off));
+            }
+          }
+          WSTAMP(0);
+          if (wave == 0) wide_wait(a, target, lane);
+          __syncthreads();
+          WSTAMP(1);
+          const u32x4_t q4 = ld16_agent(a.q + h * 64 + l8 * 8);
+          float qv[8];
+          dec::load_q8(q4, qv);
+          float s2[WCK], mx = dec::NEG;
+#pragma unroll
+          for (int u = 0; u < WCK; ++u) {
+            s2[u] = dec::NEG;
+            if (WNG * u < n) {
+              const float s = dec::score8(qv, k4[u]);
+              if (grp + WNG * u < n) s2[u] = s, mx = fmaxf(mx, s);
+            }
+          }
+          mx = wmaxf(mx);
+          if (lane == 0) wmax[wave] = mx;
+          __syncthreads();
+          float m = wmax[0];
+#pragma unroll
+          for (int w = 1; w < WW; ++w) m = fmaxf(m, wmax[w]);
+          float l = 0.f, o[8];
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) o[jj] = 0.f;
+#pragma unroll
+          for (int u = 0; u < WCK; ++u)
+            if (WNG * u < n) dec::accum_pv(grp + WNG * u < n ? __builtin_amdgcn_exp2f(s2[u] - m) : 0.f, v4[u], l, o);
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) ared[grp][l8 * 8 + jj] = o[jj];
+          if (l8 == 0) lsum[grp] = l;
+          __syncthreads();
+          if (tid < 64) {
+            float acc = 0.f, lt = 0.f;
+#pragma unroll 8
+            for (int g = 0; g < WNG; ++g) acc += ared[g][tid], lt += lsum[g];
+            float* dst = a.part + (long)wg * 66;
+            st4_agent(dst + 2 + lane, __float_as_uint(acc));
+            if (lane == 0) st4_agent(dst, __float_as_uint(m)), st4_agent(dst + 1, __float_as_uint(lt));
+            WWAIT_VM0();
+          }
+          WSTAMP(2);
+        }
+      } else {
+        // ---------------- projection: rows wg R .. wg R + R - 1 ----------------
+        const WGemv p = gemv_of(a, layer, ph);
+        const int row0 = wg * p.R;
+        if (row0 < p.N) {
+          const int KC = p.K >> 3, J = (KC + 63) >> 6;
+          int rows = p.N - row0;
+          rows = rows > p.R ? p.R : rows;
+          const int U = rows * J;
+          // wave 0: what the epilogue needs besides the sums (requested before the poll: the residual row is two phases old)
+          float bias_v = 0.f, resid_v = 0.f;
+          if (wave == 0 && lane < rows) {
+            const int nn = row0 + lane;
+            if (p.bias) bias_v = p.bias[nn];
+            if (p.resid) {
+              const unsigned rz = ld4_agent(p.resid + (nn & ~1));
+              resid_v = (nn & 1) ? bf_hi(rz) : bf_lo(rz);
+            }
+          }
+          // ... and the LayerNorm parameters of the chunks this lane will normalise (static data, 2 x 32 bytes per chunk)
+          f32x4_t lg[WLNC][2], lb[WLNC][2];
+#pragma unroll
+          for (int c = 0; c < WLNC; ++c) fresh(lg[c][0]), fresh(lg[c][1]), fresh(lb[c][0]), fresh(lb[c][1]);
+          if (wave == 0 && p.ln_g) {
+#pragma unroll
+            for (int c = 0; c < WLNC; ++c)
+              if (lane + 64 * c < KC) {
+                const int k = (lane + 64 * c) * 8;
+                lg[c][0] = *(const f32x4_t*)(p.ln_g + k), lg[c][1] = *(const f32x4_t*)(p.ln_g + k + 4);
+                lb[c][0] = *(const f32x4_t*)(p.ln_b + k), lb[c][1] = *(const f32x4_t*)(p.ln_b + k + 4);
+              }
+          }
+          WSTAMP(0);
+          if (wave == 0 && gp > 0) wide_wait(a, target, lane);
+          __syncthreads();
+          WSTAMP(1);
+          // ---- operand row -> LDS ----
+          if (p.merge) {  // merged cross-attention output: wave w merges heads w, w + 8, ...; lane = dimension; (m, l) of segment s come in through lane s
+#pragma unroll 1
+            for (int h = wave; h < a.H; h += WW) {
+              const float* src = a.part + (long)h * (WNS * 66);
+              const int sl = lane < WNS ? lane : WNS - 1;
+              const float mv = ldf_agent(src + sl * 66), lv = ldf_agent(src + sl * 66 + 1);
+              float m_s[WNS], l_s[WNS], o_s[WNS];
+#pragma unroll
+              for (int sg = 0; sg < WNS; ++sg) o_s[sg] = ldf_agent(src + sg * 66 + 2 + lane);
+#pragma unroll
+              for (int sg = 0; sg < WNS; ++sg) m_s[sg] = rdlane(mv, sg), l_s[sg] = rdlane(lv, sg);
+              const float val = merge_w(m_s, l_s, o_s), nb = dec::xor_lane<1>(val);
+              if ((lane & 1) == 0) *(uint32_t*)(xs + h * 64 + lane) = pack_bf2(val, nb);
+            }
+          } else if (p.ln_g) {  // LayerNorm folded into the operand (K = d): wave 0
+            if (wave == 0) {
+              u32x4_t raw[dec::MAXC];
+#pragma unroll
+              for (int c = 0; c < dec::MAXC; ++c) {
+                fresh(raw[c]);
+                if (c < WLNC && lane + 64 * c < KC) raw[c] = ld16_agent(p.xin + (lane + 64 * c) * 8);
+              }
+              float mean, rstd;
+              row_stats_w(raw, lane, KC, p.K, mean, rstd);
+#pragma unroll
+              for (int c = 0; c < WLNC; ++c)
+                if (lane + 64 * c < KC) {
+                  float v[8];
+                  dec::unpack8(raw[c], v);
+#pragma unroll
+                  for (int i = 0; i < 4; ++i) {  // (dec::ln_apply8's expression)
+                    v[i] = (v[i] - mean) * rstd * lg[c][0][i] + lb[c][0][i];
+                    v[4 + i] = (v[4 + i] - mean) * rstd * lg[c][1][i] + lb[c][1][i];
+                  }
+                  u32x4_t o4;
+#pragma unroll
+                  for (int i = 0; i < 4; ++i) o4[i] = pack_bf2(v[2 * i], v[2 * i + 1]);
+                  *(u32x4_t*)(xs + (lane + 64 * c) * 8) = o4;
+                }
+            }
+          } else {  // plain row: K / 8 chunks over the 512 threads
+            constexpr int NC = (4 * WMAXD / 8 + WT - 1) / WT;
+            u32x4_t raw[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+              fresh(raw[c]);
+              if (tid + WT * c < KC) raw[c] = ld16_agent(p.xin + (tid + WT * c) * 8);
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+              if (tid + WT * c < KC) *(u32x4_t*)(xs + (tid + WT * c) * 8) = raw[c];
+          }
+          __syncthreads();
+          WSTAMP(2);
+          // ---- this wave's units ----
+          if (wave > 0) {
+            if (a.stamps) {
+              WWAIT_VM0();
+              if (wg == 0 && layer == 1 && tid == 64) a.stamps[ph * 8 + 5] = __builtin_amdgcn_s_memtime();
+            }
+            const WUnits q = units_of(p, wg, wave);
+            float ps[WMAXU];
+            int j = q.j0;
+#pragma unroll
+            for (int i = 0; i < WMAXU; ++i) {
+              const int c = j * 64 + lane;
+              ps[i] = 0.f;
+              if (i < q.upw && q.u0 + i < q.U && c < q.KC) ps[i] = dot8(wreg[i], *(const u32x4_t*)(xs + c * 8));
+              if (++j == q.J) j = 0;
+            }
+            kill_units(wreg);
+#pragma unroll
+            for (int i = 0; i < WMAXU; ++i) {
+              if (i < q.upw && q.u0 + i < q.U) {
+                const float sum = wsum(ps[i]);
+                if (lane == 0) psum[q.u0 + i] = sum;
+              }
+            }
+            if (a.stamps && wg == 0 && layer == 1 && tid == 64) a.stamps[ph * 8 + 6] = __builtin_amdgcn_s_memtime();
+          }
+          __syncthreads();
+          WSTAMP(3);
+          if (wave == 0) {
+            float y = 0.f;
+            if (lane < rows) {
+              float acc = 0.f;
+              for (int jj = 0; jj < J; ++jj) acc += psum[lane * J + jj];
+              y = dec::epi_value(acc, bias_v, p.gelu, p.resid != nullptr, resid_v);
+            }
+            const float nb = dec::xor_lane<1>(y);
+            if (lane < rows && (lane & 1) == 0) st4_agent(p.out + row0 + lane, pack_bf2(y, nb));
+            WWAIT_VM0();
+          }
+          WSTAMP(4);
+        }
+      }
+      // this workgroup's rows of the phase are stored (wave 0 has waited for the acknowledgements): publish
+      if (tid == 0) st4_agent(a.flagv + wg, base + gp + 1);
+      // the next phase's weights if it is a projection: in flight through the exchange.  (Not across an attention phase: with the attention's K / V
+      // rows the 32 registers of weights would not fit, and the compiler would park them in scratch = wait for them on the spot.)
+      if (ph != 0 && ph != 3) {
+        int nl = layer, np = ph + 1;
+        if (np == 8) np = 0, ++nl;
+        kill_units(wreg);
+        if (nl < a.L) request_units(gemv_of(a, nl, np), wg, wave, lane, wreg);
+      }
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 64) {  // everybody has read the epoch base long ago; publish the next launch's once every workgroup is through
+    wide_wait(a, base + gp, threadIdx.x);
+    if (threadIdx.x == 0) a.ctrl[4] = base + gp;
+  }
+}
+
+}  // namespace
+
+// ---- host side ----------------------------------------------------------------------------------------------------------------------
+#if DW_WT == 576
+size_t decode_wide_part_floats(int H) { return (size_t)H * WNS * 66; }
+#endif
+
+#if DW_WT == 576
+#define DW_NAME(x) x
+#else
+#define DW_NAME(x) x##_256
+#endif
+bool DW_NAME(decode_wide_supports)(int d, int H, int Te, int S_max, int L, int M, int nwg) {
+  if (!(M == 1 && L >= 1 && L <= WMAXL && d % 64 == 0 && d == H * 64 && d <= WMAXD && H <= 32 && S_max >= 1 && S_max <= WNG * WSK && Te >= 1 &&
+        (Te + WNS - 1) / WNS <= WNG * WCK && nwg >= 64 && nwg <= WMAXWG && nwg % 4 == 0 && H * WNS <= nwg))
+    return false;
+  // units per wave: rows R x spans J dealt to 8 waves
+  const int Ns[3] = {3 * d, d, 4 * d}, Ks[3] = {d, 4 * d, d};
+  for (int i = 0; i < 3; ++i) {
+    const int R = 2 * ((Ns[i] + 2 * nwg - 1) / (2 * nwg)), J = (Ks[i] / 8 + 63) / 64;
+    if (R * J > WC * WMAXU || R * J > 64 || R > 64) return false;
+  }
+  return true;
+}
+
+int DW_NAME(launch_decode_wide)(const DecodeXcdArgs& h, hipStream_t s) {
+  OASR_REQUIRE(DW_NAME(decode_wide_supports)(h.d, h.H, h.Te, h.S_max, h.L, h.M, h.team), "decode_wide: unsupported shape");
+  OASR_REQUIRE(h.pos >= 0 && h.pos < h.S_max && h.layer_offsets, "decode_wide: bad launch shape");
+  WArgs a;
+  a.wflat = h.wflat, a.params = h.params, a.aux = h.aux, a.cache = h.cache, a.cache_lstride = h.cache_lstride;
+  a.x = h.x, a.x2 = h.x2, a.x3 = h.x3, a.q = h.q, a.o = h.o, a.hg = h.hg, a.part = h.part;
+  a.ctrl = h.ctrl, a.flagv = h.ctrl + 256;  // the flag array sits 1 KB into the cache's control tail
+  a.d = h.d, a.H = h.H, a.Te = h.Te, a.S_max = h.S_max, a.L = h.L, a.pos = h.pos, a.nwg = h.team, a.flags = h.flags;
+  a.stamps = (unsigned long long*)h.stamps;
+  {
+    long* dst = &a.l0.ln1g;
+    for (int i = 0; i < 18; ++i) dst[i] = (long)h.layer_offsets[i];
+    a.lstride = h.lstride, a.astride = h.astride;
+  }
+  hipLaunchKernelGGL(decode_wide_kernel, dim3(h.team), dim3(WT), 0, s, a);
+  OASR_LAUNCH_CHECK();
+  return OASR_OK;
+}

@@ -78,6 +78,7 @@ struct oasr_ctx {
   // set by oasr_decode_check when the one-launch decoder step (decode_xcd.hip) reported a poisoned team barrier: its 32 workgroups must be
   // resident at once, which a shared / CU-masked device does not guarantee.  From then on this context decodes on the multi-launch engine.
   bool xcd_disabled = false;
+  int n_cu = 0;  // compute units of the device (queried by the first decoder step)
   ~oasr_ctx() {
     for (hipEvent_t e : side.fork)
       if (e) (void)hipEventDestroy(e);
@@ -1075,7 +1076,7 @@ extern "C" int oasr_decode_logits(oasr_ctx* c, const int64_t* tokens, const void
 extern "C" size_t oasr_kv_cache_bytes(const oasr_ctx* c, int B) {
   if (!c || B <= 0) return 0;
   const size_t per_layer = ((size_t)3 * B * c->S_max * c->d + (size_t)B * c->Te * 2 * c->d) * (c->f32 ? 4 : 2);
-  return per_layer * c->L_dec + 256;
+  return per_layer * c->L_dec + OASR_KV_TAIL_BYTES;
 }
 namespace {
 template <typename T>
@@ -1088,7 +1089,7 @@ KvLayer<T> kv_layer(const oasr_ctx* c, void* cache, int B, int layer) {
   T* base = (T*)cache + per_layer * layer;
   return KvLayer<T>{base, base + (size_t)3 * B * c->S_max * c->d};
 }
-unsigned* kv_ctrl(const oasr_ctx* c, void* cache, int B) {  // 256 bytes behind the last layer (oasr_kv_cache_bytes)
+unsigned* kv_ctrl(const oasr_ctx* c, void* cache, int B) {  // the control tail behind the last layer (oasr_kv_cache_bytes)
   const size_t per_layer = ((size_t)3 * B * c->S_max * c->d + (size_t)B * c->Te * 2 * c->d) * (c->f32 ? 4 : 2);
   return (unsigned*)((char*)cache + per_layer * c->L_dec);
 }
@@ -1126,7 +1127,7 @@ extern "C" int oasr_decode_set_ln_fold(int mode) {
       return OASR_ESTATE;
     }
   }
-  g_decode_ln_fold = mode < 0 ? -1 : (mode > 4 ? 1 : mode);
+  g_decode_ln_fold = mode < 0 ? -1 : (mode > 5 ? 1 : mode);
   return OASR_OK;
 }
 
@@ -1134,7 +1135,7 @@ extern "C" size_t oasr_decode_step_workspace_bytes(const oasr_ctx* c, int B) {
   if (!c || B <= 0) return 0;
   // x, ln, q, o, x2 (5 * B*d) + u, hg (2 * B*4d) + logits (B*Vp) bf16 + stats
   return ((size_t)B * c->d * 6 + (size_t)B * 8 * c->d + (size_t)B * c->Vp + 9 * 32) * (c->f32 ? 4 : 2) + (size_t)B * c->H * 8 + (size_t)B * 16 + 8192 +
-         (B <= 4 ? decode_xcd_part_floats(B, c->H, c->Te) * 4 + 256 + 512 : 0);
+         (B <= 4 ? (decode_xcd_part_floats(B, c->H, c->Te) + decode_wide_part_floats(c->H)) * 4 + 256 + 512 : 0);
 }
 
 template <typename T>
@@ -1144,7 +1145,7 @@ static int oasr_decode_begin_impl(oasr_ctx* c, const void* xa, int B, void* kv_c
   typename Engine<T>::Runner r{c, (hipStream_t)stream, B, 1, nullptr};
   const int d = c->d;
   // the one-launch step engine's control words (barrier counter, error flag, epoch base, XCC mask) live in the cache's 256-byte tail
-  OASR_CHECK_HIP(hipMemsetAsync(kv_ctrl(c, kv_cache, B), 0, 256, (hipStream_t)stream));
+  OASR_CHECK_HIP(hipMemsetAsync(kv_ctrl(c, kv_cache, B), 0, OASR_KV_TAIL_BYTES, (hipStream_t)stream));
   for (int i = 0; i < c->L_dec; ++i) {
     const BlockP& bp = c->dec[i];
     KvLayer<T> kl = kv_layer<T>(c, kv_cache, B, i);
@@ -1209,6 +1210,16 @@ static int oasr_decode_step_impl(oasr_ctx* c, const int64_t* tokens_last, int B,
       xa.d = d, xa.H = c->H, xa.Te = c->Te, xa.S_max = S_max, xa.L = c->L_dec, xa.M = B, xa.pos = pos;
       xa.team = mode == 4 ? 64 : 32;
       xa.stride = (mode == 3 || mode == 4) ? 1 : 8;
+      // ONE sequence: the chip-wide engine (decode_wide.hip: every CU, a few weight rows each; mode 5 forces it, mode 2 the one-XCD team)
+      if (c->n_cu == 0) {
+        int dev = 0, n = 0;
+        OASR_CHECK_HIP(hipGetDevice(&dev));
+        OASR_CHECK_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+        c->n_cu = n > 0 ? n : -1;
+      }
+      const int nwg = c->n_cu >= 256 ? 256 : (c->n_cu > 0 ? c->n_cu & ~3 : 0);
+      const bool wide = (mode == -1 || mode == 5) && B == 1 && decode_wide_supports(d, c->H, c->Te, S_max, c->L_dec, B, nwg);
+      if (wide) xa.team = nwg, xa.stride = 1, xa.part = A.f32(decode_wide_part_floats(c->H));
       {  // measurement hooks (scripts/decode_xcd_probe.py; inert without OASR_TESTING_HOOKS=1): experiment flags, in-kernel stamps in the workspace tail
         static const int xflags = [] {
           const char* e = oasr_experiment_env("OASR_XCD_FLAGS");
@@ -1219,7 +1230,9 @@ static int oasr_decode_step_impl(oasr_ctx* c, const int64_t* tokens_last, int B,
       }
       xa.layer_offsets = c->xcd_offsets.data();
       xa.lstride = c->xcd_lstride, xa.astride = c->xcd_astride;
-      RC(launch_decode_xcd(xa, st));
+      if (wide && (xa.flags & 0x40) && decode_wide_supports_256(d, c->H, c->Te, S_max, c->L_dec, B, nwg)) RC(launch_decode_wide_256(xa, st));
+      else if (wide) RC(launch_decode_wide(xa, st));
+      else RC(launch_decode_xcd(xa, st));
       return launch_decode_proj(x, B, d, c->template Wt<bf16_t>(c->tok_emb), c->V, c->P(c->dec_ln_w), c->P(c->dec_ln_b), nullptr, 0, nullptr, 0,
                                 nullptr, 0, logits_out, c->V, st);
     }
@@ -1323,7 +1336,7 @@ extern "C" int oasr_decode_check(oasr_ctx* c, int B, void* kv_cache, void* strea
     // context falls back to the multi-launch engine for good, the control words are cleared, and the caller re-decodes the window
     // (olmoasr_amd.decoding.decode does; OASR_ERETRY says "same call again").
     c->xcd_disabled = true;
-    OASR_CHECK_HIP(hipMemset(kv_ctrl(c, kv_cache, B), 0, 256));
+    OASR_CHECK_HIP(hipMemset(kv_ctrl(c, kv_cache, B), 0, OASR_KV_TAIL_BYTES));
     oasr_set_error("oasr_decode_check: the one-launch decoder step reported 0x%x (1 = a team member never reached a barrier -- is the device "
                    "shared or CU-masked? --, 0x1xx = block stream out of step); XCC mask 0x%x.  The one-launch engine is now disabled for this "
                    "context; decode the window again (it will run on the multi-launch engine)", ctrl[1], ctrl[3]);

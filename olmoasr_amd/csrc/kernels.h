@@ -179,6 +179,14 @@ bool decode_xcd_supports(int d, int H, int Te, int S_max, int L, int M);
 // every 32-bit buffer offset of the launch stays below 2 GiB (else: the multi-launch step)
 bool decode_xcd_offsets_ok(const int64_t* layer0, long lstride, long cache_lstride, int d, int Te, int L, int M);
 size_t decode_xcd_part_floats(int M, int H, int Te);
+// chip-wide one-launch step for ONE sequence (decode_wide.hip): `team` = workgroups (one per CU), ctrl = the cache's control tail
+// (OASR_KV_TAIL_BYTES: words [1] error flag, [3] XCC mask, [4] epoch base; the per-workgroup flag array 1 KB in)
+int launch_decode_wide(const DecodeXcdArgs& a, hipStream_t s);
+bool decode_wide_supports(int d, int H, int Te, int S_max, int L, int M, int nwg);
+size_t decode_wide_part_floats(int H);
+// (experiment: the same engine built with 256-thread workgroups)
+int launch_decode_wide_256(const DecodeXcdArgs& a, hipStream_t s);
+bool decode_wide_supports_256(int d, int H, int Te, int S_max, int L, int M, int nwg);
 
 // ---- elementwise / reductions -------------------------------------------------------------------------
 int launch_cast_f32_bf16(const float* src, bf16_t* dst, long n, hipStream_t s);

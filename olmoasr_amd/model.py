@@ -127,7 +127,7 @@ class _EngineKV:
         lib = N.lib()
         cache = torch.empty(lib.oasr_kv_cache_bytes(m._ctx, Bn), dtype=torch.uint8, device=flat.device)
         cache[: (n_self + n_cross) // B * Bn * L * esz].view(m._act_dtype).copy_(torch.cat(parts, 1).reshape(-1))
-        cache[-256:].zero_()  # the one-launch step engine's control words (include/oasr.h, "Cached greedy decoding"): only decode_begin zeroes them
+        cache[-N.KV_TAIL_BYTES:].zero_()  # the one-launch step engines' control words (include/oasr.h, "Cached greedy decoding"): only decode_begin zeroes them
         ws = torch.empty(lib.oasr_decode_step_workspace_bytes(m._ctx, Bn), dtype=torch.uint8, device=flat.device)
         return _EngineKV(m, {"cache": cache, "ws": ws, "B": Bn, "pos": self.state["pos"]})
 

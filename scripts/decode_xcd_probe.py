@@ -12,7 +12,8 @@ from olmoasr_amd.config.model_dims import VARIANT_TO_DIMS  # noqa: E402
 from olmoasr_amd.model import OLMoASR  # noqa: E402
 
 NAMES = {-1: "library default", 0: "separate LayerNorm kernels", 1: "multi-launch, LayerNorm folded (round 2-4 default for B <= 4)", 2: "ONE launch, 32 CUs of one XCD",
-         3: "ONE launch, 32 workgroups spread over the chip", 4: "ONE launch, 64 workgroups spread over the chip"}
+         3: "ONE launch, 32 workgroups spread over the chip", 4: "ONE launch, 64 workgroups spread over the chip",
+         5: "ONE launch, every CU (decode_wide.hip)"}
 
 
 def main():
@@ -46,11 +47,23 @@ def main():
         torch.cuda.synchronize()
         net.kv_cache_check(st)
         ms = e0.elapsed_time(e1) / n
-        ctrl = st["cache"][-256:].view(torch.int32)[:4].tolist()
+        ctrl = st["cache"][-N.KV_TAIL_BYTES:].view(torch.int32)[:8].tolist()
         same = "" if ref is None else f"  logits == mode {modes[0]}: {bool(torch.equal(ref, last))} (max |d| {float((ref - last).abs().max()):.3g})"
         if ref is None:
             ref = last.clone()
-        if mode >= 2 and (int(os.environ.get("OASR_XCD_FLAGS", "0")) & 0x100):
+        if mode == 5 and (int(os.environ.get("OASR_XCD_FLAGS", "0")) & 0x100):
+            t = st["ws"][-512:].view(torch.int64).view(8, 8).cpu().tolist()
+            names = ["qkv", "self-attn", "attn.out", "cross q", "cross-attn", "cross out", "mlp.0", "mlp.2"]
+            print("   in-kernel s_memtime stamps, workgroup 0, decoder layer 1 (ticks): projection = poll | operand | units | epilogue+store ; attention = poll | rest")
+            for p_, r in enumerate(t):
+                nxt = t[p_ + 1][0] if p_ < 7 else None
+                if p_ in (1, 4):
+                    print(f"     {names[p_]:10s} poll {r[1] - r[0]:6d}  rest {r[2] - r[1]:6d}" + (f"  | to next phase {nxt - r[2]:6d}  | phase total {nxt - r[0]:6d}" if nxt else ""))
+                else:
+                    print(f"     {names[p_]:10s} poll {r[1] - r[0]:6d}  operand {r[2] - r[1]:6d}  units {r[3] - r[2]:6d} (wave 1: weights landed +{r[5] - r[2]:5d}, sums done +{r[6] - r[2]:5d})  epilogue {r[4] - r[3]:6d}"
+                          + (f"  | to next phase {nxt - r[4]:6d}  | phase total {nxt - r[0]:6d}" if nxt else ""))
+            print(f"     layer total {t[7][4] - t[0][0]} ticks")
+        elif mode >= 2 and (int(os.environ.get("OASR_XCD_FLAGS", "0")) & 0x100):
             t = st["ws"][-512:].view(torch.int64).view(8, 8).cpu().tolist()
             names = ["qkv", "self-attn", "attn.out", "cross q", "cross-attn", "cross out", "mlp.0", "mlp.2"]
             print("   in-kernel s_memtime stamps, workgroup 0, decoder layer 1 (ticks; helper: wait | operand | tiles+epilogue | arrive ; streaming wave 0: released->done):")
@@ -60,7 +73,7 @@ def main():
                       f"  | phase total {(nxt - r[0]) if nxt else r[4] - r[0]:6d}")
             print(f"     layer total {t[7][4] - t[0][0]} ticks")
         print(f"{variant} B={B} pos={pos} mode {mode} [{NAMES[mode]}]: {ms:.3f} ms/step = {dbytes / ms / 1e6:.0f} GB/s = {dbytes / ms / 1e6 / 8000:.3f} of 8 TB/s; "
-              f"ctrl (counter, flag, epoch, xcc mask) = {ctrl[0]} {ctrl[1]:#x} {ctrl[2]} {ctrl[3]:#x}{same}", flush=True)
+              f"ctrl (counter, flag, epoch, xcc mask, wide epoch) = {ctrl[0]} {ctrl[1]:#x} {ctrl[2]} {ctrl[3]:#x} {ctrl[4]}{same}", flush=True)
     N.lib().oasr_decode_set_ln_fold(-1)
 
 

@@ -1,6 +1,7 @@
 """The KV-cached decoder step's engines -- separate LayerNorm kernels, LayerNorm folded into the projections' operand loads
 (csrc/decode_proj.hip), and the ONE-launch engine of csrc/decode_xcd.hip (up to 4 sequences; on one XCD or spread over the chip) --
-against each other (bit-identical) and against the cache-less decoder.
+against each other (bit-identical) and against the cache-less decoder; the chip-wide one-launch engine for ONE sequence (csrc/decode_wide.hip,
+the default at B = 1) against them within the fp32 rounding of its differently ordered K sums.
 Reference semantics: TextDecoder.forward with the kv_cache hooks, olmoasr/model.py:786-817, 925-964."""
 import pytest
 import torch
@@ -14,9 +15,16 @@ def _dims(mo_dims):
     return ModelDimensions(**{k: getattr(mo_dims, k) for k in ModelDimensions.__dataclass_fields__})
 
 
+def _tail(state):
+    """the control words at the start of the cache's tail (include/oasr.h, OASR_KV_TAIL_BYTES)"""
+    from olmoasr_amd import _native as N
+    return state["cache"][-N.KV_TAIL_BYTES:].view(torch.int32)
+
+
 def _steps(net, xa, toks, mode):
     """mode: 1 = LayerNorm folded into the projections; 0 = separate LayerNorm / logits-widening kernels; 2 / 3 / 4 = one launch for the
-    whole decoder stack (one XCD / 32 / 64 workgroups spread), where the shape allows it (else the call falls back to the folded path)."""
+    whole decoder stack (one XCD / 32 / 64 workgroups spread), where the shape allows it (else the call falls back to the folded path);
+    5 = the chip-wide one-launch engine (one sequence; more sequences: as 2); -1 = the library's default."""
     from olmoasr_amd import _native as N
     N.lib().oasr_decode_set_ln_fold(mode)
     try:
@@ -56,9 +64,19 @@ def test_step_engines_are_bit_identical(tiny_case, width, heads, layers, B, infe
     assert torch.equal(again, folded)
     # the one-launch engine (B <= 4): every placement of its team, twice on the same buffers (the barrier epoch carries over)
     if B <= 4:
-        for mode in (2, 3, 4, -1, 2):
+        for mode in (2, 3, 4, 2) + ((-1,) if B > 1 else ()):
             one = _steps(net, xa, toks, mode)
             assert torch.equal(one, multi), (mode, float((one - multi).abs().max()))
+    # the chip-wide engine (one sequence; the default there): same rounding points, K sums in 512-element spans instead of the MFMA tiles' order
+    # -> equal up to bf16 rounding flips of intermediate rows; deterministic, and twice on the same buffers (the flag epoch carries over)
+    if B == 1:
+        wide = _steps(net, xa, toks, 5)
+        assert torch.isfinite(wide).all()
+        assert float((wide - multi).abs().max()) < 0.08 + 0.02 * scale, float((wide - multi).abs().max())
+        assert float((wide - full).abs().max()) < 0.08 + 0.02 * scale
+        assert float((wide - multi).abs().mean()) < 0.01 + 0.002 * scale
+        for mode in (-1, 5):
+            assert torch.equal(_steps(net, xa, toks, mode), wide), mode
 
 
 def test_one_launch_engine_over_a_long_window(tiny_case):
@@ -76,6 +94,28 @@ def test_one_launch_engine_over_a_long_window(tiny_case):
     one = _steps(net, xa, toks, 2)
     assert torch.isfinite(one).all()
     assert torch.equal(one, multi), float((one - multi).abs().max())
+
+
+def test_chip_wide_engine_over_a_long_window(tiny_case):
+    """ONE sequence, 300 positions: the chip-wide engine's self-attention fills 5 of its 7 keys per lane group, the flag epochs run up to
+    300 x 16 -- logits track the multi-launch step at every position and the greedy choice agrees wherever the top-2 margin is above the
+    bf16 envelope."""
+    from olmoasr_amd.model import OLMoASR
+    from oracle import model_oracle as mo
+    dims = mo.Dims(80, 1500, 512, 8, 1, 51864, 448, 512, 8, 2)
+    net = OLMoASR(_dims(dims), device=DEV, seed=3, inference=True)
+    xa = net.embed_audio(tiny_case["mel"][:1].to(DEV))
+    toks = torch.randint(0, 50000, (1, 300), generator=torch.Generator().manual_seed(1)).to(DEV)
+    toks[:, 0] = 50257
+    multi = _steps(net, xa, toks, 1)
+    wide = _steps(net, xa, toks, 5)
+    assert torch.isfinite(wide).all()
+    scale = float(multi.abs().max())
+    env = 0.08 + 0.02 * scale
+    assert float((wide - multi).abs().max()) < env, float((wide - multi).abs().max())
+    top2 = multi.topk(2, dim=-1).values
+    clear = (top2[..., 0] - top2[..., 1]) > 2 * env
+    assert bool((wide.argmax(-1) == multi.argmax(-1))[clear].all())
 
 
 def test_decode_through_every_step_engine(tiny_case):
@@ -119,7 +159,7 @@ def test_reindexed_cache_steps_on_the_one_launch_engine(tiny_case):
         junk = torch.full((N.lib().oasr_kv_cache_bytes(net._ctx, 1),), 0xA5, dtype=torch.uint8, device=DEV)
         del junk
         one = _EngineKV(net, st)[[1]].state  # sequence 1 alone: B = 1
-        assert one["B"] == 1 and int(one["cache"][-256:].to(torch.int32).sum()) == 0
+        assert one["B"] == 1 and int(one["cache"][-N.KV_TAIL_BYTES:].to(torch.int32).sum()) == 0
         ref = [net.kv_cache_step(st, toks[:, p])[1] for p in range(4, 8)]
         got = [net.kv_cache_step(one, toks[1:, p])[0] for p in range(4, 8)]
         assert net.kv_cache_check(one) is True and net.kv_cache_check(st) is True
@@ -145,14 +185,14 @@ def test_poisoned_one_launch_engine_falls_back_to_the_multi_launch_engine(tiny_c
     xa = net.embed_audio(mel)
     st = net.kv_cache_begin(xa)
     net.kv_cache_step(st, torch.tensor([50257], device=DEV))
-    st["cache"][-256:].view(torch.int32)[1] = 1  # what a timed-out team barrier writes
+    _tail(st)[1] = 1  # what a timed-out team barrier / flag poll writes
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         assert net.kv_cache_check(st) is False
     assert w and "multi-launch" in str(w[0].message)
-    assert int(st["cache"][-256:].view(torch.int32)[1]) == 0 and net.kv_cache_check(st) is True  # flag cleared, context switched
-    again = decode(net, mel, opts)  # multi-launch engine now (bit-identical engines)
-    assert again[0].tokens == clean[0].tokens and abs(again[0].avg_logprob - clean[0].avg_logprob) < 1e-6
+    assert int(_tail(st)[1]) == 0 and net.kv_cache_check(st) is True  # flag cleared, context switched
+    again = decode(net, mel, opts)  # multi-launch engine now (the same arithmetic; the chip-wide engine's K sums are ordered differently)
+    assert again[0].tokens == clean[0].tokens and abs(again[0].avg_logprob - clean[0].avg_logprob) < 2e-2
     # decode() itself repeats a window whose check asks for it
     net2 = OLMoASR(_dims(dims), device=DEV, seed=9, inference=True)
     calls = {"n": 0}
@@ -161,7 +201,7 @@ def test_poisoned_one_launch_engine_falls_back_to_the_multi_launch_engine(tiny_c
     def poison_first(state):
         calls["n"] += 1
         if calls["n"] == 1:
-            state["cache"][-256:].view(torch.int32)[1] = 1
+            _tail(state)[1] = 1
         return real(state)
     net2.kv_cache_check = poison_first
     with warnings.catch_warnings():
@@ -175,6 +215,7 @@ def test_default_engine_for_one_sequence_is_the_one_launch_engine(tiny_case, wid
     """All step engines are bit-identical, so a default that silently falls back to the multi-launch kernels passes every parity test --
     and costs 10-30 % per token (it happened: a host-side guard rejected the product's own arena layout, whose decoder blocks are stored
     last-first, i.e. with a negative layer stride).  The one-launch engine leaves a trace: its team barrier counter in the cache's tail."""
+    from olmoasr_amd import _native as N
     from olmoasr_amd.model import OLMoASR
     from oracle import model_oracle as mo
     dims = mo.Dims(80, 1500, width, heads, 1, 51864, 448, width, heads, layers)
@@ -184,8 +225,22 @@ def test_default_engine_for_one_sequence_is_the_one_launch_engine(tiny_case, wid
     for p in range(3):
         net.kv_cache_step(st, torch.tensor([50257 + p], device=DEV))
     assert net.kv_cache_check(st) is True
-    counter = int(st["cache"][-256:].view(torch.int32)[0])
-    assert counter >= 3 * 8 * layers, f"team barrier counter {counter}: the one-launch engine did not run"
+    # the chip-wide engine's trace: its flag epoch (control word 4) = phases completed, every workgroup's flag at that epoch
+    epoch = int(_tail(st)[4])
+    assert epoch == 3 * 8 * layers, f"flag epoch {epoch}: the chip-wide one-launch engine did not run"
+    flags = _tail(st)[256:512]
+    assert int(flags.min()) == epoch and int(flags.max()) == epoch and int(_tail(st)[0]) == 0
+    # forced onto the one-XCD team: its barrier counter runs instead
+    N.lib().oasr_decode_set_ln_fold(2)
+    try:
+        st2 = net.kv_cache_begin(xa)
+        for p in range(3):
+            net.kv_cache_step(st2, torch.tensor([50257 + p], device=DEV))
+        assert net.kv_cache_check(st2) is True
+    finally:
+        N.lib().oasr_decode_set_ln_fold(-1)
+    counter = int(_tail(st2)[0])
+    assert counter >= 3 * 8 * layers and int(_tail(st2)[4]) == 0, f"team barrier counter {counter}: the one-XCD engine did not run"
     two = net.kv_cache_begin(xa.repeat(2, 1, 1))  # two sequences: the multi-launch kernels by default (they spread over the chip)
     net.kv_cache_step(two, torch.tensor([50257, 50257], device=DEV))
-    assert net.kv_cache_check(two) is True and int(two["cache"][-256:].view(torch.int32)[0]) == 0
+    assert net.kv_cache_check(two) is True and int(_tail(two)[0]) == 0 and int(_tail(two)[4]) == 0
