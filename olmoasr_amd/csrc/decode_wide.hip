@@ -43,6 +43,8 @@ constexpr int WLNC = 3;    // 16-byte chunks per lane of a LayerNorm row: d <= 1
 constexpr int WMAXL = 32;
 constexpr int WMAXWG = 256;
 constexpr unsigned WSPIN = 1u << 20;
+constexpr int WREP = 8;      // flag replicas: 256 workgroups polling the same eight cache lines serialise on one memory channel; a replica per XCC, 4 KB apart
+constexpr int WFS = 1024;    // dwords between replicas
 
 #define WWAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
@@ -58,8 +60,8 @@ struct WArgs {
   bf16_t *x, *x2, *x3, *q, *o, *hg;
   float* part;      // [H * WNS][66]: m, l, o[64]
   unsigned* ctrl;   // [1] error flag  [3] XCC ids seen  [4] epoch base of this engine
-  unsigned* flagv;  // [nwg] last completed phase (epoch-based)
-  int d, H, Te, S_max, L, pos, nwg, flags;
+  unsigned* flagv;  // [WREP][WFS]: replica r (polled by the workgroups on XCC r) of the per-workgroup flags = last completed phase (epoch-based)
+  int d, H, Te, S_max, L, pos, nwg, flags, swg;
   unsigned long long* stamps;
   WLayer l0;
   long lstride, astride;
@@ -136,12 +138,12 @@ __device__ __forceinline__ void row_stats_w(const u32x4_t (&raw)[dec::MAXC], int
 }
 
 // wave 0: every workgroup has completed phase `target` (or the wait gave up and poisoned the launch)
-__device__ __forceinline__ void wide_wait(const WArgs& a, unsigned target, int lane) {
+__device__ __forceinline__ void wide_wait(const WArgs& a, const unsigned* myflags, unsigned target, int lane) {
   unsigned spins = 0;
   for (;;) {
     bool ok = true;
     if (lane * 4 < a.nwg) {  // (nwg is a multiple of 4, the flag array 16-byte aligned)
-      const u32x4_t f = ld16_agent(a.flagv + lane * 4);
+      const u32x4_t f = ld16_agent(myflags + lane * 4);
 #pragma unroll
       for (int i = 0; i < 4; ++i) ok = ok && (int)(f[i] - target) >= 0;
     }
@@ -259,9 +261,10 @@ __device__ __forceinline__ float merge_w(const float (&m_s)[WNS], const float (&
 
 #define WSTAMP(K)                                                                                                \
   do {                                                                                                           \
-    if (a.stamps && wg == 0 && layer == 1 && tid == 0) a.stamps[ph * 8 + (K)] = __builtin_amdgcn_s_memtime(); \
+    if (STAMPS && wg == a.swg && layer == 1 && tid == 0) a.stamps[ph * 8 + (K)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 
+template <bool STAMPS>  // STAMPS: the measurement instantiation (scripts/decode_xcd_probe.py); its stores cost waits of their own
 __global__ __launch_bounds__(WT) void decode_wide_kernel(WArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned short xs[4 * WMAXD];  // the operand row (bf16)
   __shared__ float psum[64];
@@ -269,11 +272,10 @@ __global__ __launch_bounds__(WT) void decode_wide_kernel(WArgs a) {
   __shared__ float lsum[WNG];
   __shared__ float wmax[WW];
   const unsigned base = a.ctrl[4];
-  if (threadIdx.x == 0) {
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    __hip_atomic_fetch_or(a.ctrl + 3, 1u << (xcc & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  const unsigned* myflags = a.flagv + (size_t)(xcc & (WREP - 1)) * WFS;
+  if (threadIdx.x == 0) __hip_atomic_fetch_or(a.ctrl + 3, 1u << (xcc & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   u32x4_t wreg[WMAXU];
   request_units(gemv_of(a, 0, 0), blockIdx.x, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), threadIdx.x & 63, wreg);
   unsigned gp = 0;  // phases before the current one
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(WT) void decode_wide_kernel(WArgs a) {
         if (wg < a.H) {
           const int h = wg, n = a.pos + 1;
           WSTAMP(0);
-          if (wave == 0) wide_wait(a, target, lane);
+          if (wave == 0) wide_wait(a, myflags, target, lane);
           __syncthreads();
           WSTAMP(1);
           const u32x4_t q4 = ld16_agent(self + (long)a.pos * 3 * a.d + h * 64 + l8 * 8);
@@ -311,6 +313,10 @@ __global__ __launch_bounds__(WT) void decode_wide_kernel(WArgs a) {
               k4[u] = ld16_agent_off(kb, off), v4[u] = ld16_agent_off(vb, off);
             }
           }
+          if (STAMPS) {
+            WWAIT_VM0();
+            WSTAMP(3);
+          }
           float qv[8];
           dec::load_q8(q4, qv);
           float s2[WSK], mx = dec::NEG;
@@ -325,6 +331,7 @@ __global__ __launch_bounds__(WT) void decode_wide_kernel(WArgs a) {
           mx = wmaxf(mx);
           if (lane == 0) wmax[wave] = mx;
           __syncthreads();
+          WSTAMP(4);
           float m = wmax[0];
 #pragma unroll
           for (int w = 1; w < WW; ++w) m = fmaxf(m, wmax[w]);
@@ -338,10 +345,12 @@ __global__ __launch_bounds__(WT) void decode_wide_kernel(WArgs a) {
           for (int jj = 0; jj < 8; ++jj) ared[grp][l8 * 8 + jj] = o[jj];
           if (l8 == 0) lsum[grp] = l;
           __syncthreads();
+          WSTAMP(5);
           if (tid < 64) {
             float acc = 0.f, lt = 0.f;
 #pragma unroll 8
             for (int g = 0; g < WNG; ++g) acc += ared[g][tid], lt += lsum[g];
+            WSTAMP(6);
             const float val = lt > 0.f ? acc / lt : 0.f, nb = dec::xor_lane<1>(val);
             if ((lane & 1) == 0) st4_agent(a.o + h * 64 + lane, pack_bf2(val, nb));
             WWAIT_VM0();
@@ -371,7 +380,7 @@ __global__ __launch_bounds__(WT) void decode_wide_kernel(WArgs a) {
             }
           }
           WSTAMP(0);
-          if (wave == 0) wide_wait(a, target, lane);
+          if (wave == 0) wide_wait(a, myflags, target, lane);
           __syncthreads();
           WSTAMP(1);
           const u32x4_t q4 = ld16_agent(a.q + h * 64 + l8 * 8);
@@ -446,7 +455,7 @@ __global__ __launch_bounds__(WT) void decode_wide_kernel(WArgs a) {
               }
           }
           WSTAMP(0);
-          if (wave == 0 && gp > 0) wide_wait(a, target, lane);
+          if (wave == 0 && gp > 0) wide_wait(a, myflags, target, lane);
           __syncthreads();
           WSTAMP(1);
           // ---- operand row -> LDS ----
@@ -506,9 +515,9 @@ __global__ __launch_bounds__(WT) void decode_wide_kernel(WArgs a) {
           WSTAMP(2);
           // ---- this wave's units ----
           if (wave > 0) {
-            if (a.stamps) {
+            if (STAMPS) {
               WWAIT_VM0();
-              if (wg == 0 && layer == 1 && tid == 64) a.stamps[ph * 8 + 5] = __builtin_amdgcn_s_memtime();
+              if (wg == a.swg && layer == 1 && tid == 64) a.stamps[ph * 8 + 5] = __builtin_amdgcn_s_memtime();
             }
             const WUnits q = units_of(p, wg, wave);
             float ps[WMAXU];
@@ -528,7 +537,7 @@ __global__ __launch_bounds__(WT) void decode_wide_kernel(WArgs a) {
                 if (lane == 0) psum[q.u0 + i] = sum;
               }
             }
-            if (a.stamps && wg == 0 && layer == 1 && tid == 64) a.stamps[ph * 8 + 6] = __builtin_amdgcn_s_memtime();
+            if (STAMPS && wg == a.swg && layer == 1 && tid == 64) a.stamps[ph * 8 + 6] = __builtin_amdgcn_s_memtime();
           }
           __syncthreads();
           WSTAMP(3);
@@ -547,7 +556,7 @@ __global__ __launch_bounds__(WT) void decode_wide_kernel(WArgs a) {
         }
       }
       // this workgroup's rows of the phase are stored (wave 0 has waited for the acknowledgements): publish
-      if (tid == 0) st4_agent(a.flagv + wg, base + gp + 1);
+      if (tid < WREP) st4_agent(a.flagv + tid * WFS + wg, base + gp + 1);  // (lanes 0-7 of wave 0: one store instruction, eight replicas)
       // the next phase's weights if it is a projection: in flight through the exchange.  (Not across an attention phase: with the attention's K / V
       // rows the 32 registers of weights would not fit, and the compiler would park them in scratch = wait for them on the spot.)
       if (ph != 0 && ph != 3) {
@@ -556,10 +565,11 @@ __global__ __launch_bounds__(WT) void decode_wide_kernel(WArgs a) {
         kill_units(wreg);
         if (nl < a.L) request_units(gemv_of(a, nl, np), wg, wave, lane, wreg);
       }
+      WSTAMP(7);
     }
   }
   if (blockIdx.x == 0 && threadIdx.x < 64) {  // everybody has read the epoch base long ago; publish the next launch's once every workgroup is through
-    wide_wait(a, base + gp, threadIdx.x);
+    wide_wait(a, myflags, base + gp, threadIdx.x);
     if (threadIdx.x == 0) a.ctrl[4] = base + gp;
   }
 }
@@ -595,15 +605,17 @@ int DW_NAME(launch_decode_wide)(const DecodeXcdArgs& h, hipStream_t s) {
   WArgs a;
   a.wflat = h.wflat, a.params = h.params, a.aux = h.aux, a.cache = h.cache, a.cache_lstride = h.cache_lstride;
   a.x = h.x, a.x2 = h.x2, a.x3 = h.x3, a.q = h.q, a.o = h.o, a.hg = h.hg, a.part = h.part;
-  a.ctrl = h.ctrl, a.flagv = h.ctrl + 256;  // the flag array sits 1 KB into the cache's control tail
+  a.ctrl = h.ctrl, a.flagv = h.ctrl + 1024;  // the flag replicas start 4 KB into the cache's control tail
   a.d = h.d, a.H = h.H, a.Te = h.Te, a.S_max = h.S_max, a.L = h.L, a.pos = h.pos, a.nwg = h.team, a.flags = h.flags;
   a.stamps = (unsigned long long*)h.stamps;
+  a.swg = (h.flags >> 8) & 0xff;  // (the engine passes OASR_XCD_FLAGS bits 9-16 here: the workgroup whose stamps are taken)
   {
     long* dst = &a.l0.ln1g;
     for (int i = 0; i < 18; ++i) dst[i] = (long)h.layer_offsets[i];
     a.lstride = h.lstride, a.astride = h.astride;
   }
-  hipLaunchKernelGGL(decode_wide_kernel, dim3(h.team), dim3(WT), 0, s, a);
+  if (a.stamps) hipLaunchKernelGGL(decode_wide_kernel<true>, dim3(h.team), dim3(WT), 0, s, a);
+  else hipLaunchKernelGGL(decode_wide_kernel<false>, dim3(h.team), dim3(WT), 0, s, a);
   OASR_LAUNCH_CHECK();
   return OASR_OK;
 }

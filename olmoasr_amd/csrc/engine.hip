@@ -1225,7 +1225,7 @@ static int oasr_decode_step_impl(oasr_ctx* c, const int64_t* tokens_last, int B,
           const char* e = oasr_experiment_env("OASR_XCD_FLAGS");
           return e ? atoi(e) : 0;
         }();
-        xa.flags = xflags & 0xff;
+        xa.flags = (xflags & 0xff) | (((xflags >> 9) & 0xff) << 8);  // (bits 9-16: the workgroup whose stamps the chip-wide engine takes)
         xa.stamps = (xflags & 0x100) ? (void*)((char*)workspace + workspace_bytes - 512) : nullptr;
       }
       xa.layer_offsets = c->xcd_offsets.data();

@@ -57,11 +57,14 @@ def main():
             print("   in-kernel s_memtime stamps, workgroup 0, decoder layer 1 (ticks): projection = poll | operand | units | epilogue+store ; attention = poll | rest")
             for p_, r in enumerate(t):
                 nxt = t[p_ + 1][0] if p_ < 7 else None
-                if p_ in (1, 4):
-                    print(f"     {names[p_]:10s} poll {r[1] - r[0]:6d}  rest {r[2] - r[1]:6d}" + (f"  | to next phase {nxt - r[2]:6d}  | phase total {nxt - r[0]:6d}" if nxt else ""))
+                if p_ == 1:
+                    print(f"     {names[p_]:10s} poll {r[1] - r[0]:6d}  q/K/V landed {r[3] - r[1]:6d}  scores+max {r[4] - r[3]:6d}  P.V {r[5] - r[4]:6d}  group sum {r[6] - r[5]:6d}  store {r[2] - r[6]:6d}  end {r[7] - r[2]:6d}"
+                          + (f"  | to next phase {nxt - r[7]:6d}  | phase total {nxt - r[0]:6d}" if nxt else ""))
+                elif p_ == 4:
+                    print(f"     {names[p_]:10s} poll {r[1] - r[0]:6d}  rest {r[2] - r[1]:6d}  end {r[7] - r[2]:6d}" + (f"  | to next phase {nxt - r[7]:6d}  | phase total {nxt - r[0]:6d}" if nxt else ""))
                 else:
-                    print(f"     {names[p_]:10s} poll {r[1] - r[0]:6d}  operand {r[2] - r[1]:6d}  units {r[3] - r[2]:6d} (wave 1: weights landed +{r[5] - r[2]:5d}, sums done +{r[6] - r[2]:5d})  epilogue {r[4] - r[3]:6d}"
-                          + (f"  | to next phase {nxt - r[4]:6d}  | phase total {nxt - r[0]:6d}" if nxt else ""))
+                    print(f"     {names[p_]:10s} poll {r[1] - r[0]:6d}  operand {r[2] - r[1]:6d}  units {r[3] - r[2]:6d} (wave 1: weights landed +{r[5] - r[2]:5d}, sums done +{r[6] - r[2]:5d})  epilogue {r[4] - r[3]:6d}  end {r[7] - r[4]:6d}"
+                          + (f"  | to next phase {nxt - r[7]:6d}  | phase total {nxt - r[0]:6d}" if nxt else ""))
             print(f"     layer total {t[7][4] - t[0][0]} ticks")
         elif mode >= 2 and (int(os.environ.get("OASR_XCD_FLAGS", "0")) & 0x100):
             t = st["ws"][-512:].view(torch.int64).view(8, 8).cpu().tolist()

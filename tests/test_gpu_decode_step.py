@@ -228,8 +228,10 @@ def test_default_engine_for_one_sequence_is_the_one_launch_engine(tiny_case, wid
     # the chip-wide engine's trace: its flag epoch (control word 4) = phases completed, every workgroup's flag at that epoch
     epoch = int(_tail(st)[4])
     assert epoch == 3 * 8 * layers, f"flag epoch {epoch}: the chip-wide one-launch engine did not run"
-    flags = _tail(st)[256:512]
-    assert int(flags.min()) == epoch and int(flags.max()) == epoch and int(_tail(st)[0]) == 0
+    for rep in range(8):  # (one replica of the flag array per XCC, 4 KB apart, the first 4 KB into the tail)
+        flags = _tail(st)[1024 * (rep + 1):1024 * (rep + 1) + 256]
+        assert int(flags.min()) == epoch and int(flags.max()) == epoch
+    assert int(_tail(st)[0]) == 0
     # forced onto the one-XCD team: its barrier counter runs instead
     N.lib().oasr_decode_set_ln_fold(2)
     try:
