@@ -66,15 +66,6 @@ struct WArgs {
   WLayer l0;
   long lstride, astride;
 };
-__device__ __forceinline__ WLayer layer_of(const WArgs& a, int l) {
-  WLayer y = a.l0;
-  const long s = (long)l * a.lstride;
-  y.ln1g += s, y.ln1b += s, y.wqkv += s, y.wo += s, y.bo += s, y.lncg += s, y.lncb += s, y.wcq += s, y.bcq += s, y.wco += s, y.bco += s;
-  y.ln2g += s, y.ln2b += s, y.w1 += s, y.b1 += s, y.w2 += s, y.b2 += s;
-  y.bqkv_aux += (long)l * a.astride;
-  return y;
-}
-
 // ---- agent-scope accesses --------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ u32x4_t ld16_agent(const void* p) {
   const uint64_t a = __hip_atomic_load((const uint64_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -167,31 +158,32 @@ struct WGemv {  // one projection phase
   const bf16_t* resid;
   bf16_t* out;
 };
-__device__ __forceinline__ WGemv gemv_of(const WArgs& a, int layer, int ph) {
-  const WLayer ly = layer_of(a, layer);
+template <int PH>
+struct WPh {  // what projection phase PH is, at compile time
+  static constexpr bool LN = PH == 0 || PH == 3 || PH == 6, MERGE = PH == 5, GELU = PH == 6, RESID = PH == 2 || PH == 5 || PH == 7;
+  static constexpr int NEXT = PH == 7 ? 0 : PH + 1;  // the phase after it
+};
+template <int PH>
+__device__ __forceinline__ WGemv gemv_of(const WArgs& a, int layer) {
+  const long s = (long)layer * a.lstride;
   WGemv p;
-  p.merge = false, p.gelu = false, p.ln_g = p.ln_b = nullptr, p.resid = nullptr, p.K = a.d, p.N = a.d, p.xin = nullptr;
-  switch (ph) {
-    case 0:  // attn_ln -> q | k | v of position pos, straight into the cache row
-      p.w = a.wflat + ly.wqkv, p.xin = a.x, p.N = 3 * a.d, p.ln_g = a.params + ly.ln1g, p.ln_b = a.params + ly.ln1b, p.bias = a.aux + ly.bqkv_aux;
-      p.out = a.cache + (long)layer * a.cache_lstride + (long)a.pos * 3 * a.d;
-      break;
-    case 2:  // self-attention output projection + residual
-      p.w = a.wflat + ly.wo, p.xin = a.o, p.bias = a.params + ly.bo, p.resid = a.x, p.out = a.x2;
-      break;
-    case 3:  // cross_attn_ln -> cross query
-      p.w = a.wflat + ly.wcq, p.xin = a.x2, p.ln_g = a.params + ly.lncg, p.ln_b = a.params + ly.lncb, p.bias = a.params + ly.bcq, p.out = a.q;
-      break;
-    case 5:  // cross-attention output projection + residual (operand = merged segment partials)
-      p.w = a.wflat + ly.wco, p.merge = true, p.bias = a.params + ly.bco, p.resid = a.x2, p.out = a.x3;
-      break;
-    case 6:  // mlp_ln -> mlp.0 + GELU
-      p.w = a.wflat + ly.w1, p.xin = a.x3, p.N = 4 * a.d, p.ln_g = a.params + ly.ln2g, p.ln_b = a.params + ly.ln2b, p.bias = a.params + ly.b1, p.gelu = true;
-      p.out = a.hg;
-      break;
-    default:  // 7: mlp.2 + residual
-      p.w = a.wflat + ly.w2, p.xin = a.hg, p.K = 4 * a.d, p.bias = a.params + ly.b2, p.resid = a.x3, p.out = a.x;
-      break;
+  p.merge = WPh<PH>::MERGE, p.gelu = WPh<PH>::GELU, p.ln_g = p.ln_b = nullptr, p.resid = nullptr, p.K = a.d, p.N = a.d, p.xin = nullptr;
+  if constexpr (PH == 0) {  // attn_ln -> q | k | v of position pos, straight into the cache row
+    p.w = a.wflat + (a.l0.wqkv + s), p.xin = a.x, p.N = 3 * a.d, p.ln_g = a.params + (a.l0.ln1g + s), p.ln_b = a.params + (a.l0.ln1b + s);
+    p.bias = a.aux + (a.l0.bqkv_aux + (long)layer * a.astride);
+    p.out = a.cache + (long)layer * a.cache_lstride + (long)a.pos * 3 * a.d;
+  } else if constexpr (PH == 2) {  // self-attention output projection + residual
+    p.w = a.wflat + (a.l0.wo + s), p.xin = a.o, p.bias = a.params + (a.l0.bo + s), p.resid = a.x, p.out = a.x2;
+  } else if constexpr (PH == 3) {  // cross_attn_ln -> cross query
+    p.w = a.wflat + (a.l0.wcq + s), p.xin = a.x2, p.ln_g = a.params + (a.l0.lncg + s), p.ln_b = a.params + (a.l0.lncb + s), p.bias = a.params + (a.l0.bcq + s);
+    p.out = a.q;
+  } else if constexpr (PH == 5) {  // cross-attention output projection + residual (operand = merged segment partials)
+    p.w = a.wflat + (a.l0.wco + s), p.bias = a.params + (a.l0.bco + s), p.resid = a.x2, p.out = a.x3;
+  } else if constexpr (PH == 6) {  // mlp_ln -> mlp.0 + GELU
+    p.w = a.wflat + (a.l0.w1 + s), p.xin = a.x3, p.N = 4 * a.d, p.ln_g = a.params + (a.l0.ln2g + s), p.ln_b = a.params + (a.l0.ln2b + s), p.bias = a.params + (a.l0.b1 + s);
+    p.out = a.hg;
+  } else {  // 7: mlp.2 + residual
+    p.w = a.wflat + (a.l0.w2 + s), p.xin = a.hg, p.K = 4 * a.d, p.bias = a.params + (a.l0.b2 + s), p.resid = a.x3, p.out = a.x;
   }
   p.R = 2 * ((p.N + 2 * a.nwg - 1) / (2 * a.nwg));
   return p;
@@ -238,6 +230,8 @@ __device__ __forceinline__ void kill_units(u32x4_t (&wreg)[WMAXU]) {
 #pragma unroll
   for (int i = 0; i < WMAXU; ++i) asm volatile("" : "=v"(wreg[i]));
 }
+// (v_dot2c_f32_bf16 would do two products per instruction; through __builtin_amdgcn_fdot2_f32_bf16 it returned wrong sums here -- max |d| 8.6 on
+// the logits, profiles/r06_decode_wide.txt -- so the products are plain fp32 FMAs on the unpacked halves)
 __device__ __forceinline__ float dot8(const u32x4_t& w, const u32x4_t& x) {
   float s = 0.f;
 #pragma unroll
@@ -259,314 +253,359 @@ __device__ __forceinline__ float merge_w(const float (&m_s)[WNS], const float (&
   return L > 0.f ? O / L : 0.f;
 }
 
+// one query row against this thread's NK keys (key u of the thread = key grp + WNG u of the workgroup's range, n keys in it; K / V rows already
+// in registers): scores, maximum over the workgroup, P (bf16) . V, and the sum over the WNG groups in two short stages (a wave's eight groups
+// first, then the waves) instead of one WNG-step walk.  Threads 0-63 (dimension tid) return the segment's maximum, normaliser and unnormalised
+// output value.
+struct WAttLds {
+  float ared[WNG][64];
+  float ared2[WW][64];
+  float lsum2[WW];
+  float wmax[WW];
+};
+template <int NK>
+__device__ __forceinline__ void attend(const float (&qv)[8], const u32x4_t (&k4)[NK], const u32x4_t (&v4)[NK], int n, int tid, WAttLds& L, float& m_out,
+                                       float& lt_out, float& acc_out) {
+  const int lane = tid & 63, l8 = tid & 7, grp = tid >> 3;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float s2[NK], mx = dec::NEG;
+#pragma unroll
+  for (int u = 0; u < NK; ++u) {
+    s2[u] = dec::NEG;
+    if (WNG * u < n) {
+      const float sc = dec::score8(qv, k4[u]);
+      if (grp + WNG * u < n) s2[u] = sc, mx = fmaxf(mx, sc);
+    }
+  }
+  mx = wmaxf(mx);
+  if (lane == 0) L.wmax[wave] = mx;
+  __syncthreads();
+  float m = L.wmax[0];
+#pragma unroll
+  for (int w = 1; w < WW; ++w) m = fmaxf(m, L.wmax[w]);
+  float l = 0.f, o[8];
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) o[jj] = 0.f;
+#pragma unroll
+  for (int u = 0; u < NK; ++u)
+    if (WNG * u < n) dec::accum_pv(grp + WNG * u < n ? __builtin_amdgcn_exp2f(s2[u] - m) : 0.f, v4[u], l, o);
+  *(f32x4_t*)&L.ared[grp][l8 * 8] = f32x4_t{o[0], o[1], o[2], o[3]};
+  *(f32x4_t*)&L.ared[grp][l8 * 8 + 4] = f32x4_t{o[4], o[5], o[6], o[7]};
+  const float lw = wsum(l) * 0.125f;  // the wave's eight groups (every group's l sits in its eight lanes)
+  if (lane == 0) L.lsum2[wave] = lw;
+  __syncthreads();
+  {  // stage 1: this wave's eight groups, dimension `lane`
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc += L.ared[wave * 8 + k][lane];
+    L.ared2[wave][lane] = acc;
+  }
+  __syncthreads();
+  m_out = m, lt_out = 0.f, acc_out = 0.f;
+  if (tid < 64) {
+#pragma unroll
+    for (int w = 0; w < WW; ++w) acc_out += L.ared2[w][tid], lt_out += L.lsum2[w];
+  }
+}
+
 #define WSTAMP(K)                                                                                                \
   do {                                                                                                           \
     if (STAMPS && wg == a.swg && layer == 1 && tid == 0) a.stamps[ph * 8 + (K)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 
+#define WPHASE_PROLOGUE                                                                                                       \
+  /* thread and workgroup ids re-materialised per phase: otherwise every address that depends on them only is hoisted out of the \
+     layer loop and spilled -- 130 VGPRs' worth */                                                                                \
+  int tid = threadIdx.x, wg = blockIdx.x;                                                                                         \
+  asm volatile("" : "+v"(tid), "+s"(wg));                                                                                       \
+  const int lane = tid & 63, l8 = tid & 7, grp = tid >> 3;                                                                        \
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                                                                      \
+  const unsigned target = base + gp; /* every workgroup has completed the phase before this one */                                \
+  (void)l8, (void)grp, (void)lane, (void)wave, (void)target
+
+struct WLds {
+  __attribute__((aligned(16))) unsigned short xs[4 * WMAXD];  // the operand row (bf16)
+  float psum[64];
+  WAttLds att;
+};
+// this workgroup's rows of the phase are stored (wave 0 has waited for the acknowledgements): publish -- lanes 0-7 of wave 0, one store
+// instruction, eight replicas
+#define WPUBLISH() \
+  if (tid < WREP) st4_agent(a.flagv + tid * WFS + wg, base + gp + 1)
+
+// ---------------- self-attention: one workgroup per head ----------------
+template <bool STAMPS>
+__device__ __forceinline__ void self_phase(const WArgs& a, int layer, unsigned gp, unsigned base, const unsigned* myflags, WLds& lds) {
+  constexpr int ph = 1;
+  WPHASE_PROLOGUE;
+  WAttLds& att = lds.att;
+  const bf16_t* self = a.cache + (long)layer * a.cache_lstride;
+  if (wg < a.H) {
+    const int h = wg, n = a.pos + 1;
+    WSTAMP(0);
+    if (wave == 0) wide_wait(a, myflags, target, lane);
+    __syncthreads();
+    WSTAMP(1);
+    const u32x4_t q4 = ld16_agent(self + (long)a.pos * 3 * a.d + h * 64 + l8 * 8);
+    const bf16_t* kb = self + a.d + h * 64;  // (uniform bases + one 32-bit offset per key: K and V rows share it)
+    const bf16_t* vb = kb + a.d;
+    u32x4_t k4[WSK], v4[WSK];
+#pragma unroll
+    for (int u = 0; u < WSK; ++u) {
+      fresh(k4[u]), fresh(v4[u]);
+      const int t = grp + WNG * u;
+      if (WNG * u < n) {  // (wave-uniform; keys of this launch and of earlier ones alike: row pos was written a phase ago)
+        const unsigned off = (unsigned)(((t < n ? t : n - 1) * 3 * a.d + l8 * 8) * 2);
+        k4[u] = ld16_agent_off(kb, off), v4[u] = ld16_agent_off(vb, off);
+      }
+    }
+    if (STAMPS) {
+      WWAIT_VM0();
+      WSTAMP(3);
+    }
+    float qv[8];
+    dec::load_q8(q4, qv);
+    float m, lt, acc;
+    attend<WSK>(qv, k4, v4, n, tid, att, m, lt, acc);
+    WSTAMP(6);
+    if (tid < 64) {
+      const float val = lt > 0.f ? acc / lt : 0.f, nb = dec::xor_lane<1>(val);
+      if ((lane & 1) == 0) st4_agent(a.o + h * 64 + lane, pack_bf2(val, nb));
+      WWAIT_VM0();
+    }
+    WSTAMP(2);
+  }
+  WPUBLISH();
+  WSTAMP(7);
+}
+
+// ---------------- cross-attention: one workgroup per (head, key segment) ----------------
+template <bool STAMPS>
+__device__ __forceinline__ void cross_phase(const WArgs& a, int layer, unsigned gp, unsigned base, const unsigned* myflags, WLds& lds) {
+  constexpr int ph = 4;
+  WPHASE_PROLOGUE;
+  WAttLds& att = lds.att;
+  const bf16_t* cross = a.cache + (long)layer * a.cache_lstride + (long)3 * a.S_max * a.d;
+  if (wg < a.H * WNS) {
+    const int h = wg >> 2, sg = wg & 3;
+    const int SL = (a.Te + WNS - 1) / WNS;
+    const int t0 = sg * SL;
+    int n = a.Te - t0;
+    n = n > SL ? SL : (n < 0 ? 0 : n);
+    // the segment's K / V rows do not depend on the token: requested before the poll
+    const bf16_t* kb = cross + (long)t0 * 2 * a.d + h * 64;
+    const bf16_t* vb = kb + a.d;
+    u32x4_t k4[WCK], v4[WCK];
+#pragma unroll
+    for (int u = 0; u < WCK; ++u) {
+      fresh(k4[u]), fresh(v4[u]);
+      const int t = grp + WNG * u;
+      if (WNG * u < n) {
+        const size_t off = (size_t)(unsigned)(((t < n ? t : n - 1) * 2 * a.d + l8 * 8) * 2);
+        k4[u] = __builtin_nontemporal_load((const u32x4_t*)((const char*)kb + off));
+        v4[u] = __builtin_nontemporal_load((const u32x4_t*)((const char*)vb + off));
+      }
+    }
+    WSTAMP(0);
+    if (wave == 0) wide_wait(a, myflags, target, lane);
+    __syncthreads();
+    WSTAMP(1);
+    const u32x4_t q4 = ld16_agent(a.q + h * 64 + l8 * 8);
+    float qv[8];
+    dec::load_q8(q4, qv);
+    float m, lt, acc;
+    attend<WCK>(qv, k4, v4, n, tid, att, m, lt, acc);
+    if (tid < 64) {
+      float* dst = a.part + (long)wg * 66;
+      st4_agent(dst + 2 + lane, __float_as_uint(acc));
+      if (lane == 0) st4_agent(dst, __float_as_uint(m)), st4_agent(dst + 1, __float_as_uint(lt));
+      WWAIT_VM0();
+    }
+    WSTAMP(2);
+  }
+  WPUBLISH();
+  WSTAMP(7);
+}
+
+// ---------------- projection PH: rows wg R .. wg R + R - 1 ----------------
+template <bool STAMPS, int PH>
+__device__ __forceinline__ void gemv_phase(const WArgs& a, int layer, unsigned gp, unsigned base, const unsigned* myflags, WLds& lds, u32x4_t (&wreg)[WMAXU]) {
+  constexpr int ph = PH;
+  WPHASE_PROLOGUE;
+  unsigned short* xs = lds.xs;
+  float* psum = lds.psum;
+  const WGemv p = gemv_of<PH>(a, layer);
+  const int row0 = wg * p.R;
+  if (row0 < p.N) {
+    const int KC = p.K >> 3, J = (KC + 63) >> 6;
+    int rows = p.N - row0;
+    rows = rows > p.R ? p.R : rows;
+    const int U = rows * J;
+    const WUnits q = units_of(p, wg, wave > 0 ? wave : 1);  // (before the poll: off the path from the flags to the stores)
+  // wave 0: what the epilogue needs besides the sums (requested before the poll: the residual row is two phases old)
+    float bias_v = 0.f, resid_v = 0.f;
+    if (wave == 0 && lane < rows) {
+      const int nn = row0 + lane;
+      if (p.bias) bias_v = p.bias[nn];
+      if constexpr (WPh<PH>::RESID) {
+        const unsigned rz = ld4_agent(p.resid + (nn & ~1));
+        resid_v = (nn & 1) ? bf_hi(rz) : bf_lo(rz);
+      }
+    }
+    // ... and the LayerNorm parameters of the chunks this lane will normalise (static data, 2 x 32 bytes per chunk)
+    f32x4_t lg[WLNC][2], lb[WLNC][2];
+#pragma unroll
+    for (int c = 0; c < WLNC; ++c) fresh(lg[c][0]), fresh(lg[c][1]), fresh(lb[c][0]), fresh(lb[c][1]);
+    if (WPh<PH>::LN && wave == 0) {
+#pragma unroll
+      for (int c = 0; c < WLNC; ++c)
+        if (lane + 64 * c < KC) {
+          const int k = (lane + 64 * c) * 8;
+          lg[c][0] = *(const f32x4_t*)(p.ln_g + k), lg[c][1] = *(const f32x4_t*)(p.ln_g + k + 4);
+          lb[c][0] = *(const f32x4_t*)(p.ln_b + k), lb[c][1] = *(const f32x4_t*)(p.ln_b + k + 4);
+        }
+    }
+    WSTAMP(0);
+    if (wave == 0 && (PH != 0 || gp > 0)) wide_wait(a, myflags, target, lane);
+    __syncthreads();
+    WSTAMP(1);
+    // ---- operand row -> LDS ----
+    if constexpr (WPh<PH>::MERGE) {  // merged cross-attention output: wave w merges heads w, w + 8, ...; lane = dimension; (m, l) of segment s come in through lane s
+#pragma unroll 1
+      for (int h = wave; h < a.H; h += WW) {
+        const float* src = a.part + (long)h * (WNS * 66);
+        const int sl = lane < WNS ? lane : WNS - 1;
+        const float mv = ldf_agent(src + sl * 66), lv = ldf_agent(src + sl * 66 + 1);
+        float m_s[WNS], l_s[WNS], o_s[WNS];
+#pragma unroll
+        for (int sg = 0; sg < WNS; ++sg) o_s[sg] = ldf_agent(src + sg * 66 + 2 + lane);
+#pragma unroll
+        for (int sg = 0; sg < WNS; ++sg) m_s[sg] = rdlane(mv, sg), l_s[sg] = rdlane(lv, sg);
+        const float val = merge_w(m_s, l_s, o_s), nb = dec::xor_lane<1>(val);
+        if ((lane & 1) == 0) *(uint32_t*)(xs + h * 64 + lane) = pack_bf2(val, nb);
+      }
+    } else if constexpr (WPh<PH>::LN) {  // LayerNorm folded into the operand (K = d): wave 0
+      if (wave == 0) {
+        u32x4_t raw[dec::MAXC];
+#pragma unroll
+        for (int c = 0; c < dec::MAXC; ++c) {
+          fresh(raw[c]);
+          if (c < WLNC && lane + 64 * c < KC) raw[c] = ld16_agent(p.xin + (lane + 64 * c) * 8);
+        }
+        float mean, rstd;
+        row_stats_w(raw, lane, KC, p.K, mean, rstd);
+#pragma unroll
+        for (int c = 0; c < WLNC; ++c)
+          if (lane + 64 * c < KC) {
+            float v[8];
+            dec::unpack8(raw[c], v);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {  // (dec::ln_apply8's expression)
+              v[i] = (v[i] - mean) * rstd * lg[c][0][i] + lb[c][0][i];
+              v[4 + i] = (v[4 + i] - mean) * rstd * lg[c][1][i] + lb[c][1][i];
+            }
+            u32x4_t o4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o4[i] = pack_bf2(v[2 * i], v[2 * i + 1]);
+            *(u32x4_t*)(xs + (lane + 64 * c) * 8) = o4;
+          }
+      }
+    } else {  // plain row: K / 8 chunks over the 512 threads
+      constexpr int NC = (4 * WMAXD / 8 + WT - 1) / WT;
+      u32x4_t raw[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        fresh(raw[c]);
+        if (tid + WT * c < KC) raw[c] = ld16_agent(p.xin + (tid + WT * c) * 8);
+      }
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+        if (tid + WT * c < KC) *(u32x4_t*)(xs + (tid + WT * c) * 8) = raw[c];
+    }
+    __syncthreads();
+    WSTAMP(2);
+    // ---- this wave's units ----
+    if (wave > 0) {
+      if (STAMPS) {
+        WWAIT_VM0();
+        if (wg == a.swg && layer == 1 && tid == 64) a.stamps[ph * 8 + 5] = __builtin_amdgcn_s_memtime();
+      }
+      const WUnits q = units_of(p, wg, wave);
+      float ps[WMAXU];
+      int j = q.j0;
+#pragma unroll
+      for (int i = 0; i < WMAXU; ++i) {
+        const int c = j * 64 + lane;
+        ps[i] = 0.f;
+        if (i < q.upw && q.u0 + i < q.U && c < q.KC) ps[i] = dot8(wreg[i], *(const u32x4_t*)(xs + c * 8));
+        if (++j == q.J) j = 0;
+      }
+      kill_units(wreg);
+#pragma unroll
+      for (int i = 0; i < WMAXU; ++i) {
+        if (i < q.upw && q.u0 + i < q.U) {
+          const float sum = wsum(ps[i]);
+          if (lane == 0) psum[q.u0 + i] = sum;
+        }
+      }
+      if (STAMPS && wg == a.swg && layer == 1 && tid == 64) a.stamps[ph * 8 + 6] = __builtin_amdgcn_s_memtime();
+    }
+    __syncthreads();
+    WSTAMP(3);
+    if (wave == 0) {
+      float y = 0.f;
+      if (lane < rows) {
+        float acc = 0.f;
+        for (int jj = 0; jj < J; ++jj) acc += psum[lane * J + jj];
+        y = dec::epi_value(acc, bias_v, WPh<PH>::GELU, WPh<PH>::RESID, resid_v);
+      }
+      const float nb = dec::xor_lane<1>(y);
+      if (lane < rows && (lane & 1) == 0) st4_agent(p.out + row0 + lane, pack_bf2(y, nb));
+      WWAIT_VM0();
+    }
+    WSTAMP(4);
+  }
+  WPUBLISH();
+  WSTAMP(7);
+}
+// the weights of projection PH into this wave's registers
+template <int PH>
+__device__ __forceinline__ void request_phase(const WArgs& a, int layer, u32x4_t (&wreg)[WMAXU]) {
+  int tid = threadIdx.x, wg = blockIdx.x;
+  asm volatile("" : "+v"(tid), "+s"(wg));
+  kill_units(wreg);
+  if (layer < a.L) request_units(gemv_of<PH>(a, layer), wg, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63, wreg);
+}
+
 template <bool STAMPS>  // STAMPS: the measurement instantiation (scripts/decode_xcd_probe.py); its stores cost waits of their own
 __global__ __launch_bounds__(WT) void decode_wide_kernel(WArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned short xs[4 * WMAXD];  // the operand row (bf16)
-  __shared__ float psum[64];
-  __shared__ float ared[WNG][64];
-  __shared__ float lsum[WNG];
-  __shared__ float wmax[WW];
+  __shared__ WLds lds;
   const unsigned base = a.ctrl[4];
   unsigned xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   const unsigned* myflags = a.flagv + (size_t)(xcc & (WREP - 1)) * WFS;
   if (threadIdx.x == 0) __hip_atomic_fetch_or(a.ctrl + 3, 1u << (xcc & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   u32x4_t wreg[WMAXU];
-  request_units(gemv_of(a, 0, 0), blockIdx.x, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), threadIdx.x & 63, wreg);
+  request_phase<0>(a, 0, wreg);
   unsigned gp = 0;  // phases before the current one
+  // A phase's weights are requested at the end of the phase before it: in flight through the exchange.  (Not across an attention phase: with
+  // the attention's K / V rows the registers of weights would not fit, and the compiler would park them in scratch = wait for them on the spot.)
 #pragma unroll 1
   for (int layer = 0; layer < a.L; ++layer) {
-    const bf16_t* self = a.cache + (long)layer * a.cache_lstride;
-    const bf16_t* cross = self + (long)3 * a.S_max * a.d;
-#pragma unroll 1
-    for (int ph = 0; ph < 8; ++ph, ++gp) {
-      const unsigned target = base + gp;  // every workgroup has completed the phase before this one
-      // (thread and workgroup ids re-materialised per phase: otherwise every address that depends on them only is hoisted out of the layer
-      // loop and spilled -- 130 VGPRs' worth)
-      int tid = threadIdx.x, wg = blockIdx.x;
-      asm volatile("" : "+v"(tid), "+s"(wg));
-      const int lane = tid & 63, l8 = tid & 7, grp = tid >> 3;
-      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-      if (ph == 1) {
-        // ---------------- self-attention: one workgroup per head ----------------
-        if (wg < a.H) {
-          const int h = wg, n = a.pos + 1;
-          WSTAMP(0);
-          if (wave == 0) wide_wait(a, myflags, target, lane);
-          __syncthreads();
-          WSTAMP(1);
-          const u32x4_t q4 = ld16_agent(self + (long)a.pos * 3 * a.d + h * 64 + l8 * 8);
-          const bf16_t* kb = self + a.d + h * 64;  // (uniform bases + one 32-bit offset per key: K and V rows share it)
-          const bf16_t* vb = kb + a.d;
-          u32x4_t k4[WSK], v4[WSK];
-#pragma unroll
-          for (int u = 0; u < WSK; ++u) {
-            fresh(k4[u]), fresh(v4[u]);
-            const int t = grp + WNG * u;
-            if (WNG * u < n) {  // (wave-uniform; keys of this launch and of earlier ones alike: row pos was written a phase ago)
-              const unsigned off = (unsigned)(((t < n ? t : n - 1) * 3 * a.d + l8 * 8) * 2);
-              k4[u] = ld16_agent_off(kb, off), v4[u] = ld16_agent_off(vb, off);
-            }
-          }
-          if (STAMPS) {
-            WWAIT_VM0();
-            WSTAMP(3);
-          }
-          float qv[8];
-          dec::load_q8(q4, qv);
-          float s2[WSK], mx = dec::NEG;
-#pragma unroll
-          for (int u = 0; u < WSK; ++u) {
-            s2[u] = dec::NEG;
-            if (WNG * u < n) {
-              const float s = dec::score8(qv, k4[u]);
-              if (grp + WNG * u < n) s2[u] = s, mx = fmaxf(mx, s);
-            }
-          }
-          mx = wmaxf(mx);
-          if (lane == 0) wmax[wave] = mx;
-          __syncthreads();
-          WSTAMP(4);
-          float m = wmax[0];
-#pragma unroll
-          for (int w = 1; w < WW; ++w) m = fmaxf(m, wmax[w]);
-          float l = 0.f, o[8];
-#pragma unroll
-          for (int jj = 0; jj < 8; ++jj) o[jj] = 0.f;
-#pragma unroll
-          for (int u = 0; u < WSK; ++u)
-            if (WNG * u < n) dec::accum_pv(grp + WNG * u < n ? __builtin_amdgcn_exp2f(s2[u] - m) : 0.f, v4[u], l, o);
-#pragma unroll
-          for (int jj = 0; jj < 8; ++jj) ared[grp][l8 * 8 + jj] = o[jj];
-          if (l8 == 0) lsum[grp] = l;
-          __syncthreads();
-          WSTAMP(5);
-          if (tid < 64) {
-            float acc = 0.f, lt = 0.f;
-#pragma unroll 8
-            for (int g = 0; g < WNG; ++g) acc += ared[g][tid], lt += lsum[g];
-            WSTAMP(6);
-            const float val = lt > 0.f ? acc / lt : 0.f, nb = dec::xor_lane<1>(val);
-            if ((lane & 1) == 0) st4_agent(a.o + h * 64 + lane, pack_bf2(val, nb));
-            WWAIT_VM0();
-          }
-          WSTAMP(2);
-        }
-      } else if (ph == 4) {
-        // ---------------- cross-attention: one workgroup per (head, key segment) ----------------
-        if (wg < a.H * WNS) {
-          const int h = wg >> 2, sg = wg & 3;
-          const int SL = (a.Te + WNS - 1) / WNS;
-          const int t0 = sg * SL;
-          int n = a.Te - t0;
-          n = n > SL ? SL : (n < 0 ? 0 : n);
-          // the segment's K / V rows do not depend on the token: requested before the poll
-          const bf16_t* kb = cross + (long)t0 * 2 * a.d + h * 64;
-          const bf16_t* vb = kb + a.d;
-          u32x4_t k4[WCK], v4[WCK];
-#pragma unroll
-          for (int u = 0; u < WCK; ++u) {
-            fresh(k4[u]), fresh(v4[u]);
-            const int t = grp + WNG * u;
-            if (WNG * u < n) {
-              const size_t off = (size_t)(unsigned)(((t < n ? t : n - 1) * 2 * a.d + l8 * 8) * 2);
-              k4[u] = __builtin_nontemporal_load((const u32x4_t*)((const char*)kb + off));
-              v4[u] = __builtin_nontemporal_load((const u32x4_t*)((const char*)vb + off));
-            }
-          }
-          WSTAMP(0);
-          if (wave == 0) wide_wait(a, myflags, target, lane);
-          __syncthreads();
-          WSTAMP(1);
-          const u32x4_t q4 = ld16_agent(a.q + h * 64 + l8 * 8);
-          float qv[8];
-          dec::load_q8(q4, qv);
-          float s2[WCK], mx = dec::NEG;
-#pragma unroll
-          for (int u = 0; u < WCK; ++u) {
-            s2[u] = dec::NEG;
-            if (WNG * u < n) {
-              const float s = dec::score8(qv, k4[u]);
-              if (grp + WNG * u < n) s2[u] = s, mx = fmaxf(mx, s);
-            }
-          }
-          mx = wmaxf(mx);
-          if (lane == 0) wmax[wave] = mx;
-          __syncthreads();
-          float m = wmax[0];
-#pragma unroll
-          for (int w = 1; w < WW; ++w) m = fmaxf(m, wmax[w]);
-          float l = 0.f, o[8];
-#pragma unroll
-          for (int jj = 0; jj < 8; ++jj) o[jj] = 0.f;
-#pragma unroll
-          for (int u = 0; u < WCK; ++u)
-            if (WNG * u < n) dec::accum_pv(grp + WNG * u < n ? __builtin_amdgcn_exp2f(s2[u] - m) : 0.f, v4[u], l, o);
-#pragma unroll
-          for (int jj = 0; jj < 8; ++jj) ared[grp][l8 * 8 + jj] = o[jj];
-          if (l8 == 0) lsum[grp] = l;
-          __syncthreads();
-          if (tid < 64) {
-            float acc = 0.f, lt = 0.f;
-#pragma unroll 8
-            for (int g = 0; g < WNG; ++g) acc += ared[g][tid], lt += lsum[g];
-            float* dst = a.part + (long)wg * 66;
-            st4_agent(dst + 2 + lane, __float_as_uint(acc));
-            if (lane == 0) st4_agent(dst, __float_as_uint(m)), st4_agent(dst + 1, __float_as_uint(lt));
-            WWAIT_VM0();
-          }
-          WSTAMP(2);
-        }
-      } else {
-        // ---------------- projection: rows wg R .. wg R + R - 1 ----------------
-        const WGemv p = gemv_of(a, layer, ph);
-        const int row0 = wg * p.R;
-        if (row0 < p.N) {
-          const int KC = p.K >> 3, J = (KC + 63) >> 6;
-          int rows = p.N - row0;
-          rows = rows > p.R ? p.R : rows;
-          const int U = rows * J;
-          // wave 0: what the epilogue needs besides the sums (requested before the poll: the residual row is two phases old)
-          float bias_v = 0.f, resid_v = 0.f;
-          if (wave == 0 && lane < rows) {
-            const int nn = row0 + lane;
-            if (p.bias) bias_v = p.bias[nn];
-            if (p.resid) {
-              const unsigned rz = ld4_agent(p.resid + (nn & ~1));
-              resid_v = (nn & 1) ? bf_hi(rz) : bf_lo(rz);
-            }
-          }
-          // ... and the LayerNorm parameters of the chunks this lane will normalise (static data, 2 x 32 bytes per chunk)
-          f32x4_t lg[WLNC][2], lb[WLNC][2];
-#pragma unroll
-          for (int c = 0; c < WLNC; ++c) fresh(lg[c][0]), fresh(lg[c][1]), fresh(lb[c][0]), fresh(lb[c][1]);
-          if (wave == 0 && p.ln_g) {
-#pragma unroll
-            for (int c = 0; c < WLNC; ++c)
-              if (lane + 64 * c < KC) {
-                const int k = (lane + 64 * c) * 8;
-                lg[c][0] = *(const f32x4_t*)(p.ln_g + k), lg[c][1] = *(const f32x4_t*)(p.ln_g + k + 4);
-                lb[c][0] = *(const f32x4_t*)(p.ln_b + k), lb[c][1] = *(const f32x4_t*)(p.ln_b + k + 4);
-              }
-          }
-          WSTAMP(0);
-          if (wave == 0 && gp > 0) wide_wait(a, myflags, target, lane);
-          __syncthreads();
-          WSTAMP(1);
-          // ---- operand row -> LDS ----
-          if (p.merge) {  // merged cross-attention output: wave w merges heads w, w + 8, ...; lane = dimension; (m, l) of segment s come in through lane s
-#pragma unroll 1
-            for (int h = wave; h < a.H; h += WW) {
-              const float* src = a.part + (long)h * (WNS * 66);
-              const int sl = lane < WNS ? lane : WNS - 1;
-              const float mv = ldf_agent(src + sl * 66), lv = ldf_agent(src + sl * 66 + 1);
-              float m_s[WNS], l_s[WNS], o_s[WNS];
-#pragma unroll
-              for (int sg = 0; sg < WNS; ++sg) o_s[sg] = ldf_agent(src + sg * 66 + 2 + lane);
-#pragma unroll
-              for (int sg = 0; sg < WNS; ++sg) m_s[sg] = rdlane(mv, sg), l_s[sg] = rdlane(lv, sg);
-              const float val = merge_w(m_s, l_s, o_s), nb = dec::xor_lane<1>(val);
-              if ((lane & 1) == 0) *(uint32_t*)(xs + h * 64 + lane) = pack_bf2(val, nb);
-            }
-          } else if (p.ln_g) {  // LayerNorm folded into the operand (K = d): wave 0
-            if (wave == 0) {
-              u32x4_t raw[dec::MAXC];
-#pragma unroll
-              for (int c = 0; c < dec::MAXC; ++c) {
-                fresh(raw[c]);
-                if (c < WLNC && lane + 64 * c < KC) raw[c] = ld16_agent(p.xin + (lane + 64 * c) * 8);
-              }
-              float mean, rstd;
-              row_stats_w(raw, lane, KC, p.K, mean, rstd);
-#pragma unroll
-              for (int c = 0; c < WLNC; ++c)
-                if (lane + 64 * c < KC) {
-                  float v[8];
-                  dec::unpack8(raw[c], v);
-#pragma unroll
-                  for (int i = 0; i < 4; ++i) {  // (dec::ln_apply8's expression)
-                    v[i] = (v[i] - mean) * rstd * lg[c][0][i] + lb[c][0][i];
-                    v[4 + i] = (v[4 + i] - mean) * rstd * lg[c][1][i] + lb[c][1][i];
-                  }
-                  u32x4_t o4;
-#pragma unroll
-                  for (int i = 0; i < 4; ++i) o4[i] = pack_bf2(v[2 * i], v[2 * i + 1]);
-                  *(u32x4_t*)(xs + (lane + 64 * c) * 8) = o4;
-                }
-            }
-          } else {  // plain row: K / 8 chunks over the 512 threads
-            constexpr int NC = (4 * WMAXD / 8 + WT - 1) / WT;
-            u32x4_t raw[NC];
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-              fresh(raw[c]);
-              if (tid + WT * c < KC) raw[c] = ld16_agent(p.xin + (tid + WT * c) * 8);
-            }
-#pragma unroll
-            for (int c = 0; c < NC; ++c)
-              if (tid + WT * c < KC) *(u32x4_t*)(xs + (tid + WT * c) * 8) = raw[c];
-          }
-          __syncthreads();
-          WSTAMP(2);
-          // ---- this wave's units ----
-          if (wave > 0) {
-            if (STAMPS) {
-              WWAIT_VM0();
-              if (wg == a.swg && layer == 1 && tid == 64) a.stamps[ph * 8 + 5] = __builtin_amdgcn_s_memtime();
-            }
-            const WUnits q = units_of(p, wg, wave);
-            float ps[WMAXU];
-            int j = q.j0;
-#pragma unroll
-            for (int i = 0; i < WMAXU; ++i) {
-              const int c = j * 64 + lane;
-              ps[i] = 0.f;
-              if (i < q.upw && q.u0 + i < q.U && c < q.KC) ps[i] = dot8(wreg[i], *(const u32x4_t*)(xs + c * 8));
-              if (++j == q.J) j = 0;
-            }
-            kill_units(wreg);
-#pragma unroll
-            for (int i = 0; i < WMAXU; ++i) {
-              if (i < q.upw && q.u0 + i < q.U) {
-                const float sum = wsum(ps[i]);
-                if (lane == 0) psum[q.u0 + i] = sum;
-              }
-            }
-            if (STAMPS && wg == a.swg && layer == 1 && tid == 64) a.stamps[ph * 8 + 6] = __builtin_amdgcn_s_memtime();
-          }
-          __syncthreads();
-          WSTAMP(3);
-          if (wave == 0) {
-            float y = 0.f;
-            if (lane < rows) {
-              float acc = 0.f;
-              for (int jj = 0; jj < J; ++jj) acc += psum[lane * J + jj];
-              y = dec::epi_value(acc, bias_v, p.gelu, p.resid != nullptr, resid_v);
-            }
-            const float nb = dec::xor_lane<1>(y);
-            if (lane < rows && (lane & 1) == 0) st4_agent(p.out + row0 + lane, pack_bf2(y, nb));
-            WWAIT_VM0();
-          }
-          WSTAMP(4);
-        }
-      }
-      // this workgroup's rows of the phase are stored (wave 0 has waited for the acknowledgements): publish
-      if (tid < WREP) st4_agent(a.flagv + tid * WFS + wg, base + gp + 1);  // (lanes 0-7 of wave 0: one store instruction, eight replicas)
-      // the next phase's weights if it is a projection: in flight through the exchange.  (Not across an attention phase: with the attention's K / V
-      // rows the 32 registers of weights would not fit, and the compiler would park them in scratch = wait for them on the spot.)
-      if (ph != 0 && ph != 3) {
-        int nl = layer, np = ph + 1;
-        if (np == 8) np = 0, ++nl;
-        kill_units(wreg);
-        if (nl < a.L) request_units(gemv_of(a, nl, np), wg, wave, lane, wreg);
-      }
-      WSTAMP(7);
-    }
+    gemv_phase<STAMPS, 0>(a, layer, gp++, base, myflags, lds, wreg);
+    self_phase<STAMPS>(a, layer, gp++, base, myflags, lds);
+    request_phase<2>(a, layer, wreg);
+    gemv_phase<STAMPS, 2>(a, layer, gp++, base, myflags, lds, wreg);
+    request_phase<3>(a, layer, wreg);
+    gemv_phase<STAMPS, 3>(a, layer, gp++, base, myflags, lds, wreg);
+    cross_phase<STAMPS>(a, layer, gp++, base, myflags, lds);
+    request_phase<5>(a, layer, wreg);
+    gemv_phase<STAMPS, 5>(a, layer, gp++, base, myflags, lds, wreg);
+    request_phase<6>(a, layer, wreg);
+    gemv_phase<STAMPS, 6>(a, layer, gp++, base, myflags, lds, wreg);
+    request_phase<7>(a, layer, wreg);
+    gemv_phase<STAMPS, 7>(a, layer, gp++, base, myflags, lds, wreg);
+    request_phase<0>(a, layer + 1, wreg);
   }
   if (blockIdx.x == 0 && threadIdx.x < 64) {  // everybody has read the epoch base long ago; publish the next launch's once every workgroup is through
     wide_wait(a, myflags, base + gp, threadIdx.x);
@@ -577,16 +616,9 @@ __global__ __launch_bounds__(WT) void decode_wide_kernel(WArgs a) {
 }  // namespace
 
 // ---- host side ----------------------------------------------------------------------------------------------------------------------
-#if DW_WT == 576
 size_t decode_wide_part_floats(int H) { return (size_t)H * WNS * 66; }
-#endif
 
-#if DW_WT == 576
-#define DW_NAME(x) x
-#else
-#define DW_NAME(x) x##_256
-#endif
-bool DW_NAME(decode_wide_supports)(int d, int H, int Te, int S_max, int L, int M, int nwg) {
+bool decode_wide_supports(int d, int H, int Te, int S_max, int L, int M, int nwg) {
   if (!(M == 1 && L >= 1 && L <= WMAXL && d % 64 == 0 && d == H * 64 && d <= WMAXD && H <= 32 && S_max >= 1 && S_max <= WNG * WSK && Te >= 1 &&
         (Te + WNS - 1) / WNS <= WNG * WCK && nwg >= 64 && nwg <= WMAXWG && nwg % 4 == 0 && H * WNS <= nwg))
     return false;
@@ -599,8 +631,8 @@ bool DW_NAME(decode_wide_supports)(int d, int H, int Te, int S_max, int L, int M
   return true;
 }
 
-int DW_NAME(launch_decode_wide)(const DecodeXcdArgs& h, hipStream_t s) {
-  OASR_REQUIRE(DW_NAME(decode_wide_supports)(h.d, h.H, h.Te, h.S_max, h.L, h.M, h.team), "decode_wide: unsupported shape");
+int launch_decode_wide(const DecodeXcdArgs& h, hipStream_t s) {
+  OASR_REQUIRE(decode_wide_supports(h.d, h.H, h.Te, h.S_max, h.L, h.M, h.team), "decode_wide: unsupported shape");
   OASR_REQUIRE(h.pos >= 0 && h.pos < h.S_max && h.layer_offsets, "decode_wide: bad launch shape");
   WArgs a;
   a.wflat = h.wflat, a.params = h.params, a.aux = h.aux, a.cache = h.cache, a.cache_lstride = h.cache_lstride;

@@ -1230,8 +1230,7 @@ static int oasr_decode_step_impl(oasr_ctx* c, const int64_t* tokens_last, int B,
       }
       xa.layer_offsets = c->xcd_offsets.data();
       xa.lstride = c->xcd_lstride, xa.astride = c->xcd_astride;
-      if (wide && (xa.flags & 0x40) && decode_wide_supports_256(d, c->H, c->Te, S_max, c->L_dec, B, nwg)) RC(launch_decode_wide_256(xa, st));
-      else if (wide) RC(launch_decode_wide(xa, st));
+      if (wide) RC(launch_decode_wide(xa, st));
       else RC(launch_decode_xcd(xa, st));
       return launch_decode_proj(x, B, d, c->template Wt<bf16_t>(c->tok_emb), c->V, c->P(c->dec_ln_w), c->P(c->dec_ln_b), nullptr, 0, nullptr, 0,
                                 nullptr, 0, logits_out, c->V, st);

@@ -184,9 +184,6 @@ size_t decode_xcd_part_floats(int M, int H, int Te);
 int launch_decode_wide(const DecodeXcdArgs& a, hipStream_t s);
 bool decode_wide_supports(int d, int H, int Te, int S_max, int L, int M, int nwg);
 size_t decode_wide_part_floats(int H);
-// (experiment: the same engine built with 256-thread workgroups)
-int launch_decode_wide_256(const DecodeXcdArgs& a, hipStream_t s);
-bool decode_wide_supports_256(int d, int H, int Te, int S_max, int L, int M, int nwg);
 
 // ---- elementwise / reductions -------------------------------------------------------------------------
 int launch_cast_f32_bf16(const float* src, bf16_t* dst, long n, hipStream_t s);

@@ -58,7 +58,7 @@ def main():
             for p_, r in enumerate(t):
                 nxt = t[p_ + 1][0] if p_ < 7 else None
                 if p_ == 1:
-                    print(f"     {names[p_]:10s} poll {r[1] - r[0]:6d}  q/K/V landed {r[3] - r[1]:6d}  scores+max {r[4] - r[3]:6d}  P.V {r[5] - r[4]:6d}  group sum {r[6] - r[5]:6d}  store {r[2] - r[6]:6d}  end {r[7] - r[2]:6d}"
+                    print(f"     {names[p_]:10s} poll {r[1] - r[0]:6d}  q/K/V landed {r[3] - r[1]:6d}  attend {r[6] - r[3]:6d}  store {r[2] - r[6]:6d}  end {r[7] - r[2]:6d}"
                           + (f"  | to next phase {nxt - r[7]:6d}  | phase total {nxt - r[0]:6d}" if nxt else ""))
                 elif p_ == 4:
                     print(f"     {names[p_]:10s} poll {r[1] - r[0]:6d}  rest {r[2] - r[1]:6d}  end {r[7] - r[2]:6d}" + (f"  | to next phase {nxt - r[7]:6d}  | phase total {nxt - r[0]:6d}" if nxt else ""))
