@@ -35,9 +35,13 @@ constexpr int WW = WT / 64;
 constexpr int WC = WW - 1;  // compute waves 1 .. WW-1; wave 0 is the helper: poll, operand row, epilogue, stores, flag -- it requests no weights, so nothing slow sits in front of its polls
 constexpr int WNG = WT / 8;  // 8-lane groups (attention: one key per group and step)
 constexpr int WMAXU = 64 / WC;  // units per compute wave and phase (64 units per workgroup at most)
-constexpr int WNS = 4;    // cross-attention key segments per head
+#ifndef DW_NS_LOG
+#define DW_NS_LOG 3
+#endif
+constexpr int WNS_LOG = DW_NS_LOG;
+constexpr int WNS = 1 << WNS_LOG;  // cross-attention key segments per head (one workgroup each)
 constexpr int WSK = (448 + WNG - 1) / WNG;  // self-attention keys per 8-lane group: S_max <= 448
-constexpr int WCK = (384 + WNG - 1) / WNG;  // cross-attention keys per group and segment: ceil(Te / 4) <= 384
+constexpr int WCK = (1536 / WNS + WNG - 1) / WNG;  // cross-attention keys per group and segment: Te <= 1536
 constexpr int WMAXD = 1280;
 constexpr int WLNC = 3;    // 16-byte chunks per lane of a LayerNorm row: d <= 1536
 constexpr int WMAXL = 32;
@@ -211,10 +215,12 @@ __device__ __forceinline__ void request_units(const WGemv& p, int wg, int wave, 
   const WUnits q = units_of(p, wg, wave);
   const bf16_t* row = p.w + (long)(wg * p.R + q.r0) * p.K;
   int j = q.j0;
+  const int cnt = q.U - q.u0 < q.upw ? q.U - q.u0 : q.upw;  // this wave's units
 #pragma unroll
   for (int i = 0; i < WMAXU; ++i) {
+    if (i >= cnt) break;  // (one branch out instead of a skipped body per remaining slot: a wave's instructions cost ~10 cycles each here)
     const int c = j * 64 + lane;
-    if (i < q.upw && q.u0 + i < q.U && c < q.KC) wreg[i] = __builtin_nontemporal_load((const u32x4_t*)(row + (long)c * 8));  // (else: never read)
+    if (c < q.KC) wreg[i] = __builtin_nontemporal_load((const u32x4_t*)(row + (long)c * 8));  // (else: never read)
     if (++j == q.J) j = 0, row += p.K;
   }
 }
@@ -387,7 +393,7 @@ __device__ __forceinline__ void cross_phase(const WArgs& a, int layer, unsigned 
   WAttLds& att = lds.att;
   const bf16_t* cross = a.cache + (long)layer * a.cache_lstride + (long)3 * a.S_max * a.d;
   if (wg < a.H * WNS) {
-    const int h = wg >> 2, sg = wg & 3;
+    const int h = wg >> WNS_LOG, sg = wg & (WNS - 1);
     const int SL = (a.Te + WNS - 1) / WNS;
     const int t0 = sg * SL;
     int n = a.Te - t0;
@@ -531,22 +537,22 @@ __device__ __forceinline__ void gemv_phase(const WArgs& a, int layer, unsigned g
         if (wg == a.swg && layer == 1 && tid == 64) a.stamps[ph * 8 + 5] = __builtin_amdgcn_s_memtime();
       }
       const WUnits q = units_of(p, wg, wave);
+      const int cnt = q.U - q.u0 < q.upw ? q.U - q.u0 : q.upw;
       float ps[WMAXU];
       int j = q.j0;
 #pragma unroll
       for (int i = 0; i < WMAXU; ++i) {
+        if (i >= cnt) break;
         const int c = j * 64 + lane;
-        ps[i] = 0.f;
-        if (i < q.upw && q.u0 + i < q.U && c < q.KC) ps[i] = dot8(wreg[i], *(const u32x4_t*)(xs + c * 8));
+        ps[i] = c < q.KC ? dot8(wreg[i], *(const u32x4_t*)(xs + c * 8)) : 0.f;
         if (++j == q.J) j = 0;
       }
       kill_units(wreg);
 #pragma unroll
       for (int i = 0; i < WMAXU; ++i) {
-        if (i < q.upw && q.u0 + i < q.U) {
-          const float sum = wsum(ps[i]);
-          if (lane == 0) psum[q.u0 + i] = sum;
-        }
+        if (i >= cnt) break;
+        const float sum = wsum(ps[i]);
+        if (lane == 0) psum[q.u0 + i] = sum;
       }
       if (STAMPS && wg == a.swg && layer == 1 && tid == 64) a.stamps[ph * 8 + 6] = __builtin_amdgcn_s_memtime();
     }
