@@ -331,7 +331,7 @@ __device__ __forceinline__ void attend(const float (&qv)[8], const u32x4_t (&k4)
 
 struct WLds {
   __attribute__((aligned(16))) unsigned short xs[4 * WMAXD];  // the operand row (bf16)
-  float psum[64];
+  __attribute__((aligned(32))) float rowsum[2][64 * WC];  // [phase parity][row of the workgroup's run][compute wave]
   WAttLds att;
 };
 // this workgroup's rows of the phase are stored (wave 0 has waited for the acknowledgements): publish -- lanes 0-7 of wave 0, one store
@@ -348,11 +348,8 @@ __device__ __forceinline__ void self_phase(const WArgs& a, int layer, unsigned g
   const bf16_t* self = a.cache + (long)layer * a.cache_lstride;
   if (wg < a.H) {
     const int h = wg, n = a.pos + 1;
-    WSTAMP(0);
-    if (wave == 0) wide_wait(a, myflags, target, lane);
-    __syncthreads();
-    WSTAMP(1);
-    const u32x4_t q4 = ld16_agent(self + (long)a.pos * 3 * a.d + h * 64 + l8 * 8);
+    // K / V rows of the positions before this one were written by earlier launches: requested before the poll (plain loads); row `pos` itself
+    // (written a phase ago by other workgroups) after it, with the query, through agent-scope loads
     const bf16_t* kb = self + a.d + h * 64;  // (uniform bases + one 32-bit offset per key: K and V rows share it)
     const bf16_t* vb = kb + a.d;
     u32x4_t k4[WSK], v4[WSK];
@@ -360,8 +357,22 @@ __device__ __forceinline__ void self_phase(const WArgs& a, int layer, unsigned g
     for (int u = 0; u < WSK; ++u) {
       fresh(k4[u]), fresh(v4[u]);
       const int t = grp + WNG * u;
-      if (WNG * u < n) {  // (wave-uniform; keys of this launch and of earlier ones alike: row pos was written a phase ago)
-        const unsigned off = (unsigned)(((t < n ? t : n - 1) * 3 * a.d + l8 * 8) * 2);
+      if (WNG * u < a.pos && t < a.pos) {
+        const size_t off = (size_t)(unsigned)((t * 3 * a.d + l8 * 8) * 2);
+        k4[u] = __builtin_nontemporal_load((const u32x4_t*)((const char*)kb + off));
+        v4[u] = __builtin_nontemporal_load((const u32x4_t*)((const char*)vb + off));
+      }
+    }
+    WSTAMP(0);
+    if (wave == 0) wide_wait(a, myflags, target, lane);
+    __syncthreads();
+    WSTAMP(1);
+    const u32x4_t q4 = ld16_agent(self + (long)a.pos * 3 * a.d + h * 64 + l8 * 8);
+#pragma unroll
+    for (int u = 0; u < WSK; ++u) {
+      const int t = grp + WNG * u;
+      if (WNG * u <= a.pos && a.pos < WNG * (u + 1) && t >= a.pos) {  // the step that holds row pos: its lanes at and past pos read that row (past: masked, finite)
+        const unsigned off = (unsigned)((a.pos * 3 * a.d + l8 * 8) * 2);
         k4[u] = ld16_agent_off(kb, off), v4[u] = ld16_agent_off(vb, off);
       }
     }
@@ -439,7 +450,9 @@ __device__ __forceinline__ void gemv_phase(const WArgs& a, int layer, unsigned g
   constexpr int ph = PH;
   WPHASE_PROLOGUE;
   unsigned short* xs = lds.xs;
-  float* psum = lds.psum;
+  // (two buffers by phase parity: the other waves zero the next phase's while wave 0 may still be reading this one's in its epilogue)
+  float* rowsum = lds.rowsum[gp & 1];
+  if (tid < 64 * WC) rowsum[tid] = 0.f;  // (before the workgroup barriers below)
   const WGemv p = gemv_of<PH>(a, layer);
   const int row0 = wg * p.R;
   if (row0 < p.N) {
@@ -537,23 +550,24 @@ __device__ __forceinline__ void gemv_phase(const WArgs& a, int layer, unsigned g
         if (wg == a.swg && layer == 1 && tid == 64) a.stamps[ph * 8 + 5] = __builtin_amdgcn_s_memtime();
       }
       const WUnits q = units_of(p, wg, wave);
+      // lane-wise partial products of consecutive spans of the SAME row are added up before the wave reduction: one reduction per (wave, row),
+      // its result in rowsum[row][wave] (zeroed at the top of the phase); the epilogue adds a row's WC slots in wave order
       const int cnt = q.U - q.u0 < q.upw ? q.U - q.u0 : q.upw;
-      float ps[WMAXU];
-      int j = q.j0;
+      float accl = 0.f;
+      int j = q.j0, r = q.r0;
 #pragma unroll
       for (int i = 0; i < WMAXU; ++i) {
         if (i >= cnt) break;
         const int c = j * 64 + lane;
-        ps[i] = c < q.KC ? dot8(wreg[i], *(const u32x4_t*)(xs + c * 8)) : 0.f;
-        if (++j == q.J) j = 0;
+        if (c < q.KC) accl += dot8(wreg[i], *(const u32x4_t*)(xs + c * 8));
+        ++j;
+        if (j == q.J || i == cnt - 1) {
+          const float sum = wsum(accl);
+          if (lane == 0) rowsum[r * WC + (wave - 1)] = sum;
+          accl = 0.f, j = 0, ++r;
+        }
       }
       kill_units(wreg);
-#pragma unroll
-      for (int i = 0; i < WMAXU; ++i) {
-        if (i >= cnt) break;
-        const float sum = wsum(ps[i]);
-        if (lane == 0) psum[q.u0 + i] = sum;
-      }
       if (STAMPS && wg == a.swg && layer == 1 && tid == 64) a.stamps[ph * 8 + 6] = __builtin_amdgcn_s_memtime();
     }
     __syncthreads();
@@ -562,7 +576,8 @@ __device__ __forceinline__ void gemv_phase(const WArgs& a, int layer, unsigned g
       float y = 0.f;
       if (lane < rows) {
         float acc = 0.f;
-        for (int jj = 0; jj < J; ++jj) acc += psum[lane * J + jj];
+#pragma unroll
+      for (int w = 0; w < WC; ++w) acc += rowsum[lane * WC + w];
         y = dec::epi_value(acc, bias_v, WPh<PH>::GELU, WPh<PH>::RESID, resid_v);
       }
       const float nb = dec::xor_lane<1>(y);
