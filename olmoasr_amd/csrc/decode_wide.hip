@@ -104,34 +104,6 @@ __device__ __forceinline__ float wmaxf(float v) {
   v = fmaxf(v, dpp_mov<0x140>(v));
   return fmaxf(fmaxf(rdl(v, 0), rdl(v, 16)), fmaxf(rdl(v, 32), rdl(v, 48)));
 }
-// mean and 1 / sqrt(var + eps) of one row held as chunks raw[c] = elements (lane + 64 c) * 8 .. + 7 (two passes, as ln_fwd_kernel)
-__device__ __forceinline__ void row_stats_w(const u32x4_t (&raw)[dec::MAXC], int lane, int nchunk, int d, float& mean_out, float& rstd_out) {
-  float s = 0.f;
-#pragma unroll
-  for (int c = 0; c < dec::MAXC; ++c)
-    if (lane + 64 * c < nchunk) {
-      float v[8];
-      dec::unpack8(raw[c], v);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) s += v[i];
-    }
-  const float mean = wsum(s) / (float)d;
-  float q = 0.f;
-#pragma unroll
-  for (int c = 0; c < dec::MAXC; ++c)
-    if (lane + 64 * c < nchunk) {
-      float v[8];
-      dec::unpack8(raw[c], v);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float t = v[i] - mean;
-        q += t * t;
-      }
-    }
-  mean_out = mean;
-  rstd_out = rsqrtf(wsum(q) / (float)d + 1e-5f);
-}
-
 // wave 0: every workgroup has completed phase `target` (or the wait gave up and poisoned the launch)
 __device__ __forceinline__ void wide_wait(const WArgs& a, const unsigned* myflags, unsigned target, int lane) {
   unsigned spins = 0;
@@ -460,7 +432,8 @@ __device__ __forceinline__ void gemv_phase(const WArgs& a, int layer, unsigned g
     int rows = p.N - row0;
     rows = rows > p.R ? p.R : rows;
     const int U = rows * J;
-    const WUnits q = units_of(p, wg, wave > 0 ? wave : 1);  // (before the poll: off the path from the flags to the stores)
+    WUnits q = {};  // (before the poll: off the path from the flags to the stores; the helper wave has no units)
+  if (wave > 0) q = units_of(p, wg, wave);
   // wave 0: what the epilogue needs besides the sums (requested before the poll: the residual row is two phases old)
     float bias_v = 0.f, resid_v = 0.f;
     if (wave == 0 && lane < rows) {
@@ -490,18 +463,30 @@ __device__ __forceinline__ void gemv_phase(const WArgs& a, int layer, unsigned g
     WSTAMP(1);
     // ---- operand row -> LDS ----
     if constexpr (WPh<PH>::MERGE) {  // merged cross-attention output: wave w merges heads w, w + 8, ...; lane = dimension; (m, l) of segment s come in through lane s
+      // (two heads per pass: both heads' partials are requested before either is merged -- one round trip for H <= 2 WW)
 #pragma unroll 1
-      for (int h = wave; h < a.H; h += WW) {
-        const float* src = a.part + (long)h * (WNS * 66);
+      for (int h0 = wave; h0 < a.H; h0 += 2 * WW) {
         const int sl = lane < WNS ? lane : WNS - 1;
-        const float mv = ldf_agent(src + sl * 66), lv = ldf_agent(src + sl * 66 + 1);
-        float m_s[WNS], l_s[WNS], o_s[WNS];
+        float mv[2], lv[2], o_s[2][WNS];
 #pragma unroll
-        for (int sg = 0; sg < WNS; ++sg) o_s[sg] = ldf_agent(src + sg * 66 + 2 + lane);
+        for (int k = 0; k < 2; ++k) {
+          const int h = h0 + WW * k < a.H ? h0 + WW * k : h0;
+          const float* src = a.part + (long)h * (WNS * 66);
+          mv[k] = ldf_agent(src + sl * 66), lv[k] = ldf_agent(src + sl * 66 + 1);
 #pragma unroll
-        for (int sg = 0; sg < WNS; ++sg) m_s[sg] = rdlane(mv, sg), l_s[sg] = rdlane(lv, sg);
-        const float val = merge_w(m_s, l_s, o_s), nb = dec::xor_lane<1>(val);
-        if ((lane & 1) == 0) *(uint32_t*)(xs + h * 64 + lane) = pack_bf2(val, nb);
+          for (int sg = 0; sg < WNS; ++sg) o_s[k][sg] = ldf_agent(src + sg * 66 + 2 + lane);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int h = h0 + WW * k;
+          if (h < a.H) {
+            float m_s[WNS], l_s[WNS];
+#pragma unroll
+            for (int sg = 0; sg < WNS; ++sg) m_s[sg] = rdlane(mv[k], sg), l_s[sg] = rdlane(lv[k], sg);
+            const float val = merge_w(m_s, l_s, o_s[k]), nb = dec::xor_lane<1>(val);
+            if ((lane & 1) == 0) *(uint32_t*)(xs + h * 64 + lane) = pack_bf2(val, nb);
+          }
+        }
       }
     } else if constexpr (WPh<PH>::LN) {  // LayerNorm folded into the operand (K = d): wave 0
       if (wave == 0) {
@@ -511,21 +496,38 @@ __device__ __forceinline__ void gemv_phase(const WArgs& a, int layer, unsigned g
           fresh(raw[c]);
           if (c < WLNC && lane + 64 * c < KC) raw[c] = ld16_agent(p.xin + (lane + 64 * c) * 8);
         }
-        float mean, rstd;
-        row_stats_w(raw, lane, KC, p.K, mean, rstd);
+        // (values unpacked ONCE and centred once: the statistics and the normalisation share v - mean; two passes as ln_fwd_kernel)
+        float v[WLNC][8], sum = 0.f;
 #pragma unroll
         for (int c = 0; c < WLNC; ++c)
           if (lane + 64 * c < KC) {
-            float v[8];
-            dec::unpack8(raw[c], v);
+            dec::unpack8(raw[c], v[c]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sum += v[c][i];
+          }
+        const float mean = wsum(sum) / (float)p.K;
+        float sq = 0.f;
+#pragma unroll
+        for (int c = 0; c < WLNC; ++c)
+          if (lane + 64 * c < KC) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              v[c][i] -= mean;
+              sq += v[c][i] * v[c][i];
+            }
+          }
+        const float rstd = rsqrtf(wsum(sq) / (float)p.K + 1e-5f);
+#pragma unroll
+        for (int c = 0; c < WLNC; ++c)
+          if (lane + 64 * c < KC) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {  // (dec::ln_apply8's expression)
-              v[i] = (v[i] - mean) * rstd * lg[c][0][i] + lb[c][0][i];
-              v[4 + i] = (v[4 + i] - mean) * rstd * lg[c][1][i] + lb[c][1][i];
+              v[c][i] = v[c][i] * rstd * lg[c][0][i] + lb[c][0][i];
+              v[c][4 + i] = v[c][4 + i] * rstd * lg[c][1][i] + lb[c][1][i];
             }
             u32x4_t o4;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o4[i] = pack_bf2(v[2 * i], v[2 * i + 1]);
+            for (int i = 0; i < 4; ++i) o4[i] = pack_bf2(v[c][2 * i], v[c][2 * i + 1]);
             *(u32x4_t*)(xs + (lane + 64 * c) * 8) = o4;
           }
       }
