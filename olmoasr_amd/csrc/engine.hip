@@ -1194,10 +1194,23 @@ static int oasr_decode_step_impl(oasr_ctx* c, const int64_t* tokens_last, int B,
     folded = d % 64 == 0 && d <= 2048 && g_decode_ln_fold != 0 && (B <= 4 || (g_decode_ln_fold == 1 && B <= 32));
     // one launch for the whole decoder stack (decode_xcd.hip): the default for a handful of sequences
     const int mode = g_decode_ln_fold;
-    // (default: ONE sequence -- the timestamp-mode transcribe loop; measured 1.75 vs 2.44 ms per token at medium, 0.85 vs 0.94 at small; at small B = 4
-    // the multi-launch kernels, which spread over the whole chip, win: profiles/r05_decode_xcd_probe_v8.txt.  Modes 2-4 force it up to B = 4.)
-    if (((mode == -1 && B == 1) || mode >= 2) && !c->xcd_disabled && !c->xcd_offsets.empty() && decode_xcd_supports(d, c->H, c->Te, S_max, c->L_dec, B) &&
-        decode_xcd_offsets_ok(c->xcd_offsets.data(), c->xcd_lstride, (long)3 * B * S_max * d + (long)B * c->Te * 2 * d, d, c->Te, c->L_dec, B)) {
+    // (default: ONE sequence -- the timestamp-mode transcribe loop -- on the chip-wide one-launch engine, decode_wide.hip: 0.74 ms per token at medium
+    // against 1.76 for the one-XCD team of decode_xcd.hip and 2.44 multi-launch, profiles/r06_decode_wide.txt; at small B = 4 the multi-launch
+    // kernels, which spread over the whole chip, win: profiles/r05_decode_xcd_probe_v8.txt.  Mode 5 forces the chip-wide engine, modes 2-4 the
+    // team engine up to B = 4.)
+    if (c->n_cu == 0) {
+      int dev = 0, n = 0;
+      OASR_CHECK_HIP(hipGetDevice(&dev));
+      OASR_CHECK_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+      c->n_cu = n > 0 ? n : -1;
+    }
+    const int nwg = c->n_cu >= 256 ? 256 : (c->n_cu > 0 ? c->n_cu & ~3 : 0);
+    const bool wide = (mode == -1 || mode == 5) && B == 1 && !c->xcd_disabled && !c->xcd_offsets.empty() &&
+                      decode_wide_supports(d, c->H, c->Te, S_max, c->L_dec, B, nwg);
+    const bool team = !wide && ((mode == -1 && B == 1) || mode >= 2) && !c->xcd_disabled && !c->xcd_offsets.empty() &&
+                      decode_xcd_supports(d, c->H, c->Te, S_max, c->L_dec, B) &&
+                      decode_xcd_offsets_ok(c->xcd_offsets.data(), c->xcd_lstride, (long)3 * B * S_max * d + (long)B * c->Te * 2 * d, d, c->Te, c->L_dec, B);
+    if (wide || team) {
       DecodeXcdArgs xa;
       xa.wflat = c->template Wt<bf16_t>(0);
       xa.params = c->params;
@@ -1210,15 +1223,6 @@ static int oasr_decode_step_impl(oasr_ctx* c, const int64_t* tokens_last, int B,
       xa.d = d, xa.H = c->H, xa.Te = c->Te, xa.S_max = S_max, xa.L = c->L_dec, xa.M = B, xa.pos = pos;
       xa.team = mode == 4 ? 64 : 32;
       xa.stride = (mode == 3 || mode == 4) ? 1 : 8;
-      // ONE sequence: the chip-wide engine (decode_wide.hip: every CU, a few weight rows each; mode 5 forces it, mode 2 the one-XCD team)
-      if (c->n_cu == 0) {
-        int dev = 0, n = 0;
-        OASR_CHECK_HIP(hipGetDevice(&dev));
-        OASR_CHECK_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
-        c->n_cu = n > 0 ? n : -1;
-      }
-      const int nwg = c->n_cu >= 256 ? 256 : (c->n_cu > 0 ? c->n_cu & ~3 : 0);
-      const bool wide = (mode == -1 || mode == 5) && B == 1 && decode_wide_supports(d, c->H, c->Te, S_max, c->L_dec, B, nwg);
       if (wide) xa.team = nwg, xa.stride = 1, xa.part = A.f32(decode_wide_part_floats(c->H));
       {  // measurement hooks (scripts/decode_xcd_probe.py; inert without OASR_TESTING_HOOKS=1): experiment flags, in-kernel stamps in the workspace tail
         static const int xflags = [] {

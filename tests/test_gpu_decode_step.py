@@ -37,7 +37,7 @@ def _steps(net, xa, toks, mode):
 
 
 @pytest.mark.parametrize("width,heads,layers,B,inference", [(384, 6, 4, 2, True), (384, 6, 2, 7, False), (768, 12, 2, 16, True),
-                                                            (512, 8, 3, 32, True), (1024, 16, 1, 1, False), (768, 12, 2, 1, True), (512, 8, 3, 3, True),
+                                                            (512, 8, 3, 32, True), (1024, 16, 1, 1, False), (768, 12, 2, 1, True), (384, 6, 3, 1, True), (1280, 20, 1, 1, True), (512, 8, 3, 3, True),
                                                             (1024, 16, 2, 4, False), (1280, 20, 1, 2, True)])
 def test_step_engines_are_bit_identical(tiny_case, width, heads, layers, B, inference):
     """Same rounding points, same skinny-GEMM accumulation scheme: the two placements must agree to the last bit on every
