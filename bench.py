@@ -327,9 +327,9 @@ def hbm_kernel_rooflines(net, dims, mb, dev):
     dbytes = 2 * (L_dec * 14 * d * d + V * d) + 2 * L_dec * (dims.n_audio_ctx * 2 * d + S_pos * 2 * d) + 4 * V
     line("decode_step(B=1)", timed(dstep, reps=20), dbytes,
          f"one KV-cached decoder step of this model at position {S_pos}: bf16 decoder weights + tied logits matrix once, cross K/V [{dims.n_audio_ctx}, {2 * d}] x {L_dec} layers, self K/V so far; "
-         f"round 5: ONE persistent launch for the decoder stack (csrc/decode_xcd.hip: a team of 32 CUs, weights / cross K/V prefetched through wave-private LDS rings, "
-         f"{8 * L_dec} team barriers) + embedding + logits launches; issue-bound at ~1.1 k cycles per 4 KB ring block (profiles/r05_decode_xcd_stamps_v8.txt, r05_decode_xcd_stamps_v5_issue_bound.txt); "
-         f"the multi-launch step it replaces: ~{8 * L_dec + 2} dependent launches")
+         f"round 6: ONE persistent launch for the decoder stack on every CU (csrc/decode_wide.hip: a few weight rows per workgroup, fp32 FMA dot products, "
+         f"{8 * L_dec} exchanges through per-workgroup phase flags) + embedding + logits launches; bound by the helper wave's dependent-instruction chain per phase "
+         f"(~3-4 us against ~1.3 us of memory round trips, profiles/r06_decode_wide.txt); round 5's one-XCD team (csrc/decode_xcd.hip) measured 0.066-0.069, the multi-launch step 0.049")
     del state, xa
     n = net.flat_params.numel()
     # (step count irrelevant for the timing; gradients are whatever the last step left, state is restored by nobody: run last)
