@@ -138,6 +138,10 @@ template <int PH>
 struct WPh {  // what projection phase PH is, at compile time
   static constexpr bool LN = PH == 0 || PH == 3 || PH == 6, MERGE = PH == 5, GELU = PH == 6, RESID = PH == 2 || PH == 5 || PH == 7;
   static constexpr int NEXT = PH == 7 ? 0 : PH + 1;  // the phase after it
+  // parity of the projection's index in the layer's six (0, 2, 3, 5, 6, 7): consecutive projections use different LDS hand-over buffers (the
+  // compute waves run ahead into the next projection -- through an attention phase without a workgroup barrier -- while the helper wave still
+  // reads the current one's in its epilogue)
+  static constexpr int PAR = (PH == 2 || PH == 5 || PH == 7) ? 1 : 0;
 };
 template <int PH>
 __device__ __forceinline__ WGemv gemv_of(const WArgs& a, int layer) {
@@ -196,6 +200,13 @@ __device__ __forceinline__ void request_units(const WGemv& p, int wg, int wave, 
     if (++j == q.J) j = 0, row += p.K;
   }
 }
+// What the compute waves fetch for the helper wave along with a phase's weights: the LayerNorm parameters of the operand row and the bias of the
+// workgroup's rows.  They go through LDS at the top of the phase.  The helper wave itself has NO load in flight when it starts to poll: loads
+// return in order, so a parameter row that misses to HBM in front of the poll would hold the poll's answer back by its latency.
+struct WStage {
+  f32x4_t g, b;  // elements 4 i .. 4 i + 3 of gamma / beta, i = tid - 64
+  float bias;    // row i of the workgroup's run
+};
 // a FRESH (undefined) value: registers that are assigned under a condition inside the layer loop would otherwise carry their previous contents
 // around the loop as far as the register allocator can tell (measured: the two attention phases' K / V rows were live at the same time)
 template <typename V>
@@ -304,6 +315,8 @@ __device__ __forceinline__ void attend(const float (&qv)[8], const u32x4_t (&k4)
 struct WLds {
   __attribute__((aligned(16))) unsigned short xs[4 * WMAXD];  // the operand row (bf16)
   __attribute__((aligned(32))) float rowsum[2][64 * WC];  // [phase parity][row of the workgroup's run][compute wave]
+  float lng[WMAXD], lnb[WMAXD];  // LayerNorm parameters of the current phase's operand row
+  float biasv[2][64];            // [phase parity] bias of the workgroup's rows
   WAttLds att;
 };
 // this workgroup's rows of the phase are stored (wave 0 has waited for the acknowledgements): publish -- lanes 0-7 of wave 0, one store
@@ -418,12 +431,13 @@ __device__ __forceinline__ void cross_phase(const WArgs& a, int layer, unsigned 
 
 // ---------------- projection PH: rows wg R .. wg R + R - 1 ----------------
 template <bool STAMPS, int PH>
-__device__ __forceinline__ void gemv_phase(const WArgs& a, int layer, unsigned gp, unsigned base, const unsigned* myflags, WLds& lds, u32x4_t (&wreg)[WMAXU]) {
+__device__ __forceinline__ void gemv_phase(const WArgs& a, int layer, unsigned gp, unsigned base, const unsigned* myflags, WLds& lds, u32x4_t (&wreg)[WMAXU],
+                                           const WStage& st) {
   constexpr int ph = PH;
   WPHASE_PROLOGUE;
   unsigned short* xs = lds.xs;
-  // (two buffers by phase parity: the other waves zero the next phase's while wave 0 may still be reading this one's in its epilogue)
-  float* rowsum = lds.rowsum[gp & 1];
+  // (two buffers, WPh::PAR: the other waves zero the next projection's while wave 0 may still be reading this one's in its epilogue)
+  float* rowsum = lds.rowsum[WPh<PH>::PAR];
   if (tid < 64 * WC) rowsum[tid] = 0.f;  // (before the workgroup barriers below)
   const WGemv p = gemv_of<PH>(a, layer);
   const int row0 = wg * p.R;
@@ -434,33 +448,19 @@ __device__ __forceinline__ void gemv_phase(const WArgs& a, int layer, unsigned g
     const int U = rows * J;
     WUnits q = {};  // (before the poll: off the path from the flags to the stores; the helper wave has no units)
   if (wave > 0) q = units_of(p, wg, wave);
-  // wave 0: what the epilogue needs besides the sums (requested before the poll: the residual row is two phases old)
-    float bias_v = 0.f, resid_v = 0.f;
-    if (wave == 0 && lane < rows) {
-      const int nn = row0 + lane;
-      if (p.bias) bias_v = p.bias[nn];
-      if constexpr (WPh<PH>::RESID) {
-        const unsigned rz = ld4_agent(p.resid + (nn & ~1));
-        resid_v = (nn & 1) ? bf_hi(rz) : bf_lo(rz);
-      }
-    }
-    // ... and the LayerNorm parameters of the chunks this lane will normalise (static data, 2 x 32 bytes per chunk)
-    f32x4_t lg[WLNC][2], lb[WLNC][2];
-#pragma unroll
-    for (int c = 0; c < WLNC; ++c) fresh(lg[c][0]), fresh(lg[c][1]), fresh(lb[c][0]), fresh(lb[c][1]);
-    if (WPh<PH>::LN && wave == 0) {
-#pragma unroll
-      for (int c = 0; c < WLNC; ++c)
-        if (lane + 64 * c < KC) {
-          const int k = (lane + 64 * c) * 8;
-          lg[c][0] = *(const f32x4_t*)(p.ln_g + k), lg[c][1] = *(const f32x4_t*)(p.ln_g + k + 4);
-          lb[c][0] = *(const f32x4_t*)(p.ln_b + k), lb[c][1] = *(const f32x4_t*)(p.ln_b + k + 4);
-        }
+    // the compute waves hand over what they fetched for the helper wave (request_phase)
+    float* biasv = lds.biasv[WPh<PH>::PAR];
+    if (tid >= 64) {
+      const int i = tid - 64;
+      if (WPh<PH>::LN && 4 * i < p.K) *(f32x4_t*)&lds.lng[4 * i] = st.g, *(f32x4_t*)&lds.lnb[4 * i] = st.b;
+      if (i < rows) biasv[i] = st.bias;
     }
     WSTAMP(0);
     if (wave == 0 && (PH != 0 || gp > 0)) wide_wait(a, myflags, target, lane);
     __syncthreads();
     WSTAMP(1);
+    float resid_v = 0.f;  // (the residual row is two phases old; needed by the epilogue only, so requested behind the operand row's loads)
+    unsigned resid_z = 0u;
     // ---- operand row -> LDS ----
     if constexpr (WPh<PH>::MERGE) {  // merged cross-attention output: wave w merges heads w, w + 8, ...; lane = dimension; (m, l) of segment s come in through lane s
       // (two heads per pass: both heads' partials are requested before either is merged -- one round trip for H <= 2 WW)
@@ -520,10 +520,13 @@ __device__ __forceinline__ void gemv_phase(const WArgs& a, int layer, unsigned g
 #pragma unroll
         for (int c = 0; c < WLNC; ++c)
           if (lane + 64 * c < KC) {
+            const int k = (lane + 64 * c) * 8;
+            const f32x4_t g0 = *(const f32x4_t*)&lds.lng[k], g1 = *(const f32x4_t*)&lds.lng[k + 4];
+            const f32x4_t b0 = *(const f32x4_t*)&lds.lnb[k], b1 = *(const f32x4_t*)&lds.lnb[k + 4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {  // (dec::ln_apply8's expression)
-              v[c][i] = v[c][i] * rstd * lg[c][0][i] + lb[c][0][i];
-              v[c][4 + i] = v[c][4 + i] * rstd * lg[c][1][i] + lb[c][1][i];
+              v[c][i] = v[c][i] * rstd * g0[i] + b0[i];
+              v[c][4 + i] = v[c][4 + i] * rstd * g1[i] + b1[i];
             }
             u32x4_t o4;
 #pragma unroll
@@ -543,6 +546,7 @@ __device__ __forceinline__ void gemv_phase(const WArgs& a, int layer, unsigned g
       for (int c = 0; c < NC; ++c)
         if (tid + WT * c < KC) *(u32x4_t*)(xs + (tid + WT * c) * 8) = raw[c];
     }
+    if (WPh<PH>::RESID && wave == 0 && lane < rows) resid_z = ld4_agent(p.resid + ((row0 + lane) & ~1));
     __syncthreads();
     WSTAMP(2);
     // ---- this wave's units ----
@@ -580,7 +584,8 @@ __device__ __forceinline__ void gemv_phase(const WArgs& a, int layer, unsigned g
         float acc = 0.f;
 #pragma unroll
       for (int w = 0; w < WC; ++w) acc += rowsum[lane * WC + w];
-        y = dec::epi_value(acc, bias_v, WPh<PH>::GELU, WPh<PH>::RESID, resid_v);
+        resid_v = ((row0 + lane) & 1) ? bf_hi(resid_z) : bf_lo(resid_z);
+      y = dec::epi_value(acc, biasv[lane], WPh<PH>::GELU, WPh<PH>::RESID, resid_v);
       }
       const float nb = dec::xor_lane<1>(y);
       if (lane < rows && (lane & 1) == 0) st4_agent(p.out + row0 + lane, pack_bf2(y, nb));
@@ -593,11 +598,19 @@ __device__ __forceinline__ void gemv_phase(const WArgs& a, int layer, unsigned g
 }
 // the weights of projection PH into this wave's registers
 template <int PH>
-__device__ __forceinline__ void request_phase(const WArgs& a, int layer, u32x4_t (&wreg)[WMAXU]) {
+__device__ __forceinline__ void request_phase(const WArgs& a, int layer, u32x4_t (&wreg)[WMAXU], WStage& st) {
   int tid = threadIdx.x, wg = blockIdx.x;
   asm volatile("" : "+v"(tid), "+s"(wg));
   kill_units(wreg);
-  if (layer < a.L) request_units(gemv_of<PH>(a, layer), wg, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63, wreg);
+  fresh(st.g), fresh(st.b), fresh(st.bias);
+  if (layer >= a.L) return;
+  const WGemv p = gemv_of<PH>(a, layer);
+  request_units(p, wg, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63, wreg);
+  const int i = tid - 64;
+  if (i >= 0) {
+    if (WPh<PH>::LN && 4 * i < p.K) st.g = *(const f32x4_t*)(p.ln_g + 4 * i), st.b = *(const f32x4_t*)(p.ln_b + 4 * i);
+    if (i < p.R && wg * p.R + i < p.N) st.bias = p.bias[wg * p.R + i];
+  }
 }
 
 template <bool STAMPS>  // STAMPS: the measurement instantiation (scripts/decode_xcd_probe.py); its stores cost waits of their own
@@ -609,26 +622,27 @@ __global__ __launch_bounds__(WT) void decode_wide_kernel(WArgs a) {
   const unsigned* myflags = a.flagv + (size_t)(xcc & (WREP - 1)) * WFS;
   if (threadIdx.x == 0) __hip_atomic_fetch_or(a.ctrl + 3, 1u << (xcc & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   u32x4_t wreg[WMAXU];
-  request_phase<0>(a, 0, wreg);
+  WStage st;
+  request_phase<0>(a, 0, wreg, st);
   unsigned gp = 0;  // phases before the current one
   // A phase's weights are requested at the end of the phase before it: in flight through the exchange.  (Not across an attention phase: with
   // the attention's K / V rows the registers of weights would not fit, and the compiler would park them in scratch = wait for them on the spot.)
 #pragma unroll 1
   for (int layer = 0; layer < a.L; ++layer) {
-    gemv_phase<STAMPS, 0>(a, layer, gp++, base, myflags, lds, wreg);
+    gemv_phase<STAMPS, 0>(a, layer, gp++, base, myflags, lds, wreg, st);
     self_phase<STAMPS>(a, layer, gp++, base, myflags, lds);
-    request_phase<2>(a, layer, wreg);
-    gemv_phase<STAMPS, 2>(a, layer, gp++, base, myflags, lds, wreg);
-    request_phase<3>(a, layer, wreg);
-    gemv_phase<STAMPS, 3>(a, layer, gp++, base, myflags, lds, wreg);
+    request_phase<2>(a, layer, wreg, st);
+    gemv_phase<STAMPS, 2>(a, layer, gp++, base, myflags, lds, wreg, st);
+    request_phase<3>(a, layer, wreg, st);
+    gemv_phase<STAMPS, 3>(a, layer, gp++, base, myflags, lds, wreg, st);
     cross_phase<STAMPS>(a, layer, gp++, base, myflags, lds);
-    request_phase<5>(a, layer, wreg);
-    gemv_phase<STAMPS, 5>(a, layer, gp++, base, myflags, lds, wreg);
-    request_phase<6>(a, layer, wreg);
-    gemv_phase<STAMPS, 6>(a, layer, gp++, base, myflags, lds, wreg);
-    request_phase<7>(a, layer, wreg);
-    gemv_phase<STAMPS, 7>(a, layer, gp++, base, myflags, lds, wreg);
-    request_phase<0>(a, layer + 1, wreg);
+    request_phase<5>(a, layer, wreg, st);
+    gemv_phase<STAMPS, 5>(a, layer, gp++, base, myflags, lds, wreg, st);
+    request_phase<6>(a, layer, wreg, st);
+    gemv_phase<STAMPS, 6>(a, layer, gp++, base, myflags, lds, wreg, st);
+    request_phase<7>(a, layer, wreg, st);
+    gemv_phase<STAMPS, 7>(a, layer, gp++, base, myflags, lds, wreg, st);
+    request_phase<0>(a, layer + 1, wreg, st);
   }
   if (blockIdx.x == 0 && threadIdx.x < 64) {  // everybody has read the epoch base long ago; publish the next launch's once every workgroup is through
     wide_wait(a, myflags, base + gp, threadIdx.x);
