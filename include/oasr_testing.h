@@ -19,10 +19,11 @@ int oasr_profile_gemm(int enable);
 /* experiments on the 256x256 kernel.  v < 0: defaults.  bits 0-3: schedule variant (8 = per-layout default); bits 4-5: 1 = plain
  * launches, 2 = persistent launches (next tile's prologue ahead of the epilogue); bit 6 / 7: non-temporal epilogue stores / side loads */
 int oasr_gemm_set_variant(int v);
-/* tests / A-B of the KV-cached step engine: -1 = default (ONE sequence on the bf16 engine: the ONE-launch engine of
- * csrc/decode_xcd.hip on the 32 CUs of one XCD; 2-4: LayerNorm folded into the projections; more: separate kernels), 0 = separate LayerNorm kernels, 1 = LayerNorm folded into the
- * projections' operand loads for every B <= 32, 2 = one launch on one XCD, 3 / 4 = one launch with 32 / 64 workgroups spread over the
- * chip.  All bit-identical (tests/test_gpu_decode_step.py). */
+/* tests / A-B of the KV-cached step engine: -1 = default (ONE sequence on the bf16 engine: the chip-wide one-launch engine of
+ * csrc/decode_wide.hip; 2-4: LayerNorm folded into the projections; more: separate kernels), 0 = separate LayerNorm kernels, 1 = LayerNorm
+ * folded into the projections' operand loads for every B <= 32, 2 = the one-launch TEAM engine of csrc/decode_xcd.hip on the 32 CUs of one
+ * XCD (B <= 4), 3 / 4 = that team as 32 / 64 workgroups spread over the chip, 5 = the chip-wide engine (one sequence; more: as 2).
+ * 0-4 are bit-identical; 5 agrees with them to the fp32 rounding of differently ordered K sums (tests/test_gpu_decode_step.py). */
 int oasr_decode_set_ln_fold(int mode);
 /* tests / A-B: side streams of the supervised-span step (oasr_train_fwd_bwd_span; csrc/engine.hip: Runner::side_mode).  Bit 0: the decoder
  * backward's weight gradients over the R active rows, bit 2: the cross-attention key|value weight gradient and d(xa) -- run on lowest-priority

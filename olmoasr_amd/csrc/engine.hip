@@ -1093,10 +1093,11 @@ unsigned* kv_ctrl(const oasr_ctx* c, void* cache, int B) {  // the control tail 
   const size_t per_layer = ((size_t)3 * B * c->S_max * c->d + (size_t)B * c->Te * 2 * c->d) * (c->f32 ? 4 : 2);
   return (unsigned*)((char*)cache + per_layer * c->L_dec);
 }
-// A/B and test switch of the step engine: -1 = default (ONE sequence on the bf16 engine: the one-launch engine of decode_xcd.hip, team = the 32
-// CUs of one XCD; 2-4 sequences: LayerNorm folded into the projections; more: separate kernels), 0 = separate LayerNorm kernels, 1 = LayerNorm folded into the projections' operand
-// loads (the round-2/3 default for B <= 4) for every B <= 32, 2 = one launch on one XCD, 3 = one launch, 32 workgroups spread over the
-// chip, 4 = the same with 64.  All bit-identical (tests/test_gpu_decode_step.py).
+// A/B and test switch of the step engine: -1 = default (ONE sequence on the bf16 engine: the chip-wide one-launch engine of decode_wide.hip; 2-4
+// sequences: LayerNorm folded into the projections; more: separate kernels), 0 = separate LayerNorm kernels, 1 = LayerNorm folded into the projections'
+// operand loads (the round-2/3 default for B <= 4) for every B <= 32, 2 = the one-launch team engine of decode_xcd.hip on one XCD, 3 = that team as 32
+// workgroups spread over the chip, 4 = the same with 64, 5 = the chip-wide engine.  0-4 bit-identical, 5 within fp32 summation-order rounding
+// (tests/test_gpu_decode_step.py).
 int g_decode_ln_fold = -1;
 }  // namespace
 // Side streams of the supervised-span step (Runner::side_mode): the setter is a testing hook, OASR_SIDE_STREAMS an experiment switch
