@@ -1,5 +1,6 @@
 // One-launch KV-cached decoder step for a handful of sequences (B <= 4) on ONE XCD, gfx950 (round 5; since round 6 the default for one sequence is
-// the chip-wide engine of decode_wide.hip, and this team engine runs where it is forced -- oasr_decode_set_ln_fold(2..4) -- or where that one does not apply) -- TextDecoder.forward for one new token per sequence, olmoasr/model.py:786-817 with the kv_cache hooks of :925-964
+// the chip-wide engine of decode_wide.hip, and this team engine runs where it is forced -- oasr_decode_set_ln_fold(2..4) -- or where that one does not apply)
+// -- TextDecoder.forward for one new token per sequence, olmoasr/model.py:786-817 with the kv_cache hooks of :925-964
 // (inference twin: olmoasr/inf_model.py:150-196, 320-362).
 //
 // Why: the multi-launch step (engine.hip::oasr_decode_step_impl) is ~8 dependent launches per layer, each a 4.7 us dispatch floor plus a
