@@ -67,6 +67,10 @@ struct WArgs {
   unsigned* flagv;  // [WREP][WFS]: replica r (polled by the workgroups on XCC r) of the per-workgroup flags = last completed phase (epoch-based)
   int d, H, Te, S_max, L, pos, nwg, flags, swg;
   unsigned long long* stamps;
+  const bf16_t* w_logits;  // the launch's last phase: logits = tok_emb . LayerNorm(x) (null logits_out: left to the caller)
+  const float *lnf_g, *lnf_b;
+  float* logits_out;
+  int V;
   WLayer l0;
   long lstride, astride;
 };
@@ -596,6 +600,122 @@ __device__ __forceinline__ void gemv_phase(const WArgs& a, int layer, unsigned g
   WPUBLISH();
   WSTAMP(7);
 }
+// ---------------- the last phase: final LayerNorm + tied logits projection (TextDecoder.forward, olmoasr/model.py:812-817) ----------------
+// V rows of d bf16 weights (106 MB at medium) dealt out in runs of ceil(V / nwg) rows per workgroup, row k of a run to compute wave k % 8; a wave
+// streams its rows in groups of WLG (the first group requested before the poll: the weights are static), one wave reduction per row, the row's
+// logit parked in lane (row ordinal) and stored once at the end.  bf16-rounded like the autocast Linear's output (decode_shared.h::epi_logit).
+constexpr int WLG = 4;   // rows per group
+constexpr int WLJ = 3;   // 512-element spans per row: d <= 1536
+template <bool STAMPS>
+__device__ __forceinline__ void logits_phase(const WArgs& a, unsigned gp, unsigned base, const unsigned* myflags, WLds& lds) {
+  WPHASE_PROLOGUE;
+  unsigned short* xs = lds.xs;
+  const int KC = a.d >> 3, J = (KC + 63) >> 6;
+  const int RW = (a.V + a.nwg - 1) / a.nwg;
+  const int row0 = wg * RW;
+  int rows = a.V - row0;
+  rows = rows > RW ? RW : (rows < 0 ? 0 : rows);
+  const int cw = wave - 1;
+  const int mine = wave > 0 && rows > cw ? (rows - cw + WC - 1) / WC : 0;  // rows of this wave: cw, cw + WC, ...
+  u32x4_t wq[WLG][WLJ];
+  auto request = [&](int k0) {  // rows k0 .. k0 + WLG - 1 of this wave
+#pragma unroll
+    for (int g = 0; g < WLG; ++g) {
+#pragma unroll
+      for (int j = 0; j < WLJ; ++j) {
+        fresh(wq[g][j]);
+        const int c = j * 64 + lane;
+        if (k0 + g < mine && j < J && c < KC)
+          wq[g][j] = __builtin_nontemporal_load((const u32x4_t*)(a.w_logits + (long)(row0 + cw + WC * (k0 + g)) * a.d + (long)c * 8));
+      }
+    }
+  };
+  request(0);
+  // the final LayerNorm's parameters: fetched by the compute waves, handed over through LDS (the helper wave polls with no load in flight)
+  if (tid >= 64) {
+    const int i = tid - 64;
+    if (4 * i < a.d) {
+      const f32x4_t g4 = *(const f32x4_t*)(a.lnf_g + 4 * i), b4 = *(const f32x4_t*)(a.lnf_b + 4 * i);
+      *(f32x4_t*)&lds.lng[4 * i] = g4, *(f32x4_t*)&lds.lnb[4 * i] = b4;
+    }
+  }
+  if (wave == 0) wide_wait(a, myflags, target, lane);
+  __syncthreads();
+  if (wave == 0) {
+    u32x4_t raw[WLNC];
+    float v[WLNC][8], sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < WLNC; ++c) {
+      fresh(raw[c]);
+      if (lane + 64 * c < KC) raw[c] = ld16_agent(a.x + (lane + 64 * c) * 8);
+    }
+#pragma unroll
+    for (int c = 0; c < WLNC; ++c)
+      if (lane + 64 * c < KC) {
+        dec::unpack8(raw[c], v[c]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sum += v[c][i];
+      }
+    const float mean = wsum(sum) / (float)a.d;
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < WLNC; ++c)
+      if (lane + 64 * c < KC) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          v[c][i] -= mean;
+          sq += v[c][i] * v[c][i];
+        }
+      }
+    const float rstd = rsqrtf(wsum(sq) / (float)a.d + 1e-5f);
+#pragma unroll
+    for (int c = 0; c < WLNC; ++c)
+      if (lane + 64 * c < KC) {
+        const int k = (lane + 64 * c) * 8;
+        const f32x4_t g0 = *(const f32x4_t*)&lds.lng[k], g1 = *(const f32x4_t*)&lds.lng[k + 4];
+        const f32x4_t b0 = *(const f32x4_t*)&lds.lnb[k], b1 = *(const f32x4_t*)&lds.lnb[k + 4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[c][i] = v[c][i] * rstd * g0[i] + b0[i];
+          v[c][4 + i] = v[c][4 + i] * rstd * g1[i] + b1[i];
+        }
+        u32x4_t o4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o4[i] = pack_bf2(v[c][2 * i], v[c][2 * i + 1]);
+        *(u32x4_t*)(xs + (lane + 64 * c) * 8) = o4;
+      }
+  }
+  __syncthreads();
+  if (mine > 0) {
+    u32x4_t xq[WLJ];  // this lane's chunks of the operand row
+#pragma unroll
+    for (int j = 0; j < WLJ; ++j) {
+      fresh(xq[j]);
+      if (j < J && j * 64 + lane < KC) xq[j] = *(const u32x4_t*)(xs + (j * 64 + lane) * 8);
+    }
+    float res = 0.f;
+#pragma unroll 1
+    for (int k0 = 0; k0 < mine; k0 += WLG) {
+      float part[WLG];
+#pragma unroll
+      for (int g = 0; g < WLG; ++g) {
+        part[g] = 0.f;
+#pragma unroll
+        for (int j = 0; j < WLJ; ++j)
+          if (k0 + g < mine && j < J && j * 64 + lane < KC) part[g] += dot8(wq[g][j], xq[j]);
+      }
+      if (k0 + WLG < mine) request(k0 + WLG);  // (the products above are done with the registers)
+#pragma unroll
+      for (int g = 0; g < WLG; ++g)
+        if (k0 + g < mine) {
+          const float y = dec::epi_logit(wsum(part[g]), 0.f);
+          if (lane == k0 + g) res = y;
+        }
+    }
+    if (lane < mine) a.logits_out[row0 + cw + WC * lane] = res;
+  }
+}
+
 // the weights of projection PH into this wave's registers
 template <int PH>
 __device__ __forceinline__ void request_phase(const WArgs& a, int layer, u32x4_t (&wreg)[WMAXU], WStage& st) {
@@ -644,6 +764,7 @@ __global__ __launch_bounds__(WT) void decode_wide_kernel(WArgs a) {
     gemv_phase<STAMPS, 7>(a, layer, gp++, base, myflags, lds, wreg, st);
     request_phase<0>(a, layer + 1, wreg, st);
   }
+  if (a.logits_out) logits_phase<STAMPS>(a, gp, base, myflags, lds);
   if (blockIdx.x == 0 && threadIdx.x < 64) {  // everybody has read the epoch base long ago; publish the next launch's once every workgroup is through
     wide_wait(a, myflags, base + gp, threadIdx.x);
     if (threadIdx.x == 0) a.ctrl[4] = base + gp;
@@ -677,6 +798,8 @@ int launch_decode_wide(const DecodeXcdArgs& h, hipStream_t s) {
   a.ctrl = h.ctrl, a.flagv = h.ctrl + 1024;  // the flag replicas start 4 KB into the cache's control tail
   a.d = h.d, a.H = h.H, a.Te = h.Te, a.S_max = h.S_max, a.L = h.L, a.pos = h.pos, a.nwg = h.team, a.flags = h.flags;
   a.stamps = (unsigned long long*)h.stamps;
+  a.w_logits = h.w_logits, a.lnf_g = h.lnf_g, a.lnf_b = h.lnf_b, a.logits_out = h.logits_out, a.V = h.V;
+  OASR_REQUIRE(!h.logits_out || (h.w_logits && h.lnf_g && h.lnf_b && h.V > 0 && (h.V + h.team - 1) / h.team <= 64 * WC), "decode_wide: bad logits phase");
   a.swg = (h.flags >> 8) & 0xff;  // (the engine passes OASR_XCD_FLAGS bits 9-16 here: the workgroup whose stamps are taken)
   {
     long* dst = &a.l0.ln1g;

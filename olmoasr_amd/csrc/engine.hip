@@ -1235,8 +1235,11 @@ static int oasr_decode_step_impl(oasr_ctx* c, const int64_t* tokens_last, int B,
       }
       xa.layer_offsets = c->xcd_offsets.data();
       xa.lstride = c->xcd_lstride, xa.astride = c->xcd_astride;
-      if (wide) RC(launch_decode_wide(xa, st));
-      else RC(launch_decode_xcd(xa, st));
+      if (wide) {  // ... and the final LayerNorm + logits projection as its last phase: one launch per token behind the embedding
+        xa.w_logits = c->template Wt<bf16_t>(c->tok_emb), xa.lnf_g = c->P(c->dec_ln_w), xa.lnf_b = c->P(c->dec_ln_b), xa.logits_out = logits_out, xa.V = c->V;
+        return launch_decode_wide(xa, st);
+      }
+      RC(launch_decode_xcd(xa, st));
       return launch_decode_proj(x, B, d, c->template Wt<bf16_t>(c->tok_emb), c->V, c->P(c->dec_ln_w), c->P(c->dec_ln_b), nullptr, 0, nullptr, 0,
                                 nullptr, 0, logits_out, c->V, st);
     }

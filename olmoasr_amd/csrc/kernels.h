@@ -171,6 +171,11 @@ struct DecodeXcdArgs {
   int flags;            // experiments (decode_xcd.hip::XArgs::flags), 0 in production
   void* stamps;         // optional 512-byte device buffer for in-kernel cycle stamps (measurement), or null
   int team, stride;     // `team` workgroups; stride 8 = one per CU of ONE XCD (grid 8 x team, blockIdx % 8 == 0), 1 = spread over the chip
+  // chip-wide engine only: the final LayerNorm + tied logits projection as the launch's last phase (null logits_out: not done there)
+  const bf16_t* w_logits = nullptr;  // bf16 token embedding [V][d]
+  const float *lnf_g = nullptr, *lnf_b = nullptr;
+  float* logits_out = nullptr;       // f32 [V]
+  int V = 0;
   const int64_t* layer_offsets;   // HOST: [18] element offsets of decoder layer 0 in decode_xcd.hip::XLayer order
   long lstride, astride;          // layer l = layer 0 + l * lstride (arena / shadow elements), + l * astride for the aux entry
 };
