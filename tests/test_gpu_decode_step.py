@@ -97,15 +97,15 @@ def test_one_launch_engine_over_a_long_window(tiny_case):
 
 
 def test_chip_wide_engine_over_a_long_window(tiny_case):
-    """ONE sequence, 300 positions: the chip-wide engine's self-attention fills 5 of its 7 keys per lane group, the flag epochs run up to
-    300 x 16 -- logits track the multi-launch step at every position and the greedy choice agrees wherever the top-2 margin is above the
-    bf16 envelope."""
+    """ONE sequence, all 448 positions of the text context: the chip-wide engine's self-attention fills every one of its 7 key steps per lane
+    group (72 groups: the step that holds row ``pos`` moves through all of them), the flag epochs run up to 448 x 16 -- logits track the
+    multi-launch step at every position and the greedy choice agrees wherever the top-2 margin is above the bf16 envelope."""
     from olmoasr_amd.model import OLMoASR
     from oracle import model_oracle as mo
     dims = mo.Dims(80, 1500, 512, 8, 1, 51864, 448, 512, 8, 2)
     net = OLMoASR(_dims(dims), device=DEV, seed=3, inference=True)
     xa = net.embed_audio(tiny_case["mel"][:1].to(DEV))
-    toks = torch.randint(0, 50000, (1, 300), generator=torch.Generator().manual_seed(1)).to(DEV)
+    toks = torch.randint(0, 50000, (1, 448), generator=torch.Generator().manual_seed(1)).to(DEV)
     toks[:, 0] = 50257
     multi = _steps(net, xa, toks, 1)
     wide = _steps(net, xa, toks, 5)
