@@ -49,6 +49,13 @@ constexpr int WMAXWG = 256;
 constexpr unsigned WSPIN = 1u << 20;
 constexpr int WREP = 8;      // flag replicas: 256 workgroups polling the same eight cache lines serialise on one memory channel; a replica per XCC, 4 KB apart
 constexpr int WFS = 1024;    // dwords between replicas
+// Rows that every workgroup consumes in the very next phase travel as PACKETS: the producing workgroup's (<= 6) bf16 values and the phase's epoch
+// number in ONE 16-byte store per replica; a consumer polls the packets themselves.  No acknowledgement wait before a flag, no separate
+// flag-then-row round trip.  Vectors: the block output x (mlp.2 -> the next attn_ln, or the final LayerNorm), x2 (attention output projection ->
+// cross_attn_ln), x3 (cross output projection -> mlp_ln), q (cross query -> cross-attention).
+constexpr int WPKV = 4, WV_X = 0, WV_X2 = 1, WV_X3 = 2, WV_Q = 3;
+constexpr int WPKS = 256;    // packet slots per replica: one per workgroup
+constexpr int WPKR = 6;      // values per packet at most: R <= 6 for an N = d projection (the kernel is instantiated per R: 2, 4, 6)
 
 #define WWAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
@@ -64,6 +71,7 @@ struct WArgs {
   bf16_t *x, *x2, *x3, *q, *o, *hg;
   float* part;      // [H * WNS][66]: m, l, o[64]
   unsigned* ctrl;   // [1] error flag  [3] XCC ids seen  [4] epoch base of this engine
+  u32x4_t* pk;      // [WPKV][WREP][WPKS] packets: {bf16 x 6, epoch}
   unsigned* flagv;  // [WREP][WFS]: replica r (polled by the workgroups on XCC r) of the per-workgroup flags = last completed phase (epoch-based)
   int d, H, Te, S_max, L, pos, nwg, flags, swg;
   unsigned long long* stamps;
@@ -86,6 +94,12 @@ __device__ __forceinline__ u32x4_t ld16_agent_off(const void* sbase, unsigned of
 __device__ __forceinline__ unsigned ld4_agent(const void* p) { return __hip_atomic_load((const unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ldf_agent(const float* p) { return __uint_as_float(ld4_agent(p)); }
 __device__ __forceinline__ void st4_agent(void* p, unsigned v) { __hip_atomic_store((unsigned*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// 16-byte agent-scope accesses as ONE instruction each (the HIP atomics stop at 8 bytes; a packet must not tear): issued from inline assembly, so the
+// compiler does not count them -- every reader below waits with an explicit s_waitcnt before it looks at the data
+__device__ __forceinline__ void st16_agent(u32x4_t* p, const u32x4_t& v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void ld16_agent_issue(u32x4_t& r, const u32x4_t* p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r) : "v"(p) : "memory"); }
+__device__ __forceinline__ float pk_value(const u32x4_t& w, int i) { return (i & 1) ? bf_hi(w[i >> 1]) : bf_lo(w[i >> 1]); }
 
 // ---- wave reductions on the DPP path (register to register: ~10 instructions; __shfl_xor is six dependent ds_bpermute round trips, ~700 cycles
 // per sum where a phase has ~4000 to spend).  All 64 lanes must be active.
@@ -127,6 +141,86 @@ __device__ __forceinline__ void wide_wait(const WArgs& a, const unsigned* myflag
   }
 }
 
+// wave 0: the packets of row vector `vec` with epoch `expect`, slot lane + 64 c in pkt[c] (slots >= nslots: not waited for)
+constexpr int WPKL = WPKS / 64;  // packets per lane
+__device__ __forceinline__ void pk_poll(const WArgs& a, int vec, int rep, unsigned expect, int nslots, int lane, u32x4_t (&pkt)[WPKL]) {
+  const u32x4_t* src = a.pk + (size_t)(vec * WREP + rep) * WPKS;
+  bool need[WPKL];
+#pragma unroll
+  for (int c = 0; c < WPKL; ++c) {
+    need[c] = lane + 64 * c < nslots;
+    pkt[c] = u32x4_t{0u, 0u, 0u, 0u};
+  }
+  unsigned spins = 0;
+  for (;;) {
+#pragma unroll
+    for (int c = 0; c < WPKL; ++c)
+      if (need[c]) ld16_agent_issue(pkt[c], src + lane + 64 * c);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pkt[0]), "+v"(pkt[1]), "+v"(pkt[2]), "+v"(pkt[3])::"memory");
+    bool missing = false;
+#pragma unroll
+    for (int c = 0; c < WPKL; ++c)
+      if (need[c]) {
+        if (pkt[c][3] == expect) need[c] = false;
+        else missing = true;
+      }
+    if (__builtin_amdgcn_ballot_w64(missing) == 0) break;
+    if (!(a.flags & 4)) __builtin_amdgcn_s_sleep(1);
+    if (++spins > WSPIN || ((spins & 63) == 0 && ld4_agent(a.ctrl + 1) != 0)) {
+      if (lane == 0) __hip_atomic_fetch_or(a.ctrl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // a packet never came: poison, do not hang
+      break;
+    }
+  }
+}
+static_assert(WPKL == 4, "pk_poll pins four packets per lane");
+// wave 0: LayerNorm of a row vector held as packets (slot lane + 64 c = rows slot RD .. slot RD + RD - 1 of d) -> bf16 operand row in LDS.  Values centred once,
+// two passes, the expression of dec::ln_apply8; gamma / beta from LDS (handed over by the compute waves).  RD = rows per workgroup of an N = d projection.
+template <int RD>
+__device__ __forceinline__ void ln_packets(const u32x4_t (&pkt)[WPKL], int d, int lane, const float* lng, const float* lnb, unsigned short* xs) {
+  float v[WPKL][RD], sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < WPKL; ++c)
+#pragma unroll
+    for (int i = 0; i < RD; ++i) {
+      v[c][i] = (lane + 64 * c) * RD + i < d ? pk_value(pkt[c], i) : 0.f;
+      sum += v[c][i];
+    }
+  const float mean = wsum(sum) / (float)d;
+  float sq = 0.f;
+#pragma unroll
+  for (int c = 0; c < WPKL; ++c)
+#pragma unroll
+    for (int i = 0; i < RD; ++i)
+      if ((lane + 64 * c) * RD + i < d) {
+        v[c][i] -= mean;
+        sq += v[c][i] * v[c][i];
+      }
+  const float rstd = rsqrtf(wsum(sq) / (float)d + 1e-5f);
+#pragma unroll
+  for (int c = 0; c < WPKL; ++c)
+#pragma unroll
+    for (int i = 0; i < RD; i += 2) {
+      const int k = (lane + 64 * c) * RD + i;
+      if (k < d) {  // (RD and d are even: pairs stay together; k is even: 8-byte reads)
+        const oasr_f32x2_t g = *(const oasr_f32x2_t*)&lng[k], b = *(const oasr_f32x2_t*)&lnb[k];
+        *(uint32_t*)(xs + k) = pack_bf2(v[c][i] * rstd * g[0] + b[0], v[c][i + 1] * rstd * g[1] + b[1]);
+      }
+    }
+}
+// wave 0: a PLAIN bf16 row (the embedding launch's, layer 0) fetched in packet layout
+template <int RD>
+__device__ __forceinline__ void pk_from_plain(const bf16_t* x, int d, int lane, u32x4_t (&pkt)[WPKL]) {
+#pragma unroll
+  for (int c = 0; c < WPKL; ++c) {
+    pkt[c] = u32x4_t{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < RD / 2; ++j) {
+      const int k = (lane + 64 * c) * RD + 2 * j;
+      if (k < d) pkt[c][j] = ld4_agent(x + k);
+    }
+  }
+}
+
 struct WGemv {  // one projection phase
   const bf16_t* w;  // [N][K]
   int K, N, R;
@@ -142,11 +236,20 @@ template <int PH>
 struct WPh {  // what projection phase PH is, at compile time
   static constexpr bool LN = PH == 0 || PH == 3 || PH == 6, MERGE = PH == 5, GELU = PH == 6, RESID = PH == 2 || PH == 5 || PH == 7;
   static constexpr int NEXT = PH == 7 ? 0 : PH + 1;  // the phase after it
+  // rows in / out as packets: the vector id, or -1 (in: the operand row; PH 0 takes packets from the layer before, a plain row in layer 0)
+  static constexpr int PKIN = PH == 0 ? WV_X : PH == 3 ? WV_X2 : PH == 6 ? WV_X3 : -1;
+  static constexpr int PKOUT = PH == 2 ? WV_X2 : PH == 3 ? WV_Q : PH == 5 ? WV_X3 : PH == 7 ? WV_X : -1;
   // parity of the projection's index in the layer's six (0, 2, 3, 5, 6, 7): consecutive projections use different LDS hand-over buffers (the
   // compute waves run ahead into the next projection -- through an attention phase without a workgroup barrier -- while the helper wave still
   // reads the current one's in its epilogue)
   static constexpr int PAR = (PH == 2 || PH == 5 || PH == 7) ? 1 : 0;
 };
+// units per compute wave and phase at most, at 256 workgroups (decode_wide_supports checks the shape against it): keeps the unrolled unit loops -- and the
+// kernel under the 64 KB of instruction cache two CUs share -- as short as the instantiation allows
+template <int RD, int PH>
+constexpr int wmu() {
+  return RD == 2 ? 1 : RD == 4 ? (PH == 0 ? 3 : (PH == 6 || PH == 7) ? 4 : 1) : (PH == 0 ? 6 : (PH == 6 || PH == 7) ? 8 : 3);
+}
 template <int PH>
 __device__ __forceinline__ WGemv gemv_of(const WArgs& a, int layer) {
   const long s = (long)layer * a.lstride;
@@ -190,6 +293,7 @@ __device__ __forceinline__ WUnits units_of(const WGemv& p, int wg, int wave) {
   q.r0 = q.u0 / q.J, q.j0 = q.u0 - q.r0 * q.J;
   return q;
 }
+template <int MU>
 __device__ __forceinline__ void request_units(const WGemv& p, int wg, int wave, int lane, u32x4_t (&wreg)[WMAXU]) {
   if (wave == 0) return;
   const WUnits q = units_of(p, wg, wave);
@@ -197,7 +301,7 @@ __device__ __forceinline__ void request_units(const WGemv& p, int wg, int wave, 
   int j = q.j0;
   const int cnt = q.U - q.u0 < q.upw ? q.U - q.u0 : q.upw;  // this wave's units
 #pragma unroll
-  for (int i = 0; i < WMAXU; ++i) {
+  for (int i = 0; i < MU; ++i) {
     if (i >= cnt) break;  // (one branch out instead of a skipped body per remaining slot: a wave's instructions cost ~10 cycles each here)
     const int c = j * 64 + lane;
     if (c < q.KC) wreg[i] = __builtin_nontemporal_load((const u32x4_t*)(row + (long)c * 8));  // (else: never read)
@@ -210,6 +314,11 @@ __device__ __forceinline__ void request_units(const WGemv& p, int wg, int wave, 
 struct WStage {
   f32x4_t g, b;  // elements 4 i .. 4 i + 3 of gamma / beta, i = tid - 64
   float bias;    // row i of the workgroup's run
+};
+// wave 0, lane i < rows: the (bf16) values this workgroup produced for rows i of x / x2 / x3 -- the NEXT projection onto the same rows adds them as its
+// residual, so they never travel
+struct WRes {
+  float x, x2, x3;
 };
 // a FRESH (undefined) value: registers that are assigned under a condition inside the layer loop would otherwise carry their previous contents
 // around the loop as far as the register allocator can tell (measured: the two attention phases' K / V rows were live at the same time)
@@ -319,7 +428,7 @@ __device__ __forceinline__ void attend(const float (&qv)[8], const u32x4_t (&k4)
 struct WLds {
   __attribute__((aligned(16))) unsigned short xs[4 * WMAXD];  // the operand row (bf16)
   __attribute__((aligned(32))) float rowsum[2][64 * WC];  // [phase parity][row of the workgroup's run][compute wave]
-  float lng[WMAXD], lnb[WMAXD];  // LayerNorm parameters of the current phase's operand row
+  __attribute__((aligned(16))) float lng[WMAXD], lnb[WMAXD];  // LayerNorm parameters of the current phase's operand row
   float biasv[2][64];            // [phase parity] bias of the workgroup's rows
   WAttLds att;
 };
@@ -386,8 +495,8 @@ __device__ __forceinline__ void self_phase(const WArgs& a, int layer, unsigned g
 }
 
 // ---------------- cross-attention: one workgroup per (head, key segment) ----------------
-template <bool STAMPS>
-__device__ __forceinline__ void cross_phase(const WArgs& a, int layer, unsigned gp, unsigned base, const unsigned* myflags, WLds& lds) {
+template <bool STAMPS, int RD>
+__device__ __forceinline__ void cross_phase(const WArgs& a, int layer, unsigned gp, unsigned base, const unsigned* myflags, int rep, WLds& lds) {
   constexpr int ph = 4;
   WPHASE_PROLOGUE;
   WAttLds& att = lds.att;
@@ -413,12 +522,36 @@ __device__ __forceinline__ void cross_phase(const WArgs& a, int layer, unsigned 
       }
     }
     WSTAMP(0);
-    if (wave == 0) wide_wait(a, myflags, target, lane);
+    if (wave == 0) {  // the head's 64 query values arrive as packets of R_d values (the cross query projection a phase ago): poll them, spread them out in LDS
+      constexpr int R_d = RD;
+      const int s0 = (h * 64) / R_d, s1 = (h * 64 + 63) / R_d;  // slots that hold rows h 64 .. h 64 + 63
+      const u32x4_t* src = a.pk + (size_t)(WV_Q * WREP + rep) * WPKS;
+      u32x4_t pq = {0u, 0u, 0u, 0u};
+      bool need = s0 + lane <= s1;
+      unsigned spins = 0;
+      for (;;) {
+        if (need) ld16_agent_issue(pq, src + s0 + lane);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pq)::"memory");
+        if (need && pq[3] == target) need = false;
+        if (__builtin_amdgcn_ballot_w64(need) == 0) break;
+        if (!(a.flags & 4)) __builtin_amdgcn_s_sleep(1);
+        if (++spins > WSPIN || ((spins & 63) == 0 && ld4_agent(a.ctrl + 1) != 0)) {
+          if (lane == 0) __hip_atomic_fetch_or(a.ctrl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+      if (s0 + lane <= s1) {
+#pragma unroll
+        for (int i = 0; i < RD; ++i) {
+          const int r = (s0 + lane) * R_d + i - h * 64;
+          if (r >= 0 && r < 64) lds.xs[r] = (unsigned short)(pq[i >> 1] >> ((i & 1) * 16));
+        }
+      }
+    }
     __syncthreads();
     WSTAMP(1);
-    const u32x4_t q4 = ld16_agent(a.q + h * 64 + l8 * 8);
     float qv[8];
-    dec::load_q8(q4, qv);
+    dec::load_q8(*(const u32x4_t*)(lds.xs + l8 * 8), qv);
     float m, lt, acc;
     attend<WCK>(qv, k4, v4, n, tid, att, m, lt, acc);
     if (tid < 64) {
@@ -434,9 +567,9 @@ __device__ __forceinline__ void cross_phase(const WArgs& a, int layer, unsigned 
 }
 
 // ---------------- projection PH: rows wg R .. wg R + R - 1 ----------------
-template <bool STAMPS, int PH>
-__device__ __forceinline__ void gemv_phase(const WArgs& a, int layer, unsigned gp, unsigned base, const unsigned* myflags, WLds& lds, u32x4_t (&wreg)[WMAXU],
-                                           const WStage& st) {
+template <bool STAMPS, int RD, int PH>
+__device__ __forceinline__ void gemv_phase(const WArgs& a, int layer, unsigned gp, unsigned base, const unsigned* myflags, int rep, WLds& lds,
+                                           u32x4_t (&wreg)[WMAXU], const WStage& st, WRes& res) {
   constexpr int ph = PH;
   WPHASE_PROLOGUE;
   unsigned short* xs = lds.xs;
@@ -460,7 +593,14 @@ __device__ __forceinline__ void gemv_phase(const WArgs& a, int layer, unsigned g
       if (i < rows) biasv[i] = st.bias;
     }
     WSTAMP(0);
-    if (wave == 0 && (PH != 0 || gp > 0)) wide_wait(a, myflags, target, lane);
+    constexpr int PKIN = WPh<PH>::PKIN, PKOUT = WPh<PH>::PKOUT;
+    const bool pk_in = PKIN >= 0 && !(PH == 0 && layer == 0);  // (layer 0's attn_ln reads the embedding launch's plain row)
+    u32x4_t pkt[WPKL];
+    if (wave == 0) {
+      if (pk_in) pk_poll(a, PKIN, rep, target, (a.d + RD - 1) / RD, lane, pkt);
+      else if (PH == 0) pk_from_plain<RD>(a.x, a.d, lane, pkt);  // (layer 0; preceded by no phase of this launch)
+      else wide_wait(a, myflags, target, lane);
+    }
     __syncthreads();
     WSTAMP(1);
     float resid_v = 0.f;  // (the residual row is two phases old; needed by the epilogue only, so requested behind the operand row's loads)
@@ -493,51 +633,7 @@ __device__ __forceinline__ void gemv_phase(const WArgs& a, int layer, unsigned g
         }
       }
     } else if constexpr (WPh<PH>::LN) {  // LayerNorm folded into the operand (K = d): wave 0
-      if (wave == 0) {
-        u32x4_t raw[dec::MAXC];
-#pragma unroll
-        for (int c = 0; c < dec::MAXC; ++c) {
-          fresh(raw[c]);
-          if (c < WLNC && lane + 64 * c < KC) raw[c] = ld16_agent(p.xin + (lane + 64 * c) * 8);
-        }
-        // (values unpacked ONCE and centred once: the statistics and the normalisation share v - mean; two passes as ln_fwd_kernel)
-        float v[WLNC][8], sum = 0.f;
-#pragma unroll
-        for (int c = 0; c < WLNC; ++c)
-          if (lane + 64 * c < KC) {
-            dec::unpack8(raw[c], v[c]);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) sum += v[c][i];
-          }
-        const float mean = wsum(sum) / (float)p.K;
-        float sq = 0.f;
-#pragma unroll
-        for (int c = 0; c < WLNC; ++c)
-          if (lane + 64 * c < KC) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-              v[c][i] -= mean;
-              sq += v[c][i] * v[c][i];
-            }
-          }
-        const float rstd = rsqrtf(wsum(sq) / (float)p.K + 1e-5f);
-#pragma unroll
-        for (int c = 0; c < WLNC; ++c)
-          if (lane + 64 * c < KC) {
-            const int k = (lane + 64 * c) * 8;
-            const f32x4_t g0 = *(const f32x4_t*)&lds.lng[k], g1 = *(const f32x4_t*)&lds.lng[k + 4];
-            const f32x4_t b0 = *(const f32x4_t*)&lds.lnb[k], b1 = *(const f32x4_t*)&lds.lnb[k + 4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {  // (dec::ln_apply8's expression)
-              v[c][i] = v[c][i] * rstd * g0[i] + b0[i];
-              v[c][4 + i] = v[c][4 + i] * rstd * g1[i] + b1[i];
-            }
-            u32x4_t o4;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) o4[i] = pack_bf2(v[c][2 * i], v[c][2 * i + 1]);
-            *(u32x4_t*)(xs + (lane + 64 * c) * 8) = o4;
-          }
-      }
+      if (wave == 0) ln_packets<RD>(pkt, a.d, lane, lds.lng, lds.lnb, xs);
     } else {  // plain row: K / 8 chunks over the 512 threads
       constexpr int NC = (4 * WMAXD / 8 + WT - 1) / WT;
       u32x4_t raw[NC];
@@ -550,7 +646,7 @@ __device__ __forceinline__ void gemv_phase(const WArgs& a, int layer, unsigned g
       for (int c = 0; c < NC; ++c)
         if (tid + WT * c < KC) *(u32x4_t*)(xs + (tid + WT * c) * 8) = raw[c];
     }
-    if (WPh<PH>::RESID && wave == 0 && lane < rows) resid_z = ld4_agent(p.resid + ((row0 + lane) & ~1));
+    if (PH == 2 && layer == 0 && wave == 0 && lane < rows) resid_z = ld4_agent(p.resid + ((row0 + lane) & ~1));  // (the embedding launch's row; later: WRes)
     __syncthreads();
     WSTAMP(2);
     // ---- this wave's units ----
@@ -566,7 +662,7 @@ __device__ __forceinline__ void gemv_phase(const WArgs& a, int layer, unsigned g
       float accl = 0.f;
       int j = q.j0, r = q.r0;
 #pragma unroll
-      for (int i = 0; i < WMAXU; ++i) {
+      for (int i = 0; i < wmu<RD, PH>(); ++i) {
         if (i >= cnt) break;
         const int c = j * 64 + lane;
         if (c < q.KC) accl += dot8(wreg[i], *(const u32x4_t*)(xs + c * 8));
@@ -588,12 +684,27 @@ __device__ __forceinline__ void gemv_phase(const WArgs& a, int layer, unsigned g
         float acc = 0.f;
 #pragma unroll
       for (int w = 0; w < WC; ++w) acc += rowsum[lane * WC + w];
-        resid_v = ((row0 + lane) & 1) ? bf_hi(resid_z) : bf_lo(resid_z);
-      y = dec::epi_value(acc, biasv[lane], WPh<PH>::GELU, WPh<PH>::RESID, resid_v);
+        if constexpr (PH == 2) resid_v = layer == 0 ? (((row0 + lane) & 1) ? bf_hi(resid_z) : bf_lo(resid_z)) : res.x;
+        if constexpr (PH == 5) resid_v = res.x2;
+        if constexpr (PH == 7) resid_v = res.x3;
+        y = dec::epi_value(acc, biasv[lane], WPh<PH>::GELU, WPh<PH>::RESID, resid_v);
       }
-      const float nb = dec::xor_lane<1>(y);
-      if (lane < rows && (lane & 1) == 0) st4_agent(p.out + row0 + lane, pack_bf2(y, nb));
-      WWAIT_VM0();
+      if constexpr (PKOUT >= 0) {
+        // the workgroup's <= 6 values + the phase's epoch in ONE 16-byte store per replica (lanes 0-7): nothing to wait for before the flag
+        const float yb = bf_round(y);
+        if constexpr (PH == 2) res.x2 = yb;
+        if constexpr (PH == 5) res.x3 = yb;
+        if constexpr (PH == 7) res.x = yb;
+        u32x4_t w;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) w[i] = i < RD / 2 ? pack_bf2(rdl(yb, 2 * i), rdl(yb, 2 * i + 1)) : 0u;  // (lanes >= rows hold 0)
+        w[3] = base + gp + 1;
+        if (lane < WREP) st16_agent(a.pk + (size_t)(PKOUT * WREP + lane) * WPKS + wg, w);
+      } else {
+        const float nb = dec::xor_lane<1>(y);
+        if (lane < rows && (lane & 1) == 0) st4_agent(p.out + row0 + lane, pack_bf2(y, nb));
+        WWAIT_VM0();
+      }
     }
     WSTAMP(4);
   }
@@ -606,8 +717,8 @@ __device__ __forceinline__ void gemv_phase(const WArgs& a, int layer, unsigned g
 // logit parked in lane (row ordinal) and stored once at the end.  bf16-rounded like the autocast Linear's output (decode_shared.h::epi_logit).
 constexpr int WLG = 4;   // rows per group
 constexpr int WLJ = 3;   // 512-element spans per row: d <= 1536
-template <bool STAMPS>
-__device__ __forceinline__ void logits_phase(const WArgs& a, unsigned gp, unsigned base, const unsigned* myflags, WLds& lds) {
+template <bool STAMPS, int RD>
+__device__ __forceinline__ void logits_phase(const WArgs& a, unsigned gp, unsigned base, const unsigned* myflags, int rep, WLds& lds) {
   WPHASE_PROLOGUE;
   unsigned short* xs = lds.xs;
   const int KC = a.d >> 3, J = (KC + 63) >> 6;
@@ -639,52 +750,10 @@ __device__ __forceinline__ void logits_phase(const WArgs& a, unsigned gp, unsign
       *(f32x4_t*)&lds.lng[4 * i] = g4, *(f32x4_t*)&lds.lnb[4 * i] = b4;
     }
   }
-  if (wave == 0) wide_wait(a, myflags, target, lane);
-  __syncthreads();
-  if (wave == 0) {
-    u32x4_t raw[WLNC];
-    float v[WLNC][8], sum = 0.f;
-#pragma unroll
-    for (int c = 0; c < WLNC; ++c) {
-      fresh(raw[c]);
-      if (lane + 64 * c < KC) raw[c] = ld16_agent(a.x + (lane + 64 * c) * 8);
-    }
-#pragma unroll
-    for (int c = 0; c < WLNC; ++c)
-      if (lane + 64 * c < KC) {
-        dec::unpack8(raw[c], v[c]);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) sum += v[c][i];
-      }
-    const float mean = wsum(sum) / (float)a.d;
-    float sq = 0.f;
-#pragma unroll
-    for (int c = 0; c < WLNC; ++c)
-      if (lane + 64 * c < KC) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          v[c][i] -= mean;
-          sq += v[c][i] * v[c][i];
-        }
-      }
-    const float rstd = rsqrtf(wsum(sq) / (float)a.d + 1e-5f);
-#pragma unroll
-    for (int c = 0; c < WLNC; ++c)
-      if (lane + 64 * c < KC) {
-        const int k = (lane + 64 * c) * 8;
-        const f32x4_t g0 = *(const f32x4_t*)&lds.lng[k], g1 = *(const f32x4_t*)&lds.lng[k + 4];
-        const f32x4_t b0 = *(const f32x4_t*)&lds.lnb[k], b1 = *(const f32x4_t*)&lds.lnb[k + 4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          v[c][i] = v[c][i] * rstd * g0[i] + b0[i];
-          v[c][4 + i] = v[c][4 + i] * rstd * g1[i] + b1[i];
-        }
-        u32x4_t o4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o4[i] = pack_bf2(v[c][2 * i], v[c][2 * i + 1]);
-        *(u32x4_t*)(xs + (lane + 64 * c) * 8) = o4;
-      }
-  }
+  u32x4_t pkt[WPKL];
+  if (wave == 0) pk_poll(a, WV_X, rep, target, (a.d + RD - 1) / RD, lane, pkt);  // the last block's output arrives as packets
+  __syncthreads();  // (... and the parameters are in LDS)
+  if (wave == 0) ln_packets<RD>(pkt, a.d, lane, lds.lng, lds.lnb, xs);
   __syncthreads();
   if (mine > 0) {
     u32x4_t xq[WLJ];  // this lane's chunks of the operand row
@@ -717,7 +786,7 @@ __device__ __forceinline__ void logits_phase(const WArgs& a, unsigned gp, unsign
 }
 
 // the weights of projection PH into this wave's registers
-template <int PH>
+template <int RD, int PH>
 __device__ __forceinline__ void request_phase(const WArgs& a, int layer, u32x4_t (&wreg)[WMAXU], WStage& st) {
   int tid = threadIdx.x, wg = blockIdx.x;
   asm volatile("" : "+v"(tid), "+s"(wg));
@@ -725,7 +794,7 @@ __device__ __forceinline__ void request_phase(const WArgs& a, int layer, u32x4_t
   fresh(st.g), fresh(st.b), fresh(st.bias);
   if (layer >= a.L) return;
   const WGemv p = gemv_of<PH>(a, layer);
-  request_units(p, wg, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63, wreg);
+  request_units<wmu<RD, PH>()>(p, wg, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63, wreg);
   const int i = tid - 64;
   if (i >= 0) {
     if (WPh<PH>::LN && 4 * i < p.K) st.g = *(const f32x4_t*)(p.ln_g + 4 * i), st.b = *(const f32x4_t*)(p.ln_b + 4 * i);
@@ -733,38 +802,42 @@ __device__ __forceinline__ void request_phase(const WArgs& a, int layer, u32x4_t
   }
 }
 
-template <bool STAMPS>  // STAMPS: the measurement instantiation (scripts/decode_xcd_probe.py); its stores cost waits of their own
+// STAMPS: the measurement instantiation (scripts/decode_xcd_probe.py; its stores cost waits of their own).  RD: rows per workgroup of an N = d projection
+// = values per packet (2: d <= 512, 4: d <= 1024, 6: d <= 1536 at 256 workgroups)
+template <bool STAMPS, int RD>
 __global__ __launch_bounds__(WT) void decode_wide_kernel(WArgs a) {
   __shared__ WLds lds;
   const unsigned base = a.ctrl[4];
   unsigned xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-  const unsigned* myflags = a.flagv + (size_t)(xcc & (WREP - 1)) * WFS;
+  const int rep = (int)(xcc & (WREP - 1));
+  const unsigned* myflags = a.flagv + (size_t)rep * WFS;
   if (threadIdx.x == 0) __hip_atomic_fetch_or(a.ctrl + 3, 1u << (xcc & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   u32x4_t wreg[WMAXU];
   WStage st;
-  request_phase<0>(a, 0, wreg, st);
+  WRes res = {0.f, 0.f, 0.f};
+  request_phase<RD, 0>(a, 0, wreg, st);
   unsigned gp = 0;  // phases before the current one
   // A phase's weights are requested at the end of the phase before it: in flight through the exchange.  (Not across an attention phase: with
   // the attention's K / V rows the registers of weights would not fit, and the compiler would park them in scratch = wait for them on the spot.)
 #pragma unroll 1
   for (int layer = 0; layer < a.L; ++layer) {
-    gemv_phase<STAMPS, 0>(a, layer, gp++, base, myflags, lds, wreg, st);
+    gemv_phase<STAMPS, RD, 0>(a, layer, gp++, base, myflags, rep, lds, wreg, st, res);
     self_phase<STAMPS>(a, layer, gp++, base, myflags, lds);
-    request_phase<2>(a, layer, wreg, st);
-    gemv_phase<STAMPS, 2>(a, layer, gp++, base, myflags, lds, wreg, st);
-    request_phase<3>(a, layer, wreg, st);
-    gemv_phase<STAMPS, 3>(a, layer, gp++, base, myflags, lds, wreg, st);
-    cross_phase<STAMPS>(a, layer, gp++, base, myflags, lds);
-    request_phase<5>(a, layer, wreg, st);
-    gemv_phase<STAMPS, 5>(a, layer, gp++, base, myflags, lds, wreg, st);
-    request_phase<6>(a, layer, wreg, st);
-    gemv_phase<STAMPS, 6>(a, layer, gp++, base, myflags, lds, wreg, st);
-    request_phase<7>(a, layer, wreg, st);
-    gemv_phase<STAMPS, 7>(a, layer, gp++, base, myflags, lds, wreg, st);
-    request_phase<0>(a, layer + 1, wreg, st);
+    request_phase<RD, 2>(a, layer, wreg, st);
+    gemv_phase<STAMPS, RD, 2>(a, layer, gp++, base, myflags, rep, lds, wreg, st, res);
+    request_phase<RD, 3>(a, layer, wreg, st);
+    gemv_phase<STAMPS, RD, 3>(a, layer, gp++, base, myflags, rep, lds, wreg, st, res);
+    cross_phase<STAMPS, RD>(a, layer, gp++, base, myflags, rep, lds);
+    request_phase<RD, 5>(a, layer, wreg, st);
+    gemv_phase<STAMPS, RD, 5>(a, layer, gp++, base, myflags, rep, lds, wreg, st, res);
+    request_phase<RD, 6>(a, layer, wreg, st);
+    gemv_phase<STAMPS, RD, 6>(a, layer, gp++, base, myflags, rep, lds, wreg, st, res);
+    request_phase<RD, 7>(a, layer, wreg, st);
+    gemv_phase<STAMPS, RD, 7>(a, layer, gp++, base, myflags, rep, lds, wreg, st, res);
+    request_phase<RD, 0>(a, layer + 1, wreg, st);
   }
-  if (a.logits_out) logits_phase<STAMPS>(a, gp, base, myflags, lds);
+  if (a.logits_out) logits_phase<STAMPS, RD>(a, gp, base, myflags, rep, lds);
   if (blockIdx.x == 0 && threadIdx.x < 64) {  // everybody has read the epoch base long ago; publish the next launch's once every workgroup is through
     wide_wait(a, myflags, base + gp, threadIdx.x);
     if (threadIdx.x == 0) a.ctrl[4] = base + gp;
@@ -780,7 +853,15 @@ bool decode_wide_supports(int d, int H, int Te, int S_max, int L, int M, int nwg
   if (!(M == 1 && L >= 1 && L <= WMAXL && d % 64 == 0 && d == H * 64 && d <= WMAXD && H <= 32 && S_max >= 1 && S_max <= WNG * WSK && Te >= 1 &&
         (Te + WNS - 1) / WNS <= WNG * WCK && nwg >= 64 && nwg <= WMAXWG && nwg % 4 == 0 && H * WNS <= nwg))
     return false;
-  // units per wave: rows R x spans J dealt to 8 waves
+  if (2 * ((d + 2 * nwg - 1) / (2 * nwg)) > WPKR) return false;  // an N = d projection's rows per workgroup fill one packet
+  // units per wave: rows R x spans J dealt to 8 waves, within what the instantiation for this R_d unrolls (wmu)
+  {
+    const int rd = 2 * ((d + 2 * nwg - 1) / (2 * nwg));
+    const int mu0 = rd == 2 ? wmu<2, 0>() : rd == 4 ? wmu<4, 0>() : wmu<6, 0>(), mu2 = rd == 2 ? wmu<2, 2>() : rd == 4 ? wmu<4, 2>() : wmu<6, 2>();
+    const int mu6 = rd == 2 ? wmu<2, 6>() : rd == 4 ? wmu<4, 6>() : wmu<6, 6>();
+    auto upw = [&](int N, int K) { return (2 * ((N + 2 * nwg - 1) / (2 * nwg)) * ((K / 8 + 63) / 64) + WC - 1) / WC; };
+    if (upw(3 * d, d) > mu0 || upw(d, d) > mu2 || upw(4 * d, d) > mu6 || upw(d, 4 * d) > mu6) return false;
+  }
   const int Ns[3] = {3 * d, d, 4 * d}, Ks[3] = {d, 4 * d, d};
   for (int i = 0; i < 3; ++i) {
     const int R = 2 * ((Ns[i] + 2 * nwg - 1) / (2 * nwg)), J = (Ks[i] / 8 + 63) / 64;
@@ -796,6 +877,7 @@ int launch_decode_wide(const DecodeXcdArgs& h, hipStream_t s) {
   a.wflat = h.wflat, a.params = h.params, a.aux = h.aux, a.cache = h.cache, a.cache_lstride = h.cache_lstride;
   a.x = h.x, a.x2 = h.x2, a.x3 = h.x3, a.q = h.q, a.o = h.o, a.hg = h.hg, a.part = h.part;
   a.ctrl = h.ctrl, a.flagv = h.ctrl + 1024;  // the flag replicas start 4 KB into the cache's control tail
+  a.pk = (u32x4_t*)(h.ctrl + 16384);         // ... the packets 64 KB in (4 vectors x 8 replicas x 256 x 16 bytes = 128 KB)
   a.d = h.d, a.H = h.H, a.Te = h.Te, a.S_max = h.S_max, a.L = h.L, a.pos = h.pos, a.nwg = h.team, a.flags = h.flags;
   a.stamps = (unsigned long long*)h.stamps;
   a.w_logits = h.w_logits, a.lnf_g = h.lnf_g, a.lnf_b = h.lnf_b, a.logits_out = h.logits_out, a.V = h.V;
@@ -806,8 +888,15 @@ int launch_decode_wide(const DecodeXcdArgs& h, hipStream_t s) {
     for (int i = 0; i < 18; ++i) dst[i] = (long)h.layer_offsets[i];
     a.lstride = h.lstride, a.astride = h.astride;
   }
-  if (a.stamps) hipLaunchKernelGGL(decode_wide_kernel<true>, dim3(h.team), dim3(WT), 0, s, a);
-  else hipLaunchKernelGGL(decode_wide_kernel<false>, dim3(h.team), dim3(WT), 0, s, a);
+  const int rd = 2 * ((h.d + 2 * h.team - 1) / (2 * h.team));
+#define DW_LAUNCH(ST, R) hipLaunchKernelGGL((decode_wide_kernel<ST, R>), dim3(h.team), dim3(WT), 0, s, a)
+  if (a.stamps) {  // (measurement: medium / small only)
+    OASR_REQUIRE(rd == 4, "decode_wide: the stamped instantiation is built for 4 rows per workgroup");
+    DW_LAUNCH(true, 4);
+  } else if (rd == 2) DW_LAUNCH(false, 2);
+  else if (rd == 4) DW_LAUNCH(false, 4);
+  else DW_LAUNCH(false, 6);
+#undef DW_LAUNCH
   OASR_LAUNCH_CHECK();
   return OASR_OK;
 }
