@@ -17,6 +17,8 @@
 //     reset); a consumer polls the 1 KB flag array with ONE 16-byte agent-scope load per lane and goes on when every flag has reached the
 //     phase before its own.  Rows travel through agent-scope (sc1) stores and loads only, so nothing depends on which XCD a workgroup is on.
 //     A workgroup without work in a phase does not poll at all.
+//   * Rows that EVERY workgroup consumes in the very next phase (block output, attention / cross output rows, cross query) skip flag + row: values and
+//     the phase's epoch in ONE 16-byte store per replica, polled directly by the consumer ("packets", below).
 //   * Attention: self-attention = one workgroup per head (<= 448 cached keys: 7 per 8-lane group, K and V rows requested together);
 //     cross-attention = one workgroup per (head, quarter of the 1500 keys) whose K / V rows -- static data -- are requested BEFORE the poll;
 //     the four partials (m, l, o[64]) of a head are merged by the consumer phase's operand stage (decode_shared.h's segment merge).
