@@ -155,9 +155,10 @@ __device__ __forceinline__ void pk_poll(const WArgs& a, int vec, int rep, unsign
   }
   unsigned spins = 0;
   for (;;) {
+    // (every lane loads every time -- slots it does not wait for: slot 0 --: an assembly load under a branch would leave the register allocator free to
+    // copy its not-yet-landed destination at the join)
 #pragma unroll
-    for (int c = 0; c < WPKL; ++c)
-      if (need[c]) ld16_agent_issue(pkt[c], src + lane + 64 * c);
+    for (int c = 0; c < WPKL; ++c) ld16_agent_issue(pkt[c], src + (lane + 64 * c < nslots ? lane + 64 * c : 0));
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(pkt[0]), "+v"(pkt[1]), "+v"(pkt[2]), "+v"(pkt[3])::"memory");
     bool missing = false;
 #pragma unroll
@@ -532,7 +533,7 @@ __device__ __forceinline__ void cross_phase(const WArgs& a, int layer, unsigned 
       bool need = s0 + lane <= s1;
       unsigned spins = 0;
       for (;;) {
-        if (need) ld16_agent_issue(pq, src + s0 + lane);
+        ld16_agent_issue(pq, src + (s0 + lane <= s1 ? s0 + lane : s0));  // (unconditional: see pk_poll)
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(pq)::"memory");
         if (need && pq[3] == target) need = false;
         if (__builtin_amdgcn_ballot_w64(need) == 0) break;
