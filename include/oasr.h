@@ -116,7 +116,7 @@ int oasr_decode_logits(oasr_ctx*, const int64_t* tokens, const void* xa, const i
  * workgroups resident at once, i.e. the device to itself: a workgroup that never arrives (a second decoder on the device, a CU mask)
  * poisons a flag instead of hanging; oasr_decode_check then clears it, switches the CONTEXT to the multi-launch engine for good and
  * returns OASR_ERETRY: the caller decodes the window again. */
-#define OASR_KV_TAIL_BYTES 196608
+#define OASR_KV_TAIL_BYTES 327680
 size_t oasr_kv_cache_bytes(const oasr_ctx*, int B);
 size_t oasr_decode_step_workspace_bytes(const oasr_ctx*, int B);
 int oasr_decode_begin(oasr_ctx*, const void* xa, int B, void* kv_cache, void* stream);

@@ -45,7 +45,7 @@ class AttnArgs(C.Structure):
 
 
 ABI_VERSION = 211  # include/oasr.h: OASR_ABI_VERSION (211: the KV cache's control tail is OASR_KV_TAIL_BYTES; 210: OASR_ERETRY from oasr_decode_check)
-KV_TAIL_BYTES = 196608  # include/oasr.h: OASR_KV_TAIL_BYTES
+KV_TAIL_BYTES = 327680  # include/oasr.h: OASR_KV_TAIL_BYTES
 ROWTAB = 16        # include/oasr.h: OASR_ROWTAB (entries per sample of a chunk-row table)
 
 

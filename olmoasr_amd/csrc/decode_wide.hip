@@ -55,7 +55,8 @@ constexpr int WFS = 1024;    // dwords between replicas
 // number in ONE 16-byte store per replica; a consumer polls the packets themselves.  No acknowledgement wait before a flag, no separate
 // flag-then-row round trip.  Vectors: the block output x (mlp.2 -> the next attn_ln, or the final LayerNorm), x2 (attention output projection ->
 // cross_attn_ln), x3 (cross output projection -> mlp_ln), q (cross query -> cross-attention).
-constexpr int WPKV = 4, WV_X = 0, WV_X2 = 1, WV_X3 = 2, WV_Q = 3;
+constexpr int WPKV = 5, WV_X = 0, WV_X2 = 1, WV_X3 = 2, WV_Q = 3, WV_O = 4;  // (O: the self-attention output, 11 packets per head, slot h 11 + j)
+constexpr int WQKS = 3 * 256;  // slots per replica of the q | k | v row of the new position: <= 3 packets per workgroup (R <= 18), slot wg 3 + j
 constexpr int WPKS = 256;    // packet slots per replica: one per workgroup
 constexpr int WPKR = 6;      // values per packet at most: R <= 6 for an N = d projection (the kernel is instantiated per R: 2, 4, 6)
 
@@ -74,6 +75,7 @@ struct WArgs {
   float* part;      // [H * WNS][66]: m, l, o[64]
   unsigned* ctrl;   // [1] error flag  [3] XCC ids seen  [4] epoch base of this engine
   u32x4_t* pk;      // [WPKV][WREP][WPKS] packets: {bf16 x 6, epoch}
+  u32x4_t* pkqkv;   // [WREP][WQKS] packets of the new position's q | k | v row
   unsigned* flagv;  // [WREP][WFS]: replica r (polled by the workgroups on XCC r) of the per-workgroup flags = last completed phase (epoch-based)
   int d, H, Te, S_max, L, pos, nwg, flags, swg;
   unsigned long long* stamps;
@@ -102,6 +104,24 @@ __device__ __forceinline__ void st4_agent(void* p, unsigned v) { __hip_atomic_st
 __device__ __forceinline__ void st16_agent(u32x4_t* p, const u32x4_t& v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ void ld16_agent_issue(u32x4_t& r, const u32x4_t* p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r) : "v"(p) : "memory"); }
 __device__ __forceinline__ float pk_value(const u32x4_t& w, int i) { return (i & 1) ? bf_hi(w[i >> 1]) : bf_lo(w[i >> 1]); }
+
+// lane L's packet of a vector whose value i sits in lane i (bf16-rounded, 0 beyond the end): values 6 L .. 6 L + 5 + the epoch
+__device__ __forceinline__ u32x4_t gather_packet(float vb, int lane, unsigned epoch) {
+  float g[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) g[i] = __shfl(vb, (6 * lane + i) & 63, 64);
+  u32x4_t w;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) w[i] = pack_bf2(g[2 * i], g[2 * i + 1]);
+  w[3] = epoch;
+  return w;
+}
+// ... stored into every replica's slot (lanes < n, each its own packet): WREP store instructions
+__device__ __forceinline__ void store_packets(u32x4_t* slot0, size_t rep_stride, const u32x4_t& w, bool active) {
+#pragma unroll
+  for (int r = 0; r < WREP; ++r)
+    if (active) st16_agent(slot0 + r * rep_stride, w);
+}
 
 // ---- wave reductions on the DPP path (register to register: ~10 instructions; __shfl_xor is six dependent ds_bpermute round trips, ~700 cycles
 // per sum where a phase has ~4000 to spend).  All 64 lanes must be active.
@@ -442,7 +462,7 @@ struct WLds {
 
 // ---------------- self-attention: one workgroup per head ----------------
 template <bool STAMPS>
-__device__ __forceinline__ void self_phase(const WArgs& a, int layer, unsigned gp, unsigned base, const unsigned* myflags, WLds& lds) {
+__device__ __forceinline__ void self_phase(const WArgs& a, int layer, unsigned gp, unsigned base, const unsigned* myflags, int rep, WLds& lds) {
   constexpr int ph = 1;
   WPHASE_PROLOGUE;
   WAttLds& att = lds.att;
@@ -465,16 +485,46 @@ __device__ __forceinline__ void self_phase(const WArgs& a, int layer, unsigned g
       }
     }
     WSTAMP(0);
-    if (wave == 0) wide_wait(a, myflags, target, lane);
+    if (wave == 0) {
+      // the new position's q | k | v values of this head arrive as packets (the projection a phase ago): lane (t, wi, j) polls packet j of the wi-th
+      // workgroup that holds rows of range t (0 q, 1 k, 2 v: rows t d + h 64 .. + 63 of the 3 d), and spreads its six values out in LDS
+      const int R0 = 2 * ((3 * a.d + 2 * a.nwg - 1) / (2 * a.nwg)), NP0 = (R0 + 5) / 6;
+      const int t = lane >> 4, li = lane & 15;
+      const int wi = li / NP0, j = li - wi * NP0;
+      const int lo = t * a.d + h * 64;               // first row of the range
+      const int wgp = lo / R0 + wi;                  // producing workgroup
+      const bool mine = t < 3 && wi * NP0 + j < 16 && wgp <= (lo + 63) / R0 && wgp * R0 + 6 * j < 3 * a.d;
+      const u32x4_t* src = a.pkqkv + (size_t)rep * WQKS;
+      u32x4_t pq = {0u, 0u, 0u, 0u};
+      bool need = mine;
+      unsigned spins = 0;
+      for (;;) {
+        ld16_agent_issue(pq, src + (mine ? wgp * 3 + j : 0));  // (unconditional: see pk_poll)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pq)::"memory");
+        if (need && pq[3] == target) need = false;
+        if (__builtin_amdgcn_ballot_w64(need) == 0) break;
+        if (!(a.flags & 4)) __builtin_amdgcn_s_sleep(1);
+        if (++spins > WSPIN || ((spins & 63) == 0 && ld4_agent(a.ctrl + 1) != 0)) {
+          if (lane == 0) __hip_atomic_fetch_or(a.ctrl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+      if (mine) {
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+          const int r = wgp * R0 + 6 * j + e - lo;  // (a packet's values past the workgroup's run belong to nobody: 6 j + e < R0)
+          if (6 * j + e < R0 && r >= 0 && r < 64) lds.xs[t * 64 + r] = (unsigned short)(pq[e >> 1] >> ((e & 1) * 16));
+        }
+      }
+    }
     __syncthreads();
     WSTAMP(1);
-    const u32x4_t q4 = ld16_agent(self + (long)a.pos * 3 * a.d + h * 64 + l8 * 8);
+    const u32x4_t q4 = *(const u32x4_t*)(lds.xs + l8 * 8);
 #pragma unroll
     for (int u = 0; u < WSK; ++u) {
       const int t = grp + WNG * u;
-      if (WNG * u <= a.pos && a.pos < WNG * (u + 1) && t >= a.pos) {  // the step that holds row pos: its lanes at and past pos read that row (past: masked, finite)
-        const unsigned off = (unsigned)((a.pos * 3 * a.d + l8 * 8) * 2);
-        k4[u] = ld16_agent_off(kb, off), v4[u] = ld16_agent_off(vb, off);
+      if (WNG * u <= a.pos && a.pos < WNG * (u + 1) && t >= a.pos) {  // the step that holds row pos: its lanes at and past pos take that row (past: masked, finite)
+        k4[u] = *(const u32x4_t*)(lds.xs + 64 + l8 * 8), v4[u] = *(const u32x4_t*)(lds.xs + 128 + l8 * 8);
       }
     }
     if (STAMPS) {
@@ -486,10 +536,10 @@ __device__ __forceinline__ void self_phase(const WArgs& a, int layer, unsigned g
     float m, lt, acc;
     attend<WSK>(qv, k4, v4, n, tid, att, m, lt, acc);
     WSTAMP(6);
-    if (tid < 64) {
-      const float val = lt > 0.f ? acc / lt : 0.f, nb = dec::xor_lane<1>(val);
-      if ((lane & 1) == 0) st4_agent(a.o + h * 64 + lane, pack_bf2(val, nb));
-      WWAIT_VM0();
+    if (tid < 64) {  // the head's 64 output values as 11 packets of six (lane L: values 6 L .. 6 L + 5): no acknowledgement wait
+      const float val = lt > 0.f ? acc / lt : 0.f;
+      const u32x4_t w = gather_packet(bf_round(val), lane, base + gp + 1);
+      store_packets(a.pk + (size_t)(WV_O * WREP) * WPKS + h * 11 + lane, WPKS, w, lane < 11);
     }
     WSTAMP(2);
   }
@@ -602,6 +652,7 @@ __device__ __forceinline__ void gemv_phase(const WArgs& a, int layer, unsigned g
     if (wave == 0) {
       if (pk_in) pk_poll(a, PKIN, rep, target, (a.d + RD - 1) / RD, lane, pkt);
       else if (PH == 0) pk_from_plain<RD>(a.x, a.d, lane, pkt);  // (layer 0; preceded by no phase of this launch)
+      else if (PH == 2) pk_poll(a, WV_O, rep, target, a.H * 11, lane, pkt);
       else wide_wait(a, myflags, target, lane);
     }
     __syncthreads();
@@ -637,6 +688,19 @@ __device__ __forceinline__ void gemv_phase(const WArgs& a, int layer, unsigned g
       }
     } else if constexpr (WPh<PH>::LN) {  // LayerNorm folded into the operand (K = d): wave 0
       if (wave == 0) ln_packets<RD>(pkt, a.d, lane, lds.lng, lds.lnb, xs);
+    } else if constexpr (PH == 2) {  // the self-attention output arrived as packets (polled above): slot h 11 + j = values h 64 + 6 j .. + 5
+      if (wave == 0) {
+#pragma unroll
+        for (int c = 0; c < WPKL; ++c) {
+          const int sl = lane + 64 * c;
+          if (sl < a.H * 11) {
+            const int h = sl / 11, j = sl - h * 11;
+#pragma unroll
+            for (int e = 0; e < 3; ++e)
+              if (6 * j + 2 * e < 64) *(uint32_t*)(xs + h * 64 + 6 * j + 2 * e) = pkt[c][e];
+          }
+        }
+      }
     } else {  // plain row: K / 8 chunks over the 512 threads
       constexpr int NC = (4 * WMAXD / 8 + WT - 1) / WT;
       u32x4_t raw[NC];
@@ -703,6 +767,13 @@ __device__ __forceinline__ void gemv_phase(const WArgs& a, int layer, unsigned g
         for (int i = 0; i < 3; ++i) w[i] = i < RD / 2 ? pack_bf2(rdl(yb, 2 * i), rdl(yb, 2 * i + 1)) : 0u;  // (lanes >= rows hold 0)
         w[3] = base + gp + 1;
         if (lane < WREP) st16_agent(a.pk + (size_t)(PKOUT * WREP + lane) * WPKS + wg, w);
+      } else if constexpr (PH == 0) {
+        // q | k | v of the new position: into the cache row for the steps to come (nobody reads it in THIS launch: no acknowledgement wait), and as
+        // packets of six for the self-attention heads of this one
+        const float nb = dec::xor_lane<1>(y);
+        if (lane < rows && (lane & 1) == 0) st4_agent(p.out + row0 + lane, pack_bf2(y, nb));
+        const u32x4_t w = gather_packet(bf_round(y), lane, base + gp + 1);
+        store_packets(a.pkqkv + wg * 3 + lane, WQKS, w, lane * 6 < rows);
       } else {
         const float nb = dec::xor_lane<1>(y);
         if (lane < rows && (lane & 1) == 0) st4_agent(p.out + row0 + lane, pack_bf2(y, nb));
@@ -826,7 +897,7 @@ __global__ __launch_bounds__(WT) void decode_wide_kernel(WArgs a) {
 #pragma unroll 1
   for (int layer = 0; layer < a.L; ++layer) {
     gemv_phase<STAMPS, RD, 0>(a, layer, gp++, base, myflags, rep, lds, wreg, st, res);
-    self_phase<STAMPS>(a, layer, gp++, base, myflags, lds);
+    self_phase<STAMPS>(a, layer, gp++, base, myflags, rep, lds);
     request_phase<RD, 2>(a, layer, wreg, st);
     gemv_phase<STAMPS, RD, 2>(a, layer, gp++, base, myflags, rep, lds, wreg, st, res);
     request_phase<RD, 3>(a, layer, wreg, st);
@@ -857,6 +928,10 @@ bool decode_wide_supports(int d, int H, int Te, int S_max, int L, int M, int nwg
         (Te + WNS - 1) / WNS <= WNG * WCK && nwg >= 64 && nwg <= WMAXWG && nwg % 4 == 0 && H * WNS <= nwg))
     return false;
   if (2 * ((d + 2 * nwg - 1) / (2 * nwg)) > WPKR) return false;  // an N = d projection's rows per workgroup fill one packet
+  {
+    const int R0 = 2 * ((3 * d + 2 * nwg - 1) / (2 * nwg)), NP0 = (R0 + 5) / 6;  // the q | k | v row: <= 3 packets per workgroup, <= 16 packets per head and range
+    if (NP0 > 3 || ((63 + R0 - 1) / R0 + 1) * NP0 > 16 || H * 11 > WPKS) return false;
+  }
   // units per wave: rows R x spans J dealt to 8 waves, within what the instantiation for this R_d unrolls (wmu)
   {
     const int rd = 2 * ((d + 2 * nwg - 1) / (2 * nwg));
@@ -880,7 +955,8 @@ int launch_decode_wide(const DecodeXcdArgs& h, hipStream_t s) {
   a.wflat = h.wflat, a.params = h.params, a.aux = h.aux, a.cache = h.cache, a.cache_lstride = h.cache_lstride;
   a.x = h.x, a.x2 = h.x2, a.x3 = h.x3, a.q = h.q, a.o = h.o, a.hg = h.hg, a.part = h.part;
   a.ctrl = h.ctrl, a.flagv = h.ctrl + 1024;  // the flag replicas start 4 KB into the cache's control tail
-  a.pk = (u32x4_t*)(h.ctrl + 16384);         // ... the packets 64 KB in (4 vectors x 8 replicas x 256 x 16 bytes = 128 KB)
+  a.pk = (u32x4_t*)(h.ctrl + 16384);         // ... the packets 64 KB in (5 vectors x 8 replicas x 256 x 16 bytes = 160 KB)
+  a.pkqkv = a.pk + (size_t)WPKV * WREP * WPKS;  // ... and the q | k | v row's behind them (8 replicas x 768 x 16 bytes = 96 KB)
   a.d = h.d, a.H = h.H, a.Te = h.Te, a.S_max = h.S_max, a.L = h.L, a.pos = h.pos, a.nwg = h.team, a.flags = h.flags;
   a.stamps = (unsigned long long*)h.stamps;
   a.w_logits = h.w_logits, a.lnf_g = h.lnf_g, a.lnf_b = h.lnf_b, a.logits_out = h.logits_out, a.V = h.V;
