@@ -37,6 +37,11 @@ int oasr_span_side_streams(void);
 int oasr_xcd_plan_debug(int d, int H, int Te, int M, int L, int team, int wg, int* out, int max_blocks);
 /* tests (CPU): 1 when every 32-bit buffer offset of a one-launch step stays below 2 GiB (layer0 = the 18 element offsets of decoder layer 0
  * in csrc/decode_xcd.hip::XLayer order, strides in elements), 0 when the engine must take the multi-launch step instead. */
+/* the chip-wide step engine (csrc/decode_wide.hip): does the shape run on it with `nwg` workgroups; the (row, 512-element K span) units of compute wave
+ * `wave` (1 .. 8) of workgroup `wg` for an [N x K] projection of a width-d model: out[2 i] = row, out[2 i + 1] = span; returns the count (-1: bad arguments or
+ * past the kernel's unrolled bound) */
+int oasr_wide_supports_debug(int d, int H, int Te, int S_max, int L, int M, int nwg);
+int oasr_wide_plan_debug(int d, int nwg, int N, int K, int wg, int wave, int* out, int max_units);
 int oasr_xcd_offsets_ok_debug(const int64_t* layer0, long long lstride, long long cache_lstride, int d, int Te, int L, int M);
 /* tests / A-B: 1 (default) = the unmasked attention cases (encoder self-, cross-attention) run the 8-wave ping-pong kernels,
  * 0 = the general (maskable) kernels run everything.  Same results up to accumulation order (tests/test_gpu_ops.py). */

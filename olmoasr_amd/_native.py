@@ -115,6 +115,8 @@ def _declare(lib):
         "oasr_span_side_streams": (i32, []),
         "oasr_xcd_plan_debug": (i32, [i32, i32, i32, i32, i32, i32, i32, vp, i32]),
         "oasr_xcd_offsets_ok_debug": (i32, [vp, C.c_longlong, C.c_longlong, i32, i32, i32, i32]),
+        "oasr_wide_supports_debug": (i32, [i32, i32, i32, i32, i32, i32, i32]),
+        "oasr_wide_plan_debug": (i32, [i32, i32, i32, i32, i32, i32, vp, i32]),
         "oasr_attention_set_pingpong": (i32, [i32]),
         "oasr_profile_gemm_collect": (i32, [vp, vp, vp, C.c_char_p, i32]),
     }

@@ -305,7 +305,7 @@ __device__ __forceinline__ WGemv gemv_of(const WArgs& a, int layer) {
 struct WUnits {
   int U, upw, u0, r0, j0, J, KC;
 };
-__device__ __forceinline__ WUnits units_of(const WGemv& p, int wg, int wave) {
+__host__ __device__ __forceinline__ WUnits units_of(const WGemv& p, int wg, int wave) {
   WUnits q;
   q.KC = p.K >> 3, q.J = (q.KC + 63) >> 6;
   int rows = p.N - wg * p.R;
@@ -978,4 +978,27 @@ int launch_decode_wide(const DecodeXcdArgs& h, hipStream_t s) {
 #undef DW_LAUNCH
   OASR_LAUNCH_CHECK();
   return OASR_OK;
+}
+
+// Test hooks (include/oasr_testing.h): the host-side view of the work split -- whether a shape runs on this engine, and which (row, K span) units compute
+// wave `wave` (1 .. 8) of workgroup `wg` is dealt for an [N x K] projection: out[2 i] = row (absolute), out[2 i + 1] = span; returns the count, or -1
+// past the instantiation's unrolled bound (wmu).  tests/test_native_abi.py checks that the units of all waves tile the matrix exactly once.
+extern "C" int oasr_wide_supports_debug(int d, int H, int Te, int S_max, int L, int M, int nwg) { return decode_wide_supports(d, H, Te, S_max, L, M, nwg) ? 1 : 0; }
+extern "C" int oasr_wide_plan_debug(int d, int nwg, int N, int K, int wg, int wave, int* out, int max_units) {
+  WGemv p{};
+  p.N = N, p.K = K, p.R = 2 * ((N + 2 * nwg - 1) / (2 * nwg));
+  if (wave < 1 || wave > WC || wg < 0 || wg >= nwg) return -1;
+  const WUnits q = units_of(p, wg, wave);
+  const int cnt = q.U - q.u0 < q.upw ? q.U - q.u0 : q.upw;
+  const int rd = 2 * ((d + 2 * nwg - 1) / (2 * nwg));
+  const int ph = N == 3 * d ? 0 : (N == 4 * d ? 6 : (K == 4 * d ? 7 : 2));
+  const int mu = rd == 2 ? (ph == 0 ? wmu<2, 0>() : ph == 2 ? wmu<2, 2>() : wmu<2, 6>()) : rd == 4 ? (ph == 0 ? wmu<4, 0>() : ph == 2 ? wmu<4, 2>() : wmu<4, 6>())
+                                                                                                   : (ph == 0 ? wmu<6, 0>() : ph == 2 ? wmu<6, 2>() : wmu<6, 6>());
+  if (cnt > mu) return -1;
+  int n = 0, j = q.j0, r = q.r0;
+  for (int i = 0; i < cnt && n < max_units; ++i, ++n) {
+    out[2 * n] = wg * p.R + r, out[2 * n + 1] = j;
+    if (++j == q.J) j = 0, ++r;
+  }
+  return n;
 }

@@ -262,3 +262,32 @@ def test_one_launch_decode_refuses_layouts_past_the_32_bit_buffer_offsets(native
         top = (ctypes.c_int64 * 18)(*[x + (L - 1) * per_layer for x in o])
         assert lib.oasr_xcd_offsets_ok_debug(top, -per_layer, 3 * 448 * d + 1500 * 2 * d, d, 1500, L, 1) == 1, name
         assert lib.oasr_xcd_offsets_ok_debug(o, -per_layer, 3 * 448 * d + 1500 * 2 * d, d, 1500, L, 1) == 0, name  # would walk below the arena
+
+
+def test_chip_wide_step_engine_work_split(native):
+    """csrc/decode_wide.hip deals a projection's rows out in runs per workgroup and a run's (row, 512-element K span) units to the workgroup's eight compute
+    waves in contiguous runs: over all workgroups and waves the units must tile the [N x K] matrix exactly once, within the unrolled bound of the kernel
+    instantiation -- for every projection shape of every model variant (no GPU needed: the host-side twin of the device function)."""
+    import ctypes as C
+    lib = native.lib()
+    buf = (C.c_int * 64)()
+    for name, d, H, L in (("tiny", 384, 6, 4), ("base", 512, 8, 6), ("small", 768, 12, 12), ("medium", 1024, 16, 24), ("large", 1280, 20, 32)):
+        assert lib.oasr_wide_supports_debug(d, H, 1500, 448, L, 1, 256) == 1, name
+        for N, K in ((3 * d, d), (d, d), (4 * d, d), (d, 4 * d)):
+            seen = {}
+            for wg in range(256):
+                for wave in range(1, 9):
+                    n = lib.oasr_wide_plan_debug(d, 256, N, K, wg, wave, buf, 32)
+                    assert 0 <= n <= 8, (name, N, K, wg, wave, n)
+                    for i in range(n):
+                        key = (buf[2 * i], buf[2 * i + 1])
+                        assert key not in seen, (name, N, K, key, seen[key], (wg, wave))
+                        seen[key] = (wg, wave)
+            spans = (K // 8 + 63) // 64
+            assert len(seen) == N * spans and all(0 <= r < N and 0 <= j < spans for r, j in seen), (name, N, K, len(seen))
+    # shapes the engine must decline: more than one sequence, a context past 448 positions, too few workgroups, a width whose rows do not fit a packet
+    assert lib.oasr_wide_supports_debug(1024, 16, 1500, 448, 24, 2, 256) == 0
+    assert lib.oasr_wide_supports_debug(1024, 16, 1500, 512, 24, 1, 256) == 0
+    assert lib.oasr_wide_supports_debug(1024, 16, 1500, 448, 24, 1, 32) == 0
+    assert lib.oasr_wide_supports_debug(2048, 32, 1500, 448, 24, 1, 256) == 0
+    assert lib.oasr_wide_supports_debug(1024, 16, 2000, 448, 24, 1, 256) == 0  # (an audio context past 8 x 216 keys)
