@@ -142,22 +142,6 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
-// The same sum on the DPP path (register to register: four row-local steps + four v_readlane) instead of six dependent ds_bpermute round trips (~150
-// against ~700 cycles of latency -- what a latency-bound one-row-per-wave kernel such as the LayerNorms waits for, twice per row).  ALL 64 lanes must be
-// active; the summation order differs from wave_sum's butterfly (fp32 rounding), so kernels that must agree to the bit use the same one.
-template <int CTRL>
-__device__ __forceinline__ float oasr_dpp_mov(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-  v += oasr_dpp_mov<0xB1>(v);   // quad_perm [1, 0, 3, 2]
-  v += oasr_dpp_mov<0x4E>(v);   // quad_perm [2, 3, 0, 1]
-  v += oasr_dpp_mov<0x141>(v);  // row_half_mirror
-  v += oasr_dpp_mov<0x140>(v);  // row_mirror: every lane holds its 16-lane row's sum
-  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
-  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
-  return (r0 + r1) + (r2 + r3);
-}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -38,7 +38,7 @@ __device__ __forceinline__ void row_stats(const u32x4_t (&raw)[MAXC], int lane, 
       for (int i = 0; i < 8; ++i) s += v[i];
     }
   }
-  const float mean = wave_sum_dpp(s) / (float)d;
+  const float mean = wave_sum(s) / (float)d;
   float q = 0.f;
 #pragma unroll
   for (int c = 0; c < MAXC; ++c) {
@@ -52,7 +52,7 @@ __device__ __forceinline__ void row_stats(const u32x4_t (&raw)[MAXC], int lane, 
       }
     }
   }
-  const float var = wave_sum_dpp(q) / (float)d;
+  const float var = wave_sum(q) / (float)d;
   mean_out = mean;
   rstd_out = rsqrtf(var + 1e-5f);
 }

@@ -130,7 +130,13 @@ __device__ __forceinline__ float dpp_mov(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 __device__ __forceinline__ float rdl(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
-__device__ __forceinline__ float wsum(float v) { return wave_sum_dpp(v); }  // (common.h: the LayerNorm kernels' sum)
+__device__ __forceinline__ float wsum(float v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm [1, 0, 3, 2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2, 3, 0, 1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror: every lane holds its 16-lane row's sum
+  return (rdl(v, 0) + rdl(v, 16)) + (rdl(v, 32) + rdl(v, 48));
+}
 __device__ __forceinline__ float wmaxf(float v) {
   v = fmaxf(v, dpp_mov<0xB1>(v));
   v = fmaxf(v, dpp_mov<0x4E>(v));

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
       for (int i = 0; i < 8; ++i) s += v[c][i];
     }
   }
-  const float mean = wave_sum_dpp(s) / (float)d;
+  const float mean = wave_sum(s) / (float)d;
   float q = 0.f;
 #pragma unroll
   for (int c = 0; c < MAXC; ++c) {
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
       }
     }
   }
-  const float var = wave_sum_dpp(q) / (float)d;
+  const float var = wave_sum(q) / (float)d;
   const float rstd = rsqrtf(var + 1e-5f);
 #pragma unroll
   for (int c = 0; c < MAXC; ++c) {
@@ -146,8 +146,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
           }
         }
       }
-      s1 = wave_sum_dpp(s1) * inv_d;
-      s2 = wave_sum_dpp(s2) * inv_d;
+      s1 = wave_sum(s1) * inv_d;
+      s2 = wave_sum(s2) * inv_d;
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
         const int ch = lane + 64 * c;
