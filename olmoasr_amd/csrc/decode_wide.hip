@@ -36,7 +36,7 @@ constexpr int WT = DW_WT;  // threads per workgroup
 constexpr int WW = WT / 64;
 constexpr int WC = WW - 1;  // compute waves 1 .. WW-1; wave 0 is the helper: poll, operand row, epilogue, stores, flag -- it requests no weights, so nothing slow sits in front of its polls
 constexpr int WNG = WT / 8;  // 8-lane groups (attention: one key per group and step)
-constexpr int WMAXU = 64 / WC;  // units per compute wave and phase (64 units per workgroup at most)
+constexpr int WMAXU = (64 + WC - 1) / WC;  // units per compute wave and phase (64 units per workgroup at most)
 #ifndef DW_NS_LOG
 #define DW_NS_LOG 3
 #endif
@@ -270,8 +270,9 @@ struct WPh {  // what projection phase PH is, at compile time
 // units per compute wave and phase at most, at 256 workgroups (decode_wide_supports checks the shape against it): keeps the unrolled unit loops -- and the
 // kernel under the 64 KB of instruction cache two CUs share -- as short as the instantiation allows
 template <int RD, int PH>
-constexpr int wmu() {
-  return RD == 2 ? 1 : RD == 4 ? (PH == 0 ? 3 : (PH == 6 || PH == 7) ? 4 : 1) : (PH == 0 ? 6 : (PH == 6 || PH == 7) ? 8 : 3);
+constexpr int wmu() {  // ceil(units of the workgroup at most / compute waves); units: RD = 2: 6 / 2 / 8 / 8 (q|k|v, N = d, mlp.0, mlp.2), 4: 24 / 8 / 32 / 32, 6 (d <= 1280): 48 / 18 / 60 / 60
+  constexpr int u = RD == 2 ? (PH == 0 ? 6 : (PH == 6 || PH == 7) ? 8 : 2) : RD == 4 ? (PH == 0 ? 24 : (PH == 6 || PH == 7) ? 32 : 8) : (PH == 0 ? 48 : (PH == 6 || PH == 7) ? 60 : 18);
+  return (u + WC - 1) / WC;
 }
 template <int PH>
 __device__ __forceinline__ WGemv gemv_of(const WArgs& a, int layer) {
@@ -943,7 +944,7 @@ bool decode_wide_supports(int d, int H, int Te, int S_max, int L, int M, int nwg
   const int Ns[3] = {3 * d, d, 4 * d}, Ks[3] = {d, 4 * d, d};
   for (int i = 0; i < 3; ++i) {
     const int R = 2 * ((Ns[i] + 2 * nwg - 1) / (2 * nwg)), J = (Ks[i] / 8 + 63) / 64;
-    if (R * J > WC * WMAXU || R * J > 64 || R > 64) return false;
+    if (R * J > 64 || R > 64) return false;
   }
   return true;
 }
